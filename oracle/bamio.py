@@ -1,0 +1,144 @@
+"""Minimal BAM / SAM record loader for the ORACLE side of the tests (test infrastructure).
+
+Pure Python on purpose: it is independent of the product's C++ BGZF/BAM reader
+(metheor_amd/csrc/host/bam_reader.cpp) so the two can be checked against each other.
+BGZF is a series of gzip members, which `gzip.decompress` concatenates.
+"""
+import gzip
+import struct
+
+import numpy as np
+
+CIGAR_OPS = "MIDNSHP=X"
+
+
+class Records:
+    """Raw alignment records in stream order (the fields readutil.rs / the drivers look at)."""
+
+    def __init__(self, refs, tid, pos, flag, mapq, cigars, xms, names=None, text=""):
+        self.refs = refs  # [(name, length)]
+        self.tid = np.asarray(tid, dtype=np.int32)
+        self.pos = np.asarray(pos, dtype=np.int32)
+        self.flag = np.asarray(flag, dtype=np.uint16)
+        self.mapq = np.asarray(mapq, dtype=np.uint8)
+        self.cigars = cigars  # list of list of packed uint32 (len<<4 | op)
+        self.xms = xms  # list of bytes or None
+        self.names = names
+        self.text = text
+
+    def __len__(self):
+        return len(self.tid)
+
+    def packed(self):
+        cigar_off = np.zeros(len(self) + 1, dtype=np.uint32)
+        xm_off = np.zeros(len(self) + 1, dtype=np.uint32)
+        for i, (c, x) in enumerate(zip(self.cigars, self.xms)):
+            cigar_off[i + 1] = cigar_off[i] + len(c)
+            xm_off[i + 1] = xm_off[i] + (len(x) if x is not None else 0)
+        cigar = np.array([v for c in self.cigars for v in c], dtype=np.uint32)
+        xm = b"".join(x for x in self.xms if x is not None)
+        return cigar_off, cigar, xm_off, xm
+
+    def subset(self, idx):
+        idx = list(idx)
+        return Records(self.refs, self.tid[idx], self.pos[idx], self.flag[idx], self.mapq[idx],
+                       [self.cigars[i] for i in idx], [self.xms[i] for i in idx],
+                       [self.names[i] for i in idx] if self.names else None, self.text)
+
+
+def _aux_xm(aux):
+    """scan the aux block for XM:Z (bam aux layout: tag[2] type[1] value)"""
+    o = 0
+    n = len(aux)
+    while o + 3 <= n:
+        tag = aux[o:o + 2]
+        typ = chr(aux[o + 2])
+        o += 3
+        if typ in "Z" "H":
+            e = aux.index(b"\0", o)
+            if tag == b"XM" and typ == "Z":
+                return aux[o:e]
+            o = e + 1
+        elif typ in "AcC":
+            o += 1
+        elif typ in "sS":
+            o += 2
+        elif typ in "iIf":
+            o += 4
+        elif typ == "B":
+            sub = chr(aux[o])
+            cnt, = struct.unpack_from("<i", aux, o + 1)
+            o += 5 + cnt * {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
+        else:
+            raise ValueError("bad aux type %r" % typ)
+    return None
+
+
+def read_bam(path):
+    with open(path, "rb") as fh:
+        d = gzip.decompress(fh.read())
+    if d[:4] != b"BAM\1":
+        raise ValueError("not a BAM file")
+    l_text, = struct.unpack_from("<i", d, 4)
+    text = d[8:8 + l_text].decode(errors="replace")
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<i", d, o)
+    o += 4
+    refs = []
+    for _ in range(n_ref):
+        l, = struct.unpack_from("<i", d, o)
+        o += 4
+        name = d[o:o + l - 1].decode()
+        o += l
+        ln, = struct.unpack_from("<i", d, o)
+        o += 4
+        refs.append((name, ln))
+    tid, pos, flag, mapq, cigars, xms, names = [], [], [], [], [], [], []
+    while o < len(d):
+        bs, = struct.unpack_from("<i", d, o)
+        o += 4
+        t, p, l_rn, mq, _bin, n_cig, fl, l_seq, _nt, _np, _tl = struct.unpack_from("<iiBBHHHiiii", d, o)
+        q = o + 32
+        names.append(d[q:q + l_rn - 1].decode())
+        q += l_rn
+        cigars.append(list(struct.unpack_from("<%dI" % n_cig, d, q)))
+        q += 4 * n_cig
+        q += (l_seq + 1) // 2 + l_seq
+        xms.append(_aux_xm(d[q:o + bs]))
+        tid.append(t); pos.append(p); flag.append(fl); mapq.append(mq)
+        o += bs
+    return Records(refs, tid, pos, flag, mapq, cigars, xms, names, text)
+
+
+def read_sam(path):
+    refs, text = [], []
+    tid, pos, flag, mapq, cigars, xms, names = [], [], [], [], [], [], []
+    name2tid = {}
+    with open(path) as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if line.startswith("@"):
+                text.append(line)
+                if line.startswith("@SQ"):
+                    f = dict(x.split(":", 1) for x in line.split("\t")[1:])
+                    name2tid[f["SN"]] = len(refs)
+                    refs.append((f["SN"], int(f["LN"])))
+                continue
+            f = line.split("\t")
+            names.append(f[0]); flag.append(int(f[1]))
+            tid.append(name2tid.get(f[2], -1)); pos.append(int(f[3]) - 1); mapq.append(int(f[4]))
+            cg, num = [], ""
+            if f[5] != "*":
+                for ch in f[5]:
+                    if ch.isdigit():
+                        num += ch
+                    else:
+                        cg.append((int(num) << 4) | CIGAR_OPS.index(ch))
+                        num = ""
+            cigars.append(cg)
+            xm = None
+            for a in f[11:]:
+                if a.startswith("XM:Z:"):
+                    xm = a[5:].encode()
+            xms.append(xm)
+    return Records(refs, tid, pos, flag, mapq, cigars, xms, names, "\n".join(text) + "\n")
