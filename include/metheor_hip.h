@@ -1,0 +1,151 @@
+/*
+ * metheor_hip.h -- C ABI of the MI355X (gfx950) methylation-heterogeneity engine.
+ *
+ * This is the drop-in boundary for the per-read CpG-pattern hot path of dohlee/metheor
+ * (v0.1.9).  The reference has no FFI of its own: the seam is cut inside each measure's
+ * `compute_helper()` AFTER `BismarkRead::new` (host: BAM iteration + XM decode) and BEFORE the
+ * hash-map accumulation.  A host (Rust via `extern "C"`, C++, ctypes) decodes records into the
+ * flat SoA batch below and calls one `mth_*_accumulate` per batch; the per-measure result
+ * getters return exactly what the corresponding `compute_helper()` returns.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every entry point returns an
+ * `int` status (MTH_OK == 0, negative on error, never throws); one `mth_ctx_t` per GPU; a ctx
+ * is not thread-safe; work is enqueued on the ctx's HIP stream and the getters synchronise.
+ * There is NO CPU fallback: without a gfx950 device `mth_ctx_create` fails.
+ *
+ * Reference interfaces replaced (paths under the reference repo):
+ *   src/pdr.rs:119-125    pdr::compute_helper(input,min_depth,min_cpgs,min_qual,cpg_set)
+ *                         -> BTreeMap<CpGPosition,(f32,u32,u32)>      => mth_pdr_lpmd_accumulate + mth_pdr_fetch
+ *   src/lpmd.rs:154-160   lpmd::compute_helper(input,min_distance,max_distance,min_qual,cpg_set)
+ *                         -> LPMDResult                               => mth_pdr_lpmd_accumulate + mth_lpmd_global (+ mth_lpmd_pairs_fetch)
+ *   src/mhl.rs:135-141    mhl::compute_helper(...) -> BTreeMap<CpGPosition,f32>        => mth_mhl_accumulate + mth_mhl_fetch
+ *   src/me.rs:90-94       me::compute_helper(input,min_qual,cpg_set) -> HashMap<Quartet,QuartetStat>
+ *   src/pm.rs:85-89       pm::compute_helper(...)                                      => mth_quartet_accumulate + mth_quartet_fetch
+ *   src/fdrp.rs:176-183   fdrp::compute_helper(input,min_qual,min_depth,max_depth,min_overlap,cpg_set)
+ *   src/qfdrp.rs:188-195  qfdrp::compute_helper(...) -> BTreeMap<CpGPosition,f32>      => mth_fdrp_accumulate + mth_fdrp_fetch
+ *   src/readutil.rs:15-21 BismarkRead {start_pos,end_pos,cpgs:Vec<CpG{relpos,abspos,methylated}>}
+ *                                                                                      => mth_batch_t (SoA)
+ */
+#ifndef METHEOR_HIP_H
+#define METHEOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTH_ABI_VERSION 1
+
+typedef struct mth_ctx mth_ctx_t;
+
+enum {
+    MTH_OK = 0,
+    MTH_ERR_INVALID = -1,   /* bad argument */
+    MTH_ERR_HIP = -2,       /* a HIP runtime call failed (mth_last_error has the text) */
+    MTH_ERR_NO_DEVICE = -3, /* no gfx950 device: there is no CPU fallback */
+    MTH_ERR_UNSORTED = -4,  /* reads of a batch are not sorted by start */
+    MTH_ERR_SPAN = -5,      /* a read spans more than batch.max_span */
+    MTH_ERR_REOPEN = -6,    /* input needs the flush re-open semantics on a path that
+                               does not implement them yet */
+    MTH_ERR_RANGE = -7,     /* a CpG of an owned site lies outside what the batch declared */
+    MTH_ERR_CAPACITY = -8,  /* an on-chip capacity was exceeded */
+    MTH_ERR_STATE = -9      /* call order violated */
+};
+
+enum { MTH_MEM_HOST = 0, MTH_MEM_DEVICE = 1 };
+
+/*
+ * One batch = the reads of ONE contig that can touch the genomic region [region_beg, region_end),
+ * sorted by `read_start` (coordinate-sorted BAM order).  Sites inside the region and reads whose
+ * start lies inside it are OWNED by the batch; reads starting outside are halo (they contribute
+ * to owned sites only).  A whole contig is region [0, contig_length).
+ *
+ * Per read  (readutil.rs:15-21; pdr.rs:150 mapq):
+ *   read_start/read_end  first / last reference position covered (readutil.rs:25-33), -1 if none
+ *   read_mapq            Record::mapq()
+ *   read_fwd             1 iff flags in {0,99,147} (readutil.rs:332) -- informational; cpg_pos
+ *                        already has the strand rule applied
+ *   cpg_off[n_reads+1]   CSR offsets into the per-call arrays
+ * Per CpG call (readutil.rs:247-251), in query order:
+ *   cpg_pos              abspos (31 bits) | methylated << 31
+ *   cpg_rel              relpos = query offset of the call (u8; use cpg_rel16 when reads > 255 bp)
+ */
+typedef struct {
+    int32_t  tid;
+    int32_t  region_beg, region_end;
+    int32_t  max_span;   /* >= max(read_end - read_start + 1) over the batch */
+    uint32_t n_reads;
+    uint32_t n_cpgs;
+    int32_t  mem;        /* MTH_MEM_HOST or MTH_MEM_DEVICE: where ALL the arrays below live */
+    const int32_t  *read_start;
+    const int32_t  *read_end;
+    const uint8_t  *read_mapq;
+    const uint8_t  *read_fwd;
+    const uint32_t *cpg_off;
+    const uint32_t *cpg_pos;
+    const uint8_t  *cpg_rel;    /* exactly one of cpg_rel / cpg_rel16 is non-NULL */
+    const uint16_t *cpg_rel16;
+} mth_batch_t;
+
+/* pdr.rs:82-89 + lpmd.rs:125-133 arguments (clap defaults: lib.rs:36-46, 206-214) */
+typedef struct {
+    uint32_t pdr_min_depth;  /* -d 10 */
+    uint32_t pdr_min_cpgs;   /* -p 4  */
+    uint8_t  pdr_min_qual;   /* -q 10 */
+    uint8_t  lpmd_min_qual;  /* -q 10 */
+    uint8_t  want_pdr, want_lpmd;
+    int32_t  lpmd_min_distance; /* -m 2  */
+    int32_t  lpmd_max_distance; /* -M 16 */
+} mth_pdr_lpmd_params_t;
+
+/* ---- context ------------------------------------------------------------------------- */
+int  mth_abi_version(void);
+int  mth_ctx_create(int device_id, mth_ctx_t **out);
+void mth_ctx_destroy(mth_ctx_t *ctx);
+/* enqueue on a caller-owned hipStream_t (e.g. torch's current stream); NULL = ctx's own stream */
+int  mth_ctx_set_stream(mth_ctx_t *ctx, void *hip_stream);
+int  mth_ctx_sync(mth_ctx_t *ctx);
+const char *mth_strerror(int status);
+const char *mth_last_error(const mth_ctx_t *ctx);
+/* forget all accumulated results (a new input file) */
+int  mth_reset(mth_ctx_t *ctx);
+
+/* ---- PDR + LPMD, fused single pass (pdr.rs:119-212, lpmd.rs:154-202) --------------------
+ * Asynchronous: kernels are enqueued on the ctx stream; data errors (UNSORTED/SPAN/REOPEN/
+ * RANGE) are detected on the device and reported by the next synchronising call below. */
+int  mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch,
+                             const mth_pdr_lpmd_params_t *params);
+/* number of emitted sites so far (synchronises) */
+int  mth_pdr_count(mth_ctx_t *ctx, uint64_t *n_sites);
+/* copy out the BTreeMap<CpGPosition,(f32,u32,u32)> rows, sorted by (tid,pos) given batches were
+ * submitted in that order; any pointer may be NULL; buffers hold >= mth_pdr_count entries */
+int  mth_pdr_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *pos, float *pdr,
+                   uint32_t *n_concordant, uint32_t *n_discordant);
+/* device pointers of the same columns (valid until the next accumulate/reset) */
+int  mth_pdr_device_view(mth_ctx_t *ctx, uint64_t *n_sites, const int32_t **pos,
+                         const float **pdr, const uint32_t **n_concordant,
+                         const uint32_t **n_discordant);
+/* LPMDResult: out[4] = {n_concordant, n_discordant, n_read, n_valid_read} (exact, int64);
+ * *lpmd = compute_lpmd() with the reference's wrapping i32 counters (lpmd.rs:11-12,51-55) */
+int  mth_lpmd_global(mth_ctx_t *ctx, int64_t out[4], float *lpmd);
+/* multi-GPU: enqueue (on the ctx stream) a copy of the 4 exact int64 counters into a DEVICE buffer
+ * the caller owns, ready for an RCCL all-reduce(sum) over ranks; no host synchronisation */
+int  mth_lpmd_export_device(mth_ctx_t *ctx, int64_t *dst_device4);
+/* compute_lpmd() (lpmd.rs:51-55, wrapping-i32 semantics) from summed integer counters, e.g. the
+ * all-reduced ones */
+float mth_lpmd_from_counts(int64_t n_concordant, int64_t n_discordant);
+
+/* ---- measurement hooks (bench.py's roofline leg) -------------------------------------- */
+/* when enabled, every kernel launch is bracketed by hipEvents on the launch stream */
+int  mth_timing_enable(mth_ctx_t *ctx, int on);
+int  mth_timing_reset(mth_ctx_t *ctx);
+/* synchronises; name is one of mth_timing_kernel_name(i); avg over recorded launches */
+int  mth_timing_get(mth_ctx_t *ctx, const char *kernel, double *avg_ms, uint64_t *launches);
+int  mth_timing_num_kernels(void);
+const char *mth_timing_kernel_name(int i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,227 @@
+"""ctypes binding of include/metheor_hip.h (one Python method per C entry point)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MTH_MEM_HOST, MTH_MEM_DEVICE = 0, 1
+
+# every symbol include/metheor_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
+    "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
+    "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
+    "mth_lpmd_export_device",
+    "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
+    "mth_timing_kernel_name",
+]
+
+
+class MthError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("metheor_hip error %d: %s" % (status, msg))
+        self.status = status
+
+
+class mth_batch_t(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("region_beg", C.c_int32), ("region_end", C.c_int32),
+                ("max_span", C.c_int32), ("n_reads", C.c_uint32), ("n_cpgs", C.c_uint32),
+                ("mem", C.c_int32),
+                ("read_start", C.c_void_p), ("read_end", C.c_void_p), ("read_mapq", C.c_void_p),
+                ("read_fwd", C.c_void_p), ("cpg_off", C.c_void_p), ("cpg_pos", C.c_void_p),
+                ("cpg_rel", C.c_void_p), ("cpg_rel16", C.c_void_p)]
+
+
+class mth_pdr_lpmd_params_t(C.Structure):
+    _fields_ = [("pdr_min_depth", C.c_uint32), ("pdr_min_cpgs", C.c_uint32),
+                ("pdr_min_qual", C.c_uint8), ("lpmd_min_qual", C.c_uint8),
+                ("want_pdr", C.c_uint8), ("want_lpmd", C.c_uint8),
+                ("lpmd_min_distance", C.c_int32), ("lpmd_max_distance", C.c_int32)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libmetheor_hip.so")
+
+
+def lib():
+    """load libmetheor_hip.so; fails loudly when it has not been built (no fallback)"""
+    global _LIB
+    if _LIB is None:
+        p = library_path()
+        if not os.path.exists(p):
+            raise ImportError("%s is missing: build it with `python -m metheor_amd.build` "
+                              "(hipcc, gfx950). There is no CPU fallback." % p)
+        L = C.CDLL(p)
+        vp = C.c_void_p
+        L.mth_abi_version.restype = C.c_int
+        L.mth_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.mth_ctx_destroy.argtypes = [vp]; L.mth_ctx_destroy.restype = None
+        L.mth_ctx_set_stream.argtypes = [vp, vp]
+        L.mth_ctx_sync.argtypes = [vp]
+        L.mth_strerror.restype = C.c_char_p; L.mth_strerror.argtypes = [C.c_int]
+        L.mth_last_error.restype = C.c_char_p; L.mth_last_error.argtypes = [vp]
+        L.mth_reset.argtypes = [vp]
+        L.mth_pdr_lpmd_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_pdr_lpmd_params_t)]
+        L.mth_pdr_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.mth_pdr_fetch.argtypes = [vp] * 6
+        L.mth_pdr_device_view.argtypes = [vp, C.POINTER(C.c_uint64)] + [C.POINTER(vp)] * 4
+        L.mth_lpmd_global.argtypes = [vp, C.POINTER(C.c_int64 * 4), C.POINTER(C.c_float)]
+        L.mth_lpmd_from_counts.restype = C.c_float
+        L.mth_lpmd_from_counts.argtypes = [C.c_int64, C.c_int64]
+        L.mth_lpmd_export_device.argtypes = [vp, vp]
+        L.mth_timing_enable.argtypes = [vp, C.c_int]
+        L.mth_timing_reset.argtypes = [vp]
+        L.mth_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.mth_timing_num_kernels.restype = C.c_int
+        L.mth_timing_kernel_name.restype = C.c_char_p; L.mth_timing_kernel_name.argtypes = [C.c_int]
+        _LIB = L
+    return _LIB
+
+
+class PdrLpmdParams:
+    """pdr.rs:82-89 / lpmd.rs:125-133 arguments with the reference's clap defaults (lib.rs)"""
+
+    def __init__(self, min_depth=10, min_cpgs=4, min_qual=10, min_distance=2, max_distance=16,
+                 lpmd_min_qual=10, want_pdr=True, want_lpmd=True):
+        self.c = mth_pdr_lpmd_params_t(min_depth, min_cpgs, min_qual, lpmd_min_qual,
+                                       int(want_pdr), int(want_lpmd), min_distance, max_distance)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Batch:
+    """mth_batch_t over numpy arrays (host) or torch CUDA tensors (device); keeps them alive"""
+
+    def __init__(self, tid, region_beg, region_end, read_start, read_end, read_mapq, cpg_off,
+                 cpg_pos, cpg_rel, read_fwd=None, max_span=None):
+        arrs = dict(read_start=read_start, read_end=read_end, read_mapq=read_mapq, cpg_off=cpg_off,
+                    cpg_pos=cpg_pos, cpg_rel=cpg_rel, read_fwd=read_fwd)
+        dev = _is_torch(read_start)
+        self.keep = []
+        ptr = {}
+        want = dict(read_start=("int32", 4), read_end=("int32", 4), read_mapq=("uint8", 1),
+                    cpg_off=("uint32", 4), cpg_pos=("uint32", 4), read_fwd=("uint8", 1))
+        for k, a in arrs.items():
+            if a is None:
+                ptr[k] = None
+                continue
+            if dev:
+                assert a.is_cuda and a.is_contiguous(), k
+                if k == "cpg_rel":
+                    assert a.element_size() in (1, 2)
+                else:
+                    assert a.element_size() == want[k][1], (k, a.dtype)
+                self.keep.append(a)
+                ptr[k] = a.data_ptr() if a.numel() else None
+            else:
+                if k == "cpg_rel":
+                    a = np.ascontiguousarray(a)
+                    assert a.dtype in (np.uint8, np.uint16), a.dtype
+                else:
+                    a = np.ascontiguousarray(a, dtype=want[k][0])
+                self.keep.append(a)
+                ptr[k] = a.ctypes.data if a.size else None
+        rel = self.keep[[k for k, v in arrs.items() if v is not None].index("cpg_rel")]
+        rel16 = (rel.element_size() if dev else rel.dtype.itemsize) == 2
+        n_reads = int(read_start.shape[0])
+        n_cpgs = int(cpg_pos.shape[0])
+        if max_span is None:
+            if dev:
+                max_span = int((read_end - read_start).max().item()) + 1 if n_reads else 0
+            else:
+                max_span = int((np.asarray(read_end, np.int64) - np.asarray(read_start, np.int64)).max()) + 1 if n_reads else 0
+        # a zero-length cpg_rel still has to say which width it is
+        dummy = self.keep[0].data_ptr() if dev else self.keep[0].ctypes.data
+        relp = ptr["cpg_rel"] or (dummy if n_reads else None)
+        self.c = mth_batch_t(tid, region_beg, region_end, max(max_span, 0), n_reads, n_cpgs,
+                             MTH_MEM_DEVICE if dev else MTH_MEM_HOST,
+                             ptr["read_start"], ptr["read_end"], ptr["read_mapq"], ptr["read_fwd"],
+                             ptr["cpg_off"], ptr["cpg_pos"],
+                             None if rel16 else relp, relp if rel16 else None)
+        self.n_reads, self.n_cpgs, self.tid = n_reads, n_cpgs, tid
+
+
+class Engine:
+    """one mth_ctx_t (one GPU).  Methods map 1:1 onto the C entry points."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.mth_ctx_create(device, C.byref(self.h))
+        if rc != 0:
+            raise MthError(rc, self.L.mth_strerror(rc).decode())
+        if stream is not None:
+            self._check(self.L.mth_ctx_set_stream(self.h, C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            self.L.mth_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.L.mth_strerror(rc).decode()
+            last = self.L.mth_last_error(self.h).decode()
+            raise MthError(rc, msg + (" (" + last + ")" if last else ""))
+
+    def reset(self):
+        self._check(self.L.mth_reset(self.h))
+
+    def sync(self):
+        self._check(self.L.mth_ctx_sync(self.h))
+
+    def pdr_lpmd_accumulate(self, batch, params):
+        self._check(self.L.mth_pdr_lpmd_accumulate(self.h, C.byref(batch.c), C.byref(params.c)))
+
+    def pdr_count(self):
+        n = C.c_uint64(0)
+        self._check(self.L.mth_pdr_count(self.h, C.byref(n)))
+        return n.value
+
+    def pdr_fetch(self):
+        n = self.pdr_count()
+        out = dict(tid=np.zeros(n, np.int32), pos=np.zeros(n, np.int32), pdr=np.zeros(n, np.float32),
+                   n_concordant=np.zeros(n, np.uint32), n_discordant=np.zeros(n, np.uint32))
+        self._check(self.L.mth_pdr_fetch(self.h, *[out[k].ctypes.data_as(C.c_void_p) for k in
+                                                   ("tid", "pos", "pdr", "n_concordant", "n_discordant")]))
+        return out
+
+    def lpmd_global(self):
+        g = (C.c_int64 * 4)()
+        v = C.c_float(0)
+        self._check(self.L.mth_lpmd_global(self.h, C.byref(g), C.byref(v)))
+        return dict(n_concordant=g[0], n_discordant=g[1], n_read=g[2], n_valid_read=g[3],
+                    lpmd=np.float32(v.value))
+
+    def lpmd_export_device(self, dst_ptr):
+        """dst_ptr: device address of 4 x int64 (e.g. torch_tensor.data_ptr())"""
+        self._check(self.L.mth_lpmd_export_device(self.h, C.c_void_p(dst_ptr)))
+
+    def lpmd_from_counts(self, n_conc, n_disc):
+        return np.float32(self.L.mth_lpmd_from_counts(int(n_conc), int(n_disc)))
+
+    def timing_enable(self, on=True):
+        self._check(self.L.mth_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._check(self.L.mth_timing_reset(self.h))
+
+    def timing(self):
+        out = {}
+        for i in range(self.L.mth_timing_num_kernels()):
+            name = self.L.mth_timing_kernel_name(i)
+            ms, n = C.c_double(0), C.c_uint64(0)
+            self._check(self.L.mth_timing_get(self.h, name, C.byref(ms), C.byref(n)))
+            out[name.decode()] = (ms.value, n.value)
+        return out

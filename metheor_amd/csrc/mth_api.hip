@@ -1,0 +1,330 @@
+// mth_api.hip -- C ABI (include/metheor_hip.h) over the gfx950 kernels: context, buffers,
+// staging of host batches, result getters, per-kernel event timing.
+#include <cstdio>
+#include <cstring>
+
+#include "mth_ctx.h"
+
+namespace mth {
+
+static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_tile_scan", "k_gather"};
+
+int fail(mth_ctx *ctx, int status, const char *what, hipError_t e) {
+    if (ctx) {
+        ctx->last_error = what ? what : "";
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return status;
+}
+
+hipError_t DevBuf::reserve(size_t bytes, hipStream_t s, bool keep, size_t keep_bytes) {
+    if (bytes <= cap) return hipSuccess;
+    size_t ncap = cap ? cap : 256;
+    while (ncap < bytes) ncap += ncap / 2 + 256;
+    void *np = nullptr;
+    // an older launch may still use the old allocation: drain the stream before replacing it
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    e = hipMalloc(&np, ncap);
+    if (e != hipSuccess) return e;
+    if (keep && p && keep_bytes) {
+        e = hipMemcpy(np, p, keep_bytes, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { (void)hipFree(np); return e; }
+    }
+    if (p) (void)hipFree(p);
+    p = np; cap = ncap;
+    return hipSuccess;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+}
+
+LaunchTimer::LaunchTimer(mth_ctx *c, int k) : ctx(c), kernel(k) {
+    if (!ctx->timing) return;
+    auto get = [&]() {
+        hipEvent_t ev = nullptr;
+        if (!ctx->event_pool.empty()) { ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+        else (void)hipEventCreate(&ev);
+        return ev;
+    };
+    beg = get(); end = get();
+    (void)hipEventRecord(beg, ctx->stream);
+}
+LaunchTimer::~LaunchTimer() {
+    if (!beg) return;
+    (void)hipEventRecord(end, ctx->stream);
+    ctx->timed.push_back(TimedLaunch{kernel, beg, end});
+}
+
+int sync_and_check(mth_ctx *ctx) {
+    MTH_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+    MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t e = ctx->h_state->err;
+    if (e & ERRB_UNSORTED) return fail(ctx, MTH_ERR_UNSORTED, "reads of a batch are not sorted by start position");
+    if (e & ERRB_SPAN) return fail(ctx, MTH_ERR_SPAN, "a read spans more reference bases than batch.max_span");
+    if (e & ERRB_RANGE) return fail(ctx, MTH_ERR_RANGE, "CpG position outside the declared range");
+    if (e & ERRB_CAPACITY) return fail(ctx, MTH_ERR_CAPACITY, "on-chip capacity exceeded");
+    return MTH_OK;
+}
+
+// copy one array of a host batch into its staging buffer
+static int stage(mth_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, const void **dst) {
+    if (!src || bytes == 0) { *dst = nullptr; return MTH_OK; }
+    MTH_HIP(ctx, buf.reserve(bytes, ctx->stream));
+    MTH_HIP(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dst = buf.p;
+    return MTH_OK;
+}
+
+}  // namespace mth
+
+using namespace mth;
+
+extern "C" {
+
+int mth_abi_version(void) { return MTH_ABI_VERSION; }
+
+const char *mth_strerror(int s) {
+    switch (s) {
+        case MTH_OK: return "ok";
+        case MTH_ERR_INVALID: return "invalid argument";
+        case MTH_ERR_HIP: return "HIP runtime error";
+        case MTH_ERR_NO_DEVICE: return "no gfx950 (MI355X) device available; there is no CPU fallback";
+        case MTH_ERR_UNSORTED: return "batch reads are not coordinate sorted";
+        case MTH_ERR_SPAN: return "read span exceeds batch.max_span";
+        case MTH_ERR_REOPEN: return "input needs flush re-open semantics not implemented on this path";
+        case MTH_ERR_RANGE: return "CpG position out of declared range";
+        case MTH_ERR_CAPACITY: return "on-chip capacity exceeded";
+        case MTH_ERR_STATE: return "call order violated";
+        default: return "unknown status";
+    }
+}
+
+const char *mth_last_error(const mth_ctx_t *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int mth_ctx_create(int device_id, mth_ctx_t **out) {
+    if (!out) return MTH_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return MTH_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return MTH_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MTH_ERR_NO_DEVICE;  // kernels are built for gfx950 only
+    auto *ctx = new mth_ctx;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_state, sizeof(DevState)) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess) {
+        mth_ctx_destroy(ctx);
+        return MTH_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    if (hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream) != hipSuccess) {
+        mth_ctx_destroy(ctx);
+        return MTH_ERR_HIP;
+    }
+    *out = ctx;
+    return MTH_OK;
+}
+
+void mth_ctx_destroy(mth_ctx_t *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&ctx->st_start, &ctx->st_end, &ctx->st_mapq, &ctx->st_fwd, &ctx->st_off, &ctx->st_pos,
+                      &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_base, &ctx->tile_lpmd, &ctx->scratch,
+                      &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd})
+        b->release();
+    for (auto &t : ctx->timed) { (void)hipEventDestroy(t.beg); (void)hipEventDestroy(t.end); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->d_state) (void)hipFree(ctx->d_state);
+    if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int mth_ctx_set_stream(mth_ctx_t *ctx, void *hip_stream) {
+    if (!ctx) return MTH_ERR_INVALID;
+    MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MTH_OK;
+}
+
+int mth_ctx_sync(mth_ctx_t *ctx) {
+    if (!ctx) return MTH_ERR_INVALID;
+    return sync_and_check(ctx);
+}
+
+int mth_reset(mth_ctx_t *ctx) {
+    if (!ctx) return MTH_ERR_INVALID;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream));
+    ctx->batches.clear();
+    ctx->out_bound = 0;
+    return MTH_OK;
+}
+
+int mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_pdr_lpmd_params_t *params) {
+    if (!ctx || !batch || !params) return MTH_ERR_INVALID;
+    const mth_batch_t &b = *batch;
+    if (b.region_end < b.region_beg || b.max_span < 0) return fail(ctx, MTH_ERR_INVALID, "bad region / max_span");
+    if (b.n_reads && (!b.read_start || !b.read_end || !b.read_mapq || !b.cpg_off))
+        return fail(ctx, MTH_ERR_INVALID, "batch arrays missing");
+    if (b.n_cpgs && (!b.cpg_pos || (!b.cpg_rel == !b.cpg_rel16)))
+        return fail(ctx, MTH_ERR_INVALID, "exactly one of cpg_rel / cpg_rel16 must be given");
+    if (!params->want_pdr && !params->want_lpmd) return fail(ctx, MTH_ERR_INVALID, "nothing requested");
+    // pdr.rs:160-177: with reads no longer than the 150-bp flush margin a coordinate-sorted input can
+    // never re-open a flushed site, and the stream result equals plain per-site counting.  Longer
+    // spans need the segment logic, which this fused path does not implement.
+    if (params->want_pdr && b.max_span > PDR_FLUSH_MARGIN)
+        return fail(ctx, MTH_ERR_REOPEN, "PDR fast path needs max_span <= 150 (flush re-open semantics)");
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+
+    mth_batch_t d = b;
+    if (b.mem == MTH_MEM_HOST) {
+        int rc;
+        const size_t nr = b.n_reads, nc = b.n_cpgs;
+        if ((rc = stage(ctx, ctx->st_start, b.read_start, nr * 4, (const void **)&d.read_start))) return rc;
+        if ((rc = stage(ctx, ctx->st_end, b.read_end, nr * 4, (const void **)&d.read_end))) return rc;
+        if ((rc = stage(ctx, ctx->st_mapq, b.read_mapq, nr, (const void **)&d.read_mapq))) return rc;
+        if ((rc = stage(ctx, ctx->st_off, b.cpg_off, (nr + 1) * 4, (const void **)&d.cpg_off))) return rc;
+        if ((rc = stage(ctx, ctx->st_pos, b.cpg_pos, nc * 4, (const void **)&d.cpg_pos))) return rc;
+        if (b.cpg_rel) { if ((rc = stage(ctx, ctx->st_rel, b.cpg_rel, nc, (const void **)&d.cpg_rel))) return rc; }
+        else { if ((rc = stage(ctx, ctx->st_rel, b.cpg_rel16, nc * 2, (const void **)&d.cpg_rel16))) return rc; }
+        d.read_fwd = nullptr;
+        d.mem = MTH_MEM_DEVICE;
+    } else if (b.mem != MTH_MEM_DEVICE) {
+        return fail(ctx, MTH_ERR_INVALID, "batch.mem");
+    }
+    if (b.n_cpgs == 0 && !d.cpg_rel && !d.cpg_rel16) d.cpg_rel = reinterpret_cast<const uint8_t *>(ctx->d_state);
+
+    // result capacity: at most one row per call and per owned position
+    if (params->want_pdr) {
+        const uint64_t region_len = (uint64_t)((int64_t)b.region_end - b.region_beg);
+        const uint64_t add = b.n_cpgs < region_len ? b.n_cpgs : region_len;
+        if (ctx->out_bound + add > ctx->out_cap) {
+            // learn how many rows are really in use before growing
+            int rc = sync_and_check(ctx);
+            if (rc) return rc;
+            const uint64_t used = ctx->h_state->n_sites;
+            uint64_t ncap = used + add;
+            ncap += ncap / 4 + 1024;
+            MTH_HIP(ctx, ctx->out_pos.reserve(ncap * 4, ctx->stream, true, used * 4));
+            MTH_HIP(ctx, ctx->out_pdr.reserve(ncap * 4, ctx->stream, true, used * 4));
+            MTH_HIP(ctx, ctx->out_nc.reserve(ncap * 4, ctx->stream, true, used * 4));
+            MTH_HIP(ctx, ctx->out_nd.reserve(ncap * 4, ctx->stream, true, used * 4));
+            ctx->out_cap = ctx->out_pos.cap / 4;
+            ctx->out_bound = used;
+        }
+        ctx->out_bound += add;
+    }
+    MTH_HIP(ctx, ctx->batch_cnt.reserve((ctx->batches.size() + 1) * 4, ctx->stream, true, ctx->batches.size() * 4));
+    int rc = launch_pdr_lpmd(ctx, d, *params);
+    if (rc) return rc;
+    ctx->batches.push_back(BatchMeta{b.tid});
+    return MTH_OK;
+}
+
+int mth_pdr_count(mth_ctx_t *ctx, uint64_t *n_sites) {
+    if (!ctx || !n_sites) return MTH_ERR_INVALID;
+    int rc = sync_and_check(ctx);
+    if (rc) return rc;
+    *n_sites = ctx->h_state->n_sites;
+    return MTH_OK;
+}
+
+int mth_pdr_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *pos, float *pdr, uint32_t *nc, uint32_t *nd) {
+    if (!ctx) return MTH_ERR_INVALID;
+    int rc = sync_and_check(ctx);
+    if (rc) return rc;
+    const uint64_t n = ctx->h_state->n_sites;
+    if (n == 0) return MTH_OK;
+    if (pos) MTH_HIP(ctx, hipMemcpy(pos, ctx->out_pos.p, n * 4, hipMemcpyDeviceToHost));
+    if (pdr) MTH_HIP(ctx, hipMemcpy(pdr, ctx->out_pdr.p, n * 4, hipMemcpyDeviceToHost));
+    if (nc) MTH_HIP(ctx, hipMemcpy(nc, ctx->out_nc.p, n * 4, hipMemcpyDeviceToHost));
+    if (nd) MTH_HIP(ctx, hipMemcpy(nd, ctx->out_nd.p, n * 4, hipMemcpyDeviceToHost));
+    if (tid) {
+        std::vector<uint32_t> cnt(ctx->batches.size());
+        if (!cnt.empty()) MTH_HIP(ctx, hipMemcpy(cnt.data(), ctx->batch_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t o = 0;
+        for (size_t b = 0; b < cnt.size(); ++b)
+            for (uint32_t j = 0; j < cnt[b]; ++j) tid[o++] = ctx->batches[b].tid;
+    }
+    return MTH_OK;
+}
+
+int mth_pdr_device_view(mth_ctx_t *ctx, uint64_t *n_sites, const int32_t **pos, const float **pdr,
+                        const uint32_t **nc, const uint32_t **nd) {
+    if (!ctx) return MTH_ERR_INVALID;
+    int rc = sync_and_check(ctx);
+    if (rc) return rc;
+    if (n_sites) *n_sites = ctx->h_state->n_sites;
+    if (pos) *pos = ctx->out_pos.as<int32_t>();
+    if (pdr) *pdr = ctx->out_pdr.as<float>();
+    if (nc) *nc = ctx->out_nc.as<uint32_t>();
+    if (nd) *nd = ctx->out_nd.as<uint32_t>();
+    return MTH_OK;
+}
+
+float mth_lpmd_from_counts(int64_t n_conc, int64_t n_disc) {
+    // lpmd.rs:11-12: i32 counters (wrapping in a release build); lpmd.rs:51-55
+    const int32_t wc = (int32_t)(uint32_t)(uint64_t)n_conc, wd = (int32_t)(uint32_t)(uint64_t)n_disc;
+    const int32_t ws = (int32_t)((uint32_t)wc + (uint32_t)wd);
+    return (float)wd / (float)ws;
+}
+
+int mth_lpmd_global(mth_ctx_t *ctx, int64_t out[4], float *lpmd) {
+    if (!ctx) return MTH_ERR_INVALID;
+    int rc = sync_and_check(ctx);
+    if (rc) return rc;
+    if (out) for (int k = 0; k < 4; ++k) out[k] = ctx->h_state->lpmd[k];
+    if (lpmd) *lpmd = mth_lpmd_from_counts(ctx->h_state->lpmd[0], ctx->h_state->lpmd[1]);
+    return MTH_OK;
+}
+
+int mth_lpmd_export_device(mth_ctx_t *ctx, int64_t *dst) {
+    if (!ctx || !dst) return MTH_ERR_INVALID;
+    MTH_HIP(ctx, hipMemcpyAsync(dst, ctx->d_state->lpmd, 4 * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return MTH_OK;
+}
+
+int mth_timing_enable(mth_ctx_t *ctx, int on) {
+    if (!ctx) return MTH_ERR_INVALID;
+    ctx->timing = on != 0;
+    return MTH_OK;
+}
+
+int mth_timing_reset(mth_ctx_t *ctx) {
+    if (!ctx) return MTH_ERR_INVALID;
+    MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &t : ctx->timed) { ctx->event_pool.push_back(t.beg); ctx->event_pool.push_back(t.end); }
+    ctx->timed.clear();
+    return MTH_OK;
+}
+
+int mth_timing_num_kernels(void) { return K_NUM; }
+const char *mth_timing_kernel_name(int i) { return (i >= 0 && i < K_NUM) ? kKernelNames[i] : ""; }
+
+int mth_timing_get(mth_ctx_t *ctx, const char *kernel, double *avg_ms, uint64_t *launches) {
+    if (!ctx || !kernel) return MTH_ERR_INVALID;
+    int id = -1;
+    for (int i = 0; i < K_NUM; ++i) if (strcmp(kernel, kKernelNames[i]) == 0) id = i;
+    if (id < 0) return fail(ctx, MTH_ERR_INVALID, "unknown kernel name");
+    MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0; uint64_t n = 0;
+    for (auto &t : ctx->timed) {
+        if (t.kernel != id) continue;
+        float ms = 0;
+        MTH_HIP(ctx, hipEventElapsedTime(&ms, t.beg, t.end));
+        total += ms; n += 1;
+    }
+    if (avg_ms) *avg_ms = n ? total / (double)n : 0.0;
+    if (launches) *launches = n;
+    return MTH_OK;
+}
+
+}  // extern "C"

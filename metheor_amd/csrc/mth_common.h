@@ -1,0 +1,46 @@
+// mth_common.h -- shared definitions of the gfx950 engine (host + device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/metheor_hip.h"
+
+namespace mth {
+
+// ---- tiling constants -------------------------------------------------------------------
+// A tile is TILE_W consecutive reference positions of one contig; one workgroup owns the sites
+// of one tile and keeps their accumulators in LDS.  The read index has one entry per IDX_Q bp.
+constexpr int TILE_W = 4096;
+constexpr int IDX_QSHIFT = 8;
+constexpr int IDX_Q = 1 << IDX_QSHIFT;
+constexpr int BLOCK = 256;
+static_assert(TILE_W % IDX_Q == 0, "tile must be a whole number of index quanta");
+
+// pdr.rs:162 -- a site is flushed once a passing read's first CpG lies more than 150 bp past it
+constexpr int PDR_FLUSH_MARGIN = 150;
+
+// device-side error bits (DevState::err)
+enum : uint32_t {
+    ERRB_UNSORTED = 1u << 0,
+    ERRB_SPAN = 1u << 1,
+    ERRB_RANGE = 1u << 2,
+    ERRB_CAPACITY = 1u << 3,
+};
+
+// small block of device-resident state, read back by the synchronising getters
+struct DevState {
+    uint32_t err;
+    uint32_t n_batches;
+    uint64_t n_sites;        // PDR rows emitted so far (all batches)
+    uint64_t cur_base;       // n_sites before the batch in flight
+    int64_t  lpmd[4];        // n_concordant, n_discordant, n_read, n_valid_read
+};
+
+struct SiteRec {  // per-tile scratch row
+    int32_t  pos;
+    uint32_t n_conc, n_disc, pad;
+};
+
+enum KernelId { K_INDEX = 0, K_TILE, K_SCAN, K_GATHER, K_NUM };
+
+}  // namespace mth

@@ -1,0 +1,78 @@
+// mth_ctx.h -- host-side context of the engine (private).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "mth_common.h"
+
+namespace mth {
+
+// grow-only device buffer
+struct DevBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes, hipStream_t s, bool keep = false, size_t keep_bytes = 0);
+    void release();
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct TimedLaunch {
+    int kernel;
+    hipEvent_t beg, end;
+};
+
+struct BatchMeta {
+    int32_t tid;
+};
+
+}  // namespace mth
+
+struct mth_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    mth::DevState *d_state = nullptr;   // device
+    mth::DevState *h_state = nullptr;   // pinned host mirror
+
+    // staging for MTH_MEM_HOST batches
+    mth::DevBuf st_start, st_end, st_mapq, st_fwd, st_off, st_pos, st_rel;
+    // per-batch work buffers
+    mth::DevBuf idx, tile_cnt, tile_base, tile_lpmd, scratch, batch_cnt;
+    // results (PDR columns)
+    mth::DevBuf out_pos, out_pdr, out_nc, out_nd;
+    uint64_t out_cap = 0;        // rows
+    uint64_t out_bound = 0;      // host-known upper bound of rows in use
+    std::vector<mth::BatchMeta> batches;
+    size_t batch_cnt_cap = 0;
+
+    bool timing = false;
+    std::vector<mth::TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace mth {
+
+int  fail(mth_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
+#define MTH_HIP(ctx, call)                                              \
+    do {                                                                \
+        hipError_t e__ = (call);                                        \
+        if (e__ != hipSuccess) return mth::fail(ctx, MTH_ERR_HIP, #call, e__); \
+    } while (0)
+
+// time-bracketed kernel launch helper
+struct LaunchTimer {
+    mth_ctx *ctx;
+    int kernel;
+    hipEvent_t beg = nullptr, end = nullptr;
+    LaunchTimer(mth_ctx *c, int k);
+    ~LaunchTimer();
+};
+
+int sync_and_check(mth_ctx *ctx);   // stream sync + read DevState + map error bits
+
+// implemented in mth_pdr_lpmd.hip
+int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p);
+
+}  // namespace mth

@@ -1,0 +1,243 @@
+"""GPU parity: the fused PDR+LPMD HIP path (through the C ABI) against the CPU oracle.
+
+Bar: n_concordant / n_discordant / LPMD counters bit-exact; PDR and LPMD floats bit-exact (they
+are computed from the integers with the reference's f32 expressions, pdr.rs:47-49, lpmd.rs:51-55).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bamio, pyoracle
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import metheor_amd
+    e = metheor_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def run_device(eng, contigs, params, device=None, regions=None, rel16=False):
+    """contigs: list of contig dicts (tid-sorted); regions: optional per-contig list of (beg,end)"""
+    from metheor_amd import shard
+    eng.reset()
+    keep = []
+    for ci, c in enumerate(contigs):
+        regs = regions[ci] if regions else [(0, c["length"])]
+        for (b, e) in regs:
+            sub = shard.slice_region(c, b, e) if regions else c
+            bt = util.device_batch(sub, region=(b, e), device=device, rel16=rel16)
+            keep.append(bt)
+            eng.pdr_lpmd_accumulate(bt, params)
+    return eng.pdr_fetch(), eng.lpmd_global()
+
+
+def check_against_oracle(dev_pdr, dev_lpmd, reads, pdr_kw, lpmd_kw):
+    o = reads.pdr(**pdr_kw)
+    assert len(dev_pdr["pos"]) == len(o), (len(dev_pdr["pos"]), len(o))
+    assert (dev_pdr["tid"] == o.tid).all()
+    assert (dev_pdr["pos"] == o.pos[:, 0]).all()
+    assert (dev_pdr["n_concordant"] == o.cnt[:, 0]).all()
+    assert (dev_pdr["n_discordant"] == o.cnt[:, 1]).all()
+    assert (dev_pdr["pdr"].view(np.uint32) == o.val.view(np.uint32)).all()   # bit-exact f32
+    l = reads.lpmd(**lpmd_kw)
+    for k in ("n_concordant", "n_discordant", "n_read", "n_valid_read"):
+        assert dev_lpmd[k] == l[k], (k, dev_lpmd[k], l[k])
+    a, b = f32(dev_lpmd["lpmd"]), f32(l["lpmd"])
+    assert (np.isnan(a) and np.isnan(b)) or a.view(np.uint32) == b.view(np.uint32)
+
+
+def fixture_contig(golden_dir, k):
+    rec = bamio.read_bam(os.path.join(golden_dir, "test%d.bam" % k))
+    reads = pyoracle.Reads.decode(rec)
+    return reads, util.contig_from_oracle_soa(reads.soa(), 0, rec.refs[0][1])
+
+
+# ---- the reference's own fixtures and known answers (pdr.rs:218-366, lpmd.rs:208-269) ----------
+@pytest.mark.parametrize("k,nsite,pdr,nc,nd,lpmd", [
+    (1, 4, 0.875, 2, 14, 0.5), (2, 4, 0.0, 16, 0, 0.0), (3, 4, 0.0, 2, 0, 0.0),
+    (4, 8, 0.875, 2, 14, 0.5), (5, 0, None, None, None, float("nan"))])
+def test_reference_fixtures(eng, golden_dir, k, nsite, pdr, nc, nd, lpmd):
+    from metheor_amd import PdrLpmdParams
+    reads, c = fixture_contig(golden_dir, k)
+    # whole chr1 (249 Mbp) as one region is what a drop-in host would submit
+    p, l = run_device(eng, [c], PdrLpmdParams(min_depth=0, min_cpgs=0, min_qual=10))
+    assert len(p["pos"]) == nsite
+    if nsite:
+        assert (p["pdr"] == f32(pdr)).all() and (p["n_concordant"] == nc).all() and (p["n_discordant"] == nd).all()
+    assert (np.isnan(lpmd) and np.isnan(l["lpmd"])) or l["lpmd"] == f32(lpmd)
+    check_against_oracle(p, l, reads, dict(min_depth=0, min_cpgs=0, min_qual=10), dict())
+
+
+def test_reference_fixture6_min_cpgs(eng, golden_dir):   # pdr.rs:326-365
+    from metheor_amd import PdrLpmdParams
+    reads, c = fixture_contig(golden_dir, 6)
+    p, l = run_device(eng, [c], PdrLpmdParams(min_depth=0, min_cpgs=1))
+    assert p["pos"].tolist() == [2, 13] and (p["n_concordant"] == 16).all() and (p["pdr"] == 0).all()
+    p, l = run_device(eng, [c], PdrLpmdParams(min_depth=0, min_cpgs=2))
+    assert len(p["pos"]) == 0
+
+
+def test_default_cli_golden(eng, golden_dir):   # metheor pdr -i tests/test1.bam defaults
+    from metheor_amd import PdrLpmdParams
+    reads, c = fixture_contig(golden_dir, 1)
+    p, l = run_device(eng, [c], PdrLpmdParams())
+    rows = list(zip(p["pos"].tolist(), p["pdr"].tolist(), p["n_concordant"].tolist(), p["n_discordant"].tolist()))
+    assert rows == [(0, 0.875, 2, 14), (2, 0.875, 2, 14), (4, 0.875, 2, 14), (6, 0.875, 2, 14)]
+    assert l["lpmd"] == f32(0.5)
+
+
+# ---- real reads (the reference's 1000-read RRBS SAM fixture: reverse strand, 25-29 bp) -----------
+def test_real_rrbs_reads(eng, golden_dir):
+    from metheor_amd import PdrLpmdParams
+    rec = bamio.read_sam(os.path.join(golden_dir, "test.chr19.XM.sam"))
+    reads = pyoracle.Reads.decode(rec)
+    c = util.contig_from_oracle_soa(reads.soa(), 0, rec.refs[0][1])
+    for kw in (dict(min_depth=0, min_cpgs=0, min_qual=10), dict(min_depth=10, min_cpgs=4, min_qual=10),
+               dict(min_depth=3, min_cpgs=2, min_qual=43)):
+        p, l = run_device(eng, [c], PdrLpmdParams(**kw))
+        check_against_oracle(p, l, reads, kw, dict())
+    for lk in (dict(min_distance=1, max_distance=3), dict(min_distance=5, max_distance=4),
+               dict(min_distance=0, max_distance=200), dict(min_distance=2, max_distance=16, min_qual=50)):
+        pr = PdrLpmdParams(min_distance=lk["min_distance"], max_distance=lk["max_distance"],
+                           lpmd_min_qual=lk.get("min_qual", 10))
+        p, l = run_device(eng, [c], pr)
+        check_against_oracle(p, l, reads, dict(), lk)
+
+
+# ---- seeded synthetic WGBS vs oracle -----------------------------------------------------------
+@pytest.mark.parametrize("device_mem", [False, True])
+def test_synthetic_vs_oracle(eng, device_mem):
+    from metheor_amd import PdrLpmdParams, synth
+    rng = np.random.default_rng(7)
+    c = synth.make_contig(3, 2_000_000, 300_000, 0.02, rng)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    dev = "cuda:0" if device_mem else None
+    for kw in (dict(min_depth=10, min_cpgs=4, min_qual=10), dict(min_depth=0, min_cpgs=0, min_qual=0)):
+        p, l = run_device(eng, [c], PdrLpmdParams(**kw), device=dev)
+        check_against_oracle(p, l, reads, kw, dict())
+        assert len(p["pos"]) > 1000
+
+
+def test_multi_contig_and_region_split(eng):
+    """3 contigs; the middle one submitted as 5 region batches with halo reads: identical rows"""
+    from metheor_amd import PdrLpmdParams, shard, synth
+    rng = np.random.default_rng(11)
+    cs = [synth.make_contig(t, ln, n, 0.03, rng) for t, (ln, n) in enumerate([(300_000, 40_000), (1_000_000, 150_000), (50_000, 3_000)])]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    regions = [[(0, cs[0]["length"])], shard.plan_regions(cs[1], 5), [(0, cs[2]["length"])]]
+    kw = dict(min_depth=5, min_cpgs=2, min_qual=10)
+    p, l = run_device(eng, cs, PdrLpmdParams(**kw), regions=regions)
+    check_against_oracle(p, l, reads, kw, dict())
+    p2, l2 = run_device(eng, cs, PdrLpmdParams(**kw))
+    for k in p:
+        assert (p[k] == p2[k]).all()
+    assert l == l2 or all((l[k] == l2[k]) or (np.isnan(l[k]) and np.isnan(l2[k])) for k in l)
+
+
+def test_high_depth_site_and_u16_rel(eng):
+    """20 000 identical reads on one spot (LDS atomic contention, counters > u16) + u16 relpos"""
+    from metheor_amd import PdrLpmdParams, synth
+    rng = np.random.default_rng(5)
+    starts = np.sort(np.concatenate([np.full(20_000, 5000), rng.integers(0, 20_000, 2000)])).astype(np.int32)
+    c = synth.make_contig(0, 30_000, len(starts), 0.05, rng, starts=starts)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    kw = dict(min_depth=10, min_cpgs=4, min_qual=10)
+    for rel16 in (False, True):
+        p, l = run_device(eng, [c], PdrLpmdParams(**kw), rel16=rel16)
+        check_against_oracle(p, l, reads, kw, dict())
+    assert p["n_concordant"].max() + p["n_discordant"].max() > 10_000
+
+
+def test_edge_cases(eng):
+    from metheor_amd import Batch, MthError, PdrLpmdParams, synth
+    z4 = np.zeros(0, np.int32)
+    # empty batch
+    eng.reset()
+    b = Batch(0, 0, 1000, z4, z4, np.zeros(0, np.uint8), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8))
+    eng.pdr_lpmd_accumulate(b, PdrLpmdParams())
+    assert eng.pdr_count() == 0
+    g = eng.lpmd_global()
+    assert g["n_read"] == 0 and np.isnan(g["lpmd"])
+    # reads without any CpG call
+    eng.reset()
+    st = np.array([5, 10, 10, 700], np.int32)
+    b = Batch(0, 0, 1000, st, st + 149, np.full(4, 42, np.uint8), np.zeros(5, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8))
+    eng.pdr_lpmd_accumulate(b, PdrLpmdParams(min_depth=0, min_cpgs=0))
+    assert eng.pdr_count() == 0 and eng.lpmd_global()["n_valid_read"] == 4
+    # unsorted reads are refused loudly
+    rng = np.random.default_rng(1)
+    c = synth.make_contig(0, 100_000, 5000, 0.02, rng)
+    bad = dict(c)
+    bad["read_start"] = c["read_start"][::-1].copy()
+    eng.reset()
+    eng.pdr_lpmd_accumulate(util.device_batch(bad), PdrLpmdParams())
+    with pytest.raises(MthError) as e:
+        eng.pdr_count()
+    assert e.value.status == -4
+    # a lying max_span is detected
+    eng.reset()
+    bt = util.device_batch(c)
+    bt.c.max_span = 100
+    eng.pdr_lpmd_accumulate(bt, PdrLpmdParams())
+    with pytest.raises(MthError) as e:
+        eng.pdr_count()
+    assert e.value.status == -5
+    # spans beyond the 150-bp flush margin need re-open semantics: refused, never silently wrong
+    eng.reset()
+    bt = util.device_batch(c)
+    bt.c.max_span = 151
+    with pytest.raises(MthError) as e:
+        eng.pdr_lpmd_accumulate(bt, PdrLpmdParams())
+    assert e.value.status == -6
+    eng.pdr_lpmd_accumulate(bt, PdrLpmdParams(want_pdr=False))   # LPMD alone has no flush
+    eng.reset()
+
+
+# ---- BASELINE config 2 at full size: size-independent properties ----------------------------------
+def test_full_size_properties(eng):
+    """10 M reads: device totals vs closed forms computed with numpy on the SoA"""
+    from metheor_amd import PdrLpmdParams, synth
+    c = synth.chr19_10m()
+    n = len(c["read_start"])
+    bt = util.device_batch(c, device="cuda:0")
+    eng.reset()
+    eng.pdr_lpmd_accumulate(bt, PdrLpmdParams(min_depth=0, min_cpgs=0, min_qual=10))
+    p, l = eng.pdr_fetch(), eng.lpmd_global()
+    off = c["cpg_off"].astype(np.int64)
+    ncpg = np.diff(off)
+    ok = (c["read_mapq"] >= 10) & (ncpg > 0)
+    meth = (c["cpg_pos"] >> 31).astype(np.int64)
+    msum = np.add.reduceat(np.concatenate([meth, [0]]), off[:-1])
+    msum[ncpg == 0] = 0
+    disc = (msum > 0) & (msum < ncpg)
+    # every call of a passing read lands in exactly one site counter
+    assert int(p["n_concordant"].sum()) == int(ncpg[ok & ~disc].sum())
+    assert int(p["n_discordant"].sum()) == int(ncpg[ok & disc].sum())
+    # sites are the distinct called positions of passing reads, strictly increasing
+    called = np.unique((c["cpg_pos"] & 0x7fffffff)[np.repeat(ok, ncpg)])
+    assert len(p["pos"]) == len(called) and (p["pos"] == called).all()
+    assert l["n_read"] == n and l["n_valid_read"] == int((c["read_mapq"] >= 10).sum())
+    # idempotence: a second pass over the same resident batch gives identical rows
+    eng.reset()
+    eng.pdr_lpmd_accumulate(bt, PdrLpmdParams(min_depth=0, min_cpgs=0, min_qual=10))
+    p2, l2 = eng.pdr_fetch(), eng.lpmd_global()
+    assert all((p[k] == p2[k]).all() for k in p) and l2["n_concordant"] == l["n_concordant"]
+    # oracle on a 300k-read prefix region (exact), same resident arrays submitted as a sub-region
+    from metheor_amd import shard
+    cut = int(c["read_start"][300_000])
+    sub = shard.slice_region(c, 0, cut)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(sub))
+    o = reads.pdr(min_depth=0, min_cpgs=0, min_qual=10)
+    keep = o.pos[:, 0] < cut
+    m = p["pos"] < cut
+    assert (p["pos"][m] == o.pos[keep, 0]).all()
+    assert (p["n_concordant"][m] == o.cnt[keep, 0]).all() and (p["n_discordant"][m] == o.cnt[keep, 1]).all()
+    assert (p["pdr"][m].view(np.uint32) == o.val[keep].view(np.uint32)).all()

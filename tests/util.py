@@ -1,0 +1,45 @@
+"""helpers shared by the parity tests (oracle side + device side)"""
+import numpy as np
+
+from metheor_amd import shard
+
+
+def oracle_soa_from_contig(c):
+    from metheor_amd import synth
+    return synth.to_oracle_soa(c)
+
+
+def contig_from_oracle_soa(soa, tid, length):
+    """oracle Reads.soa() dict restricted to one tid -> contig dict the device Batch takes"""
+    sel = np.nonzero(soa["tid"] == tid)[0]
+    assert len(sel) == 0 or (np.diff(sel) == 1).all(), "tid must be contiguous"
+    i0, i1 = (int(sel[0]), int(sel[-1]) + 1) if len(sel) else (0, 0)
+    o0, o1 = int(soa["cpg_off"][i0]), int(soa["cpg_off"][i1])
+    rel = soa["cpg_rel"][o0:o1]
+    return dict(tid=tid, length=length, read_start=soa["start"][i0:i1], read_end=soa["end"][i0:i1],
+                read_mapq=soa["mapq"][i0:i1], read_fwd=soa["fwd"][i0:i1],
+                cpg_off=(soa["cpg_off"][i0:i1 + 1] - soa["cpg_off"][i0]).astype(np.uint32),
+                cpg_pos=soa["cpg_pos"][o0:o1],
+                cpg_rel=rel.astype(np.uint8) if (len(rel) == 0 or rel.max() < 256) else rel)
+
+
+def device_batch(c, region=None, device=None, rel16=False):
+    """contig dict -> metheor_amd.Batch (host numpy, or torch tensors on `device`)"""
+    from metheor_amd import Batch
+    beg, end = region if region is not None else c.get("region", (0, c["length"]))
+    rel = c["cpg_rel"].astype(np.uint16) if rel16 else c["cpg_rel"]
+    arrs = dict(read_start=c["read_start"], read_end=c["read_end"], read_mapq=c["read_mapq"],
+                cpg_off=c["cpg_off"], cpg_pos=c["cpg_pos"], cpg_rel=rel)
+    if device is not None:
+        import torch
+        t = {}
+        for k, a in arrs.items():
+            a = np.ascontiguousarray(a)
+            if a.dtype == np.uint32:
+                t[k] = torch.from_numpy(a.view(np.int32)).to(device)
+            elif a.dtype == np.uint16:
+                t[k] = torch.from_numpy(a.view(np.int16)).to(device)
+            else:
+                t[k] = torch.from_numpy(a).to(device)
+        arrs = t
+    return Batch(c["tid"], beg, end, max_span=shard.max_span(c), **arrs)
