@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (config 2 = 10 M)")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="reads of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=20)
     args = ap.parse_args()

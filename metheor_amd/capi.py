@@ -54,6 +54,13 @@ def lib():
         if not os.path.exists(p):
             raise ImportError("%s is missing: build it with `python -m metheor_amd.build` "
                               "(hipcc, gfx950). There is no CPU fallback." % p)
+        # In a Python process PyTorch brings its own bundled ROCm runtime (libamdhip64.so.7 under
+        # torch/lib).  Two HIP/HSA runtimes in one process break each other, so make sure torch's
+        # is the one already loaded before this library's NEEDED libamdhip64.so.7 is resolved.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(p)
         vp = C.c_void_p
         L.mth_abi_version.restype = C.c_int

@@ -319,27 +319,38 @@ orc_result_t *orc_lpmd(const orc_reads_t *rd, int32_t min_d, int32_t max_d, uint
     int64_t n_read = 0, n_valid = 0, n_conc = 0, n_disc = 0;
     struct PairKey {
         Pos a, b;
+        bool operator==(const PairKey &o) const { return a == o.a && b == o.b; }
         bool operator<(const PairKey &o) const {
             if (!(a == o.a)) return a < o.a;
             return b < o.b;
         }
     };
-    // lpmd.rs:13-14: two HashMaps keyed by the pair, both upserted for every pair (76-77);
-    // an ordered map gives the sorted order print_pair_statistics produces (lpmd.rs:94).
-    std::map<PairKey, std::pair<int32_t, int32_t>> pairs;
+    struct PairHash {
+        size_t operator()(const PairKey &k) const {
+            return PosHash()(k.a) * 0x9e3779b97f4a7c15ULL ^ PosHash()(k.b);
+        }
+    };
+    // lpmd.rs:13-14: two HashMaps keyed by the pair, BOTH upserted for every pair (76-77) whether or
+    // not --pairs was asked for; never flushed.  Kept as-is: this is the reference's cost structure.
+    std::unordered_map<PairKey, int32_t, PairHash> pair2n_conc, pair2n_disc;
     std::vector<PairRec> pv;
     for (const Read &br : rd->reads) {
         n_read += 1;                        // lpmd.rs:176
         if (br.mapq < min_qual) continue;   // lpmd.rs:177 (before XM decode; decode has no side effect)
         int32_t c, d;
         pv.clear();
-        pairwise(br, min_d, max_d, c, d, want_pairs ? &pv : nullptr);  // lpmd.rs:186-187
+        pairwise(br, min_d, max_d, c, d, &pv);                          // lpmd.rs:186-187
         n_valid += 1; n_conc += c; n_disc += d;                         // lpmd.rs:189-191
         for (const PairRec &p : pv) {                                   // lpmd.rs:192-194, 70-87
-            auto &e = pairs[PairKey{p.a, p.b}];
-            if (p.concordant) e.first += 1; else e.second += 1;
+            int32_t &nc = pair2n_conc[PairKey{p.a, p.b}];
+            int32_t &nd = pair2n_disc[PairKey{p.a, p.b}];
+            if (p.concordant) nc += 1; else nd += 1;
         }
     }
+    // print_pair_statistics sorts the keys (lpmd.rs:90-94)
+    std::map<PairKey, std::pair<int32_t, int32_t>> pairs;
+    if (want_pairs)
+        for (auto &kv : pair2n_conc) pairs[kv.first] = std::make_pair(kv.second, pair2n_disc[kv.first]);
     globals[0] = n_conc; globals[1] = n_disc; globals[2] = n_read; globals[3] = n_valid;
     // lpmd.rs:11-12 the counters are i32 (wrapping in a release build); 51-55:
     const int32_t wc = (int32_t)(uint32_t)(uint64_t)n_conc, wd = (int32_t)(uint32_t)(uint64_t)n_disc;

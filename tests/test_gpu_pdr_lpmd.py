@@ -177,6 +177,7 @@ def test_edge_cases(eng):
     c = synth.make_contig(0, 100_000, 5000, 0.02, rng)
     bad = dict(c)
     bad["read_start"] = c["read_start"][::-1].copy()
+    bad["read_end"] = c["read_end"][::-1].copy()
     eng.reset()
     eng.pdr_lpmd_accumulate(util.device_batch(bad), PdrLpmdParams())
     with pytest.raises(MthError) as e:
