@@ -1,6 +1,7 @@
 // mth_api.hip -- C ABI (include/metheor_hip.h) over the gfx950 kernels: context, buffers,
 // staging of host batches, result getters, per-kernel event timing.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "mth_ctx.h"
@@ -123,6 +124,7 @@ int mth_ctx_create(int device_id, mth_ctx_t **out) {
         return MTH_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    if (const char *v = getenv("MTH_TILE_VARIANT")) { const int k = atoi(v); if (k >= 0 && k <= 6) ctx->tile_variant = k; }
     if (hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream) != hipSuccess) {
         mth_ctx_destroy(ctx);
         return MTH_ERR_HIP;

@@ -10,11 +10,10 @@ namespace mth {
 // ---- tiling constants -------------------------------------------------------------------
 // A tile is TILE_W consecutive reference positions of one contig; one workgroup owns the sites
 // of one tile and keeps their accumulators in LDS.  The read index has one entry per IDX_Q bp.
-constexpr int TILE_W = 4096;
+// (the tile width is a template parameter of the tile kernel: 1024 / 2048 / 4096)
 constexpr int IDX_QSHIFT = 8;
 constexpr int IDX_Q = 1 << IDX_QSHIFT;
 constexpr int BLOCK = 256;
-static_assert(TILE_W % IDX_Q == 0, "tile must be a whole number of index quanta");
 
 // pdr.rs:162 -- a site is flushed once a passing read's first CpG lies more than 150 bp past it
 constexpr int PDR_FLUSH_MARGIN = 150;

@@ -6,7 +6,7 @@
 //
 // How (MI355X-first, nothing like the reference's hash maps):
 //   k_build_index   one thread per read: a linear index "first read starting at or after q*256 bp"
-//                   (reads are coordinate sorted) + sortedness / span validation.
+//                   (reads are coordinate sorted) + sortedness validation.
 //   k_pdr_lpmd_tile one 256-thread workgroup per 4096-bp tile of the contig.  The tile's site
 //                   accumulators are DENSE in LDS (2 x u32 per reference position, 32 KiB), so the
 //                   scatter is an LDS atomic and HBM only sees the streamed SoA.  Reads that can
@@ -45,9 +45,8 @@ struct TileArgs {
 // ---------------------------------------------------------------------------------------------
 // idx[q] = first read i with read_start[i] >= idx_base + q*IDX_Q   (q = 0..nq)
 __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict__ read_start,
-                                                       const int32_t *__restrict__ read_end,
                                                        uint32_t n_reads, int32_t idx_base,
-                                                       uint32_t nq, int32_t max_span,
+                                                       uint32_t nq,
                                                        uint32_t *__restrict__ idx,
                                                        DevState *__restrict__ st) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -66,7 +65,6 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
             g_prev = bucket(sp);
             if (s < sp) err |= ERRB_UNSORTED;
         }
-        if (s >= 0 && (int64_t)read_end[i] - s + 1 > max_span) err |= ERRB_SPAN;
     } else {  // sentinel thread closes the index
         g_cur = nq;
         if (n_reads > 0) g_prev = bucket(read_start[n_reads - 1]);
@@ -83,73 +81,17 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;  // valid in lane 0
 }
 
-template <typename RelT>
-__global__ __launch_bounds__(BLOCK) void k_pdr_lpmd_tile(const TileArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[2 * TILE_W];  // [0,W): concordant, [W,2W): discordant
-    __shared__ uint32_t red[4][BLOCK / 64];
-    __shared__ uint32_t wave_off[BLOCK / 64 + 1];
-
+// Shared tail of the tile kernels: per-tile LPMD partials (wave DPP reduce -> LDS -> one plain
+// store per tile, no same-address global atomics) and compaction of the dense LDS counters into
+// the tile's scratch slice (block scan; rows come out sorted by position).
+template <int W, int B>
+__device__ __forceinline__ void tile_epilogue(const TileArgs &a, const uint32_t t, const int32_t T0,
+                                              uint32_t *cnt, uint32_t (*red)[B / 64], uint32_t *wave_off,
+                                              uint32_t lp_c, uint32_t lp_d, uint32_t n_read,
+                                              uint32_t n_valid, uint32_t bad) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t t = blockIdx.x;
-    const int32_t T0 = a.region_beg + (int32_t)(t * TILE_W);
-    const int32_t T1 = min(T0 + TILE_W, a.region_end);
-    const uint32_t Wt = (uint32_t)(T1 - T0);
-
-    // a batch that failed validation in k_build_index has no usable index: emit nothing
-    if (a.st->err != 0) {
-        if (tid == 0) a.tile_cnt[t] = 0;
-        if (tid < 4) a.tile_lpmd[t * 4 + tid] = 0;
-        return;
-    }
-    for (int i = tid; i < 2 * TILE_W / 4; i += BLOCK)
-        reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-
-    // candidate reads: start in [T0 - max_span + 1, T0 + TILE_W]  (a call sits in [start-1, end])
-    const uint32_t lo = a.idx[(uint32_t)(T0 - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT];
-    const uint32_t hi = min(a.idx[((uint32_t)(T0 + TILE_W - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
-    const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
-
-    uint32_t lp_c = 0, lp_d = 0, n_read = 0, n_valid = 0;
-    for (uint32_t i = lo + tid; i < hi; i += BLOCK) {
-        const int32_t s = a.read_start[i];
-        const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
-        const uint32_t n = o1 - o0;
-        const uint8_t mq = a.read_mapq[i];
-        const bool owned = (s >= T0) && (s < T1);
-        // lpmd.rs:176-179
-        const bool lp_ok = a.want_lpmd && owned && (mq >= a.lpmd_min_qual);
-        if (a.want_lpmd && owned) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
-        // pdr.rs:147-157
-        const bool pdr_ok = a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);
-        if (!(lp_ok || pdr_ok) || n == 0) continue;
-
-        // pass 1: read concordance (readutil.rs:134-145) + windowed pair counts (166-224)
-        const uint32_t first = a.cpg_pos[o0] >> 31;
-        uint32_t disc = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint32_t mk = a.cpg_pos[o0 + k] >> 31;
-            disc |= (mk ^ first);
-            if (lp_ok) {
-                const int32_t rk = (int32_t)rel[o0 + k];
-                for (uint32_t j = k; j-- > 0;) {
-                    const int32_t dist = rk - (int32_t)rel[o0 + j];
-                    if (dist > a.max_dist) break;          // readutil.rs:184 (anchors evicted)
-                    if (dist < a.min_dist) continue;       // readutil.rs:196
-                    if ((a.cpg_pos[o0 + j] >> 31) == mk) lp_c += 1; else lp_d += 1;
-                }
-            }
-        }
-        // pass 2: scatter +1 to the tile's sites (pdr.rs:180-191)
-        if (pdr_ok) {
-            uint32_t *base = cnt + (disc ? TILE_W : 0);
-            for (uint32_t k = 0; k < n; ++k) {
-                const uint32_t p = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)T0;
-                if (p < Wt) atomicAdd(base + p, 1u);
-            }
-        }
-    }
+    if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
 
     // per-tile LPMD partials (wave DPP reduce -> LDS -> one plain store per tile)
     if (a.want_lpmd) {
@@ -159,25 +101,25 @@ __global__ __launch_bounds__(BLOCK) void k_pdr_lpmd_tile(const TileArgs a) {
     __syncthreads();
     if (a.want_lpmd && tid < 4) {
         uint32_t s = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) s += red[tid][w];
+        for (int w = 0; w < B / 64; ++w) s += red[tid][w];
         a.tile_lpmd[t * 4 + tid] = s;
     }
     if (!a.want_pdr) { if (tid == 0) a.tile_cnt[t] = 0; return; }
 
-    // compaction: thread owns 16 consecutive positions; emit sites with coverage >= min_cov
-    constexpr int PER = TILE_W / BLOCK;  // 16
+    // compaction: thread owns PER consecutive positions; emit sites with coverage >= min_cov
+    constexpr int PER = W / B;
+    static_assert(PER % 4 == 0, "uint4 LDS reads");
     uint32_t c[PER], d[PER];
 #pragma unroll
-    for (int v = 0; v < PER / 4; ++v) {
-        const uint4 x = reinterpret_cast<const uint4 *>(cnt)[tid * (PER / 4) + v];
-        const uint4 y = reinterpret_cast<const uint4 *>(cnt + TILE_W)[tid * (PER / 4) + v];
-        c[4 * v] = x.x; c[4 * v + 1] = x.y; c[4 * v + 2] = x.z; c[4 * v + 3] = x.w;
-        d[4 * v] = y.x; d[4 * v + 1] = y.y; d[4 * v + 2] = y.z; d[4 * v + 3] = y.w;
+    for (int q = 0; q < PER / 4; ++q) {
+        const uint4 x = reinterpret_cast<const uint4 *>(cnt)[tid * (PER / 4) + q];
+        const uint4 y = reinterpret_cast<const uint4 *>(cnt + W)[tid * (PER / 4) + q];
+        c[4 * q] = x.x; c[4 * q + 1] = x.y; c[4 * q + 2] = x.z; c[4 * q + 3] = x.w;
+        d[4 * q] = y.x; d[4 * q + 1] = y.y; d[4 * q + 2] = y.z; d[4 * q + 3] = y.w;
     }
     uint32_t mine = 0;
 #pragma unroll
-    for (int v = 0; v < PER; ++v) mine += (c[v] + d[v] >= a.min_cov) ? 1u : 0u;
-    // block exclusive scan of `mine`
+    for (int q = 0; q < PER; ++q) mine += (c[q] + d[q] >= a.min_cov) ? 1u : 0u;
     uint32_t incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -188,19 +130,390 @@ __global__ __launch_bounds__(BLOCK) void k_pdr_lpmd_tile(const TileArgs a) {
     __syncthreads();
     if (tid == 0) {
         wave_off[0] = 0;
-        for (int w = 1; w <= BLOCK / 64; ++w) wave_off[w] += wave_off[w - 1];
-        a.tile_cnt[t] = wave_off[BLOCK / 64];
+        for (int w = 1; w <= B / 64; ++w) wave_off[w] += wave_off[w - 1];
+        a.tile_cnt[t] = wave_off[B / 64];
     }
     __syncthreads();
     uint32_t o = wave_off[wave] + incl - mine;
-    SiteRec *__restrict__ out = a.scratch + (size_t)t * TILE_W;
+    SiteRec *__restrict__ out = a.scratch + (size_t)t * W;
 #pragma unroll
-    for (int v = 0; v < PER; ++v) {
-        if (c[v] + d[v] >= a.min_cov) {
-            SiteRec r; r.pos = T0 + tid * PER + v; r.n_conc = c[v]; r.n_disc = d[v]; r.pad = 0;
-            out[o++] = r;
+    for (int q = 0; q < PER; ++q) {
+        if (c[q] + d[q] >= a.min_cov) {
+            SiteRec rr; rr.pos = T0 + tid * PER + q; rr.n_conc = c[q]; rr.n_disc = d[q]; rr.pad = 0;
+            out[o++] = rr;
         }
     }
+}
+
+// Tile kernel.  W = reference positions per tile, B = threads per workgroup, NB = CpG calls of a
+// read held in registers (reads with more calls take the memory loop for the tail).
+//
+// Latency structure (what v1 got wrong: one dependent HBM round trip per call): per tile the
+// dependent chain is  idx -> read fields -> ALL calls of the read (NB independent loads in
+// flight) -> LDS atomics.  Blocks are mapped to tiles XCD-aware so the halo reads of neighbouring
+// tiles are served by the same L2.
+template <int W, int B, int NB, typename RelT>
+__global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[2 * W];  // [0,W): concordant, [W,2W): discordant
+    __shared__ uint32_t red[4][B / 64];
+    __shared__ uint32_t wave_off[B / 64 + 1];
+
+    const int tid = threadIdx.x;
+    // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
+    const uint32_t per_xcd = (ntiles + 7) / 8;
+    const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    const int32_t T0 = a.region_beg + (int32_t)(t * W);
+    const int32_t T1 = min(T0 + W, a.region_end);
+    const uint32_t Wt = (uint32_t)(T1 - T0);
+
+    // a batch that failed validation in k_build_index has no usable index: emit nothing
+    if (a.st->err != 0) {
+        if (tid == 0) a.tile_cnt[t] = 0;
+        if (tid < 4) a.tile_lpmd[t * 4 + tid] = 0;
+        return;
+    }
+    for (int i = tid; i < 2 * W / 4; i += B)
+        reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
+
+    // candidate reads: start in [T0 - max_span + 1, T0 + W]  (a call sits in [start-1, end])
+    const uint32_t lo = a.idx[(uint32_t)(T0 - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT];
+    const uint32_t hi = min(a.idx[((uint32_t)(T0 + W - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+    const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
+    __syncthreads();
+
+    uint32_t lp_c = 0, lp_d = 0, n_read = 0, n_valid = 0, bad = 0;
+    for (uint32_t i = lo + tid; i < hi; i += B) {
+        const int32_t s = a.read_start[i];
+        const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+        const uint8_t mq = a.read_mapq[i];
+        const uint32_t n = o1 - o0;
+        const bool owned = (s >= T0) && (s < T1);
+        // lpmd.rs:176-179
+        const bool lp_ok = a.want_lpmd && owned && (mq >= a.lpmd_min_qual);
+        if (a.want_lpmd && owned) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
+        // pdr.rs:147-157
+        const bool pdr_ok = a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);
+        if (!(lp_ok || pdr_ok) || n == 0) continue;
+
+        // all calls of the read in flight at once (clamped index: duplicates are masked by k < n)
+        uint32_t v[NB];
+        int32_t r[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v[k] = a.cpg_pos[o0 + min((uint32_t)k, n - 1)];
+        if (lp_ok) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) r[k] = (int32_t)rel[o0 + min((uint32_t)k, n - 1)];
+        }
+        // every call must lie in [start-1, start+max_span-1]: this is what makes the halo complete
+        // (checked here, on the calls themselves, instead of trusting read_end)
+        const uint32_t first = v[0] >> 31;
+        uint32_t disc = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const bool live = (uint32_t)k < n;
+            disc |= live ? ((v[k] >> 31) ^ first) : 0u;
+            bad |= (live && ((v[k] & 0x7fffffffu) - (uint32_t)(s - 1) > (uint32_t)a.max_span)) ? 1u : 0u;
+        }
+        if (n > (uint32_t)NB) {
+            for (uint32_t k = NB; k < n; ++k) {
+                const uint32_t x = a.cpg_pos[o0 + k];
+                disc |= (x >> 31) ^ first;
+                bad |= ((x & 0x7fffffffu) - (uint32_t)(s - 1) > (uint32_t)a.max_span) ? 1u : 0u;
+            }
+        }
+        // windowed pair counts (readutil.rs:166-224): pairs (j<k) with min <= rel_k - rel_j <= max
+        if (lp_ok) {
+            if (n <= (uint32_t)NB) {
+#pragma unroll
+                for (int k = 1; k < NB; ++k) {
+#pragma unroll
+                    for (int j = 0; j < k; ++j) {
+                        const int32_t dist = r[k] - r[j];
+                        const bool in = ((uint32_t)k < n) && dist >= a.min_dist && dist <= a.max_dist;
+                        const bool same = (v[k] >> 31) == (v[j] >> 31);
+                        lp_c += (in && same) ? 1u : 0u;
+                        lp_d += (in && !same) ? 1u : 0u;
+                    }
+                }
+            } else {
+                for (uint32_t k = 1; k < n; ++k) {
+                    const int32_t rk = (int32_t)rel[o0 + k];
+                    const uint32_t mk = a.cpg_pos[o0 + k] >> 31;
+                    for (uint32_t j = k; j-- > 0;) {
+                        const int32_t dist = rk - (int32_t)rel[o0 + j];
+                        if (dist > a.max_dist) break;          // readutil.rs:184 (anchors evicted)
+                        if (dist < a.min_dist) continue;       // readutil.rs:196
+                        if ((a.cpg_pos[o0 + j] >> 31) == mk) lp_c += 1; else lp_d += 1;
+                    }
+                }
+            }
+        }
+        // scatter +1 to the tile's sites (pdr.rs:180-191)
+        if (pdr_ok) {
+            uint32_t *base = cnt + (disc ? W : 0);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const uint32_t p = (v[k] & 0x7fffffffu) - (uint32_t)T0;
+                if ((uint32_t)k < n && p < Wt) atomicAdd(base + p, 1u);
+            }
+            for (uint32_t k = NB; k < n; ++k) {
+                const uint32_t p = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)T0;
+                if (p < Wt) atomicAdd(base + p, 1u);
+            }
+        }
+    }
+    tile_epilogue<W, B>(a, t, T0, cnt, red, wave_off, lp_c, lp_d, n_read, n_valid, bad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-cooperative tile kernel (v3) -- EXPERIMENTAL, NOT the default: measured SLOWER than the
+// lane = read kernel above on BASELINE config 2 (tile kernel 0.301 ms vs 0.237 ms; PDR-only 0.195 vs
+// 0.111 ms; profiles/r01_tile_variants.md).  It is parity-green (tests/test_gpu_pdr_lpmd.py passes
+// under MTH_TILE_VARIANT=4/5/6) and kept selectable for A/B work only.
+// Idea: v2 pads every read to NB call slots and NB*(NB-1)/2 pair slots (rocprof: ~1650 VALU
+// wave-instructions per wave and tile, ~3 of 8 slots useful).  Here a wave takes a chunk of up to 64
+// consecutive reads (lane = read for the 9 B/read record) and then walks the chunk's CONTIGUOUS
+// call range with lane = call: coalesced loads, no padding.  What the measurement shows it costs
+// instead: a chain of dependent cross-lane ops per round (6-step bpermute max-scan, LDS look-ups)
+// with only 4 waves/SIMD to hide it, and no way to skip reads that fail --min-cpgs.
+//   read of a call   : each read lane drops its id at its first call in a per-wave LDS byte table,
+//                      a wave max-scan over the loaded table entries gives every call its read
+//   read concordance : a read is discordant iff two ADJACENT calls differ (readutil.rs:134-145) ->
+//                      one lane shift + a (rare) LDS atomic-or on the read's flag byte
+//   LPMD pairs       : call k looks back over calls k-1, k-2, .. of the same read while the query
+//                      distance stays <= max (readutil.rs:166-224) -- lane shifts, work proportional
+//                      to the pairs that exist; rounds overlap by OV lanes so no carry is needed;
+//                      look-backs deeper than OV finish with a per-lane memory loop
+//   PDR scatter      : second walk over the calls held in registers, LDS atomic add on the dense
+//                      tile counters
+constexpr int WC_MAXC = 1024;  // calls per chunk covered by the per-wave head table
+constexpr int WC_OV = 8;       // context lanes per round (look-back reach without touching memory)
+constexpr int WC_RQ = 8;       // rounds whose calls stay in registers for the scatter walk
+
+template <int W, int NW, typename RelT, bool WANT_PDR, bool WANT_LPMD>
+__global__ __launch_bounds__(NW * 64) void k_pdr_lpmd_tile_wc(const TileArgs a, const uint32_t ntiles) {
+    constexpr int B = NW * 64;
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[2 * W];
+    __shared__ uint32_t red[4][B / 64];
+    __shared__ uint32_t wave_off[B / 64 + 1];
+    __shared__ __attribute__((aligned(16))) uint8_t head_s[NW][WC_MAXC];  // 0 = not a first call, else read lane + 1
+    __shared__ uint32_t rinfo_s[NW][64];                                   // bit0 pdr_ok, bit1 lp_ok, bit2 discordant
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    const int32_t T0 = a.region_beg + (int32_t)(t * W);
+    const int32_t T1 = min(T0 + W, a.region_end);
+    const uint32_t Wt = (uint32_t)(T1 - T0);
+    uint8_t *head = head_s[wave];
+    uint32_t *rinfo = rinfo_s[wave];
+
+    for (int i = tid; i < 2 * W / 4; i += B)
+        reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
+    // candidate reads: start in [T0 - max_span + 1, T0 + W].  idx is clamped so that a batch that
+    // failed validation (stale index) only ever produces in-bounds reads; its rows are discarded
+    // because the error flag is reported by the getters.
+    const uint32_t lo = min(a.idx[(uint32_t)(T0 - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
+    const uint32_t hi = min(a.idx[((uint32_t)(T0 + W - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+    const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
+    __syncthreads();
+
+    uint32_t lp_c = 0, lp_d = 0, n_read = 0, n_valid = 0, bad = 0;
+    const uint32_t span = hi > lo ? hi - lo : 0;
+    const uint32_t per = (span + NW - 1) / NW;
+    const uint32_t r_end = min(lo + (wave + 1) * per, hi);
+    for (uint32_t i0 = lo + wave * per; i0 < r_end;) {
+        // ---- read round: lane <-> read i0 + lane ------------------------------------------
+        const uint32_t i = i0 + lane;
+        const bool inb = i < r_end;
+        const uint32_t off0 = a.cpg_off[inb ? i : i0], off1 = a.cpg_off[(inb ? i : i0) + 1];
+        const int32_t s = a.read_start[inb ? i : i0];
+        const uint32_t mq = a.read_mapq[inb ? i : i0];
+        const uint32_t cbeg = __builtin_amdgcn_readfirstlane(off0);
+        // reads of the chunk: the longest prefix whose calls fit the head table
+        const unsigned long long fits = __ballot(inb && (off1 - cbeg <= (uint32_t)WC_MAXC));
+        const int nr = fits == ~0ull ? 64 : __builtin_ctzll(~fits);
+        if (nr == 0) {
+            // one read with more than WC_MAXC calls (only possible with 16-bit relpos): the wave
+            // walks its calls from memory, lane-strided
+            const uint32_t e1 = __builtin_amdgcn_readfirstlane(off1);
+            const int32_t s0 = __builtin_amdgcn_readfirstlane(s);
+            const uint32_t mq0 = __builtin_amdgcn_readfirstlane(mq);
+            const uint32_t n = e1 - cbeg;
+            const bool owned = (s0 >= T0) && (s0 < T1);
+            const bool lp_ok = WANT_LPMD && owned && (mq0 >= a.lpmd_min_qual);
+            const bool pdr_ok = WANT_PDR && (n >= a.min_cpgs) && (mq0 >= a.pdr_min_qual);
+            if (WANT_LPMD && owned && lane == 0) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
+            if (lp_ok || pdr_ok) {
+                uint32_t dsc = 0;
+                for (uint32_t c = cbeg + lane; c < e1; c += 64) {
+                    const uint32_t x = a.cpg_pos[c];
+                    bad |= ((x & 0x7fffffffu) - (uint32_t)(s0 - 1) > (uint32_t)a.max_span) ? 1u : 0u;
+                    if (c > cbeg) dsc |= (x ^ a.cpg_pos[c - 1]) >> 31;
+                    if (lp_ok) {
+                        const int32_t rk = (int32_t)rel[c];
+                        for (uint32_t j = c; j-- > cbeg;) {
+                            const int32_t dist = rk - (int32_t)rel[j];
+                            if (dist > a.max_dist) break;
+                            if (dist < a.min_dist) continue;
+                            if ((a.cpg_pos[j] >> 31) == (x >> 31)) lp_c += 1; else lp_d += 1;
+                        }
+                    }
+                }
+                const bool disc = __ballot(dsc != 0) != 0ull;
+                if (pdr_ok) {
+                    uint32_t *base = cnt + (disc ? W : 0);
+                    for (uint32_t c = cbeg + lane; c < e1; c += 64) {
+                        const uint32_t p = (a.cpg_pos[c] & 0x7fffffffu) - (uint32_t)T0;
+                        if (p < Wt) atomicAdd(base + p, 1u);
+                    }
+                }
+            }
+            i0 += 1;
+            continue;
+        }
+        const bool act = lane < nr;
+        const uint32_t cend = __builtin_amdgcn_readlane(off1, nr - 1);
+        const uint32_t n = off1 - off0;
+        const bool owned = act && (s >= T0) && (s < T1);
+        const bool lp_ok = WANT_LPMD && owned && (mq >= a.lpmd_min_qual);                      // lpmd.rs:176-179
+        const bool pdr_ok = WANT_PDR && act && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);  // pdr.rs:147-157
+        if (WANT_LPMD && owned) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
+        if (!__any((lp_ok || pdr_ok) && n > 0)) { i0 += nr; continue; }   // nothing to do (halo chunk)
+
+        // ---- publish the chunk's read table ------------------------------------------------
+        reinterpret_cast<uint4 *>(head)[lane] = make_uint4(0, 0, 0, 0);   // 64 x 16 B = WC_MAXC
+        rinfo[lane] = (pdr_ok ? 1u : 0u) | (lp_ok ? 2u : 0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (act && n > 0) head[off0 - cbeg] = (uint8_t)(lane + 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- call rounds: lane <-> call, rounds overlap by WC_OV context lanes -----------------
+        // one round = 64 consecutive calls starting at `base`; returns the call word and its read id
+        uint32_t carry = 0;
+        auto call_round = [&](const uint32_t base, uint32_t &v_out, uint32_t &rid_out) {
+            const uint32_t c = base + lane;
+            const bool valid = (int32_t)(c - cbeg) >= 0 && c < cend;
+            const bool isnew = valid && lane >= WC_OV;    // lanes < WC_OV only give context
+            const uint32_t v = valid ? a.cpg_pos[c] : 0u;
+            const uint32_t rl = (valid && WANT_LPMD) ? (uint32_t)rel[c] : 0u;
+            uint32_t rid = valid ? (uint32_t)head[c - cbeg] : 0u;
+            // inclusive max-scan across the wave (read ids grow with the call index)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(rid, o, 64);
+                if (lane >= o) rid = max(rid, up);
+            }
+            rid = valid ? max(rid, carry) : 0u;
+            carry = __builtin_amdgcn_readlane(rid, 63 - WC_OV);   // read of the call before the next round's lane 0
+            const int rlane = rid ? (int)rid - 1 : 0;
+            const uint32_t m = v >> 31;
+            // every call must lie in [start-1, start-1+max_span] (halo completeness)
+            const int32_t sR = __shfl(s, rlane, 64);
+            bad |= (valid && ((v & 0x7fffffffu) - (uint32_t)(sR - 1) > (uint32_t)a.max_span)) ? 1u : 0u;
+            const uint32_t info = valid ? rinfo[rlane] : 0u;
+            const uint32_t pk = (rid << 24) | (m << 16) | (rl & 0xffffu);
+            // adjacent calls of one read that differ make the read discordant
+            const uint32_t p1 = __shfl_up(pk, 1, 64);
+            if (WANT_PDR) {
+                if (isnew && (p1 >> 24) == rid && (((p1 >> 16) & 1u) != m) && (info & 1u))
+                    atomicOr(&rinfo[rlane], 4u);
+            }
+            if (WANT_LPMD) {
+                const bool lpc = isnew && (info & 2u);
+                bool deeper = false;
+#pragma unroll
+                for (int d = 1; d <= WC_OV; ++d) {
+                    const uint32_t pd = d == 1 ? p1 : __shfl_up(pk, d, 64);
+                    const int32_t dist = (int32_t)rl - (int32_t)(pd & 0xffffu);
+                    const bool on = lpc && (pd >> 24) == rid && dist <= a.max_dist;   // readutil.rs:184
+                    if (!__any(on)) break;
+                    const bool in = on && dist >= a.min_dist;                         // readutil.rs:196
+                    const bool sm = ((pd >> 16) & 1u) == m;
+                    lp_c += (in && sm) ? 1u : 0u;
+                    lp_d += (in && !sm) ? 1u : 0u;
+                    if (d == WC_OV) deeper = on;
+                }
+                // look-backs that outran the register window (dense CpGs or a wide --max-distance)
+                if (__any(deeper)) {
+                    const uint32_t o0r = __shfl(off0, rlane, 64);
+                    if (deeper) {
+                        for (uint32_t j = c - WC_OV; j-- > o0r;) {
+                            const int32_t dist = (int32_t)rl - (int32_t)rel[j];
+                            if (dist > a.max_dist) break;
+                            if (dist < a.min_dist) continue;
+                            if ((a.cpg_pos[j] >> 31) == m) lp_c += 1; else lp_d += 1;
+                        }
+                    }
+                }
+            }
+            v_out = isnew ? v : 0u;
+            rid_out = isnew ? rid : 0u;
+        };
+        uint32_t vq[WC_RQ], rq[WC_RQ];   // statically indexed: stay in VGPRs
+        uint32_t base = cbeg - WC_OV;
+        bool more = true;                 // wave-uniform
+#pragma unroll
+        for (int k = 0; k < WC_RQ; ++k) {
+            vq[k] = 0u; rq[k] = 0u;
+            if (more) {
+                call_round(base, vq[k], rq[k]);
+                more = base + 64 < cend;
+                base += 64 - WC_OV;
+            }
+        }
+        const uint32_t tail_base = base;
+        const uint32_t tail_carry = carry;
+        while (more) {                    // chunks with more than WC_RQ rounds: nothing kept
+            uint32_t v_, r_;
+            call_round(base, v_, r_);
+            more = base + 64 < cend;
+            base += 64 - WC_OV;
+        }
+        // ---- scatter walk: +1 on the tile's dense counters (pdr.rs:180-191) ----------------------
+        if (WANT_PDR) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < WC_RQ; ++k) {
+                const uint32_t rid = rq[k];
+                if (rid) {
+                    const uint32_t info = rinfo[rid - 1];
+                    const uint32_t p = (vq[k] & 0x7fffffffu) - (uint32_t)T0;
+                    if ((info & 1u) && p < Wt) atomicAdd(cnt + ((info & 4u) ? W : 0) + p, 1u);
+                }
+            }
+            // rounds beyond the register window: re-derive the read of each call from the table
+            if (tail_base + WC_OV < cend) {
+                uint32_t cr = tail_carry;
+                for (uint32_t b2 = tail_base;; b2 += 64 - WC_OV) {
+                    const uint32_t c = b2 + lane;
+                    const bool valid = (int32_t)(c - cbeg) >= 0 && c < cend;
+                    uint32_t rid = valid ? (uint32_t)head[c - cbeg] : 0u;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t up = __shfl_up(rid, o, 64);
+                        if (lane >= o) rid = max(rid, up);
+                    }
+                    rid = valid ? max(rid, cr) : 0u;
+                    cr = __builtin_amdgcn_readlane(rid, 63 - WC_OV);
+                    if (valid && lane >= WC_OV) {
+                        const uint32_t info = rinfo[rid - 1];
+                        const uint32_t p = (a.cpg_pos[c] & 0x7fffffffu) - (uint32_t)T0;
+                        if ((info & 1u) && p < Wt) atomicAdd(cnt + ((info & 4u) ? W : 0) + p, 1u);
+                    }
+                    if (b2 + 64 >= cend) break;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        i0 += nr;
+    }
+    tile_epilogue<W, B>(a, t, T0, cnt, red, wave_off, lp_c, lp_d, n_read, n_valid, bad);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,13 +584,13 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *__restrict__
 __global__ __launch_bounds__(64) void k_gather(const SiteRec *__restrict__ scratch,
                                                const uint32_t *__restrict__ tile_cnt,
                                                const uint32_t *__restrict__ tile_base,
-                                               const DevState *__restrict__ st,
+                                               const DevState *__restrict__ st, uint32_t tile_w,
                                                int32_t *__restrict__ out_pos, float *__restrict__ out_pdr,
                                                uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
     const uint32_t t = blockIdx.x;
     const uint32_t n = tile_cnt[t];
     const uint64_t base = st->cur_base + tile_base[t];
-    const SiteRec *__restrict__ src = scratch + (size_t)t * TILE_W;
+    const SiteRec *__restrict__ src = scratch + (size_t)t * tile_w;
     for (uint32_t j = threadIdx.x; j < n; j += 64) {
         const SiteRec r = src[j];
         out_pos[base + j] = r.pos;
@@ -288,27 +601,45 @@ __global__ __launch_bounds__(64) void k_gather(const SiteRec *__restrict__ scrat
 }
 
 // ---------------------------------------------------------------------------------------------
+template <int W, int B, typename RelT>
+static void launch_tile(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
+    const uint32_t grid = ((ntiles + 7) / 8) * 8;   // whole rows of 8 XCDs (remap in the kernel)
+    hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT>), dim3(grid), dim3(B), 0, s, a, ntiles);
+}
+
+template <int W, int NW, typename RelT>
+static void launch_tile_wc(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
+    if (a.want_pdr && a.want_lpmd)
+        hipLaunchKernelGGL((k_pdr_lpmd_tile_wc<W, NW, RelT, true, true>), dim3(ntiles), dim3(NW * 64), 0, s, a, ntiles);
+    else if (a.want_pdr)
+        hipLaunchKernelGGL((k_pdr_lpmd_tile_wc<W, NW, RelT, true, false>), dim3(ntiles), dim3(NW * 64), 0, s, a, ntiles);
+    else
+        hipLaunchKernelGGL((k_pdr_lpmd_tile_wc<W, NW, RelT, false, true>), dim3(ntiles), dim3(NW * 64), 0, s, a, ntiles);
+}
+
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_params_t &p) {
     hipStream_t s = ctx->stream;
+    const int variant = ctx->tile_variant;
+    const int tile_w = (variant == 0 || variant == 4 || variant == 5) ? 4096 : (variant == 3 ? 1024 : 2048);
     const int64_t region_len = (int64_t)b.region_end - b.region_beg;
-    const uint32_t ntiles = (uint32_t)((region_len + TILE_W - 1) / TILE_W);
+    const uint32_t ntiles = (uint32_t)((region_len + tile_w - 1) / tile_w);
     if (ntiles == 0) return MTH_OK;
     // index origin: a whole number of quanta below the region so that halo reads are indexed
     const int32_t ext = ((b.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
     const int32_t idx_base = b.region_beg - ext;
-    const uint32_t nq = (uint32_t)(((int64_t)ntiles * TILE_W + ext) >> IDX_QSHIFT) + 2;
+    const uint32_t nq = (uint32_t)(((int64_t)ntiles * tile_w + ext) >> IDX_QSHIFT) + 2;
 
     MTH_HIP(ctx, ctx->idx.reserve((size_t)(nq + 1) * 4, s));
     MTH_HIP(ctx, ctx->tile_cnt.reserve((size_t)ntiles * 4, s));
     MTH_HIP(ctx, ctx->tile_base.reserve((size_t)ntiles * 4, s));
     MTH_HIP(ctx, ctx->tile_lpmd.reserve((size_t)ntiles * 16, s));
-    if (p.want_pdr) MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * TILE_W * sizeof(SiteRec), s));
+    if (p.want_pdr) MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * tile_w * sizeof(SiteRec), s));
 
     {
         LaunchTimer lt(ctx, K_INDEX);
         const uint32_t nb = (b.n_reads + 1 + BLOCK - 1) / BLOCK;
-        hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.read_end,
-                           b.n_reads, idx_base, nq, b.max_span, ctx->idx.as<uint32_t>(), ctx->d_state);
+        hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start,
+                           b.n_reads, idx_base, nq, ctx->idx.as<uint32_t>(), ctx->d_state);
     }
     TileArgs a;
     a.read_start = b.read_start; a.read_mapq = b.read_mapq; a.cpg_off = b.cpg_off; a.cpg_pos = b.cpg_pos;
@@ -325,10 +656,16 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     a.want_pdr = p.want_pdr; a.want_lpmd = p.want_lpmd;
     {
         LaunchTimer lt(ctx, K_TILE);
-        if (b.cpg_rel)
-            hipLaunchKernelGGL(k_pdr_lpmd_tile<uint8_t>, dim3(ntiles), dim3(BLOCK), 0, s, a);
-        else
-            hipLaunchKernelGGL(k_pdr_lpmd_tile<uint16_t>, dim3(ntiles), dim3(BLOCK), 0, s, a);
+        const bool r8 = b.cpg_rel != nullptr;
+        switch (variant) {
+            case 0: r8 ? launch_tile<4096, 256, uint8_t>(a, ntiles, s) : launch_tile<4096, 256, uint16_t>(a, ntiles, s); break;
+            case 2: r8 ? launch_tile<2048, 256, uint8_t>(a, ntiles, s) : launch_tile<2048, 256, uint16_t>(a, ntiles, s); break;
+            case 3: r8 ? launch_tile<1024, 256, uint8_t>(a, ntiles, s) : launch_tile<1024, 256, uint16_t>(a, ntiles, s); break;
+            case 4: r8 ? launch_tile_wc<4096, 4, uint8_t>(a, ntiles, s) : launch_tile_wc<4096, 4, uint16_t>(a, ntiles, s); break;
+            case 5: r8 ? launch_tile_wc<4096, 8, uint8_t>(a, ntiles, s) : launch_tile_wc<4096, 8, uint16_t>(a, ntiles, s); break;
+            case 6: r8 ? launch_tile_wc<2048, 4, uint8_t>(a, ntiles, s) : launch_tile_wc<2048, 4, uint16_t>(a, ntiles, s); break;
+            default: r8 ? launch_tile<2048, 512, uint8_t>(a, ntiles, s) : launch_tile<2048, 512, uint16_t>(a, ntiles, s); break;
+        }
     }
     {
         LaunchTimer lt(ctx, K_SCAN);
@@ -340,8 +677,8 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
         LaunchTimer lt(ctx, K_GATHER);
         hipLaunchKernelGGL(k_gather, dim3(ntiles), dim3(64), 0, s, ctx->scratch.as<SiteRec>(),
                            ctx->tile_cnt.as<uint32_t>(), ctx->tile_base.as<uint32_t>(), ctx->d_state,
-                           ctx->out_pos.as<int32_t>(), ctx->out_pdr.as<float>(), ctx->out_nc.as<uint32_t>(),
-                           ctx->out_nd.as<uint32_t>());
+                           (uint32_t)tile_w, ctx->out_pos.as<int32_t>(), ctx->out_pdr.as<float>(),
+                           ctx->out_nc.as<uint32_t>(), ctx->out_nd.as<uint32_t>());
     }
     MTH_HIP(ctx, hipGetLastError());
     return MTH_OK;

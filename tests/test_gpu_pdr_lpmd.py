@@ -242,3 +242,37 @@ def test_full_size_properties(eng):
     assert (p["pos"][m] == o.pos[keep, 0]).all()
     assert (p["n_concordant"][m] == o.cnt[keep, 0]).all() and (p["n_discordant"][m] == o.cnt[keep, 1]).all()
     assert (p["pdr"][m].view(np.uint32) == o.val[keep].view(np.uint32)).all()
+
+
+# ---- paths of the wave-cooperative kernel that ordinary WGBS density never reaches -----------------
+def test_dense_cpg_chunks(eng):
+    """~30 calls/read: a 64-read chunk has > 1024 calls (chunk splitting) and > 8 call rounds
+    (the part of the scatter walk that re-derives read ids), look-backs run deeper than 8 calls"""
+    from metheor_amd import PdrLpmdParams, synth
+    rng = np.random.default_rng(21)
+    c = synth.make_contig(0, 200_000, 40_000, 0.2, rng)
+    assert c["cpg_off"][-1] / len(c["read_start"]) > 20
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    for kw, lk in ((dict(min_depth=10, min_cpgs=4, min_qual=10), dict()),
+                   (dict(min_depth=0, min_cpgs=0, min_qual=0), dict(min_distance=1, max_distance=60))):
+        pr = PdrLpmdParams(min_distance=lk.get("min_distance", 2), max_distance=lk.get("max_distance", 16), **kw)
+        p, l = run_device(eng, [c], pr)
+        check_against_oracle(p, l, reads, kw, lk)
+
+
+def test_long_reads_lpmd_only(eng):
+    """6-kbp reads with > 1024 calls each (16-bit relpos): the single-read memory path; PDR is
+    refused for spans > 150 (re-open semantics), LPMD has no flush and must still be exact"""
+    from metheor_amd import PdrLpmdParams, synth
+    rng = np.random.default_rng(22)
+    c = synth.make_contig(0, 400_000, 600, 0.3, rng, read_len=6000)
+    assert c["cpg_rel"].dtype == np.uint16 and np.diff(c["cpg_off"].astype(np.int64)).max() > 1024
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    for lk in (dict(min_distance=2, max_distance=16), dict(min_distance=0, max_distance=300)):
+        pr = PdrLpmdParams(min_distance=lk["min_distance"], max_distance=lk["max_distance"], want_pdr=False)
+        eng.reset()
+        eng.pdr_lpmd_accumulate(util.device_batch(c), pr)
+        l, o = eng.lpmd_global(), reads.lpmd(**lk)
+        for k in ("n_concordant", "n_discordant", "n_read", "n_valid_read"):
+            assert l[k] == o[k], (k, l[k], o[k])
+        assert f32(l["lpmd"]).view(np.uint32) == f32(o["lpmd"]).view(np.uint32)
