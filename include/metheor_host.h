@@ -1,0 +1,67 @@
+/*
+ * metheor_host.h -- C ABI of the HOST side of the engine (no GPU needed): BGZF/BAM reading and the
+ * XM-tag decode that produce the SoA batches of metheor_hip.h.
+ *
+ * Reference interfaces replaced (paths under the reference repo):
+ *   src/bamutil.rs:4-11    get_reader(input) -> bam::Reader (rust-htslib / C htslib)   => mth_host_open
+ *   src/bamutil.rs:13-25   get_header / tid2chrom / chrom2tid                           => mth_host_n_refs / _ref_name / _ref_len / _ref_tid
+ *   src/readutil.rs:24-53  BismarkRead::new(&Record)   (start/end, XM tag required)
+ *   src/readutil.rs:323-345 get_cpgs (z/Z only, aligned bases only, strand rule flags in {0,99,147})
+ *   src/readutil.rs:87-95, 347-374  filter_isin / get_target_cpgs (--cpg-set BED: col0 chrom, col1 start)
+ *                                                                                        => mth_host_decode
+ * Error behaviour mirrors the reference's panics as status codes + message (mth_host_last_error):
+ *   missing file        "Error opening BAM file. file not found: <path>"     (bamutil.rs:7-9, tests/pdr-cli.rs:26-31)
+ *   not a BAM           "Error opening BAM file. ..."                         (tests/cli_error_handling.rs:214-227)
+ *   record without XM   "Error reading XM tag in BAM record. Make sure the reads are aligned using Bismark!" (readutil.rs:46,50)
+ *   bad --cpg-set       "Could not read target CpG file."                     (readutil.rs:356)
+ */
+#ifndef METHEOR_HOST_H
+#define METHEOR_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mth_host mth_host_t;
+
+enum {
+    MTH_HOST_OK = 0,
+    MTH_HOST_ERR_OPEN = -101,     /* file missing / unreadable / not BGZF-BAM */
+    MTH_HOST_ERR_FORMAT = -102,   /* truncated or corrupt BAM */
+    MTH_HOST_ERR_XM = -103,       /* a record has no XM:Z tag */
+    MTH_HOST_ERR_CPGSET = -104,   /* --cpg-set file unreadable / unknown contig / bad number */
+    MTH_HOST_ERR_INVALID = -105
+};
+
+/* open a BAM file and read its header */
+int  mth_host_open(const char *path, mth_host_t **out, char *errbuf, int errbuf_len);
+void mth_host_close(mth_host_t *h);
+const char *mth_host_last_error(const mth_host_t *h);
+int  mth_host_n_refs(const mth_host_t *h);
+const char *mth_host_ref_name(const mth_host_t *h, int tid);
+int64_t mth_host_ref_len(const mth_host_t *h, int tid);
+int  mth_host_ref_tid(const mth_host_t *h, const char *name);   /* -1 if unknown */
+
+/* Decode ALL remaining records of the file into one SoA held by the handle, in file order.
+ * cpg_set_path may be NULL.  After success the arrays below are valid until close/decode. */
+int  mth_host_decode(mth_host_t *h, const char *cpg_set_path);
+int64_t mth_host_n_reads(const mth_host_t *h);
+int64_t mth_host_n_cpgs(const mth_host_t *h);
+const int32_t  *mth_host_read_tid(const mth_host_t *h);
+const int32_t  *mth_host_read_start(const mth_host_t *h);
+const int32_t  *mth_host_read_end(const mth_host_t *h);
+const uint8_t  *mth_host_read_mapq(const mth_host_t *h);
+const uint8_t  *mth_host_read_fwd(const mth_host_t *h);
+const uint64_t *mth_host_cpg_off(const mth_host_t *h);      /* n_reads + 1 */
+const uint32_t *mth_host_cpg_pos(const mth_host_t *h);      /* abspos | methylated << 31 */
+const uint16_t *mth_host_cpg_rel(const mth_host_t *h);
+
+/* Rust `{}` of an f32 (shortest round-trip digits, positional, "NaN"/"inf"); buf >= 64 bytes */
+int  mth_host_format_f32(float v, char *buf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

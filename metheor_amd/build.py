@@ -11,6 +11,9 @@ LIB = os.path.join(HERE, "libmetheor_hip.so")
 ARCH = "gfx950"
 
 HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip"]
+HOST_LIB = os.path.join(HERE, "libmetheor_host.so")
+HOST_SOURCES = [os.path.join("host", "bam_reader.cpp"), os.path.join("host", "host_api.cpp")]
+HOST_HEADERS = [os.path.join("host", "bam_reader.h"), os.path.join("..", "..", "include", "metheor_host.h")]
 HEADERS = ["mth_common.h", "mth_ctx.h", os.path.join("..", "..", "include", "metheor_hip.h")]
 
 
@@ -28,7 +31,44 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_host(force=False, verbose=False):
+    """g++ -> metheor_amd/libmetheor_host.so (BGZF/BAM reader + XM decode; needs zlib, no GPU)"""
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HOST_HEADERS]
+    if force or _stale(HOST_LIB, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-shared", "-o", HOST_LIB] + srcs + ["-lz"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
+CLI = os.path.join(HERE, "metheor")
+
+
+def build_cli(force=False, verbose=False):
+    """g++ -> metheor_amd/metheor (the drop-in command line; links the two C-ABI libraries)"""
+    src = os.path.join(CSRC, "host", "cli_main.cpp")
+    deps = [src, LIB, HOST_LIB, os.path.join(HERE, "..", "include", "metheor_hip.h"),
+            os.path.join(HERE, "..", "include", "metheor_host.h")]
+    if force or _stale(CLI, deps):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib")
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", CLI, src, "-L" + HERE, "-lmetheor_hip",
+               "-lmetheor_host", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + rocm_lib]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CLI
+
+
 def build(force=False, verbose=False):
+    lib = _build_libs(force, verbose)
+    build_cli(force, verbose)
+    return lib
+
+
+def _build_libs(force=False, verbose=False):
+    build_host(force, verbose)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []

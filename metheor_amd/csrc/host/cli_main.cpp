@@ -1,0 +1,366 @@
+// cli_main.cpp -- the `metheor` executable: drop-in command line of dohlee/metheor v0.1.9 for the
+// measures that run on the MI355X path.  Same subcommands, short/long flags and defaults as the
+// reference's clap definitions (src/lib.rs:19-231), same TSV bytes (pdr.rs:95-116, lpmd.rs:137-151),
+// same failure behaviour the reference's tests look for (tests/cli_error_handling.rs, tests/*-cli.rs):
+// usage errors exit 2 with clap-style text on stderr; run-time failures (the reference panics) exit
+// 101 with the panic message on stderr.  There is no CPU fallback: a measure whose device kernel is
+// not built yet fails loudly.
+#include <algorithm>
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/metheor_hip.h"
+#include "../../../include/metheor_host.h"
+
+namespace {
+
+struct Opt {
+    const char *long_name;
+    char short_name;
+    const char *value_name;   // upper-case placeholder
+    const char *help;
+    const char *def;          // nullptr: no default
+    bool required;
+    char kind;                // 's' string, 'B' u8, 'U' u32, 'Z' usize, 'I' i32
+};
+struct Cmd {
+    const char *name;
+    const char *about;
+    std::vector<Opt> opts;
+};
+
+const Opt O_IN = {"input", 'i', "INPUT", "Input BAM file", nullptr, true, 's'};
+const Opt O_CPG = {"cpg-set", 'c', "CPG_SET", "(Optional) Specify a predefined set of CpGs (in BED file) to be analyzed", nullptr, false, 's'};
+
+// lib.rs:24-231
+const std::vector<Cmd> &commands() {
+    static const std::vector<Cmd> c = {
+        {"pdr", "Compute proportion of discordant reads (PDR)",
+         {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of PDR calculation", nullptr, true, 's'},
+          {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG stretches to consider", "10", false, 'U'},
+          {"min-cpgs", 'p', "MIN_CPGS", "Minimum number of consecutive CpGs in a CpG stretch to consider", "4", false, 'Z'},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+        {"pm", "Compute epipolymorphism",
+         {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of PM calculation", nullptr, true, 's'},
+          {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG quartets to consider", "10", false, 'U'},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+        {"me", "Compute methylation entropy",
+         {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of PDR calculation", nullptr, true, 's'},
+          {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG quartets to consider", "10", false, 'U'},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+        {"fdrp", "Compute fraction of discordant read pairs (FDRP)",
+         {{"input", 'i', "INPUT", "Path to input BAM file", nullptr, true, 's'},
+          {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of FDRP calculation", nullptr, true, 's'},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'},
+          {"min-depth", 'd', "MIN_DEPTH", "Minimum number of reads mapped to a CpG in order to be considered", "10", false, 'Z'},
+          {"max-depth", 'D', "MAX_DEPTH", "Maximum number of reads to consider", "40", false, 'Z'},
+          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG}},
+        {"qfdrp", "Compute quantitative fraction of discordant read pairs (qFDRP)",
+         {{"input", 'i', "INPUT", "Path to input BAM file", nullptr, true, 's'},
+          {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of FDRP calculation", nullptr, true, 's'},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'},
+          {"min-depth", 'd', "MIN_DEPTH", "Minimum number of reads mapped to a CpG in order to be considered", "10", false, 'Z'},
+          {"max-depth", 'D', "MAX_DEPTH", "Maximum number of reads to consider", "40", false, 'Z'},
+          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG}},
+        {"mhl", "Compute methylation haplotype load (MHL)",
+         {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of MHL calculation", nullptr, true, 's'},
+          {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG stretches to consider", "10", false, 'U'},
+          {"min-cpgs", 'p', "MIN_CPGS", "Minimum number of consecutive CpGs in a CpG stretch to consider", "4", false, 'Z'},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+        {"lpmd", "Compute local pairwise methylation discordance (LPMD)",
+         {{"input", 'i', "INPUT", "Path to input BAM file", nullptr, true, 's'},
+          {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of LPMD calculation", nullptr, true, 's'},
+          {"pairs", 'p', "PAIRS", "(Optional) Concordance information for all CpG pairs", nullptr, false, 's'},
+          {"min-distance", 'm', "MIN_DISTANCE", "Minimum distance between CpG pairs to consider", "2", false, 'I'},
+          {"max-distance", 'M', "MAX_DISTANCE", "Maximum distance between CpG pairs to consider", "16", false, 'I'},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+        {"tag", "Add bismark XM tag to BAM file",
+         {{"input", 'i', "INPUT", "", nullptr, true, 's'}, {"output", 'o', "OUTPUT", "", nullptr, true, 's'},
+          {"genome", 'g', "GENOME", "", nullptr, true, 's'}}},
+    };
+    return c;
+}
+
+void print_main_help(FILE *f) {
+    fprintf(f, "Summarizes the heterogeneity of DNA methylation states using BAM files.\n\nUsage: metheor <COMMAND>\n\nCommands:\n");
+    for (const Cmd &c : commands()) fprintf(f, "  %-6s %s\n", c.name, c.about);
+    fprintf(f, "  help   Print this message or the help of the given subcommand(s)\n\nOptions:\n"
+               "  -h, --help     Print help\n  -V, --version  Print version\n");
+}
+
+std::string usage_line(const Cmd &c) {
+    std::string u = std::string("Usage: metheor ") + c.name + " [OPTIONS]";
+    for (const Opt &o : c.opts) if (o.required) u += std::string(" --") + o.long_name + " <" + o.value_name + ">";
+    return u;
+}
+
+void print_cmd_help(FILE *f, const Cmd &c) {
+    fprintf(f, "%s\n\n%s\n\nOptions:\n", c.about, usage_line(c).c_str());
+    for (const Opt &o : c.opts) {
+        std::string left = std::string("  -") + o.short_name + ", --" + o.long_name + " <" + o.value_name + ">";
+        fprintf(f, "%-34s %s%s%s%s\n", left.c_str(), o.help, o.def ? " [default: " : "", o.def ? o.def : "", o.def ? "]" : "");
+    }
+    fprintf(f, "  -h, --help                       Print help\n");
+}
+
+[[noreturn]] void usage_error(const Cmd *c, const std::string &msg) {
+    fprintf(stderr, "error: %s\n\n%s\n\nFor more information, try '--help'.\n", msg.c_str(),
+            c ? usage_line(*c).c_str() : "Usage: metheor <COMMAND>");
+    exit(2);
+}
+
+// the reference panics on run-time failures: message on stderr, exit status 101
+[[noreturn]] void die(const std::string &msg) {
+    fprintf(stderr, "%s\n", msg.c_str());
+    exit(101);
+}
+
+bool parse_number(const Opt &o, const std::string &v, int64_t &out, std::string &why) {
+    if (v.empty()) { why = "cannot parse integer from empty string"; return false; }
+    char *end = nullptr;
+    errno = 0;
+    const long long x = strtoll(v.c_str(), &end, 10);
+    if (*end != 0 || errno) { why = "invalid digit found in string"; return false; }
+    int64_t lo = 0, hi = 0;
+    switch (o.kind) {
+        case 'B': lo = 0; hi = 255; break;
+        case 'U': lo = 0; hi = 4294967295LL; break;
+        case 'Z': lo = 0; hi = INT64_MAX; break;
+        case 'I': lo = INT32_MIN; hi = INT32_MAX; break;
+        default: break;
+    }
+    if (x < lo || x > hi) {
+        why = o.kind == 'B' ? v + " is not in 0..=255"
+            : (x < 0 && o.kind != 'I') ? "invalid digit found in string" : "number too large to fit in target type";
+        return false;
+    }
+    out = x;
+    return true;
+}
+
+struct Args {
+    std::map<std::string, std::string> s;
+    std::map<std::string, int64_t> n;
+    bool has(const char *k) const { return s.count(k) != 0; }
+};
+
+Args parse_args(const Cmd &c, int argc, char **argv, int first) {
+    Args a;
+    if (first >= argc) { print_cmd_help(stderr, c); exit(2); }   // arg_required_else_help
+    for (int i = first; i < argc; ++i) {
+        std::string tok = argv[i];
+        if (tok == "-h" || tok == "--help") { print_cmd_help(stdout, c); exit(0); }
+        const Opt *o = nullptr;
+        std::string val;
+        bool have_val = false;
+        if (tok.rfind("--", 0) == 0) {
+            const size_t eq = tok.find('=');
+            const std::string name = tok.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            for (const Opt &x : c.opts) if (name == x.long_name) o = &x;
+            if (eq != std::string::npos) { val = tok.substr(eq + 1); have_val = true; }
+        } else if (tok.size() >= 2 && tok[0] == '-') {
+            for (const Opt &x : c.opts) if (tok[1] == x.short_name) o = &x;
+            if (o && tok.size() > 2) { val = tok.substr(tok[2] == '=' ? 3 : 2); have_val = true; }
+        }
+        if (!o) usage_error(&c, "unexpected argument '" + tok + "' found");
+        if (!have_val) {
+            if (i + 1 >= argc) usage_error(&c, std::string("a value is required for '--") + o->long_name + " <" + o->value_name + ">' but none was supplied");
+            val = argv[++i];
+            // clap (no allow_hyphen_values / allow_negative_numbers in lib.rs): a separate token that
+            // looks like a flag is never taken as a value ("-5" after --min-depth); --opt=-5 is
+            if (val.size() > 1 && val[0] == '-')
+                usage_error(&c, "unexpected argument '" + val + "' found");
+        }
+        if (o->kind == 's') a.s[o->long_name] = val;
+        else {
+            int64_t x;
+            std::string why;
+            if (!parse_number(*o, val, x, why))
+                usage_error(&c, "invalid value '" + val + "' for '--" + o->long_name + " <" + o->value_name + ">': " + why);
+            a.n[o->long_name] = x;
+            a.s[o->long_name] = val;
+        }
+    }
+    std::string missing;
+    for (const Opt &o : c.opts) {
+        if (o.required && !a.has(o.long_name)) missing += std::string("\n  --") + o.long_name + " <" + o.value_name + ">";
+        if (o.def && !a.has(o.long_name)) { a.n[o.long_name] = strtoll(o.def, nullptr, 10); }
+    }
+    if (!missing.empty()) usage_error(&c, "the following required arguments were not provided:" + missing);
+    return a;
+}
+
+// ---- decoded input, split into per-contig batches ---------------------------------------------
+struct Contig {
+    int32_t tid;
+    std::vector<int32_t> start, end;
+    std::vector<uint8_t> mapq;
+    std::vector<uint32_t> off, pos;
+    std::vector<uint16_t> rel;
+    int32_t max_span = 0;
+};
+
+struct Input {
+    mth_host_t *h = nullptr;
+    std::vector<Contig> contigs;
+    int64_t loose_reads = 0;                 // records outside any contig batch (no contig / no aligned base)
+    std::vector<uint8_t> loose_mapq;
+};
+
+Input load(const std::string &path, const char *cpg_set) {
+    Input in;
+    char err[1024];
+    if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) die(err);    // bamutil.rs:7-9
+    if (mth_host_decode(in.h, cpg_set) != 0) die(mth_host_last_error(in.h));
+    const int64_t n = mth_host_n_reads(in.h);
+    const int32_t *tid = mth_host_read_tid(in.h), *st = mth_host_read_start(in.h), *en = mth_host_read_end(in.h);
+    const uint8_t *mq = mth_host_read_mapq(in.h);
+    const uint64_t *off = mth_host_cpg_off(in.h);
+    const uint32_t *pos = mth_host_cpg_pos(in.h);
+    const uint16_t *rel = mth_host_cpg_rel(in.h);
+    for (int64_t i = 0; i < n; ++i) {
+        if (tid[i] < 0 || st[i] < 0) { in.loose_reads += 1; in.loose_mapq.push_back(mq[i]); continue; }
+        if (in.contigs.empty() || in.contigs.back().tid != tid[i]) {
+            for (const Contig &c : in.contigs)
+                if (c.tid == tid[i]) die("input BAM is not grouped by contig (coordinate-sorted input is required on the MI355X path)");
+            in.contigs.emplace_back();
+            in.contigs.back().tid = tid[i];
+            in.contigs.back().off.push_back(0);
+        }
+        Contig &c = in.contigs.back();
+        c.start.push_back(st[i]); c.end.push_back(en[i]); c.mapq.push_back(mq[i]);
+        for (uint64_t k = off[i]; k < off[i + 1]; ++k) { c.pos.push_back(pos[k]); c.rel.push_back(rel[k]); }
+        c.off.push_back((uint32_t)c.pos.size());
+        c.max_span = std::max(c.max_span, en[i] - st[i] + 1);
+    }
+    return in;
+}
+
+void check(mth_ctx_t *ctx, int rc) {
+    if (rc == MTH_OK) return;
+    std::string m = std::string("metheor (MI355X path): ") + mth_strerror(rc);
+    if (ctx && mth_last_error(ctx)[0]) m += std::string(" -- ") + mth_last_error(ctx);
+    die(m);
+}
+
+mth_ctx_t *make_ctx() {
+    mth_ctx_t *ctx = nullptr;
+    const char *dev = getenv("METHEOR_DEVICE");
+    const int rc = mth_ctx_create(dev ? atoi(dev) : 0, &ctx);
+    if (rc != MTH_OK) die(std::string("metheor (MI355X path): ") + mth_strerror(rc));
+    return ctx;
+}
+
+void submit(mth_ctx_t *ctx, const Input &in, const mth_pdr_lpmd_params_t &p) {
+    for (const Contig &c : in.contigs) {
+        mth_batch_t b;
+        memset(&b, 0, sizeof b);
+        b.tid = c.tid;
+        b.region_beg = 0;
+        const int64_t len = mth_host_ref_len(in.h, c.tid);
+        b.region_end = (int32_t)std::min<int64_t>(len, INT32_MAX);
+        b.max_span = c.max_span;
+        b.n_reads = (uint32_t)c.start.size();
+        b.n_cpgs = (uint32_t)c.pos.size();
+        b.mem = MTH_MEM_HOST;
+        b.read_start = c.start.data(); b.read_end = c.end.data(); b.read_mapq = c.mapq.data();
+        b.cpg_off = c.off.data(); b.cpg_pos = c.pos.data(); b.cpg_rel16 = c.rel.data();
+        check(ctx, mth_pdr_lpmd_accumulate(ctx, &b, &p));
+    }
+}
+
+FILE *open_output(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "wb");   // create + truncate (pdr.rs:95-101)
+    if (!f) die("called `Result::unwrap()` on an `Err` value: cannot open output file " + path + ": " + strerror(errno));
+    static char buf[1 << 20];
+    setvbuf(f, buf, _IOFBF, sizeof buf);
+    return f;
+}
+
+int run_pdr(const Args &a) {
+    Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
+    mth_ctx_t *ctx = make_ctx();
+    mth_pdr_lpmd_params_t p;
+    memset(&p, 0, sizeof p);
+    p.pdr_min_depth = (uint32_t)a.n.at("min-depth");
+    p.pdr_min_cpgs = (uint32_t)std::min<int64_t>(a.n.at("min-cpgs"), UINT32_MAX);
+    p.pdr_min_qual = (uint8_t)a.n.at("min-qual");
+    p.want_pdr = 1;
+    submit(ctx, in, p);
+    uint64_t n = 0;
+    check(ctx, mth_pdr_count(ctx, &n));
+    std::vector<int32_t> tid(n), pos(n);
+    std::vector<float> pdr(n);
+    std::vector<uint32_t> nc(n), nd(n);
+    check(ctx, mth_pdr_fetch(ctx, tid.data(), pos.data(), pdr.data(), nc.data(), nd.data()));
+    FILE *f = open_output(a.s.at("output"));
+    char fb[64];
+    for (uint64_t i = 0; i < n; ++i) {   // pdr.rs:102-116
+        mth_host_format_f32(pdr[i], fb);
+        fprintf(f, "%s\t%d\t%d\t%s\t%u\t%u\n", mth_host_ref_name(in.h, tid[i]), pos[i], pos[i] + 2, fb, nc[i], nd[i]);
+    }
+    if (fclose(f) != 0) die("Error writing to output file.");
+    mth_ctx_destroy(ctx);
+    mth_host_close(in.h);
+    return 0;
+}
+
+int run_lpmd(const Args &a) {
+    if (a.has("pairs")) die("metheor (MI355X path): lpmd --pairs (per-pair table, lpmd.rs:89-122) is not implemented on the device path yet");
+    const std::string input = a.s.at("input");
+    const int32_t mind = (int32_t)a.n.at("min-distance"), maxd = (int32_t)a.n.at("max-distance");
+    // lpmd.rs:161-164
+    fprintf(stderr, "Computing subset-LPMD with parameters input=%s, min_distance=%d, max_distance=%d\n", input.c_str(), mind, maxd);
+    Input in = load(input, a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
+    mth_ctx_t *ctx = make_ctx();
+    mth_pdr_lpmd_params_t p;
+    memset(&p, 0, sizeof p);
+    p.lpmd_min_qual = (uint8_t)a.n.at("min-qual");
+    p.lpmd_min_distance = mind; p.lpmd_max_distance = maxd;
+    p.want_lpmd = 1;
+    submit(ctx, in, p);
+    int64_t g[4] = {0, 0, 0, 0};
+    float lp = 0.f;
+    check(ctx, mth_lpmd_global(ctx, g, &lp));
+    // records that never enter a batch only move n_read / n_valid_read (not part of the TSV)
+    FILE *f = open_output(a.s.at("output"));
+    char fb[64];
+    mth_host_format_f32(lp, fb);
+    fprintf(f, "name\tlpmd\n%s\t%s\n", input.c_str(), fb);   // lpmd.rs:145-147
+    if (fclose(f) != 0) die("Error writing to output file.");
+    mth_ctx_destroy(ctx);
+    mth_host_close(in.h);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2) { print_main_help(stderr); return 2; }   // arg_required_else_help (lib.rs:18)
+    const std::string sub = argv[1];
+    if (sub == "-h" || sub == "--help" || sub == "help") { print_main_help(stdout); return 0; }
+    if (sub == "-V" || sub == "--version") { printf("metheor 0.1.9\n"); return 0; }
+    const Cmd *cmd = nullptr;
+    for (const Cmd &c : commands()) if (sub == c.name) cmd = &c;
+    if (!cmd) {
+        if (!sub.empty() && sub[0] == '-') usage_error(nullptr, "unexpected argument '" + sub + "' found");
+        usage_error(nullptr, "unrecognized subcommand '" + sub + "'");
+    }
+    const Args a = parse_args(*cmd, argc, argv, 2);
+    if (sub == "pdr") return run_pdr(a);
+    if (sub == "lpmd") return run_lpmd(a);
+    // the reference opens the BAM first; keep its open errors visible before refusing
+    if (sub != "tag") {
+        mth_host_t *h = nullptr;
+        char err[1024];
+        if (mth_host_open(a.s.at("input").c_str(), &h, err, sizeof err) != 0) die(err);
+        mth_host_close(h);
+    }
+    die("metheor (MI355X path): subcommand '" + sub + "' has no device kernel yet; there is no CPU fallback");
+}

@@ -1,0 +1,208 @@
+// host_api.cpp -- include/metheor_host.h: BAM -> decoded SoA (the reference's BismarkRead stream).
+//
+// decode follows src/readutil.rs:24-53 (BismarkRead::new) and 323-345 (get_cpgs) in ONE walk over
+// the CIGAR with a cursor into the XM string (no per-base position vector):
+//   M/=/X  consume query+reference : XM[q] in {z,Z} -> CpG at reference r (forward: flags exactly
+//          0, 99 or 147) or r-1 (everything else), relpos = q          (readutil.rs:326-341)
+//   I/S    consume query only      : reference position None -> skipped (readutil.rs:331)
+//   D/N    consume reference only  : nothing yielded by reference_positions_full()
+//   H/P    nothing
+// start_pos / end_pos = first / last aligned reference position, -1 if none (readutil.rs:25-33).
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../../include/metheor_host.h"
+#include "bam_reader.h"
+
+using namespace mthh;
+
+struct mth_host {
+    BamReader reader;
+    std::string last_error;
+    std::unordered_map<std::string, int> name2tid;
+    std::vector<int32_t> tid, start, end;
+    std::vector<uint8_t> mapq, fwd;
+    std::vector<uint64_t> cpg_off;
+    std::vector<uint32_t> cpg_pos;
+    std::vector<uint16_t> cpg_rel;
+};
+
+namespace {
+
+// find the XM:Z value in the aux block (BAM aux: tag[2] type[1] value); returns false if absent
+bool find_xm(const uint8_t *aux, uint32_t len, const char *&xm, uint32_t &xm_len) {
+    uint32_t o = 0;
+    while (o + 3 <= len) {
+        const uint8_t t0 = aux[o], t1 = aux[o + 1], ty = aux[o + 2];
+        o += 3;
+        switch (ty) {
+            case 'A': case 'c': case 'C': o += 1; break;
+            case 's': case 'S': o += 2; break;
+            case 'i': case 'I': case 'f': o += 4; break;
+            case 'Z': case 'H': {
+                const uint32_t b = o;
+                while (o < len && aux[o] != 0) ++o;
+                if (o >= len) return false;
+                if (ty == 'Z' && t0 == 'X' && t1 == 'M') {
+                    xm = reinterpret_cast<const char *>(aux + b);
+                    xm_len = o - b;
+                    return true;
+                }
+                o += 1;
+                break;
+            }
+            case 'B': {
+                if (o + 5 > len) return false;
+                const uint8_t sub = aux[o];
+                const uint32_t cnt = read_u32(aux + o + 1);
+                const uint32_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                o += 5 + cnt * w;
+                break;
+            }
+            default: return false;
+        }
+    }
+    return false;
+}
+
+inline uint64_t site_key(int32_t tid, int32_t pos) { return ((uint64_t)(uint32_t)tid << 32) | (uint32_t)pos; }
+
+}  // namespace
+
+extern "C" {
+
+int mth_host_open(const char *path, mth_host_t **out, char *errbuf, int errbuf_len) {
+    if (!path || !out) return MTH_HOST_ERR_INVALID;
+    *out = nullptr;
+    auto *h = new mth_host;
+    if (!h->reader.open(path)) {
+        // bamutil.rs:7-9: panic!("Error opening BAM file. {}", error)
+        const std::string msg = "Error opening BAM file. " + h->reader.error();
+        if (errbuf && errbuf_len > 0) { strncpy(errbuf, msg.c_str(), (size_t)errbuf_len - 1); errbuf[errbuf_len - 1] = 0; }
+        delete h;
+        return MTH_HOST_ERR_OPEN;
+    }
+    for (size_t i = 0; i < h->reader.refs().size(); ++i) h->name2tid.emplace(h->reader.refs()[i].name, (int)i);
+    *out = h;
+    return MTH_HOST_OK;
+}
+
+void mth_host_close(mth_host_t *h) { delete h; }
+const char *mth_host_last_error(const mth_host_t *h) { return h ? h->last_error.c_str() : ""; }
+int mth_host_n_refs(const mth_host_t *h) { return (int)h->reader.refs().size(); }
+const char *mth_host_ref_name(const mth_host_t *h, int tid) {
+    return (tid >= 0 && tid < (int)h->reader.refs().size()) ? h->reader.refs()[tid].name.c_str() : "";
+}
+int64_t mth_host_ref_len(const mth_host_t *h, int tid) {
+    return (tid >= 0 && tid < (int)h->reader.refs().size()) ? h->reader.refs()[tid].length : -1;
+}
+int mth_host_ref_tid(const mth_host_t *h, const char *name) {
+    auto it = h->name2tid.find(name);
+    return it == h->name2tid.end() ? -1 : it->second;
+}
+
+int mth_host_decode(mth_host_t *h, const char *cpg_set_path) {
+    if (!h) return MTH_HOST_ERR_INVALID;
+    h->tid.clear(); h->start.clear(); h->end.clear(); h->mapq.clear(); h->fwd.clear();
+    h->cpg_off.assign(1, 0); h->cpg_pos.clear(); h->cpg_rel.clear();
+
+    // readutil.rs:347-374 get_target_cpgs: tab-split lines, col0 chrom (must be in the header),
+    // col1 start; HashSet<CpGPosition>
+    bool have_set = false;
+    std::unordered_set<uint64_t> target;
+    if (cpg_set_path) {
+        std::ifstream f(cpg_set_path);
+        if (!f) { h->last_error = "Could not read target CpG file."; return MTH_HOST_ERR_CPGSET; }
+        std::string line;
+        while (std::getline(f, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            const size_t t1 = line.find('\t');
+            if (t1 == std::string::npos) { h->last_error = "malformed --cpg-set line (needs chrom<TAB>start): " + line; return MTH_HOST_ERR_CPGSET; }
+            const size_t t2 = line.find('\t', t1 + 1);
+            const std::string chrom = line.substr(0, t1);
+            const std::string num = line.substr(t1 + 1, t2 == std::string::npos ? std::string::npos : t2 - t1 - 1);
+            int32_t pos = 0;
+            const auto r = std::from_chars(num.data(), num.data() + num.size(), pos);
+            if (r.ec != std::errc() || r.ptr != num.data() + num.size()) { h->last_error = "bad start in --cpg-set: " + line; return MTH_HOST_ERR_CPGSET; }
+            const auto it = h->name2tid.find(chrom);
+            if (it == h->name2tid.end()) { h->last_error = "unknown contig in --cpg-set: " + chrom; return MTH_HOST_ERR_CPGSET; }
+            target.insert(site_key(it->second, pos));
+        }
+        have_set = true;
+    }
+
+    BamRecord rec;
+    bool eof = false;
+    for (;;) {
+        if (!h->reader.next(rec, eof)) { h->last_error = "Error reading BAM record. " + h->reader.error(); return MTH_HOST_ERR_FORMAT; }
+        if (eof) break;
+        const char *xm = nullptr;
+        uint32_t xm_len = 0;
+        if (!find_xm(rec.aux, rec.aux_len, xm, xm_len)) {
+            h->last_error = "Error reading XM tag in BAM record. Make sure the reads are aligned using Bismark!";
+            return MTH_HOST_ERR_XM;
+        }
+        const bool forward = rec.flag == 0 || rec.flag == 99 || rec.flag == 147;   // readutil.rs:332
+        int32_t first = -1, last = -1;
+        int64_t r = rec.pos;
+        uint32_t q = 0;
+        for (uint32_t c = 0; c < rec.n_cigar; ++c) {
+            const uint32_t w = read_u32(rec.cigar + c), op = w & 15u, len = w >> 4;
+            if (op == 0 || op == 7 || op == 8) {          // M = X
+                if (len) { if (first < 0) first = (int32_t)r; last = (int32_t)(r + len - 1); }
+                const uint32_t qe = q + len;
+                for (; q < qe; ++q, ++r) {
+                    if (q >= xm_len) continue;              // zip() stops at the shorter side
+                    const char ch = xm[q];
+                    if (ch != 'z' && ch != 'Z') continue;
+                    const int32_t ap = forward ? (int32_t)r : (int32_t)(r - 1);
+                    if (have_set && !target.count(site_key(rec.tid, ap))) continue;   // filter_isin keeps relpos
+                    h->cpg_pos.push_back(((uint32_t)ap & 0x7fffffffu) | (ch == 'Z' ? 0x80000000u : 0u));
+                    h->cpg_rel.push_back((uint16_t)q);
+                }
+            } else if (op == 1 || op == 4) {               // I S
+                q += len;
+            } else if (op == 2 || op == 3) {               // D N
+                r += len;
+            }                                               // H P: nothing
+        }
+        h->tid.push_back(rec.tid);
+        h->start.push_back(first);
+        h->end.push_back(last);
+        h->mapq.push_back(rec.mapq);
+        h->fwd.push_back(forward ? 1 : 0);
+        h->cpg_off.push_back((uint64_t)h->cpg_pos.size());
+    }
+    return MTH_HOST_OK;
+}
+
+int64_t mth_host_n_reads(const mth_host_t *h) { return (int64_t)h->tid.size(); }
+int64_t mth_host_n_cpgs(const mth_host_t *h) { return (int64_t)h->cpg_pos.size(); }
+const int32_t *mth_host_read_tid(const mth_host_t *h) { return h->tid.data(); }
+const int32_t *mth_host_read_start(const mth_host_t *h) { return h->start.data(); }
+const int32_t *mth_host_read_end(const mth_host_t *h) { return h->end.data(); }
+const uint8_t *mth_host_read_mapq(const mth_host_t *h) { return h->mapq.data(); }
+const uint8_t *mth_host_read_fwd(const mth_host_t *h) { return h->fwd.data(); }
+const uint64_t *mth_host_cpg_off(const mth_host_t *h) { return h->cpg_off.data(); }
+const uint32_t *mth_host_cpg_pos(const mth_host_t *h) { return h->cpg_pos.data(); }
+const uint16_t *mth_host_cpg_rel(const mth_host_t *h) { return h->cpg_rel.data(); }
+
+// Rust `impl Display for f32`: shortest digits that round-trip, never an exponent.
+// std::to_chars(float, chars_format::fixed) without a precision is exactly that.
+int mth_host_format_f32(float v, char *buf) {
+    if (std::isnan(v)) { memcpy(buf, "NaN", 4); return 3; }
+    if (std::isinf(v)) { const char *s = v < 0 ? "-inf" : "inf"; const int n = (int)strlen(s); memcpy(buf, s, (size_t)n + 1); return n; }
+    const auto r = std::to_chars(buf, buf + 60, v, std::chars_format::fixed);
+    *r.ptr = 0;
+    return (int)(r.ptr - buf);
+}
+
+}  // extern "C"

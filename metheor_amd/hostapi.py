@@ -1,0 +1,98 @@
+"""ctypes binding of include/metheor_host.h (libmetheor_host.so: BGZF/BAM reader + XM decode, no GPU)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SYMBOLS = [
+    "mth_host_open", "mth_host_close", "mth_host_last_error", "mth_host_n_refs", "mth_host_ref_name",
+    "mth_host_ref_len", "mth_host_ref_tid", "mth_host_decode", "mth_host_n_reads", "mth_host_n_cpgs",
+    "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
+    "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32",
+]
+
+
+class HostError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(msg)
+        self.status = status
+
+
+def library_path():
+    return os.path.join(_HERE, "libmetheor_host.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = library_path()
+        if not os.path.exists(p):
+            raise ImportError("%s is missing: build it with `python -m metheor_amd.build`" % p)
+        L = C.CDLL(p)
+        vp = C.c_void_p
+        L.mth_host_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int]
+        L.mth_host_close.argtypes = [vp]; L.mth_host_close.restype = None
+        L.mth_host_last_error.argtypes = [vp]; L.mth_host_last_error.restype = C.c_char_p
+        L.mth_host_n_refs.argtypes = [vp]
+        L.mth_host_ref_name.argtypes = [vp, C.c_int]; L.mth_host_ref_name.restype = C.c_char_p
+        L.mth_host_ref_len.argtypes = [vp, C.c_int]; L.mth_host_ref_len.restype = C.c_int64
+        L.mth_host_ref_tid.argtypes = [vp, C.c_char_p]
+        L.mth_host_decode.argtypes = [vp, C.c_char_p]
+        for f in ("n_reads", "n_cpgs"):
+            getattr(L, "mth_host_" + f).argtypes = [vp]; getattr(L, "mth_host_" + f).restype = C.c_int64
+        for f in ("read_tid", "read_start", "read_end", "read_mapq", "read_fwd", "cpg_off", "cpg_pos", "cpg_rel"):
+            getattr(L, "mth_host_" + f).argtypes = [vp]; getattr(L, "mth_host_" + f).restype = vp
+        L.mth_host_format_f32.argtypes = [C.c_float, C.c_char_p]
+        _LIB = L
+    return _LIB
+
+
+def format_f32(v):
+    buf = C.create_string_buffer(80)
+    lib().mth_host_format_f32(float(np.float32(v)), buf)
+    return buf.value.decode()
+
+
+class BamFile:
+    def __init__(self, path):
+        self.L = lib()
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = self.L.mth_host_open(os.fsencode(path), C.byref(self.h), err, 1024)
+        if rc != 0:
+            self.h = None
+            raise HostError(rc, err.value.decode())
+        self.refs = [(self.L.mth_host_ref_name(self.h, t).decode(), self.L.mth_host_ref_len(self.h, t))
+                     for t in range(self.L.mth_host_n_refs(self.h))]
+
+    def close(self):
+        if self.h:
+            self.L.mth_host_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, cpg_set=None):
+        """-> SoA dict with the same keys as oracle.pyoracle.Reads.soa()"""
+        rc = self.L.mth_host_decode(self.h, os.fsencode(cpg_set) if cpg_set else None)
+        if rc != 0:
+            raise HostError(rc, self.L.mth_host_last_error(self.h).decode())
+        n, nc = self.L.mth_host_n_reads(self.h), self.L.mth_host_n_cpgs(self.h)
+
+        def arr(name, dt, cnt):
+            p = getattr(self.L, "mth_host_" + name)(self.h)
+            if cnt == 0 or not p:
+                return np.zeros(cnt, dtype=dt)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(cnt,)).copy()
+
+        return dict(tid=arr("read_tid", np.int32, n), start=arr("read_start", np.int32, n),
+                    end=arr("read_end", np.int32, n), mapq=arr("read_mapq", np.uint8, n),
+                    fwd=arr("read_fwd", np.uint8, n), cpg_off=arr("cpg_off", np.uint64, n + 1),
+                    cpg_pos=arr("cpg_pos", np.uint32, nc), cpg_rel=arr("cpg_rel", np.uint16, nc))

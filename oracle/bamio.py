@@ -142,3 +142,43 @@ def read_sam(path):
                     xm = a[5:].encode()
             xms.append(xm)
     return Records(refs, tid, pos, flag, mapq, cigars, xms, names, "\n".join(text) + "\n")
+
+
+# ---- writer (tests build BAMs with indels / clips / reverse strand / several contigs) ----------
+def _bgzf_block(data):
+    import zlib
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    bsize = len(comp) + 25
+    assert bsize <= 65536
+    hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize)
+    return hdr + comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+
+
+def write_bam(path, rec, seq_len=None):
+    """rec: Records.  Sequences/qualities are dummies (the hot path never looks at them)."""
+    text = rec.text if rec.text else "@HD\tVN:1.0\tSO:coordinate\n" + "".join(
+        "@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in rec.refs)
+    out = bytearray(b"BAM\1")
+    tb = text.encode()
+    out += struct.pack("<i", len(tb)) + tb + struct.pack("<i", len(rec.refs))
+    for name, ln in rec.refs:
+        nb = name.encode() + b"\0"
+        out += struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln)
+    for i in range(len(rec)):
+        cig = rec.cigars[i]
+        qlen = sum(c >> 4 for c in cig if (c & 15) in (0, 1, 4, 7, 8))
+        name = (rec.names[i] if rec.names else "r%d" % i).encode() + b"\0"
+        aux = b""
+        if rec.xms[i] is not None:
+            assert b"\0" not in rec.xms[i], "XM:Z value must not contain NUL (record %d)" % i
+            aux += b"NMC\x00" + b"XMZ" + rec.xms[i] + b"\0" + b"XRZCT\0"
+        body = struct.pack("<iiBBHHHiiii", int(rec.tid[i]), int(rec.pos[i]), len(name), int(rec.mapq[i]), 4680,
+                           len(cig), int(rec.flag[i]), qlen, -1, -1, 0)
+        body += name + struct.pack("<%dI" % len(cig), *cig) + b"\x11" * ((qlen + 1) // 2) + b"\x28" * qlen + aux
+        out += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as fh:
+        data = bytes(out)
+        for o in range(0, len(data), 60000):
+            fh.write(_bgzf_block(data[o:o + 60000]))
+        fh.write(_bgzf_block(b""))

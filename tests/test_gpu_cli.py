@@ -1,0 +1,115 @@
+"""End-to-end: BAM file -> `metheor` executable (C++ host + HIP kernels) -> TSV bytes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import bamio, pyoracle
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "metheor_amd", "metheor")
+
+
+def run(*args):
+    return subprocess.run([EXE, *args], capture_output=True, text=True, cwd=ROOT, timeout=600)
+
+
+def test_default_cli_goldens(golden_dir, tmp_path):
+    """SURVEY 8c derived goldens: `metheor pdr|lpmd -i tests/test1.bam -o o.tsv` with defaults"""
+    o = tmp_path / "o.tsv"
+    bam = os.path.join("tests", "golden", "test1.bam")
+    r = run("pdr", "-i", bam, "-o", str(o))
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == "chr1\t0\t2\t0.875\t2\t14\nchr1\t2\t4\t0.875\t2\t14\nchr1\t4\t6\t0.875\t2\t14\nchr1\t6\t8\t0.875\t2\t14\n"
+    r = run("lpmd", "-i", bam, "-o", str(o))
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == "name\tlpmd\n%s\t0.5\n" % bam          # lpmd.rs:147: the input path as given
+    assert r.stdout == ""                                           # progress / parameters go to stderr only
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6])
+def test_fixtures_vs_oracle_text(golden_dir, tmp_path, k):
+    bam = os.path.join(golden_dir, "test%d.bam" % k)
+    reads = pyoracle.Reads.decode(bamio.read_bam(bam))
+    o = tmp_path / "o.tsv"
+    for kw in (dict(min_depth=0, min_cpgs=0, min_qual=10), dict(min_depth=10, min_cpgs=4, min_qual=10), dict(min_depth=0, min_cpgs=1, min_qual=0)):
+        r = run("pdr", "-i", bam, "-o", str(o), "-d", str(kw["min_depth"]), "-p", str(kw["min_cpgs"]), "-q", str(kw["min_qual"]))
+        assert r.returncode == 0, r.stderr
+        assert o.read_text() == util.oracle_tsv_pdr(reads, ["chr1"], **kw)
+    r = run("lpmd", "-i", bam, "-o", str(o))
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == util.oracle_tsv_lpmd(reads, bam)       # test5: "NaN"
+
+
+def test_rrbs_and_cpg_set(golden_dir, tmp_path):
+    rec = bamio.read_sam(os.path.join(golden_dir, "test.chr19.XM.sam"))
+    bam = str(tmp_path / "rrbs.bam")
+    bamio.write_bam(bam, rec)
+    reads = pyoracle.Reads.decode(rec)
+    o = tmp_path / "o.tsv"
+    r = run("pdr", "--input", bam, "--output", str(o), "--min-depth", "3", "--min-cpgs", "2")
+    assert r.returncode == 0, r.stderr
+    want = util.oracle_tsv_pdr(reads, ["chr19"], min_depth=3, min_cpgs=2, min_qual=10)
+    assert o.read_text() == want and want.count("\n") > 20
+    r = run("lpmd", "-i", bam, "-o", str(o), "-m", "1", "-M", "8", "-q", "20")
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == util.oracle_tsv_lpmd(reads, bam, min_distance=1, max_distance=8, min_qual=20)
+    # --cpg-set: every second called site
+    soa = reads.soa()
+    sites = np.unique(soa["cpg_pos"] & 0x7fffffff)[::2]
+    bed = tmp_path / "set.bed"
+    bed.write_text("".join("chr19\t%d\t%d\n" % (p, p + 2) for p in sites))
+    filt = pyoracle.Reads.decode(rec, cpg_set=[(0, int(p)) for p in sites])
+    r = run("pdr", "-i", bam, "-o", str(o), "-d", "2", "-p", "1", "-c", str(bed))
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == util.oracle_tsv_pdr(filt, ["chr19"], min_depth=2, min_cpgs=1, min_qual=10)
+    r = run("lpmd", "-i", bam, "-o", str(o), "-c", str(bed))
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == util.oracle_tsv_lpmd(filt, bam)
+
+
+def test_synthetic_bam_two_contigs(tmp_path):
+    from metheor_amd import synth
+    rng = np.random.default_rng(17)
+    cs = [synth.make_contig(0, 150_000, 20_000, 0.03, rng), synth.make_contig(1, 60_000, 9_000, 0.03, rng)]
+    r0, r1 = util.contig_to_records(cs[0], "chrS1"), util.contig_to_records(cs[1], "chrS2")
+    rec = bamio.Records([r0.refs[0], r1.refs[0]], np.concatenate([r0.tid, r1.tid + 1]), np.concatenate([r0.pos, r1.pos]),
+                        np.concatenate([r0.flag, r1.flag]), np.concatenate([r0.mapq, r1.mapq]), r0.cigars + r1.cigars, r0.xms + r1.xms)
+    bam = str(tmp_path / "syn.bam")
+    bamio.write_bam(bam, rec)
+    reads = pyoracle.Reads.decode(rec)
+    # the decoded file equals the generator's SoA (BAM writer/reader round trip)
+    direct = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    assert (reads.soa()["cpg_pos"] == direct.soa()["cpg_pos"]).all()
+    o = tmp_path / "o.tsv"
+    r = run("pdr", "-i", bam, "-o", str(o))
+    assert r.returncode == 0, r.stderr
+    want = util.oracle_tsv_pdr(reads, ["chrS1", "chrS2"])
+    assert o.read_text() == want and "chrS2" in want
+    r = run("lpmd", "-i", bam, "-o", str(o))
+    assert r.returncode == 0 and o.read_text() == util.oracle_tsv_lpmd(reads, bam)
+
+
+def test_reference_cli_success_cases(tmp_path):
+    """cli_error_handling.rs:173-195 (min>max distance still succeeds), :350-387 (extreme / zero thresholds),
+    :198-211 (unwritable output fails)"""
+    bam = os.path.join("tests", "golden", "test1.bam")
+    o = tmp_path / "o.tsv"
+    r = run("lpmd", "--input", bam, "--output", str(o), "--min-distance", "100", "--max-distance", "50")
+    assert r.returncode == 0 and o.read_text().endswith("\tNaN\n")
+    r = run("pdr", "--input", bam, "--output", str(o), "--min-depth", "999999")
+    assert r.returncode == 0 and o.read_text() == ""
+    r = run("pdr", "--input", bam, "--output", str(o), "--min-qual", "0")
+    assert r.returncode == 0 and o.read_text().count("\n") == 4
+    r = run("pdr", "--input", bam, "--output", "/nonexistent_directory/readonly_output.tsv")
+    assert r.returncode != 0
+
+
+def test_unbuilt_measures_fail_loudly(tmp_path):
+    bam = os.path.join("tests", "golden", "test1.bam")
+    for sub in ("mhl", "pm", "me", "fdrp", "qfdrp"):
+        r = run(sub, "-i", bam, "-o", str(tmp_path / "o.tsv"))
+        assert r.returncode != 0 and "no device kernel yet" in r.stderr

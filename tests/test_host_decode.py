@@ -1,0 +1,181 @@
+"""Product host (C++ BGZF/BAM reader + XM decode, libmetheor_host.so) against the oracle's decode
+(oracle/bamio.py pure-Python loader + orc_decode): two independently written implementations of
+readutil.rs:24-53, 323-345, 87-95, 347-374 must produce the same SoA.  No GPU needed."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from metheor_amd import hostapi
+from oracle import bamio, pyoracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("tid", "start", "end", "mapq", "fwd", "cpg_off", "cpg_pos", "cpg_rel")
+
+
+def same_soa(a, b):
+    for k in KEYS:
+        assert a[k].shape == b[k].shape, k
+        assert (a[k] == b[k]).all(), k
+
+
+def test_header_symbols_exported():
+    src = open(os.path.join(ROOT, "include", "metheor_host.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mth_host_[a-z0-9_]+)\s*\(", src)))
+    L = hostapi.lib()
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(hostapi.SYMBOLS) == syms
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6])
+def test_reference_fixtures(golden_dir, k):
+    path = os.path.join(golden_dir, "test%d.bam" % k)
+    f = hostapi.BamFile(path)
+    assert f.refs == [("chr1", 248956422)]
+    same_soa(f.decode(), pyoracle.Reads.decode(bamio.read_bam(path)).soa())
+
+
+def test_real_rrbs_reads_through_bam(golden_dir, tmp_path):
+    """the reference's 1000-read RRBS SAM fixture (676 reverse-strand reads), round-tripped to BAM"""
+    rec = bamio.read_sam(os.path.join(golden_dir, "test.chr19.XM.sam"))
+    p = str(tmp_path / "rrbs.bam")
+    bamio.write_bam(p, rec)
+    f = hostapi.BamFile(p)
+    assert f.refs == [("chr19", 58617616)]
+    got = f.decode()
+    same_soa(got, pyoracle.Reads.decode(rec).soa())
+    assert (got["fwd"] == 0).sum() == 676 and len(got["tid"]) == 1000
+
+
+def _weird_records():
+    """CIGARs and flags no reference fixture has: indels, clips, ref-skips, =/X, paired flags,
+    a short XM, an unaligned record, three contigs; > 64 KiB so that records straddle BGZF blocks"""
+    M, I, D, N, S, H, P, EQ, X = range(9)
+    rng = np.random.default_rng(99)
+    refs = [("chrA", 100000), ("chrB", 50000), ("chrC", 2000)]
+    tid, pos, flag, mapq, cigars, xms = [], [], [], [], [], []
+
+    def add(t, p, fl, mq, cig, xm=None):
+        qlen = sum(l for op, l in cig if op in (M, I, S, EQ, X))
+        if xm is None:
+            xm = rng.choice(np.frombuffer(b"zZ.hHxX.", dtype=np.uint8), size=qlen).astype(np.uint8).tobytes()
+        tid.append(t); pos.append(p); flag.append(fl); mapq.append(mq)
+        cigars.append([(l << 4) | op for op, l in cig]); xms.append(xm)
+
+    add(0, 10, 0, 40, [(M, 20)], b"Z.z.Z.z.Z.z.Z.z.Z.z.")
+    add(0, 12, 16, 30, [(S, 3), (M, 10), (I, 2), (M, 8), (D, 4), (M, 6), (S, 2)])
+    add(0, 15, 99, 42, [(H, 5), (M, 7), (N, 100), (M, 9), (H, 1)])
+    add(0, 15, 147, 42, [(EQ, 6), (X, 1), (EQ, 8)])
+    add(0, 20, 83, 9, [(M, 12)])                       # paired reverse: "reverse" rule
+    add(0, 20, 163, 60, [(M, 12)])
+    add(0, 30, 0, 40, [(M, 30)], b"zzZZ")              # XM shorter than the query
+    add(0, 40, 16, 40, [(I, 4), (M, 5)])               # leading insertion
+    add(0, 41, 0, 40, [(S, 10)])                       # nothing aligned: start = end = -1
+    add(0, 50, 0, 40, [(M, 5), (P, 2), (M, 5)])
+    for _ in range(3000):
+        t = int(rng.integers(0, 3))
+        ln = refs[t][1]
+        ops = [(M, int(rng.integers(5, 60)))]
+        for _k in range(int(rng.integers(0, 4))):
+            ops.append((int(rng.choice([I, D, N, S, EQ, X])), int(rng.integers(1, 9))))
+            ops.append((M, int(rng.integers(1, 40))))
+        add(t, int(rng.integers(0, ln - 600)), int(rng.choice([0, 16, 99, 147, 83, 163, 1024])), int(rng.integers(0, 61)), ops)
+    order = sorted(range(len(tid)), key=lambda i: (tid[i], pos[i]))
+    return bamio.Records(refs, [tid[i] for i in order], [pos[i] for i in order], [flag[i] for i in order],
+                         [mapq[i] for i in order], [cigars[i] for i in order], [xms[i] for i in order])
+
+
+def test_cigar_and_strand_rules(tmp_path):
+    rec = _weird_records()
+    p = str(tmp_path / "weird.bam")
+    bamio.write_bam(p, rec)
+    assert os.path.getsize(p) > 70000
+    got = hostapi.BamFile(p).decode()
+    want = pyoracle.Reads.decode(rec).soa()
+    same_soa(got, want)
+    assert (got["start"] == -1).any() and (got["fwd"] == 0).any() and (got["fwd"] == 1).any()
+    # the pure-Python loader reads back what it wrote (guards the writer itself)
+    same_soa(pyoracle.Reads.decode(bamio.read_bam(p)).soa(), want)
+
+
+def test_cpg_set_filter(tmp_path):
+    rec = _weird_records()
+    p = str(tmp_path / "weird.bam")
+    bamio.write_bam(p, rec)
+    full = pyoracle.Reads.decode(rec).soa()
+    pos = full["cpg_pos"] & 0x7fffffff
+    tid_of_call = np.repeat(full["tid"], np.diff(full["cpg_off"]).astype(np.int64))
+    rng = np.random.default_rng(3)
+    pick = rng.random(len(pos)) < 0.3
+    sites = sorted(set(zip(tid_of_call[pick].tolist(), pos[pick].tolist())))
+    bed = str(tmp_path / "set.bed")
+    with open(bed, "w") as fh:
+        for t, q in sites:
+            fh.write("%s\t%d\t%d\n" % (rec.refs[t][0], q, q + 2))
+    got = hostapi.BamFile(p).decode(cpg_set=bed)
+    want = pyoracle.Reads.decode(rec, cpg_set=sites).soa()
+    same_soa(got, want)
+    assert 0 < len(got["cpg_pos"]) < len(full["cpg_pos"])
+    # relpos is preserved by the filter (readutil.rs:87-95)
+    assert got["cpg_rel"].max() > 10
+    # an empty set filters every call
+    empty = str(tmp_path / "empty.bed")
+    open(empty, "w").close()
+    assert len(hostapi.BamFile(p).decode(cpg_set=empty)["cpg_pos"]) == 0
+
+
+def test_error_behaviour(golden_dir, tmp_path):
+    # bamutil.rs:7-9 + tests/pdr-cli.rs:26-31
+    with pytest.raises(hostapi.HostError) as e:
+        hostapi.BamFile("tests/no_such.bam")
+    assert "Error opening BAM file" in str(e.value) and "file not found" in str(e.value) and "no_such.bam" in str(e.value)
+    # tests/cli_error_handling.rs:214-227 (a text file) and :327-347 (zero bytes)
+    for content in (b"[package]\nname = \"metheor\"\n", b""):
+        q = tmp_path / "x.bam"
+        q.write_bytes(content)
+        with pytest.raises(hostapi.HostError) as e:
+            hostapi.BamFile(str(q))
+        assert "Error opening BAM file" in str(e.value)
+    # readutil.rs:46,50
+    rec = bamio.read_bam(os.path.join(golden_dir, "test1.bam"))
+    rec.xms[3] = None
+    q = str(tmp_path / "noxm.bam")
+    bamio.write_bam(q, rec)
+    with pytest.raises(hostapi.HostError) as e:
+        hostapi.BamFile(q).decode()
+    assert "Error reading XM tag in BAM record" in str(e.value)
+    with pytest.raises(RuntimeError):
+        pyoracle.Reads.decode(rec)
+    # readutil.rs:356 and the unwrap() on an unknown contig (bamutil.rs:24)
+    f = hostapi.BamFile(os.path.join(golden_dir, "test1.bam"))
+    with pytest.raises(hostapi.HostError) as e:
+        f.decode(cpg_set=str(tmp_path / "nonexistent.bed"))
+    assert "Could not read target CpG file" in str(e.value)
+    bad = tmp_path / "bad.bed"
+    bad.write_text("chrZZ\t5\t7\n")
+    with pytest.raises(hostapi.HostError):
+        hostapi.BamFile(os.path.join(golden_dir, "test1.bam")).decode(cpg_set=str(bad))
+    # a truncated file is an error, not a short result
+    data = open(os.path.join(golden_dir, "test4.bam"), "rb").read()
+    t = tmp_path / "trunc.bam"
+    t.write_bytes(data[:200])
+    with pytest.raises(hostapi.HostError):
+        hostapi.BamFile(str(t)).decode()
+
+
+def test_format_f32_three_ways():
+    """product (std::to_chars) vs oracle (shortest %.Ne search) vs numpy: Rust `{}` of an f32"""
+    cases = {0.875: "0.875", 8.0 / 15.0: "0.53333336", 1.0: "1", 0.0: "0", 0.1625: "0.1625",
+             float("nan"): "NaN", 1e-7: "0.0000001", 0.9375: "0.9375", 1.0 / 3.0: "0.33333334", 16777216.0: "16777216"}
+    for v, s in cases.items():
+        assert hostapi.format_f32(v) == s, (v, hostapi.format_f32(v))
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.random(3000, dtype=np.float32), (rng.random(500, dtype=np.float32) * 1e-4).astype(np.float32),
+                           (rng.integers(0, 1000, 500) / rng.integers(1, 1000, 500)).astype(np.float32)])
+    for v in vals:
+        a = hostapi.format_f32(v)
+        assert a == pyoracle.format_f32(v) == np.format_float_positional(v, unique=True, trim="-"), v
+        assert np.float32(a) == v

@@ -43,3 +43,33 @@ def device_batch(c, region=None, device=None, rel16=False):
                 t[k] = torch.from_numpy(a).to(device)
         arrs = t
     return Batch(c["tid"], beg, end, max_span=shard.max_span(c), **arrs)
+
+
+def contig_to_records(c, name="chrS"):
+    """synthetic contig dict -> oracle.bamio.Records (150M reads with XM strings) so that the same
+    input can be written as a real BAM and pushed through the CLI"""
+    from oracle import bamio
+    n = len(c["read_start"])
+    off = c["cpg_off"].astype(np.int64)
+    rl = int(c["read_end"][0] - c["read_start"][0] + 1) if n else 150
+    xms = []
+    for i in range(n):
+        xm = bytearray(b"." * rl)
+        for k in range(off[i], off[i + 1]):
+            xm[int(c["cpg_rel"][k])] = ord("Z") if (int(c["cpg_pos"][k]) >> 31) else ord("z")
+        xms.append(bytes(xm))
+    flag = np.where(c["read_fwd"] == 1, 0, 16)
+    return bamio.Records([(name, int(c["length"]))], np.zeros(n, np.int32), c["read_start"], flag, c["read_mapq"],
+                         [[(rl << 4) | 0]] * n, xms)
+
+
+def oracle_tsv_pdr(reads, names, **kw):
+    from oracle import pyoracle
+    t = reads.pdr(**kw)
+    return "".join("%s\t%d\t%d\t%s\t%d\t%d\n" % (names[ti], p, p + 2, pyoracle.format_f32(v), c[0], c[1])
+                   for ti, p, v, c in zip(t.tid, t.pos[:, 0], t.val, t.cnt))
+
+
+def oracle_tsv_lpmd(reads, input_name, **kw):
+    from oracle import pyoracle
+    return "name\tlpmd\n%s\t%s\n" % (input_name, pyoracle.format_f32(reads.lpmd(**kw)["lpmd"]))
