@@ -20,7 +20,7 @@
  *                         -> LPMDResult                               => mth_pdr_lpmd_accumulate + mth_lpmd_global (+ mth_lpmd_pairs_fetch)
  *   src/mhl.rs:135-141    mhl::compute_helper(...) -> BTreeMap<CpGPosition,f32>        => mth_mhl_accumulate + mth_mhl_fetch
  *   src/me.rs:90-94       me::compute_helper(input,min_qual,cpg_set) -> HashMap<Quartet,QuartetStat>
- *   src/pm.rs:85-89       pm::compute_helper(...)                                      => mth_quartet_accumulate + mth_quartet_fetch
+ *   src/pm.rs:85-89       pm::compute_helper(...)                                      => mth_quartet_accumulate + mth_quartet_fetch (built)
  *   src/fdrp.rs:176-183   fdrp::compute_helper(input,min_qual,min_depth,max_depth,min_overlap,cpg_set)
  *   src/qfdrp.rs:188-195  qfdrp::compute_helper(...) -> BTreeMap<CpGPosition,f32>      => mth_fdrp_accumulate + mth_fdrp_fetch
  *   src/readutil.rs:15-21 BismarkRead {start_pos,end_pos,cpgs:Vec<CpG{relpos,abspos,methylated}>}
@@ -135,6 +135,21 @@ int  mth_lpmd_export_device(mth_ctx_t *ctx, int64_t *dst_device4);
 /* compute_lpmd() (lpmd.rs:51-55, wrapping-i32 semantics) from summed integer counters, e.g. the
  * all-reduced ones */
 float mth_lpmd_from_counts(int64_t n_concordant, int64_t n_discordant);
+
+/* ---- ME / PM: per-quartet 16-bin epiallele histograms (me.rs:90-132, pm.rs:85-128) ------------
+ * One accumulate serves both measures (they share the histogram).  Requires consecutive CpGs of
+ * a read to be < 2048 bp apart (MTH_ERR_CAPACITY otherwise). */
+typedef struct {
+    uint8_t min_qual;   /* -q 10 (lib.rs:66-68, 90-92) */
+} mth_quartet_params_t;
+int  mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_quartet_params_t *params);
+/* HashMap<Quartet,QuartetStat> rows with read depth >= min_depth (the write-time filter of me.rs:82 /
+ * pm.rs:77; pass 0 for compute_helper's full map).  *n_rows is always set; the arrays may be NULL
+ * (count only) or hold >= *n_rows entries: pos4[n*4] = pos1..pos4, counts16[n*16] = pattern
+ * histogram (pattern = 8*m1+4*m2+2*m3+m4), me = compute_me() (me.rs:42-55), pm = compute_pm()
+ * (pm.rs:42-51).  Row order is deterministic but arbitrary (the reference's is HashMap-random). */
+int  mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int32_t *tid, int32_t *pos4,
+                       uint32_t *counts16, float *me, float *pm);
 
 /* ---- measurement hooks (bench.py's roofline leg) -------------------------------------- */
 /* when enabled, every kernel launch is bracketed by hipEvents on the launch stream */

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmetheor_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip"]
+HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip", "mth_quartet.hip"]
 HOST_LIB = os.path.join(HERE, "libmetheor_host.so")
 HOST_SOURCES = [os.path.join("host", "bam_reader.cpp"), os.path.join("host", "host_api.cpp")]
 HOST_HEADERS = [os.path.join("host", "bam_reader.h"), os.path.join("..", "..", "include", "metheor_host.h")]
@@ -78,7 +78,9 @@ def _build_libs(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall",
+            # -ffp-contract=off: every float this engine emits must equal the reference's UNFUSED f32
+            # expressions (Rust never contracts a*b+c); hipcc's default is contract=fast
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off",
                    "-Wno-unused-result", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))

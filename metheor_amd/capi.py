@@ -14,7 +14,7 @@ SYMBOLS = [
     "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
-    "mth_lpmd_export_device",
+    "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -40,6 +40,10 @@ class mth_pdr_lpmd_params_t(C.Structure):
                 ("pdr_min_qual", C.c_uint8), ("lpmd_min_qual", C.c_uint8),
                 ("want_pdr", C.c_uint8), ("want_lpmd", C.c_uint8),
                 ("lpmd_min_distance", C.c_int32), ("lpmd_max_distance", C.c_int32)]
+
+
+class mth_quartet_params_t(C.Structure):
+    _fields_ = [("min_qual", C.c_uint8)]
 
 
 def library_path():
@@ -79,6 +83,8 @@ def lib():
         L.mth_lpmd_from_counts.restype = C.c_float
         L.mth_lpmd_from_counts.argtypes = [C.c_int64, C.c_int64]
         L.mth_lpmd_export_device.argtypes = [vp, vp]
+        L.mth_quartet_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_quartet_params_t)]
+        L.mth_quartet_fetch.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)] + [vp] * 5
         L.mth_timing_enable.argtypes = [vp, C.c_int]
         L.mth_timing_reset.argtypes = [vp]
         L.mth_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -217,6 +223,21 @@ class Engine:
 
     def lpmd_from_counts(self, n_conc, n_disc):
         return np.float32(self.L.mth_lpmd_from_counts(int(n_conc), int(n_disc)))
+
+    def quartet_accumulate(self, batch, min_qual=10):
+        p = mth_quartet_params_t(min_qual)
+        self._check(self.L.mth_quartet_accumulate(self.h, C.byref(batch.c), C.byref(p)))
+
+    def quartet_fetch(self, min_depth=10):
+        """rows (depth >= min_depth) of the HashMap<Quartet,...>: tid, pos[n,4], cnt[n,16], me, pm"""
+        n = C.c_uint64(0)
+        self._check(self.L.mth_quartet_fetch(self.h, min_depth, C.byref(n), None, None, None, None, None))
+        k = n.value
+        out = dict(tid=np.zeros(k, np.int32), pos=np.zeros((k, 4), np.int32), cnt=np.zeros((k, 16), np.uint32),
+                   me=np.zeros(k, np.float32), pm=np.zeros(k, np.float32))
+        self._check(self.L.mth_quartet_fetch(self.h, min_depth, C.byref(n), *[out[x].ctypes.data_as(C.c_void_p) for x in
+                                                                              ("tid", "pos", "cnt", "me", "pm")]))
+        return out
 
     def timing_enable(self, on=True):
         self._check(self.L.mth_timing_enable(self.h, int(on)))

@@ -257,20 +257,25 @@ mth_ctx_t *make_ctx() {
     return ctx;
 }
 
+mth_batch_t make_batch(const Input &in, const Contig &c) {
+    mth_batch_t b;
+    memset(&b, 0, sizeof b);
+    b.tid = c.tid;
+    b.region_beg = 0;
+    const int64_t len = mth_host_ref_len(in.h, c.tid);
+    b.region_end = (int32_t)std::min<int64_t>(len, INT32_MAX);
+    b.max_span = c.max_span;
+    b.n_reads = (uint32_t)c.start.size();
+    b.n_cpgs = (uint32_t)c.pos.size();
+    b.mem = MTH_MEM_HOST;
+    b.read_start = c.start.data(); b.read_end = c.end.data(); b.read_mapq = c.mapq.data();
+    b.cpg_off = c.off.data(); b.cpg_pos = c.pos.data(); b.cpg_rel16 = c.rel.data();
+    return b;
+}
+
 void submit(mth_ctx_t *ctx, const Input &in, const mth_pdr_lpmd_params_t &p) {
     for (const Contig &c : in.contigs) {
-        mth_batch_t b;
-        memset(&b, 0, sizeof b);
-        b.tid = c.tid;
-        b.region_beg = 0;
-        const int64_t len = mth_host_ref_len(in.h, c.tid);
-        b.region_end = (int32_t)std::min<int64_t>(len, INT32_MAX);
-        b.max_span = c.max_span;
-        b.n_reads = (uint32_t)c.start.size();
-        b.n_cpgs = (uint32_t)c.pos.size();
-        b.mem = MTH_MEM_HOST;
-        b.read_start = c.start.data(); b.read_end = c.end.data(); b.read_mapq = c.mapq.data();
-        b.cpg_off = c.off.data(); b.cpg_pos = c.pos.data(); b.cpg_rel16 = c.rel.data();
+        const mth_batch_t b = make_batch(in, c);
         check(ctx, mth_pdr_lpmd_accumulate(ctx, &b, &p));
     }
 }
@@ -339,6 +344,37 @@ int run_lpmd(const Args &a) {
     return 0;
 }
 
+// me.rs:68-88 / pm.rs:63-83: one line per quartet with depth >= min_depth,
+// chrom, pos1..pos4, value (me.rs:57-65).  The reference iterates a HashMap (random order).
+int run_quartet(const Args &a, bool want_me) {
+    Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
+    mth_ctx_t *ctx = make_ctx();
+    mth_quartet_params_t p;
+    p.min_qual = (uint8_t)a.n.at("min-qual");
+    for (const Contig &c : in.contigs) {
+        const mth_batch_t b = make_batch(in, c);
+        check(ctx, mth_quartet_accumulate(ctx, &b, &p));
+    }
+    const uint32_t min_depth = (uint32_t)a.n.at("min-depth");
+    uint64_t n = 0;
+    check(ctx, mth_quartet_fetch(ctx, min_depth, &n, nullptr, nullptr, nullptr, nullptr, nullptr));
+    std::vector<int32_t> tid(n), pos(n * 4);
+    std::vector<float> val(n);
+    check(ctx, mth_quartet_fetch(ctx, min_depth, &n, tid.data(), pos.data(), nullptr, want_me ? val.data() : nullptr,
+                                 want_me ? nullptr : val.data()));
+    FILE *f = open_output(a.s.at("output"));
+    char fb[64];
+    for (uint64_t i = 0; i < n; ++i) {
+        mth_host_format_f32(val[i], fb);
+        fprintf(f, "%s\t%d\t%d\t%d\t%d\t%s\n", mth_host_ref_name(in.h, tid[i]), pos[4 * i], pos[4 * i + 1],
+                pos[4 * i + 2], pos[4 * i + 3], fb);
+    }
+    if (fclose(f) != 0) die("Error writing to output file.");
+    mth_ctx_destroy(ctx);
+    mth_host_close(in.h);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -355,6 +391,8 @@ int main(int argc, char **argv) {
     const Args a = parse_args(*cmd, argc, argv, 2);
     if (sub == "pdr") return run_pdr(a);
     if (sub == "lpmd") return run_lpmd(a);
+    if (sub == "me") return run_quartet(a, true);
+    if (sub == "pm") return run_quartet(a, false);
     // the reference opens the BAM first; keep its open errors visible before refusing
     if (sub != "tag") {
         mth_host_t *h = nullptr;

@@ -8,7 +8,8 @@
 
 namespace mth {
 
-static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_tile_scan", "k_gather"};
+static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_tile_scan", "k_gather",
+                                          "k_quartet_bound", "k_quartet_insert", "k_quartet_emit"};
 
 int fail(mth_ctx *ctx, int status, const char *what, hipError_t e) {
     if (ctx) {
@@ -81,6 +82,33 @@ static int stage(mth_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, const
     return MTH_OK;
 }
 
+int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &d) {
+    if (b.region_end < b.region_beg || b.max_span < 0) return fail(ctx, MTH_ERR_INVALID, "bad region / max_span");
+    if (b.n_reads && (!b.read_start || !b.read_end || !b.read_mapq || !b.cpg_off))
+        return fail(ctx, MTH_ERR_INVALID, "batch arrays missing");
+    if (b.n_cpgs && (!b.cpg_pos || (!b.cpg_rel == !b.cpg_rel16)))
+        return fail(ctx, MTH_ERR_INVALID, "exactly one of cpg_rel / cpg_rel16 must be given");
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    d = b;
+    if (b.mem == MTH_MEM_HOST) {
+        int rc;
+        const size_t nr = b.n_reads, nc = b.n_cpgs;
+        if ((rc = stage(ctx, ctx->st_start, b.read_start, nr * 4, (const void **)&d.read_start))) return rc;
+        if ((rc = stage(ctx, ctx->st_end, b.read_end, nr * 4, (const void **)&d.read_end))) return rc;
+        if ((rc = stage(ctx, ctx->st_mapq, b.read_mapq, nr, (const void **)&d.read_mapq))) return rc;
+        if ((rc = stage(ctx, ctx->st_off, b.cpg_off, (nr + 1) * 4, (const void **)&d.cpg_off))) return rc;
+        if ((rc = stage(ctx, ctx->st_pos, b.cpg_pos, nc * 4, (const void **)&d.cpg_pos))) return rc;
+        if (b.cpg_rel) { if ((rc = stage(ctx, ctx->st_rel, b.cpg_rel, nc, (const void **)&d.cpg_rel))) return rc; }
+        else { if ((rc = stage(ctx, ctx->st_rel, b.cpg_rel16, nc * 2, (const void **)&d.cpg_rel16))) return rc; }
+        d.read_fwd = nullptr;
+        d.mem = MTH_MEM_DEVICE;
+    } else if (b.mem != MTH_MEM_DEVICE) {
+        return fail(ctx, MTH_ERR_INVALID, "batch.mem");
+    }
+    if (b.n_cpgs == 0 && !d.cpg_rel && !d.cpg_rel16) d.cpg_rel = reinterpret_cast<const uint8_t *>(ctx->d_state);
+    return MTH_OK;
+}
+
 }  // namespace mth
 
 using namespace mth;
@@ -139,7 +167,8 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->st_start, &ctx->st_end, &ctx->st_mapq, &ctx->st_fwd, &ctx->st_off, &ctx->st_pos,
                       &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_base, &ctx->tile_lpmd, &ctx->scratch,
-                      &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd})
+                      &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
+                      &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth})
         b->release();
     for (auto &t : ctx->timed) { (void)hipEventDestroy(t.beg); (void)hipEventDestroy(t.end); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -167,42 +196,26 @@ int mth_reset(mth_ctx_t *ctx) {
     MTH_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream));
     ctx->batches.clear();
     ctx->out_bound = 0;
+    if (ctx->q_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->q_state.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    ctx->q_batches.clear();
+    ctx->q_rows_bound = 0;
     return MTH_OK;
 }
 
 int mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_pdr_lpmd_params_t *params) {
     if (!ctx || !batch || !params) return MTH_ERR_INVALID;
     const mth_batch_t &b = *batch;
-    if (b.region_end < b.region_beg || b.max_span < 0) return fail(ctx, MTH_ERR_INVALID, "bad region / max_span");
-    if (b.n_reads && (!b.read_start || !b.read_end || !b.read_mapq || !b.cpg_off))
-        return fail(ctx, MTH_ERR_INVALID, "batch arrays missing");
-    if (b.n_cpgs && (!b.cpg_pos || (!b.cpg_rel == !b.cpg_rel16)))
-        return fail(ctx, MTH_ERR_INVALID, "exactly one of cpg_rel / cpg_rel16 must be given");
     if (!params->want_pdr && !params->want_lpmd) return fail(ctx, MTH_ERR_INVALID, "nothing requested");
     // pdr.rs:160-177: with reads no longer than the 150-bp flush margin a coordinate-sorted input can
     // never re-open a flushed site, and the stream result equals plain per-site counting.  Longer
     // spans need the segment logic, which this fused path does not implement.
     if (params->want_pdr && b.max_span > PDR_FLUSH_MARGIN)
         return fail(ctx, MTH_ERR_REOPEN, "PDR fast path needs max_span <= 150 (flush re-open semantics)");
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
-
-    mth_batch_t d = b;
-    if (b.mem == MTH_MEM_HOST) {
-        int rc;
-        const size_t nr = b.n_reads, nc = b.n_cpgs;
-        if ((rc = stage(ctx, ctx->st_start, b.read_start, nr * 4, (const void **)&d.read_start))) return rc;
-        if ((rc = stage(ctx, ctx->st_end, b.read_end, nr * 4, (const void **)&d.read_end))) return rc;
-        if ((rc = stage(ctx, ctx->st_mapq, b.read_mapq, nr, (const void **)&d.read_mapq))) return rc;
-        if ((rc = stage(ctx, ctx->st_off, b.cpg_off, (nr + 1) * 4, (const void **)&d.cpg_off))) return rc;
-        if ((rc = stage(ctx, ctx->st_pos, b.cpg_pos, nc * 4, (const void **)&d.cpg_pos))) return rc;
-        if (b.cpg_rel) { if ((rc = stage(ctx, ctx->st_rel, b.cpg_rel, nc, (const void **)&d.cpg_rel))) return rc; }
-        else { if ((rc = stage(ctx, ctx->st_rel, b.cpg_rel16, nc * 2, (const void **)&d.cpg_rel16))) return rc; }
-        d.read_fwd = nullptr;
-        d.mem = MTH_MEM_DEVICE;
-    } else if (b.mem != MTH_MEM_DEVICE) {
-        return fail(ctx, MTH_ERR_INVALID, "batch.mem");
+    mth_batch_t d;
+    {
+        const int rcs = stage_batch(ctx, b, d);
+        if (rcs) return rcs;
     }
-    if (b.n_cpgs == 0 && !d.cpg_rel && !d.cpg_rel16) d.cpg_rel = reinterpret_cast<const uint8_t *>(ctx->d_state);
 
     // result capacity: at most one row per call and per owned position
     if (params->want_pdr) {

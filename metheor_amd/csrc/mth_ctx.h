@@ -1,5 +1,6 @@
 // mth_ctx.h -- host-side context of the engine (private).
 #pragma once
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,12 @@ struct mth_ctx {
     std::vector<mth::BatchMeta> batches;
     size_t batch_cnt_cap = 0;
 
+    // ME / PM (mth_quartet.hip): hash table of the batch in flight + appended result rows
+    mth::DevBuf q_state, q_keys, q_hist, q_blk, q_batch_rows;
+    mth::DevBuf q_pos, q_cnt, q_me, q_pm, q_depth;
+    uint64_t q_cap = 0, q_rows_bound = 0;
+    std::vector<mth::BatchMeta> q_batches;
+
     int tile_variant = 0;        // fastest measured (profiles/r01_tile_variants.md)        // v2 lane=read: 0: 4096/256  1: 2048/512  2: 2048/256  3: 1024/256 ; v3 wave-cooperative: 4: 4096/4w  5: 4096/8w  6: 2048/4w
     bool timing = false;
     std::vector<mth::TimedLaunch> timed;
@@ -72,6 +79,8 @@ struct LaunchTimer {
 };
 
 int sync_and_check(mth_ctx *ctx);   // stream sync + read DevState + map error bits
+// validate a caller batch and make it device-resident (MTH_MEM_HOST arrays go through the staging buffers)
+int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &dev);
 
 // implemented in mth_pdr_lpmd.hip
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p);

@@ -108,8 +108,44 @@ def test_reference_cli_success_cases(tmp_path):
     assert r.returncode != 0
 
 
+def _quartet_lines(tbl, names, fmt_tol=None):
+    return sorted("%s\t%d\t%d\t%d\t%d\t%s" % (names[t], p[0], p[1], p[2], p[3], pyoracle.format_f32(v))
+                  for t, p, v in zip(tbl.tid, tbl.pos, tbl.val))
+
+
+def test_me_pm_cli(golden_dir, tmp_path):
+    """SURVEY 8c derived goldens + sets of lines against the oracle (the reference's row order is
+    HashMap-random: compare as sets).  PM text must match exactly; ME values are compared numerically
+    (1e-6) because the device's log2f may differ in the last ulp."""
+    o = tmp_path / "o.tsv"
+    bam = os.path.join("tests", "golden", "test1.bam")
+    r = run("pm", "-i", bam, "-o", str(o))
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == "chr1\t0\t2\t4\t6\t0.9375\n"
+    r = run("me", "-i", bam, "-o", str(o))
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == "chr1\t0\t2\t4\t6\t1\n"
+    rec = bamio.read_sam(os.path.join(golden_dir, "test.chr19.XM.sam"))
+    rb = str(tmp_path / "rrbs.bam")
+    bamio.write_bam(rb, rec)
+    reads = pyoracle.Reads.decode(rec)
+    r = run("pm", "-i", rb, "-o", str(o), "-d", "3", "-q", "20")
+    assert r.returncode == 0, r.stderr
+    want = _quartet_lines(reads.pm(min_depth=3, min_qual=20), ["chr19"])
+    assert sorted(o.read_text().splitlines()) == want and len(want) > 10
+    r = run("me", "-i", rb, "-o", str(o), "-d", "3", "-q", "20")
+    assert r.returncode == 0, r.stderr
+    got = sorted(o.read_text().splitlines())
+    om = reads.me(min_depth=3, min_qual=20)
+    wl = _quartet_lines(om, ["chr19"])
+    assert len(got) == len(wl)
+    for g, w in zip(got, wl):
+        gf, wf = g.split("\t"), w.split("\t")
+        assert gf[:5] == wf[:5] and abs(float(gf[5]) - float(wf[5])) <= 1e-6
+
+
 def test_unbuilt_measures_fail_loudly(tmp_path):
     bam = os.path.join("tests", "golden", "test1.bam")
-    for sub in ("mhl", "pm", "me", "fdrp", "qfdrp"):
+    for sub in ("mhl", "fdrp", "qfdrp"):
         r = run(sub, "-i", bam, "-o", str(tmp_path / "o.tsv"))
         assert r.returncode != 0 and "no device kernel yet" in r.stderr
