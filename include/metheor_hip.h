@@ -18,7 +18,7 @@
  *                         -> BTreeMap<CpGPosition,(f32,u32,u32)>      => mth_pdr_lpmd_accumulate + mth_pdr_fetch
  *   src/lpmd.rs:154-160   lpmd::compute_helper(input,min_distance,max_distance,min_qual,cpg_set)
  *                         -> LPMDResult                               => mth_pdr_lpmd_accumulate + mth_lpmd_global (+ mth_lpmd_pairs_fetch)
- *   src/mhl.rs:135-141    mhl::compute_helper(...) -> BTreeMap<CpGPosition,f32>        => mth_mhl_accumulate + mth_mhl_fetch
+ *   src/mhl.rs:135-141    mhl::compute_helper(...) -> BTreeMap<CpGPosition,f32>        => mth_mhl_accumulate + mth_mhl_fetch (built)
  *   src/me.rs:90-94       me::compute_helper(input,min_qual,cpg_set) -> HashMap<Quartet,QuartetStat>
  *   src/pm.rs:85-89       pm::compute_helper(...)                                      => mth_quartet_accumulate + mth_quartet_fetch (built)
  *   src/fdrp.rs:176-183   fdrp::compute_helper(input,min_qual,min_depth,max_depth,min_overlap,cpg_set)
@@ -150,6 +150,20 @@ int  mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_
  * (pm.rs:42-51).  Row order is deterministic but arbitrary (the reference's is HashMap-random). */
 int  mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int32_t *tid, int32_t *pos4,
                        uint32_t *counts16, float *me, float *pm);
+
+/* ---- MHL: methylation haplotype load per site (mhl.rs:135-208, 43-73) -------------------------
+ * Exact stream semantics of the reference, including its flush / re-open of sites:
+ * flush on strict '<' by any read with >= 1 CpG, before the mapq / min_cpgs filters.  Reads with
+ * more than 512 CpGs covering a site are refused (MTH_ERR_CAPACITY). */
+typedef struct {
+    uint32_t min_depth;  /* -d 10 */
+    uint32_t min_cpgs;   /* -p 4  */
+    uint8_t  min_qual;   /* -q 10 */
+} mth_mhl_params_t;
+int  mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_params_t *params);
+/* BTreeMap<CpGPosition,f32> rows sorted by (tid,pos); *n_rows always set, arrays may be NULL;
+ * coverage = number of reads of the segment the value comes from */
+int  mth_mhl_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos, float *mhl, uint32_t *coverage);
 
 /* ---- measurement hooks (bench.py's roofline leg) -------------------------------------- */
 /* when enabled, every kernel launch is bracketed by hipEvents on the launch stream */

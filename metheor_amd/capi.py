@@ -14,7 +14,7 @@ SYMBOLS = [
     "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
-    "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch",
+    "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -44,6 +44,10 @@ class mth_pdr_lpmd_params_t(C.Structure):
 
 class mth_quartet_params_t(C.Structure):
     _fields_ = [("min_qual", C.c_uint8)]
+
+
+class mth_mhl_params_t(C.Structure):
+    _fields_ = [("min_depth", C.c_uint32), ("min_cpgs", C.c_uint32), ("min_qual", C.c_uint8)]
 
 
 def library_path():
@@ -85,6 +89,8 @@ def lib():
         L.mth_lpmd_export_device.argtypes = [vp, vp]
         L.mth_quartet_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_quartet_params_t)]
         L.mth_quartet_fetch.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)] + [vp] * 5
+        L.mth_mhl_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_mhl_params_t)]
+        L.mth_mhl_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 4
         L.mth_timing_enable.argtypes = [vp, C.c_int]
         L.mth_timing_reset.argtypes = [vp]
         L.mth_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -237,6 +243,18 @@ class Engine:
                    me=np.zeros(k, np.float32), pm=np.zeros(k, np.float32))
         self._check(self.L.mth_quartet_fetch(self.h, min_depth, C.byref(n), *[out[x].ctypes.data_as(C.c_void_p) for x in
                                                                               ("tid", "pos", "cnt", "me", "pm")]))
+        return out
+
+    def mhl_accumulate(self, batch, min_depth=10, min_cpgs=4, min_qual=10):
+        p = mth_mhl_params_t(min_depth, min_cpgs, min_qual)
+        self._check(self.L.mth_mhl_accumulate(self.h, C.byref(batch.c), C.byref(p)))
+
+    def mhl_fetch(self):
+        n = C.c_uint64(0)
+        self._check(self.L.mth_mhl_fetch(self.h, C.byref(n), None, None, None, None))
+        k = n.value
+        out = dict(tid=np.zeros(k, np.int32), pos=np.zeros(k, np.int32), mhl=np.zeros(k, np.float32), cov=np.zeros(k, np.uint32))
+        self._check(self.L.mth_mhl_fetch(self.h, C.byref(n), *[out[x].ctypes.data_as(C.c_void_p) for x in ("tid", "pos", "mhl", "cov")]))
         return out
 
     def timing_enable(self, on=True):

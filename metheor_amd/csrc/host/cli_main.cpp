@@ -375,6 +375,35 @@ int run_quartet(const Args &a, bool want_me) {
     return 0;
 }
 
+// mhl.rs:101-133: chrom, pos, pos+2, mhl -- sorted by (tid,pos)
+int run_mhl(const Args &a) {
+    Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
+    mth_ctx_t *ctx = make_ctx();
+    mth_mhl_params_t p;
+    p.min_depth = (uint32_t)a.n.at("min-depth");
+    p.min_cpgs = (uint32_t)std::min<int64_t>(a.n.at("min-cpgs"), UINT32_MAX);
+    p.min_qual = (uint8_t)a.n.at("min-qual");
+    for (const Contig &c : in.contigs) {
+        const mth_batch_t b = make_batch(in, c);
+        check(ctx, mth_mhl_accumulate(ctx, &b, &p));
+    }
+    uint64_t n = 0;
+    check(ctx, mth_mhl_fetch(ctx, &n, nullptr, nullptr, nullptr, nullptr));
+    std::vector<int32_t> tid(n), pos(n);
+    std::vector<float> val(n);
+    check(ctx, mth_mhl_fetch(ctx, &n, tid.data(), pos.data(), val.data(), nullptr));
+    FILE *f = open_output(a.s.at("output"));
+    char fb[64];
+    for (uint64_t i = 0; i < n; ++i) {
+        mth_host_format_f32(val[i], fb);
+        fprintf(f, "%s\t%d\t%d\t%s\n", mth_host_ref_name(in.h, tid[i]), pos[i], pos[i] + 2, fb);
+    }
+    if (fclose(f) != 0) die("Error writing to output file.");
+    mth_ctx_destroy(ctx);
+    mth_host_close(in.h);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -391,6 +420,7 @@ int main(int argc, char **argv) {
     const Args a = parse_args(*cmd, argc, argv, 2);
     if (sub == "pdr") return run_pdr(a);
     if (sub == "lpmd") return run_lpmd(a);
+    if (sub == "mhl") return run_mhl(a);
     if (sub == "me") return run_quartet(a, true);
     if (sub == "pm") return run_quartet(a, false);
     // the reference opens the BAM first; keep its open errors visible before refusing

@@ -1,5 +1,6 @@
 // mth_ctx.h -- host-side context of the engine (private).
 #pragma once
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +55,14 @@ struct mth_ctx {
     uint64_t q_cap = 0, q_rows_bound = 0;
     std::vector<mth::BatchMeta> q_batches;
 
+    // site-walk measures (mth_sites.hip): discovery sink, per-candidate work arrays, MHL result rows
+    mth::DevState *d_state2 = nullptr;
+    mth::DevBuf s_pos, s_pdr, s_nc, s_nd, s_batch_cnt;
+    mth::DevBuf w_val, w_cov, w_flags, w_blk;
+    mth::DevBuf m_state, m_pos, m_val, m_cov, m_batch_rows;
+    uint64_t m_cap = 0, m_rows_bound = 0;
+    std::vector<mth::BatchMeta> m_batches;
+
     int tile_variant = 0;        // fastest measured (profiles/r01_tile_variants.md)        // v2 lane=read: 0: 4096/256  1: 2048/512  2: 2048/256  3: 1024/256 ; v3 wave-cooperative: 4: 4096/4w  5: 4096/8w  6: 2048/4w
     bool timing = false;
     std::vector<mth::TimedLaunch> timed;
@@ -82,7 +91,15 @@ int sync_and_check(mth_ctx *ctx);   // stream sync + read DevState + map error b
 // validate a caller batch and make it device-resident (MTH_MEM_HOST arrays go through the staging buffers)
 int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &dev);
 
-// implemented in mth_pdr_lpmd.hip
-int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p);
+// implemented in mth_pdr_lpmd.hip.  sink == nullptr: rows go to the ctx's PDR result columns.
+struct TileSink {
+    DevState *st;          // counters (n_sites / cur_base / n_batches / lpmd) of this sink
+    int32_t *pos;
+    float *pdr;
+    uint32_t *nc, *nd;
+    uint32_t *batch_cnt;
+};
+int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p,
+                    const TileSink *sink = nullptr);
 
 }  // namespace mth

@@ -635,8 +635,16 @@ static void launch_tile_wc(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
         hipLaunchKernelGGL((k_pdr_lpmd_tile_wc<W, NW, RelT, false, true>), dim3(ntiles), dim3(NW * 64), 0, s, a, ntiles);
 }
 
-int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_params_t &p) {
+int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_params_t &p, const TileSink *sink) {
     hipStream_t s = ctx->stream;
+    // where the compacted rows and their counters go: the PDR result columns by default, or a
+    // caller-supplied sink (site discovery for the site-walk measures)
+    DevState *cst = sink ? sink->st : ctx->d_state;
+    uint32_t *bcnt = sink ? sink->batch_cnt : ctx->batch_cnt.as<uint32_t>();
+    int32_t *o_pos = sink ? sink->pos : ctx->out_pos.as<int32_t>();
+    float *o_pdr = sink ? sink->pdr : ctx->out_pdr.as<float>();
+    uint32_t *o_nc = sink ? sink->nc : ctx->out_nc.as<uint32_t>();
+    uint32_t *o_nd = sink ? sink->nd : ctx->out_nd.as<uint32_t>();
     const int variant = ctx->tile_variant;
     const int tile_w = (variant == 0 || variant == 4 || variant == 5) ? 4096 : (variant == 3 ? 1024 : 2048);
     const int64_t region_len = (int64_t)b.region_end - b.region_beg;
@@ -690,14 +698,13 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
         LaunchTimer lt(ctx, K_SCAN);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, ctx->tile_cnt.as<uint32_t>(),
                            ctx->tile_lpmd.as<uint32_t>(), ntiles, ctx->tile_base.as<uint32_t>(),
-                           ctx->batch_cnt.as<uint32_t>(), (int)p.want_lpmd, ctx->d_state);
+                           bcnt, (int)p.want_lpmd, cst);
     }
     if (p.want_pdr) {
         LaunchTimer lt(ctx, K_GATHER);
         hipLaunchKernelGGL(k_gather, dim3(ntiles), dim3(64), 0, s, ctx->scratch.as<SiteRec>(),
-                           ctx->tile_cnt.as<uint32_t>(), ctx->tile_base.as<uint32_t>(), ctx->d_state,
-                           (uint32_t)tile_w, ctx->out_pos.as<int32_t>(), ctx->out_pdr.as<float>(),
-                           ctx->out_nc.as<uint32_t>(), ctx->out_nd.as<uint32_t>());
+                           ctx->tile_cnt.as<uint32_t>(), ctx->tile_base.as<uint32_t>(), cst,
+                           (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
     }
     MTH_HIP(ctx, hipGetLastError());
     return MTH_OK;

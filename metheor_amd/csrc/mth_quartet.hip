@@ -14,6 +14,7 @@
 // sharding needs no exchange.  Rows are emitted in slot order (deterministic; the reference's order
 // is HashMap-random, compare as sets).
 #include "mth_ctx.h"
+#include "mth_scan.h"
 
 namespace mth {
 
@@ -92,44 +93,6 @@ __global__ __launch_bounds__(256) void k_quartet_blockcount(const unsigned long 
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) blk[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-// single block: exclusive scan of the per-block row counts; appends the batch to the totals
-__global__ __launch_bounds__(1024) void k_quartet_scan(uint32_t *__restrict__ blk, uint32_t nblk,
-                                                       unsigned long long *__restrict__ q_total,
-                                                       unsigned long long *__restrict__ q_base,
-                                                       uint32_t *__restrict__ batch_rows, uint32_t batch_idx) {
-    __shared__ uint32_t wsum[17];
-    __shared__ uint32_t running;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) running = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < nblk; b0 += 1024) {
-        const uint32_t i = b0 + tid;
-        const uint32_t v = i < nblk ? blk[i] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        if (lane == 63) wsum[wave + 1] = incl;
-        __syncthreads();
-        if (tid == 0) {
-            wsum[0] = running;
-            for (int w = 1; w <= 16; ++w) wsum[w] += wsum[w - 1];
-        }
-        __syncthreads();
-        if (i < nblk) blk[i] = wsum[wave] + incl - v;
-        __syncthreads();
-        if (tid == 0) running = wsum[16];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        *q_base = *q_total;
-        *q_total += running;
-        batch_rows[batch_idx] = running;
-    }
 }
 
 // me.rs:42-55 and pm.rs:42-51 with the reference's operation order.  Plain operators, and the whole
@@ -267,7 +230,7 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
         LaunchTimer lt(ctx, K_QEMIT);
         hipLaunchKernelGGL(k_quartet_blockcount, dim3(nblk), dim3(256), 0, s, ctx->q_keys.as<unsigned long long>(),
                            n_slots, ctx->q_blk.as<uint32_t>());
-        hipLaunchKernelGGL(k_quartet_scan, dim3(1), dim3(1024), 0, s, ctx->q_blk.as<uint32_t>(), nblk, qs + 1, qs + 2,
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->q_blk.as<uint32_t>(), nblk, qs + 1, qs + 2,
                            ctx->q_batch_rows.as<uint32_t>(), (uint32_t)ctx->q_batches.size());
         hipLaunchKernelGGL(k_quartet_emit, dim3(nblk), dim3(256), 0, s, ctx->q_keys.as<unsigned long long>(),
                            ctx->q_hist.as<uint32_t>(), n_slots, ctx->q_blk.as<uint32_t>(), qs + 2,

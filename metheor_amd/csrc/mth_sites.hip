@@ -1,0 +1,277 @@
+// mth_sites.hip -- "site walk": measures whose reference implementation flushes per-site state while
+// streaming.  Built here: MHL (mhl.rs:135-208, 43-73; readutil.rs:147-164).
+//
+// Exact stream semantics without a stream: all reads that can contribute to site c -- and every
+// read that sits BETWEEN two contributions in file order -- have start in [c-max_span+1, c+1], a
+// contiguous index range of the coordinate-sorted batch.  One thread per site walks that range in
+// file order and applies the reference's loop literally:
+//   flusher k (any read with >= 1 CpG, mhl.rs:162-173) with c < first_cpg(k)  -> the open segment is
+//       finalised (kept only if coverage >= min_depth; a later qualifying segment overwrites it) and
+//       removed; a later contribution re-opens the site
+//   contributor (mapq >= min_qual, n_cpgs >= min_cpgs, has a call at c)       -> coverage, n_r, stretch counts
+//   end of range                                                               -> final flush (mhl.rs:201-205)
+// f32 work follows compute_mhl(): denom accumulated in f32 in read order, terms summed over
+// ascending l (the reference iterates a HashMap: its own order is random), no FMA contraction.
+//
+// Sites come from the tile pipeline run as a site-discovery pass (positions called by >= 1
+// contributor), redirected into a private sink.
+#include "mth_ctx.h"
+#include "mth_scan.h"
+
+namespace mth {
+
+struct WalkArgs {
+    const int32_t  *read_start;
+    const uint8_t  *read_mapq;
+    const uint32_t *cpg_off;
+    const uint32_t *cpg_pos;
+    const uint32_t *idx;
+    const DevState *sites_st;   // n_sites of the discovery pass
+    const int32_t  *site_pos;
+    DevState *st;               // main state (error bits)
+    float    *val;              // per candidate site
+    uint32_t *cov;
+    uint32_t *flags;            // bit0 keep (some segment reached min_depth), bit1 needs the big variant
+    int32_t idx_base, max_span;
+    uint32_t n_reads, min_depth, min_cpgs;
+    uint8_t min_qual;
+};
+
+// LCAP: longest read (in CpGs) the variant can represent.  STATIC: arrays indexed only by unrolled
+// constants -> VGPRs; the big variant indexes dynamically -> scratch (rare sites only).
+template <int LCAP, bool STATIC>
+__global__ __launch_bounds__(256) void k_mhl_walk(const WalkArgs a) {
+    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n_sites; j += gridDim.x * 256) {
+        if (!STATIC && !(a.flags[j] & 2u)) continue;       // big variant: only what the fast one deferred
+        const int32_t c = a.site_pos[j];
+        const uint32_t lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
+        const uint32_t hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        uint32_t S[LCAP];      // S[l-1] = sum over covering reads of count_l   (mhl.rs:36-41)
+        float D[LCAP];         // D[l-1] = sum over covering reads with n_r >= l of (n_r-l+1) as f32   (mhl.rs:53-58)
+#pragma unroll
+        for (int l = 0; l < LCAP; ++l) { S[l] = 0; D[l] = 0.0f; }
+        uint32_t seg_cov = 0, maxn = 0, res_cov = 0;
+        float res = 0.0f;
+        bool have = false, overflow = false;
+        auto finalize = [&]() {   // compute_mhl, mhl.rs:43-73
+            float l_sum = 0.0f;
+            for (uint32_t l = 1; l < maxn + 1; ++l) l_sum = l_sum + (float)l;
+            float mhl = 0.0f;
+            if (STATIC) {
+#pragma unroll
+                for (int l = 1; l <= LCAP; ++l)
+                    if (S[l - 1] > 0) { const float t = ((float)l * (float)S[l - 1]) / D[l - 1]; mhl = mhl + t; }
+            } else {
+                for (uint32_t l = 1; l <= min(maxn, (uint32_t)LCAP); ++l)
+                    if (S[l - 1] > 0) { const float t = ((float)l * (float)S[l - 1]) / D[l - 1]; mhl = mhl + t; }
+            }
+            return mhl / l_sum;
+        };
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+            const uint32_t n = o1 - o0;
+            if (n == 0) continue;                                          // no first CpG: neither flushes nor contributes
+            const int32_t first = (int32_t)(a.cpg_pos[o0] & 0x7fffffffu);
+            if (c < first && seg_cov > 0) {                                // mhl.rs:163-171 (strict '<', before the filters)
+                if (seg_cov >= a.min_depth) { res = finalize(); res_cov = seg_cov; have = true; }
+                seg_cov = 0; maxn = 0;
+#pragma unroll
+                for (int l = 0; l < LCAP; ++l) { S[l] = 0; D[l] = 0.0f; }
+            }
+            if (a.read_mapq[i] < a.min_qual) continue;                     // mhl.rs:176
+            if (n < a.min_cpgs) continue;                                  // mhl.rs:181
+            bool hit = false;                                              // does the read call c ?
+            for (uint32_t k = o0; k < o1; ++k) {
+                const int32_t p = (int32_t)(a.cpg_pos[k] & 0x7fffffffu);
+                if (p == c) { hit = true; break; }
+                if (p > c) break;
+            }
+            if (!hit) continue;
+            if (n > (uint32_t)LCAP) { overflow = true; continue; }         // deferred to the big variant / refused
+            seg_cov += 1;                                                   // add_num_cpgs, mhl.rs:75-80
+            maxn = max(maxn, n);
+            if (STATIC) {
+#pragma unroll
+                for (int l = 1; l <= LCAP; ++l) if (n >= (uint32_t)l) D[l - 1] = D[l - 1] + (float)(n - l + 1);
+            } else {
+                for (uint32_t l = 1; l <= n; ++l) D[l - 1] = D[l - 1] + (float)(n - l + 1);
+            }
+            uint32_t cur = 0;                                               // get_stretch_info, readutil.rs:147-164
+            for (uint32_t k = o0; k < o1; ++k) {
+                if (a.cpg_pos[k] >> 31) {
+                    cur += 1;
+                    if (STATIC) {
+#pragma unroll
+                        for (int l = 1; l <= LCAP; ++l) S[l - 1] += ((uint32_t)l <= cur) ? 1u : 0u;
+                    } else {
+                        for (uint32_t l = 1; l <= cur; ++l) S[l - 1] += 1u;
+                    }
+                } else {
+                    cur = 0;
+                }
+            }
+        }
+        if (seg_cov > 0 && seg_cov >= a.min_depth) { res = finalize(); res_cov = seg_cov; have = true; }   // mhl.rs:201-205
+        if (overflow) {
+            if (STATIC) { a.flags[j] = 2u; continue; }
+            atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);                 // a read with > LCAP CpGs covers the site
+            a.flags[j] = 0u;
+            continue;
+        }
+        a.val[j] = res;
+        a.cov[j] = res_cov;
+        a.flags[j] = have ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mhl_emit(const uint32_t *__restrict__ flags, const int32_t *__restrict__ site_pos,
+                                                  const float *__restrict__ val, const uint32_t *__restrict__ cov,
+                                                  const DevState *__restrict__ sites_st, const uint32_t *__restrict__ blk,
+                                                  const unsigned long long *__restrict__ base,
+                                                  int32_t *__restrict__ out_pos, float *__restrict__ out_val,
+                                                  uint32_t *__restrict__ out_cov) {
+    const uint32_t n = (uint32_t)sites_st->n_sites;
+    const uint32_t s0 = (blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
+    uint32_t m = 0;
+    uint32_t f[SCAN_PER];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) { f[k] = (s0 + k < n) ? (flags[s0 + k] & 1u) : 0u; m += f[k]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    __shared__ uint32_t ws[5];
+    if (lane == 63) ws[wave + 1] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { ws[0] = 0; for (int w = 1; w <= 4; ++w) ws[w] += ws[w - 1]; }
+    __syncthreads();
+    unsigned long long o = *base + blk[blockIdx.x] + ws[wave] + incl - m;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        if (!f[k]) continue;
+        out_pos[o] = site_pos[s0 + k];
+        out_val[o] = val[s0 + k];
+        out_cov[o] = cov[s0 + k];
+        ++o;
+    }
+}
+
+// run the tile pipeline as a site-discovery pass: positions called by >= 1 read that passes
+// (mapq >= min_qual, n_cpgs >= max(min_cpgs,1)) -> ctx->s_pos (sorted), count in ctx->d_state2
+int discover_sites(mth_ctx *ctx, const mth_batch_t &d, uint32_t min_cpgs, uint8_t min_qual, uint64_t &bound) {
+    hipStream_t s = ctx->stream;
+    const uint64_t region_len = (uint64_t)((int64_t)d.region_end - d.region_beg);
+    bound = d.n_cpgs < region_len ? d.n_cpgs : region_len;
+    if (!ctx->d_state2) MTH_HIP(ctx, hipMalloc((void **)&ctx->d_state2, sizeof(DevState)));
+    MTH_HIP(ctx, hipMemsetAsync(ctx->d_state2, 0, sizeof(DevState), s));
+    MTH_HIP(ctx, ctx->s_pos.reserve((bound + 1) * 4, s));
+    MTH_HIP(ctx, ctx->s_pdr.reserve((bound + 1) * 4, s));
+    MTH_HIP(ctx, ctx->s_nc.reserve((bound + 1) * 4, s));
+    MTH_HIP(ctx, ctx->s_nd.reserve((bound + 1) * 4, s));
+    MTH_HIP(ctx, ctx->s_batch_cnt.reserve(16, s));
+    mth_pdr_lpmd_params_t p;
+    memset(&p, 0, sizeof p);
+    p.pdr_min_depth = 0; p.pdr_min_cpgs = min_cpgs; p.pdr_min_qual = min_qual; p.want_pdr = 1;
+    TileSink sink{ctx->d_state2, ctx->s_pos.as<int32_t>(), ctx->s_pdr.as<float>(), ctx->s_nc.as<uint32_t>(),
+                  ctx->s_nd.as<uint32_t>(), ctx->s_batch_cnt.as<uint32_t>()};
+    return launch_pdr_lpmd(ctx, d, p, &sink);
+}
+
+}  // namespace mth
+
+using namespace mth;
+
+extern "C" {
+
+int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_params_t *params) {
+    if (!ctx || !batch || !params) return MTH_ERR_INVALID;
+    mth_batch_t d;
+    int rc = stage_batch(ctx, *batch, d);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    uint64_t bound = 0;
+    if ((rc = discover_sites(ctx, d, params->min_cpgs, params->min_qual, bound))) return rc;
+    if (bound == 0) { ctx->m_batches.push_back(BatchMeta{batch->tid}); bound = 1; }
+    else ctx->m_batches.push_back(BatchMeta{batch->tid});
+    // per-candidate-site work arrays
+    MTH_HIP(ctx, ctx->w_val.reserve(bound * 4, s));
+    MTH_HIP(ctx, ctx->w_cov.reserve(bound * 4, s));
+    MTH_HIP(ctx, ctx->w_flags.reserve(bound * 4, s));
+    // result rows (appended over batches)
+    if (!ctx->m_state.p) {
+        MTH_HIP(ctx, ctx->m_state.reserve(4 * sizeof(unsigned long long), s));
+        MTH_HIP(ctx, hipMemsetAsync(ctx->m_state.p, 0, 4 * sizeof(unsigned long long), s));
+    }
+    const uint64_t need = ctx->m_rows_bound + bound;
+    if (need > ctx->m_cap) {
+        const uint64_t ncap = need + need / 4 + 1024, used = ctx->m_rows_bound;
+        MTH_HIP(ctx, ctx->m_pos.reserve(ncap * 4, s, true, used * 4));
+        MTH_HIP(ctx, ctx->m_val.reserve(ncap * 4, s, true, used * 4));
+        MTH_HIP(ctx, ctx->m_cov.reserve(ncap * 4, s, true, used * 4));
+        ctx->m_cap = ncap;
+    }
+    ctx->m_rows_bound = need;
+    const size_t nb = ctx->m_batches.size() - 1;
+    MTH_HIP(ctx, ctx->m_batch_rows.reserve((nb + 1) * 4, s, true, nb * 4));
+
+    // the walk uses the index the discovery pass just built (same batch, same idx_base arithmetic)
+    const int32_t ext = ((d.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
+    WalkArgs a;
+    a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
+    a.idx = ctx->idx.as<uint32_t>(); a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>();
+    a.st = ctx->d_state; a.val = ctx->w_val.as<float>(); a.cov = ctx->w_cov.as<uint32_t>(); a.flags = ctx->w_flags.as<uint32_t>();
+    a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.n_reads = d.n_reads;
+    a.min_depth = params->min_depth; a.min_cpgs = params->min_cpgs; a.min_qual = params->min_qual;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 255) / 256, 8192);
+    {
+        LaunchTimer lt(ctx, K_MHLWALK);
+        hipLaunchKernelGGL((k_mhl_walk<16, true>), dim3(grid), dim3(256), 0, s, a);
+    }
+    {
+        LaunchTimer lt(ctx, K_MHLWALKBIG);
+        hipLaunchKernelGGL((k_mhl_walk<512, false>), dim3(grid), dim3(256), 0, s, a);
+    }
+    unsigned long long *ms = ctx->m_state.as<unsigned long long>();   // [0] total rows [1] base of the batch
+    const uint32_t nblk = (uint32_t)((bound + 256 * SCAN_PER - 1) / (256 * SCAN_PER));
+    MTH_HIP(ctx, ctx->w_blk.reserve((size_t)nblk * 4, s));
+    {
+        LaunchTimer lt(ctx, K_MHLEMIT);
+        hipLaunchKernelGGL(k_flags_blockcount, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
+                           (const unsigned long long *)&ctx->d_state2->n_sites, ctx->w_blk.as<uint32_t>());
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk, ms, ms + 1,
+                           ctx->m_batch_rows.as<uint32_t>(), (uint32_t)nb);
+        hipLaunchKernelGGL(k_mhl_emit, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
+                           ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->d_state2, ctx->w_blk.as<uint32_t>(),
+                           ms + 1, ctx->m_pos.as<int32_t>(), ctx->m_val.as<float>(), ctx->m_cov.as<uint32_t>());
+    }
+    MTH_HIP(ctx, hipGetLastError());
+    return MTH_OK;
+}
+
+int mth_mhl_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos, float *mhl, uint32_t *coverage) {
+    if (!ctx) return MTH_ERR_INVALID;
+    int rc = sync_and_check(ctx);
+    if (rc) return rc;
+    unsigned long long ms[2] = {0, 0};
+    if (ctx->m_state.p) MTH_HIP(ctx, hipMemcpy(ms, ctx->m_state.p, sizeof ms, hipMemcpyDeviceToHost));
+    const uint64_t n = ms[0];
+    if (n_rows) *n_rows = n;
+    if (n == 0) return MTH_OK;
+    if (pos) MTH_HIP(ctx, hipMemcpy(pos, ctx->m_pos.p, n * 4, hipMemcpyDeviceToHost));
+    if (mhl) MTH_HIP(ctx, hipMemcpy(mhl, ctx->m_val.p, n * 4, hipMemcpyDeviceToHost));
+    if (coverage) MTH_HIP(ctx, hipMemcpy(coverage, ctx->m_cov.p, n * 4, hipMemcpyDeviceToHost));
+    if (tid) {
+        std::vector<uint32_t> rows(ctx->m_batches.size());
+        if (!rows.empty()) MTH_HIP(ctx, hipMemcpy(rows.data(), ctx->m_batch_rows.p, rows.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t o = 0;
+        for (size_t b = 0; b < rows.size(); ++b)
+            for (uint32_t j = 0; j < rows[b]; ++j) tid[o++] = ctx->m_batches[b].tid;
+    }
+    return MTH_OK;
+}
+
+}  // extern "C"

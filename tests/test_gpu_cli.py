@@ -144,8 +144,25 @@ def test_me_pm_cli(golden_dir, tmp_path):
         assert gf[:5] == wf[:5] and abs(float(gf[5]) - float(wf[5])) <= 1e-6
 
 
+def test_mhl_cli(golden_dir, tmp_path):
+    o = tmp_path / "o.tsv"
+    bam = os.path.join("tests", "golden", "test1.bam")
+    r = run("mhl", "-i", bam, "-o", str(o))
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == "".join("chr1\t%d\t%d\t0.1625\n" % (p, p + 2) for p in (0, 2, 4, 6))
+    rec = bamio.read_sam(os.path.join(golden_dir, "test.chr19.XM.sam"))
+    rb = str(tmp_path / "rrbs.bam")
+    bamio.write_bam(rb, rec)
+    reads = pyoracle.Reads.decode(rec)
+    r = run("mhl", "-i", rb, "-o", str(o), "-d", "3", "-p", "2")
+    assert r.returncode == 0, r.stderr
+    t = reads.mhl(min_depth=3, min_cpgs=2, min_qual=10)
+    want = "".join("chr19\t%d\t%d\t%s\n" % (p, p + 2, pyoracle.format_f32(v)) for p, v in zip(t.pos[:, 0], t.val))
+    assert o.read_text() == want and want.count("\n") > 20
+
+
 def test_unbuilt_measures_fail_loudly(tmp_path):
     bam = os.path.join("tests", "golden", "test1.bam")
-    for sub in ("mhl", "fdrp", "qfdrp"):
+    for sub in ("fdrp", "qfdrp"):
         r = run(sub, "-i", bam, "-o", str(tmp_path / "o.tsv"))
         assert r.returncode != 0 and "no device kernel yet" in r.stderr
