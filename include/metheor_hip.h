@@ -46,8 +46,7 @@ enum {
     MTH_ERR_NO_DEVICE = -3, /* no gfx950 device: there is no CPU fallback */
     MTH_ERR_UNSORTED = -4,  /* reads of a batch are not sorted by start */
     MTH_ERR_SPAN = -5,      /* a read spans more than batch.max_span */
-    MTH_ERR_REOPEN = -6,    /* input needs the flush re-open semantics on a path that
-                               does not implement them yet */
+    MTH_ERR_REOPEN = -6,    /* reserved (was: flush re-open semantics not implemented; they are now) */
     MTH_ERR_RANGE = -7,     /* a CpG of an owned site lies outside what the batch declared */
     MTH_ERR_CAPACITY = -8,  /* an on-chip capacity was exceeded */
     MTH_ERR_STATE = -9      /* call order violated */

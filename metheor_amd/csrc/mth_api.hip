@@ -10,7 +10,7 @@ namespace mth {
 
 static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_tile_scan", "k_gather",
                                           "k_quartet_bound", "k_quartet_insert", "k_quartet_emit",
-                                          "k_mhl_walk", "k_mhl_walk_big", "k_mhl_emit"};
+                                          "k_mhl_walk", "k_mhl_walk_big", "k_mhl_emit", "k_pdr_walk"};
 
 int fail(mth_ctx *ctx, int status, const char *what, hipError_t e) {
     if (ctx) {
@@ -170,7 +170,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
                       &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_base, &ctx->tile_lpmd, &ctx->scratch,
                       &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
                       &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
-                      &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_flags,
+                      &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_aux, &ctx->w_flags,
                       &ctx->w_blk, &ctx->m_state, &ctx->m_pos, &ctx->m_val, &ctx->m_cov, &ctx->m_batch_rows})
         b->release();
     for (auto &t : ctx->timed) { (void)hipEventDestroy(t.beg); (void)hipEventDestroy(t.end); }
@@ -214,10 +214,9 @@ int mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_
     const mth_batch_t &b = *batch;
     if (!params->want_pdr && !params->want_lpmd) return fail(ctx, MTH_ERR_INVALID, "nothing requested");
     // pdr.rs:160-177: with reads no longer than the 150-bp flush margin a coordinate-sorted input can
-    // never re-open a flushed site, and the stream result equals plain per-site counting.  Longer
-    // spans need the segment logic, which this fused path does not implement.
-    if (params->want_pdr && b.max_span > PDR_FLUSH_MARGIN)
-        return fail(ctx, MTH_ERR_REOPEN, "PDR fast path needs max_span <= 150 (flush re-open semantics)");
+    // never re-open a flushed site, and the stream result equals plain per-site counting (the fused
+    // tile kernel).  Longer spans take the exact site walk (mth_sites.hip) for the PDR half.
+    const bool pdr_exact = params->want_pdr && b.max_span > PDR_FLUSH_MARGIN;
     mth_batch_t d;
     {
         const int rcs = stage_batch(ctx, b, d);
@@ -245,8 +244,21 @@ int mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_
         ctx->out_bound += add;
     }
     MTH_HIP(ctx, ctx->batch_cnt.reserve((ctx->batches.size() + 1) * 4, ctx->stream, true, ctx->batches.size() * 4));
-    int rc = launch_pdr_lpmd(ctx, d, *params);
-    if (rc) return rc;
+    int rc;
+    if (!pdr_exact) {
+        if ((rc = launch_pdr_lpmd(ctx, d, *params))) return rc;
+        ctx->batches.push_back(BatchMeta{b.tid});
+        return MTH_OK;
+    }
+    // every pass appends one (possibly empty) entry to the per-batch row counts: keep host and device in step
+    MTH_HIP(ctx, ctx->batch_cnt.reserve((ctx->batches.size() + 2) * 4, ctx->stream, true, ctx->batches.size() * 4));
+    if (params->want_lpmd) {
+        mth_pdr_lpmd_params_t lp = *params;
+        lp.want_pdr = 0;
+        if ((rc = launch_pdr_lpmd(ctx, d, lp))) return rc;
+        ctx->batches.push_back(BatchMeta{b.tid});
+    }
+    if ((rc = launch_pdr_exact(ctx, d, *params))) return rc;
     ctx->batches.push_back(BatchMeta{b.tid});
     return MTH_OK;
 }

@@ -58,7 +58,7 @@ struct mth_ctx {
     // site-walk measures (mth_sites.hip): discovery sink, per-candidate work arrays, MHL result rows
     mth::DevState *d_state2 = nullptr;
     mth::DevBuf s_pos, s_pdr, s_nc, s_nd, s_batch_cnt;
-    mth::DevBuf w_val, w_cov, w_flags, w_blk;
+    mth::DevBuf w_val, w_cov, w_aux, w_flags, w_blk;
     mth::DevBuf m_state, m_pos, m_val, m_cov, m_batch_rows;
     uint64_t m_cap = 0, m_rows_bound = 0;
     std::vector<mth::BatchMeta> m_batches;
@@ -90,6 +90,8 @@ struct LaunchTimer {
 int sync_and_check(mth_ctx *ctx);   // stream sync + read DevState + map error bits
 // validate a caller batch and make it device-resident (MTH_MEM_HOST arrays go through the staging buffers)
 int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &dev);
+// implemented in mth_sites.hip: PDR with exact flush / re-open semantics (spans > 150 bp)
+int launch_pdr_exact(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p);
 
 // implemented in mth_pdr_lpmd.hip.  sink == nullptr: rows go to the ctx's PDR result columns.
 struct TileSink {

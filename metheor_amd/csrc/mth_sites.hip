@@ -160,6 +160,94 @@ __global__ __launch_bounds__(256) void k_mhl_emit(const uint32_t *__restrict__ f
     }
 }
 
+// ---- PDR with the exact flush / re-open semantics (pdr.rs:139-210) ------------------------------
+// Used when a read spans more than the 150-bp flush margin, where plain per-site counting (the
+// fused tile kernel) is no longer equivalent to the stream.  Only PASSING reads (n_cpgs >= min_cpgs,
+// mapq >= min_qual, >= 1 CpG) flush, and a site c is flushed when c + 150 < first_cpg (pdr.rs:162).
+struct PdrWalkArgs {
+    const uint8_t  *read_mapq;
+    const uint32_t *cpg_off;
+    const uint32_t *cpg_pos;
+    const uint32_t *idx;
+    const DevState *sites_st;
+    const int32_t  *site_pos;
+    float    *pdr;
+    uint32_t *nc, *nd, *flags;
+    int32_t idx_base, max_span;
+    uint32_t n_reads, min_depth, min_cpgs;
+    uint8_t min_qual;
+};
+
+__global__ __launch_bounds__(256) void k_pdr_walk(const PdrWalkArgs a) {
+    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n_sites; j += gridDim.x * 256) {
+        const int32_t c = a.site_pos[j];
+        const uint32_t lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
+        const uint32_t hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        uint32_t sc = 0, sd = 0, rc = 0, rd = 0;
+        bool have = false;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+            const uint32_t n = o1 - o0;
+            if (n < a.min_cpgs || n == 0) continue;                       // pdr.rs:147, 155
+            if (a.read_mapq[i] < a.min_qual) continue;                    // pdr.rs:150
+            const uint32_t w0 = a.cpg_pos[o0];
+            const int32_t first = (int32_t)(w0 & 0x7fffffffu);
+            if (c + PDR_FLUSH_MARGIN < first && (sc + sd) > 0) {          // pdr.rs:160-177 is_before(first,150)
+                if (sc + sd >= a.min_depth) { rc = sc; rd = sd; have = true; }
+                sc = 0; sd = 0;
+            }
+            bool hit = false;
+            uint32_t disc = 0;                                            // readutil.rs:134-145
+            for (uint32_t k = o0; k < o1; ++k) {
+                const uint32_t w = a.cpg_pos[k];
+                hit |= (int32_t)(w & 0x7fffffffu) == c;
+                disc |= (w ^ w0) >> 31;
+            }
+            if (!hit) continue;
+            if (disc) sd += 1; else sc += 1;                               // pdr.rs:180-191
+        }
+        if ((sc + sd) > 0 && sc + sd >= a.min_depth) { rc = sc; rd = sd; have = true; }   // pdr.rs:199-210
+        a.nc[j] = rc; a.nd[j] = rd;
+        a.pdr[j] = (float)rd / ((float)rc + (float)rd);                   // pdr.rs:47-49
+        a.flags[j] = have ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pdr_walk_emit(const uint32_t *__restrict__ flags, const int32_t *__restrict__ site_pos,
+                                                       const float *__restrict__ pdr, const uint32_t *__restrict__ nc,
+                                                       const uint32_t *__restrict__ nd, const DevState *__restrict__ sites_st,
+                                                       const uint32_t *__restrict__ blk, DevState *__restrict__ st,
+                                                       int32_t *__restrict__ out_pos, float *__restrict__ out_pdr,
+                                                       uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
+    const uint32_t n = (uint32_t)sites_st->n_sites;
+    const uint32_t s0 = (blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
+    uint32_t m = 0, f[SCAN_PER];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) { f[k] = (s0 + k < n) ? (flags[s0 + k] & 1u) : 0u; m += f[k]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    __shared__ uint32_t ws[5];
+    if (lane == 63) ws[wave + 1] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { ws[0] = 0; for (int w = 1; w <= 4; ++w) ws[w] += ws[w - 1]; }
+    __syncthreads();
+    unsigned long long o = st->cur_base + blk[blockIdx.x] + ws[wave] + incl - m;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        if (!f[k]) continue;
+        out_pos[o] = site_pos[s0 + k]; out_pdr[o] = pdr[s0 + k]; out_nc[o] = nc[s0 + k]; out_nd[o] = nd[s0 + k];
+        ++o;
+    }
+}
+
+__global__ void k_bump_batches(DevState *st) { st->n_batches += 1; }
+
 // run the tile pipeline as a site-discovery pass: positions called by >= 1 read that passes
 // (mapq >= min_qual, n_cpgs >= max(min_cpgs,1)) -> ctx->s_pos (sorted), count in ctx->d_state2
 int discover_sites(mth_ctx *ctx, const mth_batch_t &d, uint32_t min_cpgs, uint8_t min_qual, uint64_t &bound) {
@@ -179,6 +267,47 @@ int discover_sites(mth_ctx *ctx, const mth_batch_t &d, uint32_t min_cpgs, uint8_
     TileSink sink{ctx->d_state2, ctx->s_pos.as<int32_t>(), ctx->s_pdr.as<float>(), ctx->s_nc.as<uint32_t>(),
                   ctx->s_nd.as<uint32_t>(), ctx->s_batch_cnt.as<uint32_t>()};
     return launch_pdr_lpmd(ctx, d, p, &sink);
+}
+
+// exact PDR of one batch appended to the ctx's PDR result columns (capacity reserved by the caller)
+int launch_pdr_exact(mth_ctx *ctx, const mth_batch_t &d, const mth_pdr_lpmd_params_t &p) {
+    hipStream_t s = ctx->stream;
+    uint64_t bound = 0;
+    int rc = discover_sites(ctx, d, p.pdr_min_cpgs, p.pdr_min_qual, bound);
+    if (rc) return rc;
+    if (bound == 0) bound = 1;
+    MTH_HIP(ctx, ctx->w_val.reserve(bound * 4, s));
+    MTH_HIP(ctx, ctx->w_cov.reserve(bound * 4, s));
+    MTH_HIP(ctx, ctx->w_aux.reserve(bound * 4, s));
+    MTH_HIP(ctx, ctx->w_flags.reserve(bound * 4, s));
+    const int32_t ext = ((d.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
+    PdrWalkArgs a;
+    a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos; a.idx = ctx->idx.as<uint32_t>();
+    a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>();
+    a.pdr = ctx->w_val.as<float>(); a.nc = ctx->w_cov.as<uint32_t>(); a.nd = ctx->w_aux.as<uint32_t>();
+    a.flags = ctx->w_flags.as<uint32_t>();
+    a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.n_reads = d.n_reads;
+    a.min_depth = p.pdr_min_depth; a.min_cpgs = p.pdr_min_cpgs; a.min_qual = p.pdr_min_qual;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 255) / 256, 8192);
+    const uint32_t nblk = (uint32_t)((bound + 256 * SCAN_PER - 1) / (256 * SCAN_PER));
+    MTH_HIP(ctx, ctx->w_blk.reserve((size_t)nblk * 4, s));
+    {
+        LaunchTimer lt(ctx, K_PDRWALK);
+        hipLaunchKernelGGL(k_pdr_walk, dim3(grid), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_flags_blockcount, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
+                           (const unsigned long long *)&ctx->d_state2->n_sites, ctx->w_blk.as<uint32_t>());
+        // totals live in the main DevState: n_sites is the running total, cur_base the batch's base
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk,
+                           (unsigned long long *)&ctx->d_state->n_sites, (unsigned long long *)&ctx->d_state->cur_base,
+                           ctx->batch_cnt.as<uint32_t>(), (uint32_t)ctx->batches.size());
+        hipLaunchKernelGGL(k_pdr_walk_emit, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
+                           ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->w_aux.as<uint32_t>(), ctx->d_state2,
+                           ctx->w_blk.as<uint32_t>(), ctx->d_state, ctx->out_pos.as<int32_t>(), ctx->out_pdr.as<float>(),
+                           ctx->out_nc.as<uint32_t>(), ctx->out_nd.as<uint32_t>());
+        hipLaunchKernelGGL(k_bump_batches, dim3(1), dim3(1), 0, s, ctx->d_state);
+    }
+    MTH_HIP(ctx, hipGetLastError());
+    return MTH_OK;
 }
 
 }  // namespace mth

@@ -191,15 +191,66 @@ def test_edge_cases(eng):
     with pytest.raises(MthError) as e:
         eng.pdr_count()
     assert e.value.status == -5
-    # spans beyond the 150-bp flush margin need re-open semantics: refused, never silently wrong
     eng.reset()
-    bt = util.device_batch(c)
-    bt.c.max_span = 151
-    with pytest.raises(MthError) as e:
-        eng.pdr_lpmd_accumulate(bt, PdrLpmdParams())
-    assert e.value.status == -6
-    eng.pdr_lpmd_accumulate(bt, PdrLpmdParams(want_pdr=False))   # LPMD alone has no flush
-    eng.reset()
+
+
+# ---- spans beyond the 150-bp flush margin: the exact site walk (flush / re-open, pdr.rs:160-177) ------
+def test_pdr_reopen_hand_built(eng):
+    """read B (passing, span 400) starts before site c=1000 but its FIRST CpG is at 1200 > c+150: it
+    flushes c; read C then contributes to c again and re-opens it.  Last segment with coverage >=
+    min_depth wins; a shallow later segment does not erase an earlier qualifying one."""
+    from metheor_amd import PdrLpmdParams, synth
+    def contig(rows):
+        start = np.array([r[0] for r in rows], np.int32)
+        end = np.array([r[1] for r in rows], np.int32)
+        off = np.zeros(len(rows) + 1, np.uint32)
+        pos, rel = [], []
+        for i, r in enumerate(rows):
+            for (p, m) in r[2]:
+                pos.append(p | (int(m) << 31)); rel.append(p - r[0])
+            off[i + 1] = len(pos)
+        return dict(tid=0, length=50_000, read_start=start, read_end=end, read_mapq=np.full(len(rows), 40, np.uint8),
+                    read_fwd=np.ones(len(rows), np.uint8), cpg_off=off, cpg_pos=np.array(pos, np.uint32),
+                    cpg_rel=np.array(rel, np.uint16))
+    rows = [(990, 1089, [(1000, 1), (1010, 1)])] * 3                  # segment 1: 3 concordant reads on c=1000
+    rows += [(995, 1394, [(1200, 1), (1300, 0)])]                      # B: first CpG 1200 > 1000+150 -> flush
+    rows += [(999, 1098, [(1000, 1), (1010, 0)])] * 2                  # segment 2: 2 discordant reads re-open c
+    c = contig(rows)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    for md in (0, 2, 3):
+        kw = dict(min_depth=md, min_cpgs=0, min_qual=10)
+        p, l = run_device(eng, [c], PdrLpmdParams(**kw))
+        check_against_oracle(p, l, reads, kw, dict())
+        row = {int(q): (int(a), int(b)) for q, a, b in zip(p["pos"], p["n_concordant"], p["n_discordant"])}
+        assert row[1000] == ((0, 2) if md <= 2 else (3, 0))
+
+
+def test_pdr_long_spans_vs_oracle(eng):
+    """400-bp reads (span > 150): sites are flushed and re-opened in the reference's stream; the device
+    takes the site-walk path for PDR and the tile kernel for LPMD, in one accumulate call"""
+    from metheor_amd import PdrLpmdParams, shard, synth
+    rng = np.random.default_rng(51)
+    cs = [synth.make_contig(0, 400_000, 30_000, 0.02, rng, read_len=400), synth.make_contig(1, 200_000, 9_000, 0.03, rng, read_len=400)]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    nrows = []
+    for kw in (dict(min_depth=10, min_cpgs=4, min_qual=10), dict(min_depth=0, min_cpgs=0, min_qual=0), dict(min_depth=40, min_cpgs=8, min_qual=10)):
+        p, l = run_device(eng, cs, PdrLpmdParams(**kw))
+        check_against_oracle(p, l, reads, kw, dict())
+        nrows.append(len(p["pos"]))
+    assert nrows[0] > 1000 and nrows[1] > nrows[0] and nrows[2] > 0      # not vacuous
+    # the stream really re-opens sites here: plain pooled counting differs from the oracle somewhere
+    kw = dict(min_depth=0, min_cpgs=0, min_qual=0)
+    o = reads.pdr(**kw)
+    pooled = np.bincount((cs[0]["cpg_pos"] & 0x7fffffff).astype(np.int64), minlength=cs[0]["length"])
+    sel = o.tid == 0
+    assert (pooled[o.pos[sel, 0]] != o.cnt[sel].sum(1)).sum() > 0
+    # region-split batches of the long-span contig give the same rows; PDR-only and LPMD-only too
+    regions = [shard.plan_regions(cs[0], 3), [(0, cs[1]["length"])]]
+    kw = dict(min_depth=10, min_cpgs=4, min_qual=10)
+    p2, l2 = run_device(eng, cs, PdrLpmdParams(**kw), regions=regions)
+    check_against_oracle(p2, l2, reads, kw, dict())
+    p3, _ = run_device(eng, cs, PdrLpmdParams(want_lpmd=False, **kw))
+    assert (p3["pos"] == p2["pos"]).all() and (p3["n_discordant"] == p2["n_discordant"]).all()
 
 
 # ---- BASELINE config 2 at full size: size-independent properties ----------------------------------
@@ -261,8 +312,8 @@ def test_dense_cpg_chunks(eng):
 
 
 def test_long_reads_lpmd_only(eng):
-    """6-kbp reads with > 1024 calls each (16-bit relpos): the single-read memory path; PDR is
-    refused for spans > 150 (re-open semantics), LPMD has no flush and must still be exact"""
+    """6-kbp reads with > 1024 calls each (16-bit relpos): the LPMD-only launch of the tile kernel
+    (and, under MTH_TILE_VARIANT=4..6, the wave-cooperative kernel's single-read memory path)"""
     from metheor_amd import PdrLpmdParams, synth
     rng = np.random.default_rng(22)
     c = synth.make_contig(0, 400_000, 600, 0.3, rng, read_len=6000)
