@@ -22,7 +22,7 @@
  *   src/me.rs:90-94       me::compute_helper(input,min_qual,cpg_set) -> HashMap<Quartet,QuartetStat>
  *   src/pm.rs:85-89       pm::compute_helper(...)                                      => mth_quartet_accumulate + mth_quartet_fetch (built)
  *   src/fdrp.rs:176-183   fdrp::compute_helper(input,min_qual,min_depth,max_depth,min_overlap,cpg_set)
- *   src/qfdrp.rs:188-195  qfdrp::compute_helper(...) -> BTreeMap<CpGPosition,f32>      => mth_fdrp_accumulate + mth_fdrp_fetch
+ *   src/qfdrp.rs:188-195  qfdrp::compute_helper(...) -> BTreeMap<CpGPosition,f32>      => mth_fdrp_accumulate + mth_fdrp_fetch (built)
  *   src/readutil.rs:15-21 BismarkRead {start_pos,end_pos,cpgs:Vec<CpG{relpos,abspos,methylated}>}
  *                                                                                      => mth_batch_t (SoA)
  */
@@ -163,6 +163,24 @@ int  mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_
 /* BTreeMap<CpGPosition,f32> rows sorted by (tid,pos); *n_rows always set, arrays may be NULL;
  * coverage = number of reads of the segment the value comes from */
 int  mth_mhl_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos, float *mhl, uint32_t *coverage);
+
+/* ---- FDRP and qFDRP (fdrp.rs:176-246, qfdrp.rs:188-258): both from one pass ---------------------
+ * Exact stream semantics (strict '<' flush by reads passing mapq with >= 1 CpG, +-201-bp window
+ * drop, fill to max_depth in file order).  Beyond max_depth the reference replaces stored reads at
+ * random from an OS-seeded RNG (fdrp.rs:90) -- not reproducible; here the draw is the counter-based
+ * hash of (seed, tid, pos, n-th read) shared with the test oracle.  max_depth <= 64. */
+typedef struct {
+    uint64_t min_depth;    /* -d 10 */
+    uint64_t seed;         /* reservoir draws; any value */
+    uint32_t max_depth;    /* -D 40 */
+    int32_t  min_overlap;  /* -l 35 */
+    uint8_t  min_qual;     /* -q 10 */
+} mth_fdrp_params_t;
+int  mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp_params_t *params);
+/* BTreeMap<CpGPosition,f32> rows of BOTH measures, sorted by (tid,pos); n_reads = num_sampled_read of
+ * the segment the values come from; *n_rows always set, arrays may be NULL */
+int  mth_fdrp_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos, float *fdrp, float *qfdrp,
+                    uint32_t *n_reads);
 
 /* ---- measurement hooks (bench.py's roofline leg) -------------------------------------- */
 /* when enabled, every kernel launch is bracketed by hipEvents on the launch stream */

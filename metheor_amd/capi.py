@@ -14,7 +14,7 @@ SYMBOLS = [
     "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
-    "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch",
+    "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -48,6 +48,11 @@ class mth_quartet_params_t(C.Structure):
 
 class mth_mhl_params_t(C.Structure):
     _fields_ = [("min_depth", C.c_uint32), ("min_cpgs", C.c_uint32), ("min_qual", C.c_uint8)]
+
+
+class mth_fdrp_params_t(C.Structure):
+    _fields_ = [("min_depth", C.c_uint64), ("seed", C.c_uint64), ("max_depth", C.c_uint32),
+                ("min_overlap", C.c_int32), ("min_qual", C.c_uint8)]
 
 
 def library_path():
@@ -91,6 +96,8 @@ def lib():
         L.mth_quartet_fetch.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)] + [vp] * 5
         L.mth_mhl_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_mhl_params_t)]
         L.mth_mhl_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 4
+        L.mth_fdrp_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_fdrp_params_t)]
+        L.mth_fdrp_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 5
         L.mth_timing_enable.argtypes = [vp, C.c_int]
         L.mth_timing_reset.argtypes = [vp]
         L.mth_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -255,6 +262,20 @@ class Engine:
         k = n.value
         out = dict(tid=np.zeros(k, np.int32), pos=np.zeros(k, np.int32), mhl=np.zeros(k, np.float32), cov=np.zeros(k, np.uint32))
         self._check(self.L.mth_mhl_fetch(self.h, C.byref(n), *[out[x].ctypes.data_as(C.c_void_p) for x in ("tid", "pos", "mhl", "cov")]))
+        return out
+
+    def fdrp_accumulate(self, batch, min_qual=10, min_depth=10, max_depth=40, min_overlap=35, seed=0):
+        p = mth_fdrp_params_t(min_depth, seed, max_depth, min_overlap, min_qual)
+        self._check(self.L.mth_fdrp_accumulate(self.h, C.byref(batch.c), C.byref(p)))
+
+    def fdrp_fetch(self):
+        n = C.c_uint64(0)
+        self._check(self.L.mth_fdrp_fetch(self.h, C.byref(n), None, None, None, None, None))
+        k = n.value
+        out = dict(tid=np.zeros(k, np.int32), pos=np.zeros(k, np.int32), fdrp=np.zeros(k, np.float32),
+                   qfdrp=np.zeros(k, np.float32), n_reads=np.zeros(k, np.uint32))
+        self._check(self.L.mth_fdrp_fetch(self.h, C.byref(n), *[out[x].ctypes.data_as(C.c_void_p) for x in
+                                                                ("tid", "pos", "fdrp", "qfdrp", "n_reads")]))
         return out
 
     def timing_enable(self, on=True):

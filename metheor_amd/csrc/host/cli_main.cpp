@@ -404,6 +404,40 @@ int run_mhl(const Args &a) {
     return 0;
 }
 
+// fdrp.rs:148-174 / qfdrp.rs:160-186: chrom, pos, pos+2, value -- sorted by (tid,pos)
+int run_fdrp(const Args &a, bool quantitative) {
+    Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
+    mth_ctx_t *ctx = make_ctx();
+    mth_fdrp_params_t p;
+    memset(&p, 0, sizeof p);
+    p.min_qual = (uint8_t)a.n.at("min-qual");
+    p.min_depth = (uint64_t)a.n.at("min-depth");
+    p.max_depth = (uint32_t)std::min<int64_t>(a.n.at("max-depth"), UINT32_MAX);
+    p.min_overlap = (int32_t)a.n.at("min-overlap");
+    const char *seed = getenv("METHEOR_SEED");       // reservoir draws (the reference's are OS-seeded)
+    p.seed = seed ? strtoull(seed, nullptr, 10) : 0;
+    for (const Contig &c : in.contigs) {
+        const mth_batch_t b = make_batch(in, c);
+        check(ctx, mth_fdrp_accumulate(ctx, &b, &p));
+    }
+    uint64_t n = 0;
+    check(ctx, mth_fdrp_fetch(ctx, &n, nullptr, nullptr, nullptr, nullptr, nullptr));
+    std::vector<int32_t> tid(n), pos(n);
+    std::vector<float> val(n);
+    check(ctx, mth_fdrp_fetch(ctx, &n, tid.data(), pos.data(), quantitative ? nullptr : val.data(),
+                              quantitative ? val.data() : nullptr, nullptr));
+    FILE *f = open_output(a.s.at("output"));
+    char fb[64];
+    for (uint64_t i = 0; i < n; ++i) {
+        mth_host_format_f32(val[i], fb);
+        fprintf(f, "%s\t%d\t%d\t%s\n", mth_host_ref_name(in.h, tid[i]), pos[i], pos[i] + 2, fb);
+    }
+    if (fclose(f) != 0) die("Error writing to output file.");
+    mth_ctx_destroy(ctx);
+    mth_host_close(in.h);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -421,6 +455,8 @@ int main(int argc, char **argv) {
     if (sub == "pdr") return run_pdr(a);
     if (sub == "lpmd") return run_lpmd(a);
     if (sub == "mhl") return run_mhl(a);
+    if (sub == "fdrp") return run_fdrp(a, false);
+    if (sub == "qfdrp") return run_fdrp(a, true);
     if (sub == "me") return run_quartet(a, true);
     if (sub == "pm") return run_quartet(a, false);
     // the reference opens the BAM first; keep its open errors visible before refusing

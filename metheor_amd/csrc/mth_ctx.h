@@ -63,6 +63,11 @@ struct mth_ctx {
     uint64_t m_cap = 0, m_rows_bound = 0;
     std::vector<mth::BatchMeta> m_batches;
 
+    // FDRP / qFDRP result rows (mth_fdrp.hip)
+    mth::DevBuf f_state, f_pos, f_val, f_qval, f_n, f_batch_rows;
+    uint64_t f_cap = 0, f_rows_bound = 0;
+    std::vector<mth::BatchMeta> f_batches;
+
     int tile_variant = 0;        // fastest measured (profiles/r01_tile_variants.md)        // v2 lane=read: 0: 4096/256  1: 2048/512  2: 2048/256  3: 1024/256 ; v3 wave-cooperative: 4: 4096/4w  5: 4096/8w  6: 2048/4w
     bool timing = false;
     std::vector<mth::TimedLaunch> timed;
@@ -92,6 +97,9 @@ int sync_and_check(mth_ctx *ctx);   // stream sync + read DevState + map error b
 int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &dev);
 // implemented in mth_sites.hip: PDR with exact flush / re-open semantics (spans > 150 bp)
 int launch_pdr_exact(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p);
+// site discovery (tile pipeline into the private sink): positions called by >= 1 read with
+// mapq >= min_qual and n_cpgs >= max(min_cpgs,1); bound = host-known upper bound of the site count
+int discover_sites(mth_ctx *ctx, const mth_batch_t &dev_batch, uint32_t min_cpgs, uint8_t min_qual, uint64_t &bound);
 
 // implemented in mth_pdr_lpmd.hip.  sink == nullptr: rows go to the ctx's PDR result columns.
 struct TileSink {

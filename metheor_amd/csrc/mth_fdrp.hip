@@ -1,0 +1,294 @@
+// mth_fdrp.hip -- FDRP and qFDRP (fdrp.rs:176-246, 51-145; qfdrp.rs:188-258, 109-157) on gfx950.
+//
+// Reference, per CpG site c: keep up to max_depth covering reads (reservoir sampling beyond that) as
+// 403-slot byte arrays centred on c (bit0 base covered, bit1 CpG call, bit2 methylated; a read that does
+// not fit +-201 bp is dropped), flush with strict '<' by reads passing mapq with >= 1 CpG, and at
+// flush evaluate all C(n,2) read pairs: skip if fewer than min_overlap bases are covered by both;
+// FDRP counts pairs with >= 1 position that both reads cover AND call with different states, qFDRP
+// adds (#such positions) / (#positions both reads call) in lexicographic (i,j) order; both divide by
+// (n*(n-1)) as f32 / 2.0 -- skipped pairs stay in the denominator.
+//
+// Device: the site walk of mth_sites.hip with ONE WAVE per site; lane s is stored-read slot s
+// (max_depth <= 64).  The 403-byte arrays are never materialised: covered-by-both is interval
+// arithmetic on [start,end], and the per-position tests become "for each CpG call of read i, does
+// read j call the same position" (read i's calls are wave-uniform loads, read j's sit in lane j's
+// registers).  The qFDRP sum is accumulated serially in the reference's (i,j) order so the f32
+// rounding matches.  Both measures come out of one walk.
+//
+// Reservoir branch (depth > max_depth): the reference draws from an OS-seeded RNG (fdrp.rs:90), so
+// there is nothing to be bit-equal to; device and oracle share the counter-based sample_j below.
+#include "mth_ctx.h"
+#include "mth_scan.h"
+
+namespace mth {
+
+constexpr int FD_WIN = 201;   // MAX_READ_LEN, fdrp.rs:10
+constexpr int FD_NB = 8;      // calls of a stored read held in the slot's registers
+
+struct FdrpArgs {
+    const int32_t  *read_start, *read_end;
+    const uint8_t  *read_mapq;
+    const uint32_t *cpg_off;
+    const uint32_t *cpg_pos;
+    const uint32_t *idx;
+    const DevState *sites_st;
+    const int32_t  *site_pos;
+    DevState *st;
+    float    *fdrp, *qfdrp;     // per candidate site
+    uint32_t *nreads, *flags;
+    unsigned long long seed;
+    int32_t idx_base, max_span, tid, min_overlap;
+    uint32_t n_reads, min_depth, max_depth;
+    uint8_t min_qual;
+};
+
+// the oracle's orc_sample_j: splitmix64 over (seed, tid, pos, total) -> 1..=total
+__device__ __forceinline__ int32_t sample_j(unsigned long long seed, int32_t tid, int32_t pos, int32_t total) {
+    unsigned long long z = seed ^ (((unsigned long long)(uint32_t)tid << 32) | (uint32_t)pos);
+    z += 0x9e3779b97f4a7c15ULL * (unsigned long long)(uint32_t)total;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    z = z ^ (z >> 31);
+    return (int32_t)(z % (unsigned long long)(uint32_t)total) + 1;
+}
+
+__global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
+        const int32_t c = a.site_pos[j];
+        const uint32_t lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
+        const uint32_t hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        // slot state (lane = slot)
+        uint32_t r_o0 = 0, r_n = 0, v[FD_NB];
+        int32_t r_s = 0, r_e = 0;
+#pragma unroll
+        for (int k = 0; k < FD_NB; ++k) v[k] = 0;
+        // wave-uniform segment state
+        int32_t total = 0, sampled = 0;
+        bool entry = false, have = false;
+        float res_f = 0.0f, res_q = 0.0f;
+        uint32_t res_n = 0;
+
+        auto finalize = [&]() {   // compute_fdrp / compute_qfdrp over slots 0..sampled-1
+            const int nS = sampled;
+            uint32_t n_disc = 0;
+            float q = 0.0f;
+            for (int i = 0; i + 1 < nS; ++i) {
+                const uint32_t bo0 = __builtin_amdgcn_readlane(r_o0, i), bn = __builtin_amdgcn_readlane(r_n, i);
+                const int32_t bs = __builtin_amdgcn_readlane(r_s, i), be = __builtin_amdgcn_readlane(r_e, i);
+                const bool mine = lane > i && lane < nS;
+                int32_t ov = min(be, r_e) - max(bs, r_s) + 1;               // get_num_overlap_bases, fdrp.rs:97-107
+                ov = ov < 0 ? 0 : ov;
+                const bool pair_ok = mine && ov >= a.min_overlap;           // fdrp.rs:134
+                uint32_t ham = 0, ncpg = 0;
+                for (uint32_t k = 0; k < bn; ++k) {
+                    const uint32_t w = a.cpg_pos[bo0 + k];                   // wave-uniform
+                    const int32_t p = (int32_t)(w & 0x7fffffffu);
+                    if ((uint32_t)(p - (c - FD_WIN)) > 2u * FD_WIN) continue;   // outside the 403-slot array
+                    bool found = false;
+                    uint32_t own = 0;
+#pragma unroll
+                    for (int t = 0; t < FD_NB; ++t)
+                        if ((uint32_t)t < r_n && (int32_t)(v[t] & 0x7fffffffu) == p) { found = true; own = v[t]; }
+                    if (r_n > (uint32_t)FD_NB)
+                        for (uint32_t t = FD_NB; t < r_n; ++t) {
+                            const uint32_t x = a.cpg_pos[r_o0 + t];
+                            if ((int32_t)(x & 0x7fffffffu) == p) { found = true; own = x; }
+                        }
+                    if (found) {
+                        ncpg += 1;                                           // get_num_overlap_cpgs, qfdrp.rs:109-119 (bit1 & bit1)
+                        // hamming / is_discordant: (r1 & r2 & 3) == 3 and bit2 differs (fdrp.rs:114-115, qfdrp.rs:127-131)
+                        if (p >= bs && p <= be && p >= r_s && p <= r_e && ((own ^ w) >> 31)) ham += 1;
+                    }
+                }
+                n_disc += __popcll(__ballot(pair_ok && ham > 0));            // fdrp.rs:138-140
+                const float term = (float)ham / (float)ncpg;                // qfdrp.rs:152
+                const unsigned long long okm = __ballot(pair_ok);
+                for (int jj = i + 1; jj < nS; ++jj) {                       // lexicographic (i,j): same rounding as the reference
+                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), jj));
+                    if ((okm >> jj) & 1ull) q = q + t;
+                }
+            }
+            // (num_reads * (num_reads - 1)) as f32 / 2.0 in usize arithmetic (fdrp.rs:143)
+            const unsigned long long prod = (unsigned long long)(long long)nS * (unsigned long long)((long long)nS - 1);
+            const float den = (float)prod / 2.0f;
+            res_f = (float)n_disc / den;
+            res_q = q / den;
+            res_n = (uint32_t)nS;
+            have = true;
+        };
+
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+            const uint32_t n = o1 - o0;
+            if (a.read_mapq[i] < a.min_qual) continue;                       // fdrp.rs:205
+            if (n == 0) continue;                                            // fdrp.rs:208
+            const int32_t first = (int32_t)(a.cpg_pos[o0] & 0x7fffffffu);
+            if (c < first && entry) {                                        // fdrp.rs:212-223
+                if ((uint32_t)sampled >= a.min_depth) finalize();
+                entry = false; total = 0; sampled = 0;
+            }
+            bool hit = false;                                                // does the read call c ?  (lanes scan its calls)
+            for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+                const int32_t p = (k0 + lane < n) ? (int32_t)(a.cpg_pos[o0 + k0 + lane] & 0x7fffffffu) : -1;
+                hit = hit || (__ballot(p == c) != 0ull);
+            }
+            if (!hit) continue;
+            entry = true;                                                    // entry().or_insert(...), fdrp.rs:226-228
+            const int32_t s = a.read_start[i], e = a.read_end[i];
+            if (FD_WIN + (s - c) < 0) continue;                              // add_read, fdrp.rs:58-63
+            if (FD_WIN + (e - c) > 2 * FD_WIN) continue;
+            int slot;
+            if (total < (int32_t)a.max_depth) {                              // fdrp.rs:81-85
+                slot = total; total += 1; sampled += 1;
+            } else {                                                          // fdrp.rs:87-94 (reservoir)
+                total += 1;
+                const int32_t jr = sample_j(a.seed, a.tid, c, total);
+                if (jr > (int32_t)a.max_depth) continue;
+                slot = jr - 1;
+            }
+            if (lane == slot) {
+                r_o0 = o0; r_n = n; r_s = s; r_e = e;
+#pragma unroll
+                for (int k = 0; k < FD_NB; ++k) v[k] = ((uint32_t)k < n) ? a.cpg_pos[o0 + k] : 0u;
+            }
+        }
+        if (entry && (uint32_t)sampled >= a.min_depth) finalize();           // fdrp.rs:239-243
+        if (lane == 0) {
+            a.fdrp[j] = res_f; a.qfdrp[j] = res_q; a.nreads[j] = res_n;
+            a.flags[j] = have ? 1u : 0u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fdrp_emit(const uint32_t *__restrict__ flags, const int32_t *__restrict__ site_pos,
+                                                   const float *__restrict__ f, const float *__restrict__ q,
+                                                   const uint32_t *__restrict__ nr, const DevState *__restrict__ sites_st,
+                                                   const uint32_t *__restrict__ blk, const unsigned long long *__restrict__ base,
+                                                   int32_t *__restrict__ out_pos, float *__restrict__ out_f,
+                                                   float *__restrict__ out_q, uint32_t *__restrict__ out_n) {
+    const uint32_t n = (uint32_t)sites_st->n_sites;
+    const uint32_t s0 = (blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
+    uint32_t m = 0, fl[SCAN_PER];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) { fl[k] = (s0 + k < n) ? (flags[s0 + k] & 1u) : 0u; m += fl[k]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    __shared__ uint32_t ws[5];
+    if (lane == 63) ws[wave + 1] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { ws[0] = 0; for (int w = 1; w <= 4; ++w) ws[w] += ws[w - 1]; }
+    __syncthreads();
+    unsigned long long o = *base + blk[blockIdx.x] + ws[wave] + incl - m;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        if (!fl[k]) continue;
+        out_pos[o] = site_pos[s0 + k]; out_f[o] = f[s0 + k]; out_q[o] = q[s0 + k]; out_n[o] = nr[s0 + k];
+        ++o;
+    }
+}
+
+}  // namespace mth
+
+using namespace mth;
+
+extern "C" {
+
+int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp_params_t *params) {
+    if (!ctx || !batch || !params) return MTH_ERR_INVALID;
+    if (params->max_depth > 64) return fail(ctx, MTH_ERR_CAPACITY, "fdrp/qfdrp: max_depth > 64 is not supported by the device path (one lane per stored read)");
+    mth_batch_t d;
+    int rc = stage_batch(ctx, *batch, d);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    uint64_t bound = 0;
+    // sites = positions called by reads passing mapq with >= 1 CpG (fdrp.rs:205-231)
+    if ((rc = discover_sites(ctx, d, 0, params->min_qual, bound))) return rc;
+    ctx->f_batches.push_back(BatchMeta{batch->tid});
+    if (bound == 0) bound = 1;
+    MTH_HIP(ctx, ctx->w_val.reserve(bound * 4, s));
+    MTH_HIP(ctx, ctx->w_cov.reserve(bound * 4, s));
+    MTH_HIP(ctx, ctx->w_aux.reserve(bound * 4, s));
+    MTH_HIP(ctx, ctx->w_flags.reserve(bound * 4, s));
+    if (!ctx->f_state.p) {
+        MTH_HIP(ctx, ctx->f_state.reserve(4 * sizeof(unsigned long long), s));
+        MTH_HIP(ctx, hipMemsetAsync(ctx->f_state.p, 0, 4 * sizeof(unsigned long long), s));
+    }
+    const uint64_t need = ctx->f_rows_bound + bound;
+    if (need > ctx->f_cap) {
+        const uint64_t ncap = need + need / 4 + 1024, used = ctx->f_rows_bound;
+        MTH_HIP(ctx, ctx->f_pos.reserve(ncap * 4, s, true, used * 4));
+        MTH_HIP(ctx, ctx->f_val.reserve(ncap * 4, s, true, used * 4));
+        MTH_HIP(ctx, ctx->f_qval.reserve(ncap * 4, s, true, used * 4));
+        MTH_HIP(ctx, ctx->f_n.reserve(ncap * 4, s, true, used * 4));
+        ctx->f_cap = ncap;
+    }
+    ctx->f_rows_bound = need;
+    const size_t nb = ctx->f_batches.size() - 1;
+    MTH_HIP(ctx, ctx->f_batch_rows.reserve((nb + 1) * 4, s, true, nb * 4));
+
+    const int32_t ext = ((d.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
+    FdrpArgs a;
+    a.read_start = d.read_start; a.read_end = d.read_end; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
+    a.idx = ctx->idx.as<uint32_t>(); a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>(); a.st = ctx->d_state;
+    a.fdrp = ctx->w_val.as<float>(); a.qfdrp = reinterpret_cast<float *>(ctx->w_aux.p); a.nreads = ctx->w_cov.as<uint32_t>();
+    a.flags = ctx->w_flags.as<uint32_t>();
+    a.seed = params->seed; a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.tid = d.tid;
+    a.min_overlap = params->min_overlap; a.n_reads = d.n_reads;
+    a.min_depth = (uint32_t)std::min<uint64_t>(params->min_depth, 0xffffffffull); a.max_depth = params->max_depth;
+    a.min_qual = params->min_qual;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 3) / 4, 16384);   // 4 waves (sites) per block
+    {
+        LaunchTimer lt(ctx, K_FDRPWALK);
+        hipLaunchKernelGGL(k_fdrp_walk, dim3(grid), dim3(256), 0, s, a);
+    }
+    unsigned long long *fs = ctx->f_state.as<unsigned long long>();
+    const uint32_t nblk = (uint32_t)((bound + 256 * SCAN_PER - 1) / (256 * SCAN_PER));
+    MTH_HIP(ctx, ctx->w_blk.reserve((size_t)nblk * 4, s));
+    {
+        LaunchTimer lt(ctx, K_FDRPEMIT);
+        hipLaunchKernelGGL(k_flags_blockcount, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
+                           (const unsigned long long *)&ctx->d_state2->n_sites, ctx->w_blk.as<uint32_t>());
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk, fs, fs + 1,
+                           ctx->f_batch_rows.as<uint32_t>(), (uint32_t)nb);
+        hipLaunchKernelGGL(k_fdrp_emit, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
+                           ctx->w_val.as<float>(), reinterpret_cast<const float *>(ctx->w_aux.p), ctx->w_cov.as<uint32_t>(),
+                           ctx->d_state2, ctx->w_blk.as<uint32_t>(), fs + 1, ctx->f_pos.as<int32_t>(), ctx->f_val.as<float>(),
+                           ctx->f_qval.as<float>(), ctx->f_n.as<uint32_t>());
+    }
+    MTH_HIP(ctx, hipGetLastError());
+    return MTH_OK;
+}
+
+int mth_fdrp_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos, float *fdrp, float *qfdrp,
+                   uint32_t *n_reads) {
+    if (!ctx) return MTH_ERR_INVALID;
+    int rc = sync_and_check(ctx);
+    if (rc) return rc;
+    unsigned long long fs[2] = {0, 0};
+    if (ctx->f_state.p) MTH_HIP(ctx, hipMemcpy(fs, ctx->f_state.p, sizeof fs, hipMemcpyDeviceToHost));
+    const uint64_t n = fs[0];
+    if (n_rows) *n_rows = n;
+    if (n == 0) return MTH_OK;
+    if (pos) MTH_HIP(ctx, hipMemcpy(pos, ctx->f_pos.p, n * 4, hipMemcpyDeviceToHost));
+    if (fdrp) MTH_HIP(ctx, hipMemcpy(fdrp, ctx->f_val.p, n * 4, hipMemcpyDeviceToHost));
+    if (qfdrp) MTH_HIP(ctx, hipMemcpy(qfdrp, ctx->f_qval.p, n * 4, hipMemcpyDeviceToHost));
+    if (n_reads) MTH_HIP(ctx, hipMemcpy(n_reads, ctx->f_n.p, n * 4, hipMemcpyDeviceToHost));
+    if (tid) {
+        std::vector<uint32_t> rows(ctx->f_batches.size());
+        if (!rows.empty()) MTH_HIP(ctx, hipMemcpy(rows.data(), ctx->f_batch_rows.p, rows.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t o = 0;
+        for (size_t b = 0; b < rows.size(); ++b)
+            for (uint32_t j = 0; j < rows[b]; ++j) tid[o++] = ctx->f_batches[b].tid;
+    }
+    return MTH_OK;
+}
+
+}  // extern "C"

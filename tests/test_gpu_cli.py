@@ -161,8 +161,32 @@ def test_mhl_cli(golden_dir, tmp_path):
     assert o.read_text() == want and want.count("\n") > 20
 
 
-def test_unbuilt_measures_fail_loudly(tmp_path):
+def test_fdrp_qfdrp_cli(golden_dir, tmp_path):
+    o = tmp_path / "o.tsv"
     bam = os.path.join("tests", "golden", "test1.bam")
-    for sub in ("fdrp", "qfdrp"):
-        r = run(sub, "-i", bam, "-o", str(tmp_path / "o.tsv"))
-        assert r.returncode != 0 and "no device kernel yet" in r.stderr
+    for sub in ("fdrp", "qfdrp"):        # defaults -> 4 lines, value 0
+        r = run(sub, "-i", bam, "-o", str(o))
+        assert r.returncode == 0, r.stderr
+        assert o.read_text() == "".join("chr1\t%d\t%d\t0\n" % (p, p + 2) for p in (0, 2, 4, 6))
+    r = run("qfdrp", "-i", bam, "-o", str(o), "-q", "0", "-d", "2", "-D", "40", "-l", "4")     # qfdrp.rs:357-374
+    assert r.returncode == 0 and o.read_text() == "".join("chr1\t%d\t%d\t0.53333336\n" % (p, p + 2) for p in (0, 2, 4, 6))
+    r = run("fdrp", "-i", bam, "-o", str(o), "-q", "0", "-d", "2", "-D", "40", "-l", "4")      # fdrp.rs:253-268
+    assert r.returncode == 0 and o.read_text() == "".join("chr1\t%d\t%d\t1\n" % (p, p + 2) for p in (0, 2, 4, 6))
+    rec = bamio.read_sam(os.path.join(golden_dir, "test.chr19.XM.sam"))
+    rb = str(tmp_path / "rrbs.bam")
+    bamio.write_bam(rb, rec)
+    reads = pyoracle.Reads.decode(rec)
+    kw = dict(min_qual=10, min_depth=3, max_depth=40, min_overlap=20)
+    for sub, t in (("fdrp", reads.fdrp(**kw)), ("qfdrp", reads.qfdrp(**kw))):
+        r = run(sub, "-i", rb, "-o", str(o), "-d", "3", "-l", "20")
+        assert r.returncode == 0, r.stderr
+        want = "".join("chr19\t%d\t%d\t%s\n" % (p, p + 2, pyoracle.format_f32(v)) for p, v in zip(t.pos[:, 0], t.val))
+        assert o.read_text() == want and want.count("\n") > 20
+
+
+def test_unbuilt_parts_fail_loudly(tmp_path):
+    bam = os.path.join("tests", "golden", "test1.bam")
+    r = run("lpmd", "-i", bam, "-o", str(tmp_path / "o.tsv"), "-p", str(tmp_path / "pairs.tsv"))
+    assert r.returncode != 0 and "not implemented on the device path yet" in r.stderr
+    r = run("tag", "-i", bam, "-o", str(tmp_path / "o.sam"), "-g", "x.fa")
+    assert r.returncode != 0 and "no device kernel yet" in r.stderr

@@ -1,0 +1,192 @@
+"""GPU parity of FDRP / qFDRP (mth_fdrp_accumulate / mth_fdrp_fetch) against the CPU oracle.
+
+Bar: sites and stored-read counts bit-exact; FDRP/qFDRP within 1e-6 absolute.  Where depth exceeds
+max_depth the reference samples with an OS-seeded RNG (fdrp.rs:90) -- nothing can be bit-equal to it;
+device and oracle share a counter-based draw, so they are compared with each other (the branch is
+"parity unpinned" against the reference)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bamio, pyoracle
+from tests import util
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import metheor_amd
+    e = metheor_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def run_device(eng, contigs, kw, device=None, regions=None):
+    from metheor_amd import shard
+    eng.reset()
+    keep = []
+    for ci, c in enumerate(contigs):
+        regs = regions[ci] if regions else [(0, c["length"])]
+        for (b, e) in regs:
+            sub = shard.slice_region(c, b, e, halo=shard.max_span(c) + 202) if regions else c
+            bt = util.device_batch(sub, region=(b, e), device=device)
+            keep.append(bt)
+            eng.fdrp_accumulate(bt, **kw)
+    return eng.fdrp_fetch()
+
+
+def same(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.abs(a - b)
+    d[both_nan] = 0
+    assert not np.isnan(d).any()
+    return d.max() if len(d) else 0.0
+
+
+def check(dev, reads, kw):
+    of, oq = reads.fdrp(**kw), reads.qfdrp(**kw)
+    assert len(dev["pos"]) == len(of) == len(oq)
+    assert (dev["tid"] == of.tid).all() and (dev["pos"] == of.pos[:, 0]).all()
+    assert (dev["n_reads"] == of.cnt[:, 0]).all()
+    df, dq = same(dev["fdrp"], of.val), same(dev["qfdrp"], oq.val)
+    assert df <= TOL and dq <= TOL, (df, dq)
+    nf = int((dev["fdrp"].view(np.uint32) != of.val.view(np.uint32)).sum())
+    nq = int((dev["qfdrp"].view(np.uint32) != oq.val.view(np.uint32)).sum())
+    return len(of), nf, nq
+
+
+def fixture(golden_dir, k):
+    rec = bamio.read_bam(os.path.join(golden_dir, "test%d.bam" % k))
+    reads = pyoracle.Reads.decode(rec)
+    return reads, util.contig_from_oracle_soa(reads.soa(), 0, rec.refs[0][1])
+
+
+# ---- the reference's fixtures and known answers (fdrp.rs:252-332, qfdrp.rs:357-439) -----------------
+def test_reference_fixtures(eng, golden_dir):
+    kw0 = dict(min_qual=0, min_depth=2, max_depth=40, min_overlap=4)
+    kw1 = dict(min_qual=1, min_depth=2, max_depth=40, min_overlap=4)
+    reads, c = fixture(golden_dir, 1)
+    d = run_device(eng, [c], kw0)
+    assert d["pos"].tolist() == [0, 2, 4, 6] and (d["fdrp"] == 1.0).all()                     # fdrp.rs:253-268
+    assert (np.abs(d["qfdrp"] - f32(8.0 / 15.0)) < 1e-5).all() and (d["n_reads"] == 16).all()  # qfdrp.rs:357-374, 309-332
+    check(d, reads, kw0)
+    reads, c = fixture(golden_dir, 2)
+    d = run_device(eng, [c], kw0)
+    assert (np.abs(d["fdrp"] - (1.0 - 56.0 / 120.0)) < 1e-4).all()                            # fdrp.rs:270-285
+    assert (d["qfdrp"] == f32(8.0 / 15.0)).all()                                               # qfdrp.rs:376-392 (exact)
+    check(d, reads, kw0)
+    reads, c = fixture(golden_dir, 3)
+    d = run_device(eng, [c], kw1)
+    assert d["pos"].tolist() == [0, 2, 4, 6] and (d["fdrp"] == 1.0).all() and (d["qfdrp"] == 1.0).all()   # fdrp.rs:287-302, qfdrp.rs:394-409
+    check(d, reads, kw1)
+    reads, c = fixture(golden_dir, 4)
+    d = run_device(eng, [c], kw1)
+    assert d["pos"].tolist() == [0, 2, 4, 6, 13, 15, 17, 19] and (d["fdrp"] == 1.0).all()     # fdrp.rs:304-319
+    assert (d["qfdrp"] == f32(8.0 / 15.0)).all()                                               # qfdrp.rs:411-427 (exact)
+    check(d, reads, kw1)
+    reads, c = fixture(golden_dir, 5)
+    assert len(run_device(eng, [c], kw1)["pos"]) == 0                                          # fdrp.rs:321-332
+    # defaults on test1 -> 4 sites with value 0 (8-bp reads never reach --min-overlap 35)
+    reads, c = fixture(golden_dir, 1)
+    d = run_device(eng, [c], dict())
+    assert d["pos"].tolist() == [0, 2, 4, 6] and (d["fdrp"] == 0).all() and (d["qfdrp"] == 0).all()
+    check(d, reads, dict())
+
+
+def test_call_outside_covered_interval(eng):
+    """a reverse read reports its first CpG at start-1: bit1 (call) without bit0 (covered).  Such a
+    position counts in qFDRP's num_overlap_cpgs (qfdrp.rs:115) but never as a difference (fdrp.rs:114)."""
+    from metheor_amd import synth
+    rows = [(1000, 1, [(0, 1000, 1), (10, 1010, 1)]), (1001, 0, [(0, 1000, 0), (9, 1010, 1)]), (1001, 0, [(0, 1000, 0), (9, 1010, 0)])]
+    start = np.array([r[0] for r in rows], np.int32)
+    off = np.array([0, 2, 4, 6], np.uint32)
+    pos = np.array([p | (m << 31) for r in rows for (_, p, m) in r[2]], np.uint32)
+    rel = np.array([q for r in rows for (q, _, _) in r[2]], np.uint8)
+    c = dict(tid=0, length=10_000, read_start=start, read_end=start + 49, read_mapq=np.full(3, 40, np.uint8),
+             read_fwd=np.array([r[1] for r in rows], np.uint8), cpg_off=off, cpg_pos=pos, cpg_rel=rel)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    kw = dict(min_qual=0, min_depth=0, max_depth=40, min_overlap=1)
+    d = run_device(eng, [c], kw)
+    check(d, reads, kw)
+    row = {int(p): (float(a), float(b), int(n)) for p, a, b, n in zip(d["pos"], d["fdrp"], d["qfdrp"], d["n_reads"])}
+    # site 1000: pairs (0,1): 1000 uncovered by read 1 -> only 1010 compared (equal) -> ham 0/2; (0,2): 1010 differs -> 1/2; (1,2): 1/2
+    assert row[1000][2] == 3 and abs(row[1000][0] - 2.0 / 3.0) < 1e-6 and abs(row[1000][1] - (0.5 + 0.5) / 3.0) < 1e-6
+
+
+def test_real_rrbs_reads(eng, golden_dir):
+    rec = bamio.read_sam(os.path.join(golden_dir, "test.chr19.XM.sam"))
+    reads = pyoracle.Reads.decode(rec)
+    c = util.contig_from_oracle_soa(reads.soa(), 0, rec.refs[0][1])
+    for kw in (dict(min_qual=10, min_depth=10, max_depth=40, min_overlap=35), dict(min_qual=10, min_depth=2, max_depth=64, min_overlap=10),
+               dict(min_qual=43, min_depth=0, max_depth=40, min_overlap=0), dict(min_qual=0, min_depth=3, max_depth=5, min_overlap=20, seed=7)):
+        print("RRBS", kw, "rows/notbit(f)/notbit(q):", check(run_device(eng, [c], kw), reads, kw))
+
+
+@pytest.mark.parametrize("device_mem", [False, True])
+def test_synthetic_vs_oracle(eng, device_mem):
+    from metheor_amd import synth
+    c = synth.make_contig(1, 600_000, 100_000, 0.02, np.random.default_rng(61))
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    dev = "cuda:0" if device_mem else None
+    for kw in (dict(min_qual=10, min_depth=10, max_depth=64, min_overlap=35),     # depth ~25x <= 64: no sampling, exact
+               dict(min_qual=0, min_depth=0, max_depth=64, min_overlap=0),
+               dict(min_qual=10, min_depth=10, max_depth=12, min_overlap=35, seed=1234)):   # reservoir branch (shared draw)
+        n, nf, nq = check(run_device(eng, [c], kw, device=dev), reads, kw)
+        print("synthetic", kw, "rows", n, "not bit-identical fdrp/qfdrp:", nf, nq)
+        assert n > 5000
+
+
+def test_hotspot_depth_50(eng):
+    """BASELINE config 4 in small: 1-kbp windows at exactly 50x, -D 64 (no sampling => exact parity)"""
+    from metheor_amd import synth
+    c = synth.hotspots(n_windows=40, window=1000, depth=50, density=0.08, seed=50)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    kw = dict(min_qual=10, min_depth=10, max_depth=64, min_overlap=35)
+    n, nf, nq = check(run_device(eng, [c], kw), reads, kw)
+    print("hotspot rows", n, "not bit-identical fdrp/qfdrp:", nf, nq)
+    assert n > 1000
+
+
+def test_window_drop_and_nan_rows(eng):
+    """400-bp forward reads mostly do not fit the +-201-bp array (fdrp.rs:58-63): they still create the
+    site's entry, so with min_depth 0 the reference emits 0/0 = NaN rows (release arithmetic)"""
+    from metheor_amd import synth
+    c = synth.make_contig(0, 120_000, 6_000, 0.02, np.random.default_rng(63), read_len=400)
+    c = util.subset_reads(c, c["read_fwd"] == 1)        # a reverse read's call at start-1 can index -1: the reference panics there
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    kw = dict(min_qual=10, min_depth=0, max_depth=40, min_overlap=35)
+    d = run_device(eng, [c], kw)
+    n, nf, nq = check(d, reads, kw)
+    assert np.isnan(d["fdrp"]).sum() > 100 and (d["n_reads"] <= 1)[np.isnan(d["fdrp"])].all()
+    kw = dict(min_qual=10, min_depth=2, max_depth=40, min_overlap=35)
+    check(run_device(eng, [c], kw), reads, kw)
+
+
+def test_multi_contig_and_region_split(eng):
+    from metheor_amd import shard, synth
+    rng = np.random.default_rng(65)
+    cs = [synth.make_contig(0, 150_000, 25_000, 0.03, rng), synth.make_contig(1, 300_000, 55_000, 0.03, rng)]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    kw = dict(min_qual=10, min_depth=10, max_depth=64, min_overlap=35)
+    d = run_device(eng, cs, kw, regions=[[(0, cs[0]["length"])], shard.plan_regions(cs[1], 4)])
+    check(d, reads, kw)
+    d2 = run_device(eng, cs, kw)
+    assert (d["pos"] == d2["pos"]).all() and (d["qfdrp"].view(np.uint32) == d2["qfdrp"].view(np.uint32)).all()
+
+
+def test_capacity_and_empty(eng):
+    from metheor_amd import Batch, MthError
+    z4 = np.zeros(0, np.int32)
+    b = Batch(0, 0, 1000, z4, z4, np.zeros(0, np.uint8), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8))
+    eng.reset()
+    eng.fdrp_accumulate(b)
+    assert len(eng.fdrp_fetch()["pos"]) == 0
+    with pytest.raises(MthError) as e:
+        eng.fdrp_accumulate(b, max_depth=65)
+    assert e.value.status == -8
+    eng.reset()

@@ -73,3 +73,20 @@ def oracle_tsv_pdr(reads, names, **kw):
 def oracle_tsv_lpmd(reads, input_name, **kw):
     from oracle import pyoracle
     return "name\tlpmd\n%s\t%s\n" % (input_name, pyoracle.format_f32(reads.lpmd(**kw)["lpmd"]))
+
+
+def subset_reads(c, mask):
+    """keep the reads where mask is True (CSR rebuilt)"""
+    mask = np.asarray(mask, bool)
+    off = c["cpg_off"].astype(np.int64)
+    n = np.diff(off)
+    keep_call = np.repeat(mask, n)
+    out = dict(c)
+    for k in ("read_start", "read_end", "read_mapq", "read_fwd"):
+        out[k] = c[k][mask]
+    no = np.zeros(int(mask.sum()) + 1, np.int64)
+    np.cumsum(n[mask], out=no[1:])
+    out["cpg_off"] = no.astype(np.uint32)
+    out["cpg_pos"] = c["cpg_pos"][keep_call]
+    out["cpg_rel"] = c["cpg_rel"][keep_call]
+    return out
