@@ -17,7 +17,7 @@
  *   src/pdr.rs:119-125    pdr::compute_helper(input,min_depth,min_cpgs,min_qual,cpg_set)
  *                         -> BTreeMap<CpGPosition,(f32,u32,u32)>      => mth_pdr_lpmd_accumulate + mth_pdr_fetch
  *   src/lpmd.rs:154-160   lpmd::compute_helper(input,min_distance,max_distance,min_qual,cpg_set)
- *                         -> LPMDResult                               => mth_pdr_lpmd_accumulate + mth_lpmd_global (+ mth_lpmd_pairs_fetch)
+ *                         -> LPMDResult                               => mth_pdr_lpmd_accumulate + mth_lpmd_global (+ mth_lpmd_pairs_accumulate/_fetch)
  *   src/mhl.rs:135-141    mhl::compute_helper(...) -> BTreeMap<CpGPosition,f32>        => mth_mhl_accumulate + mth_mhl_fetch (built)
  *   src/me.rs:90-94       me::compute_helper(input,min_qual,cpg_set) -> HashMap<Quartet,QuartetStat>
  *   src/pm.rs:85-89       pm::compute_helper(...)                                      => mth_quartet_accumulate + mth_quartet_fetch (built)
@@ -134,6 +134,19 @@ int  mth_lpmd_export_device(mth_ctx_t *ctx, int64_t *dst_device4);
 /* compute_lpmd() (lpmd.rs:51-55, wrapping-i32 semantics) from summed integer counters, e.g. the
  * all-reduced ones */
 float mth_lpmd_from_counts(int64_t n_concordant, int64_t n_discordant);
+
+/* ---- LPMD per-pair table (`lpmd --pairs`; lpmd.rs:70-122) -------------------------------------
+ * Separate pass over the same batches (the global counters above do not need it). */
+typedef struct {
+    int32_t min_distance;  /* -m 2  */
+    int32_t max_distance;  /* -M 16 */
+    uint8_t min_qual;      /* -q 10 */
+} mth_lpmd_pairs_params_t;
+int  mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_lpmd_pairs_params_t *params);
+/* rows of print_pair_statistics, sorted by ((tid,cpg1),(tid,cpg2)); lpmd = n_d as f32/(n_c as f32+n_d as f32)
+ * (lpmd.rs:111); *n_rows always set, arrays may be NULL */
+int  mth_lpmd_pairs_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos1, int32_t *pos2, float *lpmd,
+                          uint32_t *n_concordant, uint32_t *n_discordant);
 
 /* ---- ME / PM: per-quartet 16-bin epiallele histograms (me.rs:90-132, pm.rs:85-128) ------------
  * One accumulate serves both measures (they share the histogram).  Requires consecutive CpGs of

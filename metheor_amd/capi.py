@@ -14,7 +14,7 @@ SYMBOLS = [
     "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
-    "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch",
+    "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -53,6 +53,10 @@ class mth_mhl_params_t(C.Structure):
 class mth_fdrp_params_t(C.Structure):
     _fields_ = [("min_depth", C.c_uint64), ("seed", C.c_uint64), ("max_depth", C.c_uint32),
                 ("min_overlap", C.c_int32), ("min_qual", C.c_uint8)]
+
+
+class mth_lpmd_pairs_params_t(C.Structure):
+    _fields_ = [("min_distance", C.c_int32), ("max_distance", C.c_int32), ("min_qual", C.c_uint8)]
 
 
 def library_path():
@@ -98,6 +102,8 @@ def lib():
         L.mth_mhl_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 4
         L.mth_fdrp_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_fdrp_params_t)]
         L.mth_fdrp_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 5
+        L.mth_lpmd_pairs_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_lpmd_pairs_params_t)]
+        L.mth_lpmd_pairs_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 6
         L.mth_timing_enable.argtypes = [vp, C.c_int]
         L.mth_timing_reset.argtypes = [vp]
         L.mth_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -276,6 +282,20 @@ class Engine:
                    qfdrp=np.zeros(k, np.float32), n_reads=np.zeros(k, np.uint32))
         self._check(self.L.mth_fdrp_fetch(self.h, C.byref(n), *[out[x].ctypes.data_as(C.c_void_p) for x in
                                                                 ("tid", "pos", "fdrp", "qfdrp", "n_reads")]))
+        return out
+
+    def lpmd_pairs_accumulate(self, batch, min_distance=2, max_distance=16, min_qual=10):
+        p = mth_lpmd_pairs_params_t(min_distance, max_distance, min_qual)
+        self._check(self.L.mth_lpmd_pairs_accumulate(self.h, C.byref(batch.c), C.byref(p)))
+
+    def lpmd_pairs_fetch(self):
+        n = C.c_uint64(0)
+        self._check(self.L.mth_lpmd_pairs_fetch(self.h, C.byref(n), None, None, None, None, None, None))
+        k = n.value
+        out = dict(tid=np.zeros(k, np.int32), pos1=np.zeros(k, np.int32), pos2=np.zeros(k, np.int32),
+                   lpmd=np.zeros(k, np.float32), n_concordant=np.zeros(k, np.uint32), n_discordant=np.zeros(k, np.uint32))
+        self._check(self.L.mth_lpmd_pairs_fetch(self.h, C.byref(n), *[out[x].ctypes.data_as(C.c_void_p) for x in
+                                                                      ("tid", "pos1", "pos2", "lpmd", "n_concordant", "n_discordant")]))
         return out
 
     def timing_enable(self, on=True):

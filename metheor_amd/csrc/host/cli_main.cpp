@@ -317,7 +317,6 @@ int run_pdr(const Args &a) {
 }
 
 int run_lpmd(const Args &a) {
-    if (a.has("pairs")) die("metheor (MI355X path): lpmd --pairs (per-pair table, lpmd.rs:89-122) is not implemented on the device path yet");
     const std::string input = a.s.at("input");
     const int32_t mind = (int32_t)a.n.at("min-distance"), maxd = (int32_t)a.n.at("max-distance");
     // lpmd.rs:161-164
@@ -339,6 +338,27 @@ int run_lpmd(const Args &a) {
     mth_host_format_f32(lp, fb);
     fprintf(f, "name\tlpmd\n%s\t%s\n", input.c_str(), fb);   // lpmd.rs:145-147
     if (fclose(f) != 0) die("Error writing to output file.");
+    if (a.has("pairs")) {                                       // lpmd.rs:149-151, 89-122
+        mth_lpmd_pairs_params_t pp;
+        pp.min_distance = mind; pp.max_distance = maxd; pp.min_qual = p.lpmd_min_qual;
+        for (const Contig &c : in.contigs) {
+            const mth_batch_t b = make_batch(in, c);
+            check(ctx, mth_lpmd_pairs_accumulate(ctx, &b, &pp));
+        }
+        uint64_t n = 0;
+        check(ctx, mth_lpmd_pairs_fetch(ctx, &n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+        std::vector<int32_t> tid(n), p1(n), p2(n);
+        std::vector<float> v(n);
+        std::vector<uint32_t> nc(n), nd(n);
+        check(ctx, mth_lpmd_pairs_fetch(ctx, &n, tid.data(), p1.data(), p2.data(), v.data(), nc.data(), nd.data()));
+        FILE *g = open_output(a.s.at("pairs"));
+        fprintf(g, "chrom\tcpg1\tcpg2\tlpmd\tn_concordant\tn_discordant\n");
+        for (uint64_t i = 0; i < n; ++i) {
+            mth_host_format_f32(v[i], fb);
+            fprintf(g, "%s\t%d\t%d\t%s\t%u\t%u\n", mth_host_ref_name(in.h, tid[i]), p1[i], p2[i], fb, nc[i], nd[i]);
+        }
+        if (fclose(g) != 0) die("Error writing to output file.");
+    }
     mth_ctx_destroy(ctx);
     mth_host_close(in.h);
     return 0;

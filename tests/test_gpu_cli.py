@@ -184,9 +184,24 @@ def test_fdrp_qfdrp_cli(golden_dir, tmp_path):
         assert o.read_text() == want and want.count("\n") > 20
 
 
+def test_lpmd_pairs_cli(golden_dir, tmp_path):
+    """lpmd.rs:89-122: header + rows sorted by (cpg1,cpg2)"""
+    rec = bamio.read_sam(os.path.join(golden_dir, "test.chr19.XM.sam"))
+    rb = str(tmp_path / "rrbs.bam")
+    bamio.write_bam(rb, rec)
+    reads = pyoracle.Reads.decode(rec)
+    o, pf = tmp_path / "o.tsv", tmp_path / "pairs.tsv"
+    r = run("lpmd", "-i", rb, "-o", str(o), "-p", str(pf), "-m", "2", "-M", "10")
+    assert r.returncode == 0, r.stderr
+    res = reads.lpmd(min_distance=2, max_distance=10, min_qual=10, pairs=True)
+    assert o.read_text() == "name\tlpmd\n%s\t%s\n" % (rb, pyoracle.format_f32(res["lpmd"]))
+    t = res["pairs"]
+    want = "chrom\tcpg1\tcpg2\tlpmd\tn_concordant\tn_discordant\n" + "".join(
+        "chr19\t%d\t%d\t%s\t%d\t%d\n" % (p[0], p[1], pyoracle.format_f32(v), c[0], c[1]) for p, v, c in zip(t.pos, t.val, t.cnt))
+    assert pf.read_text() == want and want.count("\n") > 50
+
+
 def test_unbuilt_parts_fail_loudly(tmp_path):
     bam = os.path.join("tests", "golden", "test1.bam")
-    r = run("lpmd", "-i", bam, "-o", str(tmp_path / "o.tsv"), "-p", str(tmp_path / "pairs.tsv"))
-    assert r.returncode != 0 and "not implemented on the device path yet" in r.stderr
     r = run("tag", "-i", bam, "-o", str(tmp_path / "o.sam"), "-g", "x.fa")
     assert r.returncode != 0 and "no device kernel yet" in r.stderr
