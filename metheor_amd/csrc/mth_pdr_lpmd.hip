@@ -283,20 +283,20 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave-cooperative tile kernel (v3) -- EXPERIMENTAL, NOT the default: measured SLOWER than the
-// lane = read kernel above on BASELINE config 2 (tile kernel 0.301 ms vs 0.237 ms; PDR-only 0.195 vs
-// 0.111 ms; profiles/r01_tile_variants.md).  It is parity-green (tests/test_gpu_pdr_lpmd.py passes
-// under MTH_TILE_VARIANT=4/5/6) and kept selectable for A/B work only.
-// Idea: v2 pads every read to NB call slots and NB*(NB-1)/2 pair slots (rocprof: ~1650 VALU
-// wave-instructions per wave and tile, ~3 of 8 slots useful).  Here a wave takes a chunk of up to 64
-// consecutive reads (lane = read for the 9 B/read record) and then walks the chunk's CONTIGUOUS
-// call range with lane = call: coalesced loads, no padding.  What the measurement shows it costs
-// instead: a chain of dependent cross-lane ops per round (6-step bpermute max-scan, LDS look-ups)
-// with only 4 waves/SIMD to hide it, and no way to skip reads that fail --min-cpgs.
-//   read of a call   : each read lane drops its id at its first call in a per-wave LDS byte table,
-//                      a wave max-scan over the loaded table entries gives every call its read
+// Wave-cooperative tile kernel -- EXPERIMENTAL, NOT the default (select with MTH_TILE_VARIANT=4..6).
+// History: its first form (v3) gave every call its read with a 6-step cross-lane max-scan and measured
+// SLOWER than the lane = read kernel above (tile kernel 0.301 vs 0.237 ms, profiles/r01_tile_variants.md).
+// This form (v4) keeps the structure but finds segment heads with one ballot + count-leading-zeros.
+// Idea: the lane = read kernel pads every read to NB call slots and NB*(NB-1)/2 pair slots (rocprof:
+// ~1650 VALU wave-instructions per wave and tile, ~3 of 8 slots useful).  Here a wave takes a chunk of
+// up to 64 consecutive reads (lane = read for the 9 B/read record) and then walks the chunk's CONTIGUOUS
+// call range with lane = call: coalesced loads, no padding.
+//   read of a call   : each read lane drops (lane+1 | flags) at its first call in a per-wave LDS u16
+//                      table; a round loads the 64 entries, ballot(entry != 0) is the head mask, the
+//                      nearest head at or before lane t is 63 - clz(mask & low_bits(t)), its entry comes
+//                      with one bpermute; "distance to head" makes same-read tests a compare
 //   read concordance : a read is discordant iff two ADJACENT calls differ (readutil.rs:134-145) ->
-//                      one lane shift + a (rare) LDS atomic-or on the read's flag byte
+//                      one lane shift + a (rare) LDS atomic-or on the read's flag word
 //   LPMD pairs       : call k looks back over calls k-1, k-2, .. of the same read while the query
 //                      distance stays <= max (readutil.rs:166-224) -- lane shifts, work proportional
 //                      to the pairs that exist; rounds overlap by OV lanes so no carry is needed;
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(NW * 64) void k_pdr_lpmd_tile_wc(const TileArgs a, 
     __shared__ __attribute__((aligned(16))) uint32_t cnt[2 * W];
     __shared__ uint32_t red[4][B / 64];
     __shared__ uint32_t wave_off[B / 64 + 1];
-    __shared__ __attribute__((aligned(16))) uint8_t head_s[NW][WC_MAXC];  // 0 = not a first call, else read lane + 1
-    __shared__ uint32_t rinfo_s[NW][64];                                   // bit0 pdr_ok, bit1 lp_ok, bit2 discordant
+    __shared__ __attribute__((aligned(16))) uint16_t head_s[NW][WC_MAXC];  // 0 = not a first call, else (read lane + 1)
+    __shared__ uint32_t rinfo_s[NW][64];                                    // bit0 pdr_ok, bit1 lp_ok, bit2 discordant
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NW * 64) void k_pdr_lpmd_tile_wc(const TileArgs a, 
     const int32_t T0 = a.region_beg + (int32_t)(t * W);
     const int32_t T1 = min(T0 + W, a.region_end);
     const uint32_t Wt = (uint32_t)(T1 - T0);
-    uint8_t *head = head_s[wave];
+    uint16_t *head = head_s[wave];
     uint32_t *rinfo = rinfo_s[wave];
 
     for (int i = tid; i < 2 * W / 4; i += B)
@@ -400,31 +400,32 @@ __global__ __launch_bounds__(NW * 64) void k_pdr_lpmd_tile_wc(const TileArgs a, 
         if (!__any((lp_ok || pdr_ok) && n > 0)) { i0 += nr; continue; }   // nothing to do (halo chunk)
 
         // ---- publish the chunk's read table ------------------------------------------------
-        reinterpret_cast<uint4 *>(head)[lane] = make_uint4(0, 0, 0, 0);   // 64 x 16 B = WC_MAXC
+        reinterpret_cast<uint4 *>(head)[lane] = make_uint4(0, 0, 0, 0);            // 2 x 64 x 16 B = WC_MAXC u16
+        reinterpret_cast<uint4 *>(head)[lane + 64] = make_uint4(0, 0, 0, 0);
         rinfo[lane] = (pdr_ok ? 1u : 0u) | (lp_ok ? 2u : 0u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (act && n > 0) head[off0 - cbeg] = (uint8_t)(lane + 1);
+        if (act && n > 0) head[off0 - cbeg] = (uint16_t)(lane + 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
         // ---- call rounds: lane <-> call, rounds overlap by WC_OV context lanes -----------------
         // one round = 64 consecutive calls starting at `base`; returns the call word and its read id
-        uint32_t carry = 0;
+        uint32_t carry = 0;   // read id (lane+1) of the call just before the round's lane 0
         auto call_round = [&](const uint32_t base, uint32_t &v_out, uint32_t &rid_out) {
             const uint32_t c = base + lane;
             const bool valid = (int32_t)(c - cbeg) >= 0 && c < cend;
             const bool isnew = valid && lane >= WC_OV;    // lanes < WC_OV only give context
             const uint32_t v = valid ? a.cpg_pos[c] : 0u;
             const uint32_t rl = (valid && WANT_LPMD) ? (uint32_t)rel[c] : 0u;
-            uint32_t rid = valid ? (uint32_t)head[c - cbeg] : 0u;
-            // inclusive max-scan across the wave (read ids grow with the call index)
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(rid, o, 64);
-                if (lane >= o) rid = max(rid, up);
-            }
-            rid = valid ? max(rid, carry) : 0u;
+            const uint32_t h = valid ? (uint32_t)head[c - cbeg] : 0u;
+            // segment heads: one ballot, then count-leading-zeros on the heads at or before this lane
+            const unsigned long long hm = __ballot(h != 0u);
+            const unsigned long long below = hm & ((2ull << lane) - 1ull);
+            const int hp = below ? 63 - __builtin_clzll(below) : 0;
+            const uint32_t hv = __shfl(h, hp, 64);
+            const uint32_t rid = valid ? (below ? hv : carry) : 0u;
+            const uint32_t dh = below ? (uint32_t)(lane - hp) : 255u;       // lanes since the head (255: head before the round)
             carry = __builtin_amdgcn_readlane(rid, 63 - WC_OV);   // read of the call before the next round's lane 0
             const int rlane = rid ? (int)rid - 1 : 0;
             const uint32_t m = v >> 31;
@@ -432,11 +433,11 @@ __global__ __launch_bounds__(NW * 64) void k_pdr_lpmd_tile_wc(const TileArgs a, 
             const int32_t sR = __shfl(s, rlane, 64);
             bad |= (valid && ((v & 0x7fffffffu) - (uint32_t)(sR - 1) > (uint32_t)a.max_span)) ? 1u : 0u;
             const uint32_t info = valid ? rinfo[rlane] : 0u;
-            const uint32_t pk = (rid << 24) | (m << 16) | (rl & 0xffffu);
+            const uint32_t pk = (m << 16) | (rl & 0xffffu);
             // adjacent calls of one read that differ make the read discordant
             const uint32_t p1 = __shfl_up(pk, 1, 64);
             if (WANT_PDR) {
-                if (isnew && (p1 >> 24) == rid && (((p1 >> 16) & 1u) != m) && (info & 1u))
+                if (isnew && dh >= 1u && ((p1 >> 16) != m) && (info & 1u))
                     atomicOr(&rinfo[rlane], 4u);
             }
             if (WANT_LPMD) {
@@ -446,10 +447,10 @@ __global__ __launch_bounds__(NW * 64) void k_pdr_lpmd_tile_wc(const TileArgs a, 
                 for (int d = 1; d <= WC_OV; ++d) {
                     const uint32_t pd = d == 1 ? p1 : __shfl_up(pk, d, 64);
                     const int32_t dist = (int32_t)rl - (int32_t)(pd & 0xffffu);
-                    const bool on = lpc && (pd >> 24) == rid && dist <= a.max_dist;   // readutil.rs:184
+                    const bool on = lpc && dh >= (uint32_t)d && dist <= a.max_dist;   // same read; readutil.rs:184
                     if (!__any(on)) break;
                     const bool in = on && dist >= a.min_dist;                         // readutil.rs:196
-                    const bool sm = ((pd >> 16) & 1u) == m;
+                    const bool sm = (pd >> 16) == m;
                     lp_c += (in && sm) ? 1u : 0u;
                     lp_d += (in && !sm) ? 1u : 0u;
                     if (d == WC_OV) deeper = on;
@@ -509,13 +510,12 @@ __global__ __launch_bounds__(NW * 64) void k_pdr_lpmd_tile_wc(const TileArgs a, 
                 for (uint32_t b2 = tail_base;; b2 += 64 - WC_OV) {
                     const uint32_t c = b2 + lane;
                     const bool valid = (int32_t)(c - cbeg) >= 0 && c < cend;
-                    uint32_t rid = valid ? (uint32_t)head[c - cbeg] : 0u;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const uint32_t up = __shfl_up(rid, o, 64);
-                        if (lane >= o) rid = max(rid, up);
-                    }
-                    rid = valid ? max(rid, cr) : 0u;
+                    const uint32_t h = valid ? (uint32_t)head[c - cbeg] : 0u;
+                    const unsigned long long hm = __ballot(h != 0u);
+                    const unsigned long long below = hm & ((2ull << lane) - 1ull);
+                    const int hp = below ? 63 - __builtin_clzll(below) : 0;
+                    const uint32_t hv = __shfl(h, hp, 64);
+                    const uint32_t rid = valid ? (below ? hv : cr) : 0u;
                     cr = __builtin_amdgcn_readlane(rid, 63 - WC_OV);
                     if (valid && lane >= WC_OV) {
                         const uint32_t info = rinfo[rid - 1];
