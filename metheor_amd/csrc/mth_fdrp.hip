@@ -52,19 +52,30 @@ __device__ __forceinline__ int32_t sample_j(unsigned long long seed, int32_t tid
     return (int32_t)(z % (unsigned long long)(uint32_t)total) + 1;
 }
 
+// PMC of the first version (profiles/r01_fdrp_pmc.md): 10 400 SALU vs 6 200 VALU instructions per site,
+// the per-CU scalar unit ~81 % busy -- wave-uniform loops compiled as divergent ones (bounds came from
+// vector loads) and '&&' predicate chains compiled to s_and_b64 sequences.  Hence: every wave-uniform
+// value is made explicitly scalar with readfirstlane (loops become scalar loops, uniform loads become
+// s_load), slot updates and call matches are selects, and the serial qFDRP sum adds 0.0 for skipped
+// pairs (x + 0.0 == x exactly) instead of branching per element.
+constexpr uint32_t FD_NOPOS = 0xffffffffu;   // "no call" in a slot's call registers (never equals a 31-bit position)
+
+__device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int32_t sgpr(int32_t x) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)x); }
+
 __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
     const int lane = threadIdx.x & 63;
-    const uint32_t wave_id = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+    const uint32_t wave_id = sgpr((uint32_t)((blockIdx.x * 256 + threadIdx.x) >> 6)), n_waves = (gridDim.x * 256) >> 6;
     const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
     for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
-        const int32_t c = a.site_pos[j];
-        const uint32_t lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
-        const uint32_t hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
-        // slot state (lane = slot)
-        uint32_t r_o0 = 0, r_n = 0, v[FD_NB];
+        const int32_t c = sgpr(a.site_pos[j]);
+        const uint32_t lo = sgpr(min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads));
+        const uint32_t hi = sgpr(min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads));
+        // slot state (lane = slot): position and methylation bit of up to FD_NB calls, FD_NOPOS = none
+        uint32_t r_o0 = 0, r_n = 0, vp[FD_NB], vm[FD_NB];
         int32_t r_s = 0, r_e = 0;
 #pragma unroll
-        for (int k = 0; k < FD_NB; ++k) v[k] = 0;
+        for (int k = 0; k < FD_NB; ++k) { vp[k] = FD_NOPOS; vm[k] = 0; }
         // wave-uniform segment state
         int32_t total = 0, sampled = 0;
         bool entry = false, have = false;
@@ -78,38 +89,46 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             for (int i = 0; i + 1 < nS; ++i) {
                 const uint32_t bo0 = __builtin_amdgcn_readlane(r_o0, i), bn = __builtin_amdgcn_readlane(r_n, i);
                 const int32_t bs = __builtin_amdgcn_readlane(r_s, i), be = __builtin_amdgcn_readlane(r_e, i);
-                const bool mine = lane > i && lane < nS;
-                int32_t ov = min(be, r_e) - max(bs, r_s) + 1;               // get_num_overlap_bases, fdrp.rs:97-107
-                ov = ov < 0 ? 0 : ov;
-                const bool pair_ok = mine && ov >= a.min_overlap;           // fdrp.rs:134
+                const int32_t ov = min(be, r_e) - max(bs, r_s) + 1;         // get_num_overlap_bases, fdrp.rs:97-107
+                const uint32_t mine = (lane > i) & (lane < nS);
+                const uint32_t pair_ok2 = mine & (uint32_t)(max(ov, 0) >= a.min_overlap);   // fdrp.rs:134 (an empty overlap counts 0 bases)
                 uint32_t ham = 0, ncpg = 0;
                 for (uint32_t k = 0; k < bn; ++k) {
-                    const uint32_t w = a.cpg_pos[bo0 + k];                   // wave-uniform
-                    const int32_t p = (int32_t)(w & 0x7fffffffu);
-                    if ((uint32_t)(p - (c - FD_WIN)) > 2u * FD_WIN) continue;   // outside the 403-slot array
-                    bool found = false;
-                    uint32_t own = 0;
+                    const uint32_t w = a.cpg_pos[bo0 + k];                   // wave-uniform -> scalar load
+                    const uint32_t p = w & 0x7fffffffu;
+                    if ((uint32_t)((int32_t)p - (c - FD_WIN)) > 2u * FD_WIN) continue;   // outside the 403-slot array (uniform branch)
+                    // does the slot's read call position p ?  (selects, no predicate chains)
+                    uint32_t fnd = 0, own_m = 0;
 #pragma unroll
-                    for (int t = 0; t < FD_NB; ++t)
-                        if ((uint32_t)t < r_n && (int32_t)(v[t] & 0x7fffffffu) == p) { found = true; own = v[t]; }
-                    if (r_n > (uint32_t)FD_NB)
+                    for (int t = 0; t < FD_NB; ++t) {
+                        const uint32_t e = vp[t] == p;
+                        fnd |= e;
+                        own_m = e ? vm[t] : own_m;
+                    }
+                    if (r_n > (uint32_t)FD_NB) {                              // rare: more than FD_NB calls in the stored read
                         for (uint32_t t = FD_NB; t < r_n; ++t) {
                             const uint32_t x = a.cpg_pos[r_o0 + t];
-                            if ((int32_t)(x & 0x7fffffffu) == p) { found = true; own = x; }
+                            if ((x & 0x7fffffffu) == p) { fnd = 1; own_m = x >> 31; }
                         }
-                    if (found) {
-                        ncpg += 1;                                           // get_num_overlap_cpgs, qfdrp.rs:109-119 (bit1 & bit1)
-                        // hamming / is_discordant: (r1 & r2 & 3) == 3 and bit2 differs (fdrp.rs:114-115, qfdrp.rs:127-131)
-                        if (p >= bs && p <= be && p >= r_s && p <= r_e && ((own ^ w) >> 31)) ham += 1;
                     }
+                    ncpg += fnd;                                              // get_num_overlap_cpgs, qfdrp.rs:109-119 (bit1 & bit1)
+                    // hamming / is_discordant: both cover p (bit0), both call it, states differ (fdrp.rs:114-115)
+                    const uint32_t cov_i = (uint32_t)(((int32_t)p >= bs) & ((int32_t)p <= be));          // uniform
+                    const uint32_t cov_j = (uint32_t)((uint32_t)((int32_t)p - r_s) <= (uint32_t)(r_e - r_s));
+                    ham += fnd & cov_i & cov_j & (own_m ^ (w >> 31));
                 }
-                n_disc += __popcll(__ballot(pair_ok && ham > 0));            // fdrp.rs:138-140
-                const float term = (float)ham / (float)ncpg;                // qfdrp.rs:152
-                const unsigned long long okm = __ballot(pair_ok);
-                for (int jj = i + 1; jj < nS; ++jj) {                       // lexicographic (i,j): same rounding as the reference
-                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, term), jj));
-                    if ((okm >> jj) & 1ull) q = q + t;
+                n_disc += __popcll(__ballot((pair_ok2 & (uint32_t)(ham > 0)) != 0));     // fdrp.rs:138-140
+                // qfdrp.rs:152 -- skipped pairs contribute +0.0, which leaves the f32 sum unchanged
+                const float term = pair_ok2 ? (float)ham / (float)ncpg : 0.0f;
+                const int ti = __builtin_bit_cast(int, term);
+                int jj = i + 1;
+                for (; jj + 4 <= nS; jj += 4) {                              // lexicographic (i,j): the reference's rounding
+                    q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj));
+                    q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj + 1));
+                    q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj + 2));
+                    q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj + 3));
                 }
+                for (; jj < nS; ++jj) q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj));
             }
             // (num_reads * (num_reads - 1)) as f32 / 2.0 in usize arithmetic (fdrp.rs:143)
             const unsigned long long prod = (unsigned long long)(long long)nS * (unsigned long long)((long long)nS - 1);
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             have = true;
         };
 
-        for (uint32_t i = lo; i < hi; ++i) {
+        for (uint32_t i = lo; i < hi; ++i) {                                  // scalar loop, scalar loads
             const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
             const uint32_t n = o1 - o0;
             if (a.read_mapq[i] < a.min_qual) continue;                       // fdrp.rs:205
@@ -149,10 +168,14 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 if (jr > (int32_t)a.max_depth) continue;
                 slot = jr - 1;
             }
-            if (lane == slot) {
-                r_o0 = o0; r_n = n; r_s = s; r_e = e;
+            const bool me = lane == slot;                                     // the slot's lane takes the read (selects)
+            r_o0 = me ? o0 : r_o0; r_n = me ? n : r_n; r_s = me ? s : r_s; r_e = me ? e : r_e;
 #pragma unroll
-                for (int k = 0; k < FD_NB; ++k) v[k] = ((uint32_t)k < n) ? a.cpg_pos[o0 + k] : 0u;
+            for (int k = 0; k < FD_NB; ++k) {
+                const uint32_t w = ((uint32_t)k < n) ? a.cpg_pos[o0 + k] : 0u;    // uniform
+                const uint32_t wp = ((uint32_t)k < n) ? (w & 0x7fffffffu) : FD_NOPOS;
+                vp[k] = me ? wp : vp[k];
+                vm[k] = me ? (w >> 31) : vm[k];
             }
         }
         if (entry && (uint32_t)sampled >= a.min_depth) finalize();           // fdrp.rs:239-243
