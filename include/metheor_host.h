@@ -58,6 +58,14 @@ const uint64_t *mth_host_cpg_off(const mth_host_t *h);      /* n_reads + 1 */
 const uint32_t *mth_host_cpg_pos(const mth_host_t *h);      /* abspos | methylated << 31 */
 const uint16_t *mth_host_cpg_rel(const mth_host_t *h);
 
+/* Tooling: write a synthetic single-contig Bismark-style BAM (read_len 'M' reads, XM:Z from the SoA's
+ * calls, random sequence/quality bytes) -- the seeded generator used by the end-to-end benchmarks.
+ * cpg_off/cpg_rel/cpg_pos as produced by mth_host_decode (cpg_pos bit 31 = methylated). */
+int  mth_host_write_synthetic_bam(const char *path, const char *contig, int64_t contig_len, int64_t n_reads,
+                                  int32_t read_len, const int32_t *start, const uint8_t *fwd, const uint8_t *mapq,
+                                  const uint64_t *cpg_off, const uint16_t *cpg_rel, const uint32_t *cpg_pos,
+                                  uint64_t seed, int nthreads);
+
 /* Rust `{}` of an f32 (shortest round-trip digits, positional, "NaN"/"inf"); buf >= 64 bytes */
 int  mth_host_format_f32(float v, char *buf);
 

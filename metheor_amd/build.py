@@ -12,8 +12,9 @@ ARCH = "gfx950"
 
 HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip", "mth_quartet.hip", "mth_scan.hip", "mth_sites.hip", "mth_fdrp.hip", "mth_pairs.hip"]
 HOST_LIB = os.path.join(HERE, "libmetheor_host.so")
-HOST_SOURCES = [os.path.join("host", "bam_reader.cpp"), os.path.join("host", "host_api.cpp")]
-HOST_HEADERS = [os.path.join("host", "bam_reader.h"), os.path.join("..", "..", "include", "metheor_host.h")]
+HOST_SOURCES = [os.path.join("host", "bam_reader.cpp"), os.path.join("host", "host_api.cpp"),
+                os.path.join("host", "parallel_decode.cpp"), os.path.join("host", "synth_bam.cpp")]
+HOST_HEADERS = [os.path.join("host", "bam_reader.h"), os.path.join("host", "parallel_decode.h"), os.path.join("..", "..", "include", "metheor_host.h")]
 HEADERS = ["mth_common.h", "mth_ctx.h", "mth_scan.h", os.path.join("..", "..", "include", "metheor_hip.h")]
 
 
@@ -36,7 +37,7 @@ def build_host(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HOST_HEADERS]
     if force or _stale(HOST_LIB, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-shared", "-o", HOST_LIB] + srcs + ["-lz"]
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-shared", "-pthread", "-o", HOST_LIB] + srcs + ["-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -79,6 +79,7 @@ bool BamReader::read_bytes(void *dst, size_t n, bool &eof_at_start) {
         memcpy(d + done, buf_.data() + off_, take);
         off_ += take;
         done += take;
+        consumed_ += take;
     }
     return true;
 }

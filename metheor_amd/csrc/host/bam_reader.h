@@ -33,6 +33,8 @@ class BamReader {
     const std::vector<BamRef> &refs() const { return refs_; }
     const std::string &header_text() const { return text_; }
     const std::string &error() const { return err_; }
+    // uncompressed bytes handed out so far (right after open(): the size of the BAM header)
+    size_t consumed() const { return consumed_; }
 
   private:
     bool fill();                               // inflate the next BGZF block into buf_
@@ -41,7 +43,7 @@ class BamReader {
     std::string path_, err_, text_;
     std::vector<BamRef> refs_;
     std::vector<uint8_t> buf_;                 // uncompressed bytes not yet consumed
-    size_t off_ = 0;
+    size_t off_ = 0, consumed_ = 0;
     std::vector<uint8_t> cbuf_, rec_;
 };
 

@@ -7,6 +7,7 @@
 // not built yet fails loudly.
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -196,48 +197,90 @@ Args parse_args(const Cmd &c, int argc, char **argv, int first) {
     return a;
 }
 
-// ---- decoded input, split into per-contig batches ---------------------------------------------
+// ---- decoded input as per-contig batches --------------------------------------------------------
+// A contig's reads are a contiguous slice of the decoded SoA (the file is coordinate-sorted), so the
+// batch points straight into the decoder's arrays; only the CSR offsets are rebased (4 B/read).  A
+// contig that contains a read without any aligned base (start = -1) is copied without those reads.
 struct Contig {
     int32_t tid;
-    std::vector<int32_t> start, end;
-    std::vector<uint8_t> mapq;
-    std::vector<uint32_t> off, pos;
-    std::vector<uint16_t> rel;
+    const int32_t *start, *end;
+    const uint8_t *mapq;
+    const uint32_t *pos;
+    const uint16_t *rel;
+    size_t n_reads, n_cpgs;
+    std::vector<uint32_t> off;
     int32_t max_span = 0;
+    // owned copies (only when filtering was needed)
+    std::vector<int32_t> o_start, o_end;
+    std::vector<uint8_t> o_mapq;
+    std::vector<uint32_t> o_pos;
+    std::vector<uint16_t> o_rel;
 };
 
 struct Input {
     mth_host_t *h = nullptr;
     std::vector<Contig> contigs;
-    int64_t loose_reads = 0;                 // records outside any contig batch (no contig / no aligned base)
-    std::vector<uint8_t> loose_mapq;
+};
+
+// METHEOR_TIMING=1: phase wall times on stderr (never stdout)
+struct Phase {
+    const char *name;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit Phase(const char *n) : name(n) {}
+    ~Phase() {
+        if (!getenv("METHEOR_TIMING")) return;
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[metheor timing] %-28s %.3f s\n", name, s);
+    }
 };
 
 Input load(const std::string &path, const char *cpg_set) {
+    Phase ph_all("load: open+decode+batch");
     Input in;
     char err[1024];
     if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) die(err);    // bamutil.rs:7-9
-    if (mth_host_decode(in.h, cpg_set) != 0) die(mth_host_last_error(in.h));
+    {
+        Phase ph("  host decode (BGZF+BAM+XM)");
+        if (mth_host_decode(in.h, cpg_set) != 0) die(mth_host_last_error(in.h));
+    }
+    Phase ph2("  contig batches");
     const int64_t n = mth_host_n_reads(in.h);
     const int32_t *tid = mth_host_read_tid(in.h), *st = mth_host_read_start(in.h), *en = mth_host_read_end(in.h);
     const uint8_t *mq = mth_host_read_mapq(in.h);
     const uint64_t *off = mth_host_cpg_off(in.h);
     const uint32_t *pos = mth_host_cpg_pos(in.h);
     const uint16_t *rel = mth_host_cpg_rel(in.h);
-    for (int64_t i = 0; i < n; ++i) {
-        if (tid[i] < 0 || st[i] < 0) { in.loose_reads += 1; in.loose_mapq.push_back(mq[i]); continue; }
-        if (in.contigs.empty() || in.contigs.back().tid != tid[i]) {
-            for (const Contig &c : in.contigs)
-                if (c.tid == tid[i]) die("input BAM is not grouped by contig (coordinate-sorted input is required on the MI355X path)");
-            in.contigs.emplace_back();
-            in.contigs.back().tid = tid[i];
-            in.contigs.back().off.push_back(0);
-        }
+    for (int64_t i = 0; i < n;) {
+        int64_t e = i;
+        bool loose = false;
+        while (e < n && tid[e] == tid[i]) { loose |= st[e] < 0; ++e; }
+        if (tid[i] < 0) { i = e; continue; }                       // records without a contig never enter a batch
+        for (const Contig &c : in.contigs)
+            if (c.tid == tid[i]) die("input BAM is not grouped by contig (coordinate-sorted input is required on the MI355X path)");
+        in.contigs.emplace_back();
         Contig &c = in.contigs.back();
-        c.start.push_back(st[i]); c.end.push_back(en[i]); c.mapq.push_back(mq[i]);
-        for (uint64_t k = off[i]; k < off[i + 1]; ++k) { c.pos.push_back(pos[k]); c.rel.push_back(rel[k]); }
-        c.off.push_back((uint32_t)c.pos.size());
-        c.max_span = std::max(c.max_span, en[i] - st[i] + 1);
+        c.tid = tid[i];
+        if (!loose) {
+            c.start = st + i; c.end = en + i; c.mapq = mq + i; c.pos = pos + off[i]; c.rel = rel + off[i];
+            c.n_reads = (size_t)(e - i); c.n_cpgs = (size_t)(off[e] - off[i]);
+            c.off.resize(c.n_reads + 1);
+            int32_t ms = 0;
+            for (int64_t r = i; r < e; ++r) { c.off[(size_t)(r - i)] = (uint32_t)(off[r] - off[i]); ms = std::max(ms, en[r] - st[r] + 1); }
+            c.off[c.n_reads] = (uint32_t)(off[e] - off[i]);
+            c.max_span = ms;
+        } else {
+            c.off.push_back(0);
+            for (int64_t r = i; r < e; ++r) {
+                if (st[r] < 0) continue;                           // no aligned base: no CpG, no position
+                c.o_start.push_back(st[r]); c.o_end.push_back(en[r]); c.o_mapq.push_back(mq[r]);
+                for (uint64_t k = off[r]; k < off[r + 1]; ++k) { c.o_pos.push_back(pos[k]); c.o_rel.push_back(rel[k]); }
+                c.off.push_back((uint32_t)c.o_pos.size());
+                c.max_span = std::max(c.max_span, en[r] - st[r] + 1);
+            }
+            c.start = c.o_start.data(); c.end = c.o_end.data(); c.mapq = c.o_mapq.data(); c.pos = c.o_pos.data(); c.rel = c.o_rel.data();
+            c.n_reads = c.o_start.size(); c.n_cpgs = c.o_pos.size();
+        }
+        i = e;
     }
     return in;
 }
@@ -250,6 +293,7 @@ void check(mth_ctx_t *ctx, int rc) {
 }
 
 mth_ctx_t *make_ctx() {
+    Phase ph("device context");
     mth_ctx_t *ctx = nullptr;
     const char *dev = getenv("METHEOR_DEVICE");
     const int rc = mth_ctx_create(dev ? atoi(dev) : 0, &ctx);
@@ -265,11 +309,11 @@ mth_batch_t make_batch(const Input &in, const Contig &c) {
     const int64_t len = mth_host_ref_len(in.h, c.tid);
     b.region_end = (int32_t)std::min<int64_t>(len, INT32_MAX);
     b.max_span = c.max_span;
-    b.n_reads = (uint32_t)c.start.size();
-    b.n_cpgs = (uint32_t)c.pos.size();
+    b.n_reads = (uint32_t)c.n_reads;
+    b.n_cpgs = (uint32_t)c.n_cpgs;
     b.mem = MTH_MEM_HOST;
-    b.read_start = c.start.data(); b.read_end = c.end.data(); b.read_mapq = c.mapq.data();
-    b.cpg_off = c.off.data(); b.cpg_pos = c.pos.data(); b.cpg_rel16 = c.rel.data();
+    b.read_start = c.start; b.read_end = c.end; b.read_mapq = c.mapq;
+    b.cpg_off = c.off.data(); b.cpg_pos = c.pos; b.cpg_rel16 = c.rel;
     return b;
 }
 
@@ -279,6 +323,25 @@ void submit(mth_ctx_t *ctx, const Input &in, const mth_pdr_lpmd_params_t &p) {
         check(ctx, mth_pdr_lpmd_accumulate(ctx, &b, &p));
     }
 }
+
+// TSV lines are assembled by hand into a large buffer (one write per ~4 MiB instead of one per line)
+struct LineWriter {
+    FILE *f;
+    std::vector<char> buf;
+    explicit LineWriter(FILE *file) : f(file) { buf.reserve(4u << 20); }
+    void str(const char *s) { buf.insert(buf.end(), s, s + strlen(s)); }
+    void ch(char c) { buf.push_back(c); }
+    void i64(long long v) { char t[24]; const int n = snprintf(t, sizeof t, "%lld", v); buf.insert(buf.end(), t, t + n); }
+    void u32(uint32_t v) {
+        char t[12]; int n = 0;
+        do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) buf.push_back(t[--n]);
+    }
+    void i32(int32_t v) { if (v < 0) { ch('-'); u32((uint32_t)(-(int64_t)v)); } else u32((uint32_t)v); }
+    void f32(float v) { char t[64]; const int n = mth_host_format_f32(v, t); buf.insert(buf.end(), t, t + n); }
+    void eol() { ch('\n'); if (buf.size() > (4u << 20) - 256) flush(); }
+    void flush() { if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) die("Error writing to output file."); buf.clear(); }
+};
 
 FILE *open_output(const std::string &path) {
     FILE *f = fopen(path.c_str(), "wb");   // create + truncate (pdr.rs:95-101)
@@ -297,19 +360,24 @@ int run_pdr(const Args &a) {
     p.pdr_min_cpgs = (uint32_t)std::min<int64_t>(a.n.at("min-cpgs"), UINT32_MAX);
     p.pdr_min_qual = (uint8_t)a.n.at("min-qual");
     p.want_pdr = 1;
-    submit(ctx, in, p);
     uint64_t n = 0;
-    check(ctx, mth_pdr_count(ctx, &n));
+    {
+        Phase ph("H2D + kernels (sync)");
+        submit(ctx, in, p);
+        check(ctx, mth_pdr_count(ctx, &n));
+    }
+    Phase ph3("fetch + TSV write");
     std::vector<int32_t> tid(n), pos(n);
     std::vector<float> pdr(n);
     std::vector<uint32_t> nc(n), nd(n);
     check(ctx, mth_pdr_fetch(ctx, tid.data(), pos.data(), pdr.data(), nc.data(), nd.data()));
     FILE *f = open_output(a.s.at("output"));
-    char fb[64];
+    LineWriter w(f);
     for (uint64_t i = 0; i < n; ++i) {   // pdr.rs:102-116
-        mth_host_format_f32(pdr[i], fb);
-        fprintf(f, "%s\t%d\t%d\t%s\t%u\t%u\n", mth_host_ref_name(in.h, tid[i]), pos[i], pos[i] + 2, fb, nc[i], nd[i]);
+        w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(pos[i]); w.ch('\t'); w.i32(pos[i] + 2); w.ch('\t');
+        w.f32(pdr[i]); w.ch('\t'); w.u32(nc[i]); w.ch('\t'); w.u32(nd[i]); w.eol();
     }
+    w.flush();
     if (fclose(f) != 0) die("Error writing to output file.");
     mth_ctx_destroy(ctx);
     mth_host_close(in.h);
@@ -353,10 +421,12 @@ int run_lpmd(const Args &a) {
         check(ctx, mth_lpmd_pairs_fetch(ctx, &n, tid.data(), p1.data(), p2.data(), v.data(), nc.data(), nd.data()));
         FILE *g = open_output(a.s.at("pairs"));
         fprintf(g, "chrom\tcpg1\tcpg2\tlpmd\tn_concordant\tn_discordant\n");
+        LineWriter w(g);
         for (uint64_t i = 0; i < n; ++i) {
-            mth_host_format_f32(v[i], fb);
-            fprintf(g, "%s\t%d\t%d\t%s\t%u\t%u\n", mth_host_ref_name(in.h, tid[i]), p1[i], p2[i], fb, nc[i], nd[i]);
+            w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(p1[i]); w.ch('\t'); w.i32(p2[i]); w.ch('\t');
+            w.f32(v[i]); w.ch('\t'); w.u32(nc[i]); w.ch('\t'); w.u32(nd[i]); w.eol();
         }
+        w.flush();
         if (fclose(g) != 0) die("Error writing to output file.");
     }
     mth_ctx_destroy(ctx);
@@ -383,12 +453,13 @@ int run_quartet(const Args &a, bool want_me) {
     check(ctx, mth_quartet_fetch(ctx, min_depth, &n, tid.data(), pos.data(), nullptr, want_me ? val.data() : nullptr,
                                  want_me ? nullptr : val.data()));
     FILE *f = open_output(a.s.at("output"));
-    char fb[64];
+    LineWriter w(f);
     for (uint64_t i = 0; i < n; ++i) {
-        mth_host_format_f32(val[i], fb);
-        fprintf(f, "%s\t%d\t%d\t%d\t%d\t%s\n", mth_host_ref_name(in.h, tid[i]), pos[4 * i], pos[4 * i + 1],
-                pos[4 * i + 2], pos[4 * i + 3], fb);
+        w.str(mth_host_ref_name(in.h, tid[i]));
+        for (int k = 0; k < 4; ++k) { w.ch('\t'); w.i32(pos[4 * i + k]); }
+        w.ch('\t'); w.f32(val[i]); w.eol();
     }
+    w.flush();
     if (fclose(f) != 0) die("Error writing to output file.");
     mth_ctx_destroy(ctx);
     mth_host_close(in.h);
@@ -413,11 +484,11 @@ int run_mhl(const Args &a) {
     std::vector<float> val(n);
     check(ctx, mth_mhl_fetch(ctx, &n, tid.data(), pos.data(), val.data(), nullptr));
     FILE *f = open_output(a.s.at("output"));
-    char fb[64];
+    LineWriter w(f);
     for (uint64_t i = 0; i < n; ++i) {
-        mth_host_format_f32(val[i], fb);
-        fprintf(f, "%s\t%d\t%d\t%s\n", mth_host_ref_name(in.h, tid[i]), pos[i], pos[i] + 2, fb);
+        w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(pos[i]); w.ch('\t'); w.i32(pos[i] + 2); w.ch('\t'); w.f32(val[i]); w.eol();
     }
+    w.flush();
     if (fclose(f) != 0) die("Error writing to output file.");
     mth_ctx_destroy(ctx);
     mth_host_close(in.h);
@@ -447,11 +518,11 @@ int run_fdrp(const Args &a, bool quantitative) {
     check(ctx, mth_fdrp_fetch(ctx, &n, tid.data(), pos.data(), quantitative ? nullptr : val.data(),
                               quantitative ? val.data() : nullptr, nullptr));
     FILE *f = open_output(a.s.at("output"));
-    char fb[64];
+    LineWriter w(f);
     for (uint64_t i = 0; i < n; ++i) {
-        mth_host_format_f32(val[i], fb);
-        fprintf(f, "%s\t%d\t%d\t%s\n", mth_host_ref_name(in.h, tid[i]), pos[i], pos[i] + 2, fb);
+        w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(pos[i]); w.ch('\t'); w.i32(pos[i] + 2); w.ch('\t'); w.f32(val[i]); w.eol();
     }
+    w.flush();
     if (fclose(f) != 0) die("Error writing to output file.");
     mth_ctx_destroy(ctx);
     mth_host_close(in.h);

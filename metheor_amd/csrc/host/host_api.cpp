@@ -1,7 +1,8 @@
 // host_api.cpp -- include/metheor_host.h: BAM -> decoded SoA (the reference's BismarkRead stream).
 //
-// decode follows src/readutil.rs:24-53 (BismarkRead::new) and 323-345 (get_cpgs) in ONE walk over
-// the CIGAR with a cursor into the XM string (no per-base position vector):
+// The record decode itself lives in parallel_decode.cpp (multi-threaded inflate + decode); it follows
+// src/readutil.rs:24-53 (BismarkRead::new) and 323-345 (get_cpgs) in ONE walk over the CIGAR with a
+// cursor into the XM string (no per-base position vector):
 //   M/=/X  consume query+reference : XM[q] in {z,Z} -> CpG at reference r (forward: flags exactly
 //          0, 99 or 147) or r-1 (everything else), relpos = q          (readutil.rs:326-341)
 //   I/S    consume query only      : reference position None -> skipped (readutil.rs:331)
@@ -21,57 +22,20 @@
 
 #include "../../../include/metheor_host.h"
 #include "bam_reader.h"
+#include "parallel_decode.h"
+
+#include <thread>
 
 using namespace mthh;
 
-struct mth_host {
+struct mth_host : DecodedSoA {
     BamReader reader;
-    std::string last_error;
+    std::string path, last_error;
     std::unordered_map<std::string, int> name2tid;
-    std::vector<int32_t> tid, start, end;
-    std::vector<uint8_t> mapq, fwd;
-    std::vector<uint64_t> cpg_off;
-    std::vector<uint32_t> cpg_pos;
-    std::vector<uint16_t> cpg_rel;
+    size_t header_bytes = 0;
 };
 
 namespace {
-
-// find the XM:Z value in the aux block (BAM aux: tag[2] type[1] value); returns false if absent
-bool find_xm(const uint8_t *aux, uint32_t len, const char *&xm, uint32_t &xm_len) {
-    uint32_t o = 0;
-    while (o + 3 <= len) {
-        const uint8_t t0 = aux[o], t1 = aux[o + 1], ty = aux[o + 2];
-        o += 3;
-        switch (ty) {
-            case 'A': case 'c': case 'C': o += 1; break;
-            case 's': case 'S': o += 2; break;
-            case 'i': case 'I': case 'f': o += 4; break;
-            case 'Z': case 'H': {
-                const uint32_t b = o;
-                while (o < len && aux[o] != 0) ++o;
-                if (o >= len) return false;
-                if (ty == 'Z' && t0 == 'X' && t1 == 'M') {
-                    xm = reinterpret_cast<const char *>(aux + b);
-                    xm_len = o - b;
-                    return true;
-                }
-                o += 1;
-                break;
-            }
-            case 'B': {
-                if (o + 5 > len) return false;
-                const uint8_t sub = aux[o];
-                const uint32_t cnt = read_u32(aux + o + 1);
-                const uint32_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                o += 5 + cnt * w;
-                break;
-            }
-            default: return false;
-        }
-    }
-    return false;
-}
 
 inline uint64_t site_key(int32_t tid, int32_t pos) { return ((uint64_t)(uint32_t)tid << 32) | (uint32_t)pos; }
 
@@ -91,6 +55,8 @@ int mth_host_open(const char *path, mth_host_t **out, char *errbuf, int errbuf_l
         return MTH_HOST_ERR_OPEN;
     }
     for (size_t i = 0; i < h->reader.refs().size(); ++i) h->name2tid.emplace(h->reader.refs()[i].name, (int)i);
+    h->path = path;
+    h->header_bytes = h->reader.consumed();
     *out = h;
     return MTH_HOST_OK;
 }
@@ -139,47 +105,17 @@ int mth_host_decode(mth_host_t *h, const char *cpg_set_path) {
         have_set = true;
     }
 
-    BamRecord rec;
-    bool eof = false;
-    for (;;) {
-        if (!h->reader.next(rec, eof)) { h->last_error = "Error reading BAM record. " + h->reader.error(); return MTH_HOST_ERR_FORMAT; }
-        if (eof) break;
-        const char *xm = nullptr;
-        uint32_t xm_len = 0;
-        if (!find_xm(rec.aux, rec.aux_len, xm, xm_len)) {
-            h->last_error = "Error reading XM tag in BAM record. Make sure the reads are aligned using Bismark!";
-            return MTH_HOST_ERR_XM;
-        }
-        const bool forward = rec.flag == 0 || rec.flag == 99 || rec.flag == 147;   // readutil.rs:332
-        int32_t first = -1, last = -1;
-        int64_t r = rec.pos;
-        uint32_t q = 0;
-        for (uint32_t c = 0; c < rec.n_cigar; ++c) {
-            const uint32_t w = read_u32(rec.cigar + c), op = w & 15u, len = w >> 4;
-            if (op == 0 || op == 7 || op == 8) {          // M = X
-                if (len) { if (first < 0) first = (int32_t)r; last = (int32_t)(r + len - 1); }
-                const uint32_t qe = q + len;
-                for (; q < qe; ++q, ++r) {
-                    if (q >= xm_len) continue;              // zip() stops at the shorter side
-                    const char ch = xm[q];
-                    if (ch != 'z' && ch != 'Z') continue;
-                    const int32_t ap = forward ? (int32_t)r : (int32_t)(r - 1);
-                    if (have_set && !target.count(site_key(rec.tid, ap))) continue;   // filter_isin keeps relpos
-                    h->cpg_pos.push_back(((uint32_t)ap & 0x7fffffffu) | (ch == 'Z' ? 0x80000000u : 0u));
-                    h->cpg_rel.push_back((uint16_t)q);
-                }
-            } else if (op == 1 || op == 4) {               // I S
-                q += len;
-            } else if (op == 2 || op == 3) {               // D N
-                r += len;
-            }                                               // H P: nothing
-        }
-        h->tid.push_back(rec.tid);
-        h->start.push_back(first);
-        h->end.push_back(last);
-        h->mapq.push_back(rec.mapq);
-        h->fwd.push_back(forward ? 1 : 0);
-        h->cpg_off.push_back((uint64_t)h->cpg_pos.size());
+    // records: multi-threaded inflate + decode (parallel_decode.cpp); METHEOR_THREADS overrides the thread count
+    int nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) nthreads = 1;
+    if (nthreads > 128) nthreads = 128;
+    if (const char *e = getenv("METHEOR_THREADS")) { const int k = atoi(e); if (k >= 1 && k <= 1024) nthreads = k; }
+    std::string err;
+    int kind = 0;
+    if (!parallel_decode(h->path, h->header_bytes, have_set ? &target : nullptr, nthreads, *h, err, kind)) {
+        if (kind == 2) { h->last_error = err; return MTH_HOST_ERR_XM; }
+        h->last_error = "Error reading BAM record. " + err;
+        return MTH_HOST_ERR_FORMAT;
     }
     return MTH_HOST_OK;
 }

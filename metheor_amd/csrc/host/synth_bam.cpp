@@ -1,0 +1,105 @@
+// synth_bam.cpp -- fast writer of a synthetic Bismark-style BAM from the decoded SoA (bench / test
+// tooling: the SURVEY's "seeded synthetic Bismark BAM generator").  One contig, `read_len`M reads,
+// XM:Z strings with z/Z at the call offsets, random sequence and quality bytes so that the file
+// compresses like a real BAM.  Records are built and deflated (BGZF, zlib level 6) in parallel.
+#include <zlib.h>
+
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/metheor_host.h"
+
+namespace {
+
+void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+void put16(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
+
+// append `n` uncompressed bytes as BGZF blocks (<= 60000 bytes each)
+void bgzf_append(std::vector<uint8_t> &out, const uint8_t *p, size_t n) {
+    size_t o = 0;
+    do {
+        const size_t take = std::min<size_t>(60000, n - o);
+        uint8_t comp[70000];
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = const_cast<uint8_t *>(p + o); zs.avail_in = (uInt)take;
+        zs.next_out = comp; zs.avail_out = sizeof comp;
+        deflate(&zs, Z_FINISH);
+        const size_t clen = sizeof comp - zs.avail_out;
+        deflateEnd(&zs);
+        const uint8_t hdr[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
+        out.insert(out.end(), hdr, hdr + 12);
+        out.push_back('B'); out.push_back('C'); put16(out, 2); put16(out, (uint32_t)(clen + 25));
+        out.insert(out.end(), comp, comp + clen);
+        put32(out, (uint32_t)crc32(crc32(0L, Z_NULL, 0), p + o, (uInt)take));
+        put32(out, (uint32_t)take);
+        o += take;
+    } while (o < n);
+}
+
+inline uint64_t rng_next(uint64_t &s) { s += 0x9e3779b97f4a7c15ULL; uint64_t z = s; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); }
+
+}  // namespace
+
+extern "C" int mth_host_write_synthetic_bam(const char *path, const char *contig, int64_t contig_len, int64_t n_reads,
+                                            int32_t read_len, const int32_t *start, const uint8_t *fwd, const uint8_t *mapq,
+                                            const uint64_t *cpg_off, const uint16_t *cpg_rel, const uint32_t *cpg_pos,
+                                            uint64_t seed, int nthreads) {
+    if (!path || !contig || n_reads < 0 || read_len <= 0) return MTH_HOST_ERR_INVALID;
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) nthreads = 1;
+    if (nthreads > 128) nthreads = 128;
+    std::vector<uint8_t> head;
+    const std::string text = std::string("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:") + contig + "\tLN:" + std::to_string(contig_len) + "\n";
+    head.insert(head.end(), {'B', 'A', 'M', 1});
+    put32(head, (uint32_t)text.size()); head.insert(head.end(), text.begin(), text.end());
+    put32(head, 1);
+    put32(head, (uint32_t)strlen(contig) + 1); head.insert(head.end(), contig, contig + strlen(contig) + 1);
+    put32(head, (uint32_t)contig_len);
+    std::vector<std::vector<uint8_t>> parts((size_t)nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t] {
+        const int64_t r0 = n_reads * t / nthreads, r1 = n_reads * (t + 1) / nthreads;
+        std::vector<uint8_t> raw;
+        raw.reserve(1 << 22);
+        std::vector<uint8_t> &out = parts[(size_t)t];
+        uint64_t rs = seed ^ (0x51ed27ULL * (uint64_t)(t + 1));
+        const uint32_t seqb = (uint32_t)(read_len + 1) / 2;
+        for (int64_t i = r0; i < r1; ++i) {
+            char name[32];
+            const int ln = snprintf(name, sizeof name, "r%lld", (long long)i) + 1;
+            const uint32_t aux_len = 4 + 3 + (uint32_t)read_len + 1 + 6;
+            const uint32_t bs = 32 + (uint32_t)ln + 4 + seqb + (uint32_t)read_len + aux_len;
+            put32(raw, bs); put32(raw, 0); put32(raw, (uint32_t)start[i]);
+            raw.push_back((uint8_t)ln); raw.push_back(mapq[i]); put16(raw, 4680); put16(raw, 1);
+            put16(raw, fwd[i] ? 0 : 16); put32(raw, (uint32_t)read_len); put32(raw, 0xffffffffu); put32(raw, 0xffffffffu); put32(raw, 0);
+            raw.insert(raw.end(), name, name + ln);
+            put32(raw, ((uint32_t)read_len << 4) | 0);
+            for (uint32_t k = 0; k < seqb; k += 8) { uint64_t x = rng_next(rs); for (uint32_t q = 0; q < 8 && k + q < seqb; ++q, x >>= 8) raw.push_back((uint8_t)((1u << (x & 3)) << 4 | (1u << ((x >> 2) & 3)))); }
+            for (int32_t k = 0; k < read_len; k += 8) { uint64_t x = rng_next(rs); for (int q = 0; q < 8 && k + q < read_len; ++q, x >>= 8) raw.push_back((uint8_t)(2 + (x & 0xff) % 39)); }
+            raw.insert(raw.end(), {'N', 'M', 'C', 0, 'X', 'M', 'Z'});
+            const size_t xo = raw.size();
+            raw.insert(raw.end(), (size_t)read_len, (uint8_t)'.');
+            for (uint64_t c = cpg_off[i]; c < cpg_off[i + 1]; ++c)
+                if (cpg_rel[c] < (uint32_t)read_len) raw[xo + cpg_rel[c]] = (cpg_pos[c] >> 31) ? 'Z' : 'z';
+            raw.push_back(0);
+            raw.insert(raw.end(), {'X', 'R', 'Z', 'C', 'T', 0});
+            if (raw.size() >= (1u << 22)) { bgzf_append(out, raw.data(), raw.size()); raw.clear(); }
+        }
+        if (!raw.empty()) bgzf_append(out, raw.data(), raw.size());
+    });
+    for (auto &x : th) x.join();
+    FILE *f = fopen(path, "wb");
+    if (!f) return MTH_HOST_ERR_OPEN;
+    std::vector<uint8_t> hb;
+    bgzf_append(hb, head.data(), head.size());
+    bool ok = fwrite(hb.data(), 1, hb.size(), f) == hb.size();
+    for (auto &p : parts) ok = ok && (p.empty() || fwrite(p.data(), 1, p.size(), f) == p.size());
+    static const uint8_t eof_blk[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ok = ok && fwrite(eof_blk, 1, 28, f) == 28;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? MTH_HOST_OK : MTH_HOST_ERR_OPEN;
+}

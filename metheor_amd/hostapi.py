@@ -11,7 +11,7 @@ SYMBOLS = [
     "mth_host_open", "mth_host_close", "mth_host_last_error", "mth_host_n_refs", "mth_host_ref_name",
     "mth_host_ref_len", "mth_host_ref_tid", "mth_host_decode", "mth_host_n_reads", "mth_host_n_cpgs",
     "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
-    "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32",
+    "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32", "mth_host_write_synthetic_bam",
 ]
 
 
@@ -46,6 +46,7 @@ def lib():
         for f in ("read_tid", "read_start", "read_end", "read_mapq", "read_fwd", "cpg_off", "cpg_pos", "cpg_rel"):
             getattr(L, "mth_host_" + f).argtypes = [vp]; getattr(L, "mth_host_" + f).restype = vp
         L.mth_host_format_f32.argtypes = [C.c_float, C.c_char_p]
+        L.mth_host_write_synthetic_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int32] + [vp] * 6 + [C.c_uint64, C.c_int]
         _LIB = L
     return _LIB
 
@@ -54,6 +55,19 @@ def format_f32(v):
     buf = C.create_string_buffer(80)
     lib().mth_host_format_f32(float(np.float32(v)), buf)
     return buf.value.decode()
+
+
+def write_synthetic_bam(path, c, contig="chr19", seed=0, threads=0):
+    """c: a metheor_amd.synth contig dict -> BAM file (fast C++ writer, realistic byte content)"""
+    n = len(c["read_start"])
+    rl = int(c["read_end"][0] - c["read_start"][0] + 1) if n else 150
+    arrs = [np.ascontiguousarray(c["read_start"], np.int32), np.ascontiguousarray(c["read_fwd"], np.uint8),
+            np.ascontiguousarray(c["read_mapq"], np.uint8), np.ascontiguousarray(c["cpg_off"], np.uint64),
+            np.ascontiguousarray(c["cpg_rel"], np.uint16), np.ascontiguousarray(c["cpg_pos"], np.uint32)]
+    rc = lib().mth_host_write_synthetic_bam(os.fsencode(path), contig.encode(), int(c["length"]), n, rl,
+                                            *[a.ctypes.data_as(C.c_void_p) for a in arrs], seed, threads)
+    if rc != 0:
+        raise HostError(rc, "cannot write " + path)
 
 
 class BamFile:

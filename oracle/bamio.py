@@ -155,8 +155,10 @@ def _bgzf_block(data):
     return hdr + comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
 
 
-def write_bam(path, rec, seq_len=None):
-    """rec: Records.  Sequences/qualities are dummies (the hot path never looks at them)."""
+def write_bam(path, rec, seq_len=None, realistic=False, seed=0):
+    """rec: Records.  Sequences/qualities are dummies (the hot path never looks at them); with
+    realistic=True they are random bytes so that the file compresses like a real BAM (~35 %)."""
+    rng = np.random.default_rng(seed) if realistic else None
     text = rec.text if rec.text else "@HD\tVN:1.0\tSO:coordinate\n" + "".join(
         "@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in rec.refs)
     out = bytearray(b"BAM\1")
@@ -175,7 +177,13 @@ def write_bam(path, rec, seq_len=None):
             aux += b"NMC\x00" + b"XMZ" + rec.xms[i] + b"\0" + b"XRZCT\0"
         body = struct.pack("<iiBBHHHiiii", int(rec.tid[i]), int(rec.pos[i]), len(name), int(rec.mapq[i]), 4680,
                            len(cig), int(rec.flag[i]), qlen, -1, -1, 0)
-        body += name + struct.pack("<%dI" % len(cig), *cig) + b"\x11" * ((qlen + 1) // 2) + b"\x28" * qlen + aux
+        if realistic:
+            sq = (rng.integers(0, 4, size=(qlen + 1) // 2 * 2, dtype=np.uint8) + 1).astype(np.uint8)
+            sq = ((1 << (sq[0::2] - 1)) << 4 | (1 << (sq[1::2] - 1))).astype(np.uint8).tobytes()
+            ql = rng.integers(2, 41, size=qlen, dtype=np.uint8).tobytes()
+        else:
+            sq, ql = b"\x11" * ((qlen + 1) // 2), b"\x28" * qlen
+        body += name + struct.pack("<%dI" % len(cig), *cig) + sq + ql + aux
         out += struct.pack("<i", len(body)) + body
     with open(path, "wb") as fh:
         data = bytes(out)

@@ -179,3 +179,36 @@ def test_format_f32_three_ways():
         a = hostapi.format_f32(v)
         assert a == pyoracle.format_f32(v) == np.format_float_positional(v, unique=True, trim="-"), v
         assert np.float32(a) == v
+
+
+def test_thread_count_invariance(tmp_path, monkeypatch):
+    """the multi-threaded decoder returns the same SoA for any thread count (records straddle
+    BGZF blocks and decode windows; realistic sequence/quality bytes)"""
+    rec = _weird_records()
+    rec2 = bamio.Records(rec.refs, np.tile(rec.tid, 6), np.tile(rec.pos, 6), np.tile(rec.flag, 6), np.tile(rec.mapq, 6),
+                         rec.cigars * 6, rec.xms * 6)
+    p = str(tmp_path / "big.bam")
+    bamio.write_bam(p, rec2, realistic=True)
+    assert os.path.getsize(p) > 1_000_000
+    want = pyoracle.Reads.decode(rec2).soa()
+    monkeypatch.setenv("METHEOR_DECODE_WINDOW_MB", "1")     # several decode windows: records are carried across them
+    for nt in ("1", "2", "7", "64"):
+        monkeypatch.setenv("METHEOR_THREADS", nt)
+        same_soa(hostapi.BamFile(p).decode(), want)
+    monkeypatch.delenv("METHEOR_DECODE_WINDOW_MB")
+    same_soa(hostapi.BamFile(p).decode(), want)
+
+
+def test_fast_synthetic_writer_round_trip(tmp_path):
+    """the C++ synthetic-BAM writer (bench tooling): what it writes decodes back to the generator's SoA,
+    through the product reader and through the independent pure-Python loader"""
+    from metheor_amd import synth
+    c = synth.make_contig(0, 300_000, 40_000, 0.03, np.random.default_rng(9))
+    p = str(tmp_path / "fast.bam")
+    hostapi.write_synthetic_bam(p, c, contig="chrT", seed=3, threads=5)
+    want = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c)).soa()
+    f = hostapi.BamFile(p)
+    assert f.refs == [("chrT", 300_000)]
+    same_soa(f.decode(), want)
+    same_soa(pyoracle.Reads.decode(bamio.read_bam(p)).soa(), want)
+    assert os.path.getsize(p) > 40_000 * 100        # realistic compression (> 100 B/read)
