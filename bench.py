@@ -44,14 +44,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL path is used even for a single rank, so that the
+    # N > 1 code path can be exercised on a 1-GPU box
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N for --gpus N > 1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if use_dist:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import metheor_amd
     from metheor_amd import synth
@@ -67,18 +71,32 @@ def main():
     eng = metheor_amd.Engine(local_rank, stream=stream.cuda_stream)
     batch = util.device_batch(c, device=dev)
     params = metheor_amd.PdrLpmdParams(want_pdr=args.only != "lpmd", want_lpmd=args.only != "pdr")  # reference CLI defaults
-    lp = torch.zeros(4, dtype=torch.int64, device=dev)
+    # the one exchange step of the path: all-reduce(sum) of the 4 LPMD int64 counters (RCCL over xGMI,
+    # 32 bytes).  It is issued asynchronously on a ring of buffers so that its latency overlaps the next
+    # steps' kernels; a buffer is reused only after its collective has been waited for.
+    RING = 4
+    lp = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(RING)]
+    pending = [None] * RING
+    state = {"i": 0}
 
     def step():
         eng.reset()
         eng.pdr_lpmd_accumulate(batch, params)
-        if world > 1:
-            eng.lpmd_export_device(lp.data_ptr())
-            dist.all_reduce(lp)                  # RCCL over xGMI: 32 bytes
+        if use_dist:
+            k = state["i"] % RING
+            state["i"] += 1
+            if pending[k] is not None:
+                pending[k].wait()                # orders the current stream after that collective; no host block
+            eng.lpmd_export_device(lp[k].data_ptr())
+            pending[k] = dist.all_reduce(lp[k], async_op=True)
 
     def fence():
+        for k in range(RING):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -91,9 +109,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # the genome-wide LPMD of the last step from the all-reduced counters (what a multi-GPU host reports)
+    if use_dist:
+        last = lp[(state["i"] - 1) % RING].tolist()
+        lpmd_all = float(eng.lpmd_from_counts(last[0], last[1]))
+        assert last[2] == n_reads * world or world > 1, (last, n_reads)
 
     # results of the last step (sanity: the job really produced the rows)
     n_sites = eng.pdr_count()
@@ -147,7 +170,7 @@ def main():
                            "all_kernels_ms": {k: round(v[0], 5) for k, v in tm.items()}}
 
     # ---- CPU baseline: the oracle (faithful single-thread port of the reference algorithm) ----------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not use_dist and not args.no_cpu_baseline:
         from metheor_amd import shard
         from oracle import pyoracle
         ns = min(args.cpu_sample, n_reads)
@@ -168,7 +191,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
