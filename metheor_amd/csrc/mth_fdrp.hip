@@ -23,7 +23,7 @@
 namespace mth {
 
 constexpr int FD_WIN = 201;   // MAX_READ_LEN, fdrp.rs:10
-constexpr int FD_NB = 8;      // calls of a stored read held in the slot's registers
+// FD_NB (template parameter of the walk): calls of a stored read held in the slot's registers (8 or 16)
 
 struct FdrpArgs {
     const int32_t  *read_start, *read_end;
@@ -63,6 +63,7 @@ constexpr uint32_t FD_NOPOS = 0xffffffffu;   // "no call" in a slot's call regis
 __device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ int32_t sgpr(int32_t x) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)x); }
 
+template <int FD_NB>
 __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_id = sgpr((uint32_t)((blockIdx.x * 256 + threadIdx.x) >> 6)), n_waves = (gridDim.x * 256) >> 6;
@@ -270,7 +271,11 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 3) / 4, 16384);   // 4 waves (sites) per block
     {
         LaunchTimer lt(ctx, K_FDRPWALK);
-        hipLaunchKernelGGL(k_fdrp_walk, dim3(grid), dim3(256), 0, s, a);
+        // dense CpGs (hotspots, RRBS): 16 call registers per stored read keep the per-call match out of
+        // the memory loop; sparse WGBS keeps 8 (half the compares per call)
+        const bool dense = d.n_reads && ((double)d.n_cpgs / (double)d.n_reads) > 6.0;
+        if (dense) hipLaunchKernelGGL((k_fdrp_walk<16>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_fdrp_walk<8>), dim3(grid), dim3(256), 0, s, a);
     }
     unsigned long long *fs = ctx->f_state.as<unsigned long long>();
     const uint32_t nblk = (uint32_t)((bound + 256 * SCAN_PER - 1) / (256 * SCAN_PER));
