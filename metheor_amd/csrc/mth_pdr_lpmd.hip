@@ -35,7 +35,7 @@ struct TileArgs {
     uint32_t *tile_lpmd;   // 4 x u32 per tile
     SiteRec  *scratch;     // TILE_W rows per tile
     int32_t region_beg, region_end, idx_base, max_span;
-    uint32_t n_reads;
+    uint32_t n_reads, n_cpgs;
     uint32_t min_cov;      // max(pdr_min_depth, 1)
     uint32_t min_cpgs;
     int32_t  min_dist, max_dist;
@@ -212,14 +212,30 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
         const bool pdr_ok = a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);
         if (!(lp_ok || pdr_ok) || n == 0) continue;
 
-        // all calls of the read in flight at once (clamped index: duplicates are masked by k < n)
+        // all calls of the read in flight at once.  Slots k >= n are masked below, so the loads are
+        // unconditional from a per-read base (immediate offsets, no per-load address arithmetic); they
+        // may touch the NEXT reads' calls but must not run past the end of the array, which only the
+        // batch's last few reads can do: those take the clamped form (wave-uniform choice).
         uint32_t v[NB];
         int32_t r[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) v[k] = a.cpg_pos[o0 + min((uint32_t)k, n - 1)];
-        if (lp_ok) {
+        for (int k = 0; k < NB; ++k) r[k] = 0;
+        const uint32_t *__restrict__ cp = a.cpg_pos + o0;
+        const RelT *__restrict__ rp = rel + o0;
+        if (!__any(o0 + (uint32_t)NB > a.n_cpgs)) {
 #pragma unroll
-            for (int k = 0; k < NB; ++k) r[k] = (int32_t)rel[o0 + min((uint32_t)k, n - 1)];
+            for (int k = 0; k < NB; ++k) v[k] = cp[k];
+            if (lp_ok) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) r[k] = (int32_t)rp[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) v[k] = cp[min((uint32_t)k, n - 1)];
+            if (lp_ok) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) r[k] = (int32_t)rp[min((uint32_t)k, n - 1)];
+            }
         }
         // every call must lie in [start-1, start+max_span-1]: this is what makes the halo complete
         // (checked here, on the calls themselves, instead of trusting read_end)
@@ -238,21 +254,33 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
                 bad |= ((x & 0x7fffffffu) - (uint32_t)(s - 1) > (uint32_t)a.max_span) ? 1u : 0u;
             }
         }
-        // windowed pair counts (readutil.rs:166-224): pairs (j<k) with min <= rel_k - rel_j <= max
-        if (lp_ok) {
-            if (n <= (uint32_t)NB) {
+        // windowed pair counts (readutil.rs:166-224): pairs (j<k) with min <= rel_k - rel_j <= max.
+        // Ablation (profiles/r01_tile_variants.md) put the full 28-slot block at 38 % of the kernel.  The
+        // calls are sorted by relpos, so the distance at call-index gap g+1 is >= the distance at gap g:
+        // walk the pair matrix by diagonals g = 1, 2, .. and stop once NO lane of the wave has a pair
+        // within max_distance on the current diagonal (wave-uniform break).
+        const bool lp_reg = lp_ok && n > 1 && n <= (uint32_t)NB;      // pairs evaluated from the registers
+        if (__any(lp_reg)) {
+            {
 #pragma unroll
-                for (int k = 1; k < NB; ++k) {
+                for (int g = 1; g < NB; ++g) {
+                    bool within = false;
 #pragma unroll
-                    for (int j = 0; j < k; ++j) {
-                        const int32_t dist = r[k] - r[j];
-                        const bool in = ((uint32_t)k < n) && dist >= a.min_dist && dist <= a.max_dist;
-                        const bool same = (v[k] >> 31) == (v[j] >> 31);
-                        lp_c += (in && same) ? 1u : 0u;
-                        lp_d += (in && !same) ? 1u : 0u;
+                    for (int k = g; k < NB; ++k) {
+                        const int32_t dist = r[k] - r[k - g];
+                        const bool le = lp_reg && ((uint32_t)k < n) && dist <= a.max_dist;
+                        const bool in = le && dist >= a.min_dist;
+                        const uint32_t diff = (v[k] ^ v[k - g]) >> 31;
+                        lp_c += in ? (diff ^ 1u) : 0u;
+                        lp_d += in ? diff : 0u;
+                        within |= le;
                     }
+                    if (!__any(within)) break;
                 }
-            } else {
+            }
+        }
+        if (lp_ok && n > (uint32_t)NB) {   // a read with more than NB calls: memory loop (divergent, rare)
+            {
                 for (uint32_t k = 1; k < n; ++k) {
                     const int32_t rk = (int32_t)rel[o0 + k];
                     const uint32_t mk = a.cpg_pos[o0 + k] >> 31;
@@ -675,7 +703,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     a.tile_cnt = ctx->tile_cnt.as<uint32_t>(); a.tile_lpmd = ctx->tile_lpmd.as<uint32_t>();
     a.scratch = ctx->scratch.as<SiteRec>();
     a.region_beg = b.region_beg; a.region_end = b.region_end; a.idx_base = idx_base; a.max_span = b.max_span;
-    a.n_reads = b.n_reads;
+    a.n_reads = b.n_reads; a.n_cpgs = b.n_cpgs;
     a.min_cov = p.pdr_min_depth > 1 ? p.pdr_min_depth : 1;
     a.min_cpgs = p.pdr_min_cpgs;
     a.min_dist = p.lpmd_min_distance; a.max_dist = p.lpmd_max_distance;
