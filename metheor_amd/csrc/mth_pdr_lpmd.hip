@@ -183,19 +183,16 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
     const int32_t T1 = min(T0 + W, a.region_end);
     const uint32_t Wt = (uint32_t)(T1 - T0);
 
-    // a batch that failed validation in k_build_index has no usable index: emit nothing
-    if (a.st->err != 0) {
-        if (tid == 0) a.tile_cnt[t] = 0;
-        if (tid < 4) a.tile_lpmd[t * 4 + tid] = 0;
-        return;
-    }
-    for (int i = tid; i < 2 * W / 4; i += B)
-        reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
-
-    // candidate reads: start in [T0 - max_span + 1, T0 + W]  (a call sits in [start-1, end])
-    const uint32_t lo = a.idx[(uint32_t)(T0 - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT];
+    // candidate reads: start in [T0 - max_span + 1, T0 + W]  (a call sits in [start-1, end]).
+    // Both bounds are clamped to n_reads: a batch that failed validation in k_build_index (stale or
+    // partial index) then only ever touches in-bounds reads, and its rows are discarded because the
+    // getters report the error.  (An explicit load of the error flag here cost every tile a dependent
+    // round trip before its first useful load.)
+    const uint32_t lo = min(a.idx[(uint32_t)(T0 - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
     const uint32_t hi = min(a.idx[((uint32_t)(T0 + W - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
     const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
+    for (int i = tid; i < 2 * W / 4; i += B)
+        reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     uint32_t lp_c = 0, lp_d = 0, n_read = 0, n_valid = 0, bad = 0;
