@@ -38,8 +38,10 @@ struct FdrpArgs {
     uint32_t *nreads, *flags;
     unsigned long long seed;
     int32_t idx_base, max_span, tid, min_overlap;
+    int32_t region_beg, region_end;   // sites are discovered for [region_beg, region_end) only
     uint32_t n_reads, min_depth, max_depth;
     uint8_t min_qual;
+    uint32_t abl;
 };
 
 // the oracle's orc_sample_j: splitmix64 over (seed, tid, pos, total) -> 1..=total
@@ -68,69 +70,139 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_id = sgpr((uint32_t)((blockIdx.x * 256 + threadIdx.x) >> 6)), n_waves = (gridDim.x * 256) >> 6;
     const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    // per wave: window position (p - (c - FD_WIN)) -> index of that CpG in the wave's 64-site window
+    __shared__ uint8_t s_bit[4][2 * FD_WIN + 1 + 13];
+    uint8_t *const bit_of = s_bit[threadIdx.x >> 6];
     for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
         const int32_t c = sgpr(a.site_pos[j]);
         const uint32_t lo = sgpr(min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads));
         const uint32_t hi = sgpr(min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads));
-        // slot state (lane = slot): position and methylation bit of up to FD_NB calls, FD_NOPOS = none
-        uint32_t r_o0 = 0, r_n = 0, vp[FD_NB], vm[FD_NB];
+        // slot state (lane = slot): up to FD_NB calls as packed words (position | state << 31), FD_NOPOS = none
+        uint32_t r_o0 = 0, r_n = 0, vw[FD_NB];
         int32_t r_s = 0, r_e = 0;
 #pragma unroll
-        for (int k = 0; k < FD_NB; ++k) { vp[k] = FD_NOPOS; vm[k] = 0; }
+        for (int k = 0; k < FD_NB; ++k) vw[k] = FD_NOPOS;
         // wave-uniform segment state
         int32_t total = 0, sampled = 0;
         bool entry = false, have = false;
         float res_f = 0.0f, res_q = 0.0f;
         uint32_t res_n = 0;
+        const bool win_check = a.max_span > 200;   // a stored read calls c and spans <= 200 bp: all its calls are inside +-201
 
         auto finalize = [&]() {   // compute_fdrp / compute_qfdrp over slots 0..sampled-1
             const int nS = sampled;
-            uint32_t n_disc = 0;
+            uint32_t disc = 0;     // per lane j: discordant pairs (i, j)
             float q = 0.0f;
+            if (a.abl & 1u) { res_f = 0; res_q = 0; res_n = nS; have = true; return; }
+            const bool any_long = __any(lane < nS && r_n > (uint32_t)FD_NB);   // uniform: some stored read has calls beyond its registers
+            // Compact path.  Every position a stored read calls is one of the discovered sites, so when the
+            // 64 sites around c cover +-200 bp each call maps to a bit: a stored read becomes three 64-bit
+            // masks (calls, covered calls, methylated covered calls) and a pair costs a few and/xor/popcounts
+            // instead of an FD_NB-way compare per call.  Denser windows and spans > 200 bp keep the
+            // call-by-call path below (same results).
+            unsigned long long mC = 0, mA = 0, mM = 0;
+            bool compact = false;
+            // (halo reads of a region slice call positions outside the region; those are not in the site list)
+            if (!win_check && c - 200 >= a.region_beg && c + 200 < a.region_end && !(a.abl & 16u)) {
+                const uint32_t j0 = (j >= 32u) ? min(j - 32u, n_sites > 64u ? n_sites - 64u : 0u) : 0u;
+                const int32_t sp = (j0 + (uint32_t)lane < n_sites) ? a.site_pos[j0 + lane] : 0x7fffffff;
+                const int32_t sp_lo = __builtin_amdgcn_readlane(sp, 0), sp_hi = __builtin_amdgcn_readlane(sp, 63);
+                compact = (j0 == 0u || sp_lo < c - 200) && sp_hi > c + 200;       // absent sites read as +inf
+                if (compact) {
+                    const uint32_t rel = (uint32_t)(sp - (c - FD_WIN));
+                    if (rel <= 2u * FD_WIN) bit_of[rel] = (uint8_t)lane;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    auto add_call = [&](const uint32_t w, const bool valid) {
+                        const uint32_t p = w & 0x7fffffffu;
+                        const uint32_t rel_p = valid ? (uint32_t)((int32_t)p - (c - FD_WIN)) : 0u;
+                        const unsigned long long b = valid ? (1ull << bit_of[rel_p]) : 0ull;
+                        const bool cov = (int32_t)p >= r_s;                    // a call lies in [start-1, end]
+                        mC |= b;
+                        mA |= cov ? b : 0ull;
+                        mM |= (cov && (w >> 31)) ? b : 0ull;
+                    };
+                    const bool live = lane < nS;
+#pragma unroll
+                    for (int k = 0; k < FD_NB; ++k) add_call(vw[k], live && vw[k] != FD_NOPOS);
+                    if (any_long && live)
+                        for (uint32_t t = FD_NB; t < r_n; ++t) add_call(a.cpg_pos[r_o0 + t], true);
+                    __builtin_amdgcn_wave_barrier();                          // table reads done before the next site's writes
+                }
+            }
+            const uint32_t mC0 = (uint32_t)mC, mC1 = (uint32_t)(mC >> 32), mA0 = (uint32_t)mA, mA1 = (uint32_t)(mA >> 32);
+            const uint32_t mM0 = (uint32_t)mM, mM1 = (uint32_t)(mM >> 32);
             for (int i = 0; i + 1 < nS; ++i) {
-                const uint32_t bo0 = __builtin_amdgcn_readlane(r_o0, i), bn = __builtin_amdgcn_readlane(r_n, i);
+                const uint32_t bn = __builtin_amdgcn_readlane(r_n, i);
                 const int32_t bs = __builtin_amdgcn_readlane(r_s, i), be = __builtin_amdgcn_readlane(r_e, i);
-                const int32_t ov = min(be, r_e) - max(bs, r_s) + 1;         // get_num_overlap_bases, fdrp.rs:97-107
-                const uint32_t mine = (lane > i) & (lane < nS);
-                const uint32_t pair_ok2 = mine & (uint32_t)(max(ov, 0) >= a.min_overlap);   // fdrp.rs:134 (an empty overlap counts 0 bases)
+                const int32_t mx = max(bs, r_s);
+                const int32_t ov = min(be, r_e) - mx + 1;                    // get_num_overlap_bases, fdrp.rs:97-107
+                const bool pair_ok = (lane > i) & (lane < nS) & (max(ov, 0) >= a.min_overlap);   // fdrp.rs:134 (an empty overlap counts 0 bases)
                 uint32_t ham = 0, ncpg = 0;
-                for (uint32_t k = 0; k < bn; ++k) {
-                    const uint32_t w = a.cpg_pos[bo0 + k];                   // wave-uniform -> scalar load
-                    const uint32_t p = w & 0x7fffffffu;
-                    if ((uint32_t)((int32_t)p - (c - FD_WIN)) > 2u * FD_WIN) continue;   // outside the 403-slot array (uniform branch)
-                    // does the slot's read call position p ?  (selects, no predicate chains)
-                    uint32_t fnd = 0, own_m = 0;
+                if (compact) {
+                    const uint32_t iC0 = __builtin_amdgcn_readlane(mC0, i), iC1 = __builtin_amdgcn_readlane(mC1, i);
+                    const uint32_t iA0 = __builtin_amdgcn_readlane(mA0, i), iA1 = __builtin_amdgcn_readlane(mA1, i);
+                    const uint32_t iM0 = __builtin_amdgcn_readlane(mM0, i), iM1 = __builtin_amdgcn_readlane(mM1, i);
+                    ncpg = __builtin_popcount(iC0 & mC0) + __builtin_popcount(iC1 & mC1);      // qfdrp.rs:109-119
+                    ham = __builtin_popcount(iA0 & mA0 & (iM0 ^ mM0)) + __builtin_popcount(iA1 & mA1 & (iM1 ^ mM1));   // fdrp.rs:114-115
+                } else {
+                // One call pw of read i against every slot.  Integer arithmetic only -- comparisons whose
+                // results are OR-ed together compile to s_or_b64 chains on the (per-CU) scalar unit.
+                auto match = [&](const uint32_t pw) {
+                    const uint32_t p = pw & 0x7fffffffu;
+                    if (win_check && (uint32_t)((int32_t)p - (c - FD_WIN)) > 2u * FD_WIN) return;   // outside the 403-slot array (uniform)
+                    // key = rotl(word ^ p, 1): 0 = the slot calls p unmethylated, 1 = methylated, >= 2 = other position
+                    uint32_t mn = 0xffffffffu;
 #pragma unroll
                     for (int t = 0; t < FD_NB; ++t) {
-                        const uint32_t e = vp[t] == p;
-                        fnd |= e;
-                        own_m = e ? vm[t] : own_m;
+                        const uint32_t x = vw[t] ^ p;
+                        mn = min(mn, __builtin_amdgcn_alignbit(x, x, 31));
                     }
-                    if (r_n > (uint32_t)FD_NB) {                              // rare: more than FD_NB calls in the stored read
+                    if (any_long) {                                           // rare: more than FD_NB calls in a stored read
                         for (uint32_t t = FD_NB; t < r_n; ++t) {
-                            const uint32_t x = a.cpg_pos[r_o0 + t];
-                            if ((x & 0x7fffffffu) == p) { fnd = 1; own_m = x >> 31; }
+                            const uint32_t x = a.cpg_pos[r_o0 + t] ^ p;
+                            mn = min(mn, __builtin_amdgcn_alignbit(x, x, 31));
                         }
                     }
+                    const uint32_t fnd = 1u - min(mn >> 1, 1u);
                     ncpg += fnd;                                              // get_num_overlap_cpgs, qfdrp.rs:109-119 (bit1 & bit1)
-                    // hamming / is_discordant: both cover p (bit0), both call it, states differ (fdrp.rs:114-115)
-                    const uint32_t cov_i = (uint32_t)(((int32_t)p >= bs) & ((int32_t)p <= be));          // uniform
-                    const uint32_t cov_j = (uint32_t)((uint32_t)((int32_t)p - r_s) <= (uint32_t)(r_e - r_s));
-                    ham += fnd & cov_i & cov_j & (own_m ^ (w >> 31));
+                    // hamming / is_discordant: both cover p (bit0), both call it, states differ (fdrp.rs:114-115).
+                    // A read calls only positions in [start-1, end], so for a position both call,
+                    // "both cover it" is p >= max(start_i, start_j).
+                    const uint32_t cov = (uint32_t)(((int32_t)p - mx) >> 31) + 1u;
+                    ham += fnd & cov & (mn ^ (pw >> 31));
+                };
+                // read i's first FD_NB calls come from lane i's registers (no memory in the pair loop);
+                // nested so a read with bn calls costs bn+1 uniform branches
+                const uint32_t bn_eff = (a.abl & 2u) ? 0u : bn;
+                [&]() {
+#define MTH_FD_STEP(K) if ((K) >= FD_NB || (uint32_t)(K) >= bn_eff) return; match(__builtin_amdgcn_readlane(vw[(K) < FD_NB ? (K) : 0], i));
+                    MTH_FD_STEP(0) MTH_FD_STEP(1) MTH_FD_STEP(2) MTH_FD_STEP(3) MTH_FD_STEP(4) MTH_FD_STEP(5) MTH_FD_STEP(6) MTH_FD_STEP(7)
+                    MTH_FD_STEP(8) MTH_FD_STEP(9) MTH_FD_STEP(10) MTH_FD_STEP(11) MTH_FD_STEP(12) MTH_FD_STEP(13) MTH_FD_STEP(14) MTH_FD_STEP(15)
+#undef MTH_FD_STEP
+                }();
+                if (bn_eff > (uint32_t)FD_NB) {                               // beyond the registers: wave-uniform scalar loads
+                    const uint32_t bo0 = __builtin_amdgcn_readlane(r_o0, i);
+                    for (uint32_t k = FD_NB; k < bn_eff; ++k) match(a.cpg_pos[bo0 + k]);
                 }
-                n_disc += __popcll(__ballot((pair_ok2 & (uint32_t)(ham > 0)) != 0));     // fdrp.rs:138-140
-                // qfdrp.rs:152 -- skipped pairs contribute +0.0, which leaves the f32 sum unchanged
-                const float term = pair_ok2 ? (float)ham / (float)ncpg : 0.0f;
-                const int ti = __builtin_bit_cast(int, term);
-                int jj = i + 1;
-                for (; jj + 4 <= nS; jj += 4) {                              // lexicographic (i,j): the reference's rounding
-                    q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj));
-                    q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj + 1));
-                    q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj + 2));
-                    q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj + 3));
                 }
-                for (; jj < nS; ++jj) q = q + __builtin_bit_cast(float, __builtin_amdgcn_readlane(ti, jj));
+                disc += (pair_ok && ham != 0u) ? 1u : 0u;                     // fdrp.rs:138-140
+                // qfdrp.rs:152 in the reference's lexicographic (i,j) order, so the f32 rounding matches: the
+                // running sum sits in lane i, the pair terms in lanes i+1..nS-1 (+0.0 for skipped pairs leaves
+                // an f32 sum unchanged); each DPP step computes x[j] = x[j-1] + term[j], so after nS-1-i steps
+                // lane nS-1 holds ((q + t[i+1]) + t[i+2]) + ... -- one VALU and no scalar work per element.
+                const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;
+                float x = (lane == i) ? q : term;
+                const int steps = (a.abl & 4u) ? 0 : nS - 1 - i;
+                for (int st = 0; st < steps; ++st)
+                    x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)) + term;
+                q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), nS - 1));
             }
+            uint32_t n_disc = disc;                                           // wave sum of the per-lane counts
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) n_disc += __shfl_xor(n_disc, o, 64);
+            n_disc = sgpr(n_disc);
             // (num_reads * (num_reads - 1)) as f32 / 2.0 in usize arithmetic (fdrp.rs:143)
             const unsigned long long prod = (unsigned long long)(long long)nS * (unsigned long long)((long long)nS - 1);
             const float den = (float)prod / 2.0f;
@@ -140,43 +212,60 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             have = true;
         };
 
-        for (uint32_t i = lo; i < hi; ++i) {                                  // scalar loop, scalar loads
-            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+        // Candidates are inspected 64 at a time, one per lane (their field and call loads are issued together:
+        // the one-candidate-per-iteration scalar walk was latency-bound, ~3 dependent loads x ~35 candidates
+        // per site); the ordered part below runs over ballots and touches no memory.
+        for (uint32_t base = lo; base < hi; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            const bool valid = i < hi;
+            const uint32_t o0 = valid ? a.cpg_off[i] : 0u, o1 = valid ? a.cpg_off[i + 1] : 0u;
             const uint32_t n = o1 - o0;
-            if (a.read_mapq[i] < a.min_qual) continue;                       // fdrp.rs:205
-            if (n == 0) continue;                                            // fdrp.rs:208
-            const int32_t first = (int32_t)(a.cpg_pos[o0] & 0x7fffffffu);
-            if (c < first && entry) {                                        // fdrp.rs:212-223
-                if ((uint32_t)sampled >= a.min_depth) finalize();
-                entry = false; total = 0; sampled = 0;
-            }
-            bool hit = false;                                                // does the read call c ?  (lanes scan its calls)
-            for (uint32_t k0 = 0; k0 < n; k0 += 64) {
-                const int32_t p = (k0 + lane < n) ? (int32_t)(a.cpg_pos[o0 + k0 + lane] & 0x7fffffffu) : -1;
-                hit = hit || (__ballot(p == c) != 0ull);
-            }
-            if (!hit) continue;
-            entry = true;                                                    // entry().or_insert(...), fdrp.rs:226-228
-            const int32_t s = a.read_start[i], e = a.read_end[i];
-            if (FD_WIN + (s - c) < 0) continue;                              // add_read, fdrp.rs:58-63
-            if (FD_WIN + (e - c) > 2 * FD_WIN) continue;
-            int slot;
-            if (total < (int32_t)a.max_depth) {                              // fdrp.rs:81-85
-                slot = total; total += 1; sampled += 1;
-            } else {                                                          // fdrp.rs:87-94 (reservoir)
-                total += 1;
-                const int32_t jr = sample_j(a.seed, a.tid, c, total);
-                if (jr > (int32_t)a.max_depth) continue;
-                slot = jr - 1;
-            }
-            const bool me = lane == slot;                                     // the slot's lane takes the read (selects)
-            r_o0 = me ? o0 : r_o0; r_n = me ? n : r_n; r_s = me ? s : r_s; r_e = me ? e : r_e;
+            const bool pass = valid && a.read_mapq[i] >= a.min_qual && n > 0;   // fdrp.rs:205, 208
+            const int32_t cs = pass ? a.read_start[i] : 0, ce = pass ? a.read_end[i] : 0;
+            uint32_t cw[FD_NB];
+            bool hit = false;                                                // does the candidate call c ?
 #pragma unroll
             for (int k = 0; k < FD_NB; ++k) {
-                const uint32_t w = ((uint32_t)k < n) ? a.cpg_pos[o0 + k] : 0u;    // uniform
-                const uint32_t wp = ((uint32_t)k < n) ? (w & 0x7fffffffu) : FD_NOPOS;
-                vp[k] = me ? wp : vp[k];
-                vm[k] = me ? (w >> 31) : vm[k];
+                cw[k] = (pass && (uint32_t)k < n) ? a.cpg_pos[o0 + k] : FD_NOPOS;
+                hit = hit || (cw[k] & 0x7fffffffu) == (uint32_t)c;
+            }
+            if (pass && n > (uint32_t)FD_NB)
+                for (uint32_t k = FD_NB; k < n; ++k) hit = hit || (a.cpg_pos[o0 + k] & 0x7fffffffu) == (uint32_t)c;
+            const unsigned long long m_hit = __ballot(pass && hit);
+            const unsigned long long m_flush = __ballot(pass && c < (int32_t)(cw[0] & 0x7fffffffu));   // c < first call, fdrp.rs:212
+            unsigned long long ev = m_hit | m_flush;                          // a read calling c has first <= c: never both
+            while (ev) {                                                      // stream order; wave-uniform
+                const int l = __builtin_ctzll(ev);
+                ev &= ev - 1;
+                if ((m_flush >> l) & 1ull) {                                  // fdrp.rs:212-223
+                    if (entry) {
+                        if ((uint32_t)sampled >= a.min_depth) finalize();
+                        entry = false; total = 0; sampled = 0;
+                    }
+                    continue;
+                }
+                entry = true;                                                 // entry().or_insert(...), fdrp.rs:226-228
+                const int32_t s = __builtin_amdgcn_readlane(cs, l), e = __builtin_amdgcn_readlane(ce, l);
+                if (FD_WIN + (s - c) < 0) continue;                           // add_read, fdrp.rs:58-63
+                if (FD_WIN + (e - c) > 2 * FD_WIN) continue;
+                int slot;
+                if (total < (int32_t)a.max_depth) {                           // fdrp.rs:81-85
+                    slot = total; total += 1; sampled += 1;
+                } else {                                                       // fdrp.rs:87-94 (reservoir)
+                    total += 1;
+                    const int32_t jr = sample_j(a.seed, a.tid, c, total);
+                    if (jr > (int32_t)a.max_depth) continue;
+                    slot = jr - 1;
+                }
+                if (a.abl & 8u) continue;
+                const bool me = lane == slot;                                  // the slot's lane takes the read (selects)
+                const uint32_t so0 = __builtin_amdgcn_readlane(o0, l), sn = __builtin_amdgcn_readlane(n, l);
+                r_o0 = me ? so0 : r_o0; r_n = me ? sn : r_n; r_s = me ? s : r_s; r_e = me ? e : r_e;
+#pragma unroll
+                for (int k = 0; k < FD_NB; ++k) {
+                    const uint32_t w = __builtin_amdgcn_readlane(cw[k], l);
+                    vw[k] = me ? w : vw[k];
+                }
             }
         }
         if (entry && (uint32_t)sampled >= a.min_depth) finalize();           // fdrp.rs:239-243
@@ -265,9 +354,10 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     a.fdrp = ctx->w_val.as<float>(); a.qfdrp = reinterpret_cast<float *>(ctx->w_aux.p); a.nreads = ctx->w_cov.as<uint32_t>();
     a.flags = ctx->w_flags.as<uint32_t>();
     a.seed = params->seed; a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.tid = d.tid;
-    a.min_overlap = params->min_overlap; a.n_reads = d.n_reads;
+    a.min_overlap = params->min_overlap; a.n_reads = d.n_reads; a.region_beg = d.region_beg; a.region_end = d.region_end;
     a.min_depth = (uint32_t)std::min<uint64_t>(params->min_depth, 0xffffffffull); a.max_depth = params->max_depth;
     a.min_qual = params->min_qual;
+    { const char *e = getenv("MTH_FDRP_ABL"); a.abl = e ? (uint32_t)atoi(e) : 0u; }
     const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 3) / 4, 16384);   // 4 waves (sites) per block
     {
         LaunchTimer lt(ctx, K_FDRPWALK);
