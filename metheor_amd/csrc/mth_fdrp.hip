@@ -8,12 +8,23 @@
 // adds (#such positions) / (#positions both reads call) in lexicographic (i,j) order; both divide by
 // (n*(n-1)) as f32 / 2.0 -- skipped pairs stay in the denominator.
 //
-// Device: the site walk of mth_sites.hip with ONE WAVE per site; lane s is stored-read slot s
-// (max_depth <= 64).  The 403-byte arrays are never materialised: covered-by-both is interval
-// arithmetic on [start,end], and the per-position tests become "for each CpG call of read i, does
-// read j call the same position" (read i's calls are wave-uniform loads, read j's sit in lane j's
-// registers).  The qFDRP sum is accumulated serially in the reference's (i,j) order so the f32
-// rounding matches.  Both measures come out of one walk.
+// Device: ONE WAVE per site (sites come from the tile pipeline's site discovery, mth_sites.hip).
+//  walk      the candidate reads (linear read index, file order) are inspected 64 at a time, one per lane:
+//            mapq / n_cpgs filters, "calls c" and "first call > c" (the flush test) become ballots.  The common
+//            chunk -- hits, then optionally reads starting past c+1 -- is handled without a serial loop: each
+//            hit lane writes its row {cpg_off, n, start, end, FD_NB packed calls} into the wave's LDS slot
+//            array at slot = arrival order.  Anything else (reservoir replacement, a flush followed by
+//            re-opening reads, spans > 200 bp where add_read can drop a read) runs the reference's
+//            per-read state machine over the ballots, still without touching memory.
+//  finalize  lane = slot loads its row.  The 403-byte arrays are never materialised.  Compact path: every
+//            position a stored read calls is a discovered site, so with the 64 sites around c covering
+//            +-200 bp a read is three 64-bit masks (calls, covered calls, methylated covered calls) and a
+//            pair is a few and/xor/popcounts, evaluated pair-parallel (lane k = k-th pair in (i,j) order).
+//            Otherwise (denser window, region-edge site, spans > 200 bp): i-uniform loop, read i's calls
+//            matched against every slot's call registers by an integer min-chain.
+//  qFDRP sum accumulated in the reference's lexicographic (i,j) order so the f32 rounding matches: a DPP
+//            wave_shr:1 chain x[l] = x[l-1] + term[l] (one VALU per pair, no scalar work).
+// Both measures come out of one walk.  History and counters: profiles/r01_fdrp_pmc.md.
 //
 // Reservoir branch (depth > max_depth): the reference draws from an OS-seeded RNG (fdrp.rs:90), so
 // there is nothing to be bit-equal to; device and oracle share the counter-based sample_j below.
@@ -41,7 +52,6 @@ struct FdrpArgs {
     int32_t region_beg, region_end;   // sites are discovered for [region_beg, region_end) only
     uint32_t n_reads, min_depth, max_depth;
     uint8_t min_qual;
-    uint32_t abl;
 };
 
 // the oracle's orc_sample_j: splitmix64 over (seed, tid, pos, total) -> 1..=total
@@ -54,12 +64,10 @@ __device__ __forceinline__ int32_t sample_j(unsigned long long seed, int32_t tid
     return (int32_t)(z % (unsigned long long)(uint32_t)total) + 1;
 }
 
-// PMC of the first version (profiles/r01_fdrp_pmc.md): 10 400 SALU vs 6 200 VALU instructions per site,
-// the per-CU scalar unit ~81 % busy -- wave-uniform loops compiled as divergent ones (bounds came from
-// vector loads) and '&&' predicate chains compiled to s_and_b64 sequences.  Hence: every wave-uniform
-// value is made explicitly scalar with readfirstlane (loops become scalar loops, uniform loads become
-// s_load), slot updates and call matches are selects, and the serial qFDRP sum adds 0.0 for skipped
-// pairs (x + 0.0 == x exactly) instead of branching per element.
+// PMC of the first version (profiles/r01_fdrp_pmc.md): the per-CU scalar unit was ~81 % busy -- wave-uniform
+// loops compiled as divergent ones, '&&' / '|=' over comparisons became s_and/s_or_b64 chains.  Hence:
+// wave-uniform values are made explicitly scalar with readfirstlane, per-lane logic is integer arithmetic
+// or selects, and skipped pairs add +0.0 (x + 0.0 == x exactly) instead of branching.
 constexpr uint32_t FD_NOPOS = 0xffffffffu;   // "no call" in a slot's call registers (never equals a 31-bit position)
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -73,15 +81,14 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
     // per wave: window position (p - (c - FD_WIN)) -> index of that CpG in the wave's 64-site window
     __shared__ uint8_t s_bit[4][2 * FD_WIN + 1 + 13];
     uint8_t *const bit_of = s_bit[threadIdx.x >> 6];
+    // per wave: the stored reads of the open segment, one row per slot: {cpg_off, n_calls, start, end, FD_NB packed calls}
+    constexpr int ROW = 4 + FD_NB;
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[4][64 * ROW];
+    uint32_t *const rows = s_rows[threadIdx.x >> 6];
     for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
         const int32_t c = sgpr(a.site_pos[j]);
         const uint32_t lo = sgpr(min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads));
         const uint32_t hi = sgpr(min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads));
-        // slot state (lane = slot): up to FD_NB calls as packed words (position | state << 31), FD_NOPOS = none
-        uint32_t r_o0 = 0, r_n = 0, vw[FD_NB];
-        int32_t r_s = 0, r_e = 0;
-#pragma unroll
-        for (int k = 0; k < FD_NB; ++k) vw[k] = FD_NOPOS;
         // wave-uniform segment state
         int32_t total = 0, sampled = 0;
         bool entry = false, have = false;
@@ -93,7 +100,18 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             const int nS = sampled;
             uint32_t disc = 0;     // per lane j: discordant pairs (i, j)
             float q = 0.0f;
-            if (a.abl & 1u) { res_f = 0; res_q = 0; res_n = nS; have = true; return; }
+            // lane = slot: the slot's row; calls are packed words (position | state << 31), FD_NOPOS = none
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t r_o0 = 0, r_n = 0, vw[FD_NB];
+            int32_t r_s = 0, r_e = 0;
+            {
+                const uint32_t *r = rows + (lane < nS ? lane : 0) * ROW;
+                r_o0 = r[0]; r_n = r[1]; r_s = (int32_t)r[2]; r_e = (int32_t)r[3];
+#pragma unroll
+                for (int k = 0; k < FD_NB; ++k) vw[k] = r[4 + k];
+            }
             const bool any_long = __any(lane < nS && r_n > (uint32_t)FD_NB);   // uniform: some stored read has calls beyond its registers
             // Compact path.  Every position a stored read calls is one of the discovered sites, so when the
             // 64 sites around c cover +-200 bp each call maps to a bit: a stored read becomes three 64-bit
@@ -103,7 +121,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             unsigned long long mC = 0, mA = 0, mM = 0;
             bool compact = false;
             // (halo reads of a region slice call positions outside the region; those are not in the site list)
-            if (!win_check && c - 200 >= a.region_beg && c + 200 < a.region_end && !(a.abl & 16u)) {
+            if (!win_check && c - 200 >= a.region_beg && c + 200 < a.region_end) {
                 const uint32_t j0 = (j >= 32u) ? min(j - 32u, n_sites > 64u ? n_sites - 64u : 0u) : 0u;
                 const int32_t sp = (j0 + (uint32_t)lane < n_sites) ? a.site_pos[j0 + lane] : 0x7fffffff;
                 const int32_t sp_lo = __builtin_amdgcn_readlane(sp, 0), sp_hi = __builtin_amdgcn_readlane(sp, 63);
@@ -128,25 +146,64 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                     for (int k = 0; k < FD_NB; ++k) add_call(vw[k], live && vw[k] != FD_NOPOS);
                     if (any_long && live)
                         for (uint32_t t = FD_NB; t < r_n; ++t) add_call(a.cpg_pos[r_o0 + t], true);
-                    __builtin_amdgcn_wave_barrier();                          // table reads done before the next site's writes
                 }
             }
-            const uint32_t mC0 = (uint32_t)mC, mC1 = (uint32_t)(mC >> 32), mA0 = (uint32_t)mA, mA1 = (uint32_t)(mA >> 32);
-            const uint32_t mM0 = (uint32_t)mM, mM1 = (uint32_t)(mM >> 32);
-            for (int i = 0; i + 1 < nS; ++i) {
+#define MTH_FD_DPP x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)) + term;
+#define MTH_FD_DPP8 MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP
+            if (compact) {
+                // Pair-parallel: the slots' {start, end, masks} go back to the LDS rows, lane k of a round takes
+                // the k-th pair of the reference's lexicographic (i,j) order (all 64 lanes busy instead of the
+                // j > i lanes of one i), and the round's 64 terms are chained in that order by DPP adds:
+                // x[l] = x[l-1] + term[l], lane 0 seeded with the running sum -- the reference's rounding.
+                if (lane < nS) {
+                    uint32_t *r = rows + lane * ROW;
+                    r[0] = (uint32_t)r_s; r[1] = (uint32_t)r_e;
+                    r[2] = (uint32_t)mC; r[3] = (uint32_t)(mC >> 32); r[4] = (uint32_t)mA; r[5] = (uint32_t)(mA >> 32);
+                    r[6] = (uint32_t)mM; r[7] = (uint32_t)(mM >> 32);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int P = (nS * (nS - 1)) >> 1;
+                const int twoN = 2 * nS;
+                const float bq = (float)(twoN - 1);
+                for (int k0 = 0; k0 < P; k0 += 64) {
+                    const int k = min(k0 + lane, P - 1);
+                    // row i of the strict upper triangle starts at off(i) = i * (2 nS - i - 1) / 2
+                    int pi = (int)((bq - __builtin_sqrtf(bq * bq - 8.0f * (float)k)) * 0.5f);
+                    pi = max(0, min(pi, nS - 2));
+                    int off = (pi * (twoN - pi - 1)) >> 1;
+                    if (k < off) { pi -= 1; off = (pi * (twoN - pi - 1)) >> 1; }
+                    const int off1 = ((pi + 1) * (twoN - pi - 2)) >> 1;
+                    if (k >= off1) { pi += 1; off = off1; }
+                    const int pj = k - off + pi + 1;
+                    const uint32_t *ri = rows + pi * ROW, *rj = rows + pj * ROW;
+                    const int32_t si = (int32_t)ri[0], ei = (int32_t)ri[1], sj = (int32_t)rj[0], ej = (int32_t)rj[1];
+                    const int32_t ov = min(ei, ej) - max(si, sj) + 1;        // get_num_overlap_bases, fdrp.rs:97-107
+                    const bool pair_ok = (k0 + lane < P) & (max(ov, 0) >= a.min_overlap);   // fdrp.rs:134
+                    const uint32_t ncpg = __builtin_popcount(ri[2] & rj[2]) + __builtin_popcount(ri[3] & rj[3]);   // qfdrp.rs:109-119
+                    const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) +
+                                         __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));                      // fdrp.rs:114-115
+                    disc += (pair_ok && ham != 0u) ? 1u : 0u;                // fdrp.rs:138-140
+                    const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;   // qfdrp.rs:152; +0.0 for skipped pairs
+                    float x = (lane == 0) ? q + term : term;
+                    const int steps = min(64, P - k0) - 1;
+                    const int up8 = (steps + 7) & ~7;                        // lanes past the last pair hold +0.0: sliding is exact
+                    const bool slide = up8 <= 56;
+                    const int blocks = slide ? up8 >> 3 : 7;
+                    for (int b8 = 0; b8 < blocks; ++b8) { MTH_FD_DPP8 }
+                    if (!slide) { MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP }
+                    q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), slide ? up8 : 63));
+                }
+            }
+            for (int i = 0; !compact && i + 1 < nS; ++i) {
                 const uint32_t bn = __builtin_amdgcn_readlane(r_n, i);
                 const int32_t bs = __builtin_amdgcn_readlane(r_s, i), be = __builtin_amdgcn_readlane(r_e, i);
                 const int32_t mx = max(bs, r_s);
                 const int32_t ov = min(be, r_e) - mx + 1;                    // get_num_overlap_bases, fdrp.rs:97-107
                 const bool pair_ok = (lane > i) & (lane < nS) & (max(ov, 0) >= a.min_overlap);   // fdrp.rs:134 (an empty overlap counts 0 bases)
                 uint32_t ham = 0, ncpg = 0;
-                if (compact) {
-                    const uint32_t iC0 = __builtin_amdgcn_readlane(mC0, i), iC1 = __builtin_amdgcn_readlane(mC1, i);
-                    const uint32_t iA0 = __builtin_amdgcn_readlane(mA0, i), iA1 = __builtin_amdgcn_readlane(mA1, i);
-                    const uint32_t iM0 = __builtin_amdgcn_readlane(mM0, i), iM1 = __builtin_amdgcn_readlane(mM1, i);
-                    ncpg = __builtin_popcount(iC0 & mC0) + __builtin_popcount(iC1 & mC1);      // qfdrp.rs:109-119
-                    ham = __builtin_popcount(iA0 & mA0 & (iM0 ^ mM0)) + __builtin_popcount(iA1 & mA1 & (iM1 ^ mM1));   // fdrp.rs:114-115
-                } else {
+                {
                 // One call pw of read i against every slot.  Integer arithmetic only -- comparisons whose
                 // results are OR-ed together compile to s_or_b64 chains on the (per-CU) scalar unit.
                 auto match = [&](const uint32_t pw) {
@@ -175,7 +232,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 };
                 // read i's first FD_NB calls come from lane i's registers (no memory in the pair loop);
                 // nested so a read with bn calls costs bn+1 uniform branches
-                const uint32_t bn_eff = (a.abl & 2u) ? 0u : bn;
+                const uint32_t bn_eff = bn;
                 [&]() {
 #define MTH_FD_STEP(K) if ((K) >= FD_NB || (uint32_t)(K) >= bn_eff) return; match(__builtin_amdgcn_readlane(vw[(K) < FD_NB ? (K) : 0], i));
                     MTH_FD_STEP(0) MTH_FD_STEP(1) MTH_FD_STEP(2) MTH_FD_STEP(3) MTH_FD_STEP(4) MTH_FD_STEP(5) MTH_FD_STEP(6) MTH_FD_STEP(7)
@@ -194,11 +251,18 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 // lane nS-1 holds ((q + t[i+1]) + t[i+2]) + ... -- one VALU and no scalar work per element.
                 const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;
                 float x = (lane == i) ? q : term;
-                const int steps = (a.abl & 4u) ? 0 : nS - 1 - i;
-                for (int st = 0; st < steps; ++st)
-                    x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)) + term;
-                q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), nS - 1));
+                // Blocks of 8 steps; lanes >= nS hold +0.0, so overshooting just slides the finished sum to a
+                // higher lane (while one exists).
+                const int steps = nS - 1 - i;
+                const int up8 = (steps + 7) & ~7;
+                const bool slide = i + up8 <= 63;
+                const int blocks = slide ? up8 >> 3 : steps >> 3;
+                for (int b8 = 0; b8 < blocks; ++b8) { MTH_FD_DPP8 }
+                if (!slide) for (int st = blocks << 3; st < steps; ++st) { MTH_FD_DPP }
+                q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), slide ? i + up8 : nS - 1));
             }
+#undef MTH_FD_DPP8
+#undef MTH_FD_DPP
             uint32_t n_disc = disc;                                           // wave sum of the per-lane counts
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) n_disc += __shfl_xor(n_disc, o, 64);
@@ -210,6 +274,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             res_q = q / den;
             res_n = (uint32_t)nS;
             have = true;
+            __builtin_amdgcn_wave_barrier();                                  // LDS reads done before the next segment's / site's writes
         };
 
         // Candidates are inspected 64 at a time, one per lane (their field and call loads are issued together:
@@ -233,6 +298,37 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 for (uint32_t k = FD_NB; k < n; ++k) hit = hit || (a.cpg_pos[o0 + k] & 0x7fffffffu) == (uint32_t)c;
             const unsigned long long m_hit = __ballot(pass && hit);
             const unsigned long long m_flush = __ballot(pass && c < (int32_t)(cw[0] & 0x7fffffffu));   // c < first call, fdrp.rs:212
+            auto put_row = [&](const int slot) {                              // executed by the candidate's lane
+                uint32_t *r = rows + slot * ROW;
+                r[0] = o0; r[1] = n; r[2] = (uint32_t)cs; r[3] = (uint32_t)ce;
+#pragma unroll
+                for (int k = 0; k < FD_NB; ++k) r[4 + k] = cw[k];
+            };
+            if ((m_hit | m_flush) == 0ull) continue;
+            // Common shape of a chunk: the reads calling c, then (optionally) reads that start past c + 1 and
+            // so flush the site for good.  With spans <= 200 bp add_read drops nothing, and below max_depth
+            // slot = arrival order, so every hit lane stores itself (slot = total + hits in lower lanes).
+            const int n_hit = __popcll(m_hit);
+            const int first_flush = m_flush ? __builtin_ctzll(m_flush) : 64;
+            const bool fast = !win_check && total + n_hit <= (int32_t)a.max_depth &&
+                              (m_hit == 0ull || 63 - __builtin_clzll(m_hit) < first_flush) &&
+                              (m_flush == 0ull || (int32_t)__builtin_amdgcn_readlane(cs, first_flush & 63) > c + 1);
+            if (fast) {
+                if (m_hit) {
+                    entry = true;                                             // fdrp.rs:226-228, 81-85
+                    const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_hit, 0u));
+                    if (pass && hit) put_row(total + pre);
+                    total += n_hit; sampled += n_hit;
+                }
+                if (m_flush) {                                                // fdrp.rs:212-223
+                    if (entry) {
+                        if ((uint32_t)sampled >= a.min_depth) finalize();
+                        entry = false; total = 0; sampled = 0;
+                    }
+                    break;   // reads are sorted by start: none from here on can call c, and further flushes find no entry
+                }
+                continue;
+            }
             unsigned long long ev = m_hit | m_flush;                          // a read calling c has first <= c: never both
             while (ev) {                                                      // stream order; wave-uniform
                 const int l = __builtin_ctzll(ev);
@@ -257,15 +353,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                     if (jr > (int32_t)a.max_depth) continue;
                     slot = jr - 1;
                 }
-                if (a.abl & 8u) continue;
-                const bool me = lane == slot;                                  // the slot's lane takes the read (selects)
-                const uint32_t so0 = __builtin_amdgcn_readlane(o0, l), sn = __builtin_amdgcn_readlane(n, l);
-                r_o0 = me ? so0 : r_o0; r_n = me ? sn : r_n; r_s = me ? s : r_s; r_e = me ? e : r_e;
-#pragma unroll
-                for (int k = 0; k < FD_NB; ++k) {
-                    const uint32_t w = __builtin_amdgcn_readlane(cw[k], l);
-                    vw[k] = me ? w : vw[k];
-                }
+                if (lane == l) put_row(slot);
             }
         }
         if (entry && (uint32_t)sampled >= a.min_depth) finalize();           // fdrp.rs:239-243
@@ -357,7 +445,6 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     a.min_overlap = params->min_overlap; a.n_reads = d.n_reads; a.region_beg = d.region_beg; a.region_end = d.region_end;
     a.min_depth = (uint32_t)std::min<uint64_t>(params->min_depth, 0xffffffffull); a.max_depth = params->max_depth;
     a.min_qual = params->min_qual;
-    { const char *e = getenv("MTH_FDRP_ABL"); a.abl = e ? (uint32_t)atoi(e) : 0u; }
     const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 3) / 4, 16384);   // 4 waves (sites) per block
     {
         LaunchTimer lt(ctx, K_FDRPWALK);

@@ -167,6 +167,48 @@ def test_window_drop_and_nan_rows(eng):
     check(run_device(eng, [c], kw), reads, kw)
 
 
+def test_dense_window_takes_call_by_call_path(eng):
+    """a CpG every ~4 bp: > 64 sites inside +-200 bp (no 64-bit site masks) and ~37 calls per read (more than
+    the 16 call registers of a stored read) -- the kernel's call-by-call pair evaluation"""
+    from metheor_amd import synth
+    c = synth.make_contig(0, 60_000, 8_000, 0.25, np.random.default_rng(67))
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    assert len(c["cpg_pos"]) / len(c["read_start"]) > 20
+    for kw in (dict(min_qual=10, min_depth=5, max_depth=64, min_overlap=35), dict(min_qual=0, min_depth=0, max_depth=10, min_overlap=0, seed=3)):
+        n, nf, nq = check(run_device(eng, [c], kw), reads, kw)
+        print("dense", kw, "rows", n, "not bit-identical fdrp/qfdrp:", nf, nq)
+        assert n > 5000
+
+
+def test_flush_then_reopen_inside_one_site(eng):
+    """fdrp.rs:212-228: a read that starts at/before c+1 but whose first call lies past c flushes site c; a later
+    read calling c re-opens it and the LAST segment is what the reference reports (HashMap insert overwrites)"""
+    from metheor_amd import synth
+    # (start, fwd, [(rel, pos, meth)])
+    rows = [(1000, 1, [(0, 1000, 1), (50, 1050, 1)]),      # opens 1000 and 1050
+            (1000, 1, [(0, 1000, 0), (50, 1050, 0)]),
+            (1001, 1, [(49, 1050, 1)]),                     # first call 1050 > 1000: flushes site 1000 (2 reads)
+            (1001, 0, [(0, 1000, 1), (49, 1050, 0)]),      # reverse read calling start-1 = 1000: re-opens site 1000
+            (1001, 0, [(0, 1000, 0), (49, 1050, 1)]),
+            (1001, 0, [(0, 1000, 0), (49, 1050, 1)]),
+            (1500, 1, [(0, 1500, 1)])]
+    start = np.array([r[0] for r in rows], np.int32)
+    off = np.cumsum([0] + [len(r[2]) for r in rows]).astype(np.uint32)
+    pos = np.array([p | (m << 31) for r in rows for (_, p, m) in r[2]], np.uint32)
+    rel = np.array([q for r in rows for (q, _, _) in r[2]], np.uint8)
+    c = dict(tid=0, length=10_000, read_start=start, read_end=start + 59, read_mapq=np.full(len(rows), 40, np.uint8),
+             read_fwd=np.array([r[1] for r in rows], np.uint8), cpg_off=off, cpg_pos=pos, cpg_rel=rel)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    for kw in (dict(min_qual=0, min_depth=0, max_depth=40, min_overlap=1), dict(min_qual=0, min_depth=3, max_depth=40, min_overlap=1),
+               dict(min_qual=0, min_depth=2, max_depth=2, min_overlap=1, seed=5)):
+        d = run_device(eng, [c], kw)
+        check(d, reads, kw)
+    kw = dict(min_qual=0, min_depth=0, max_depth=40, min_overlap=1)
+    d = run_device(eng, [c], kw)
+    row = {int(p): int(n) for p, n in zip(d["pos"], d["n_reads"])}
+    assert row[1000] == 3 and row[1050] == 6, row      # site 1000: the re-opened segment (3 reverse reads), not the first 2
+
+
 def test_multi_contig_and_region_split(eng):
     from metheor_amd import shard, synth
     rng = np.random.default_rng(65)
