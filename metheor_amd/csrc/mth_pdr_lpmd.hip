@@ -91,15 +91,26 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;  // valid in lane 0
+// DPP controls (gfx9 family): no LDS traffic, one VALU per step
+#define MTH_DPP(v, ctrl, rmask, bctl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, (bctl)))
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {   // wave-uniform result
+    v += MTH_DPP(v, 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, true);
+    v += MTH_DPP(v, 0x4e /*quad_perm [2,3,0,1]*/, 0xf, true);
+    v += MTH_DPP(v, 0x141 /*row_half_mirror*/, 0xf, true);
+    v += MTH_DPP(v, 0x140 /*row_mirror*/, 0xf, true);          // every lane: sum of its row of 16
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += MTH_DPP(v, 0x111 /*row_shr:1*/, 0xf, true);
+    v += MTH_DPP(v, 0x112 /*row_shr:2*/, 0xf, true);
+    v += MTH_DPP(v, 0x114 /*row_shr:4*/, 0xf, true);
+    v += MTH_DPP(v, 0x118 /*row_shr:8*/, 0xf, true);
+    v += MTH_DPP(v, 0x142 /*row_bcast:15*/, 0xa, false);
+    v += MTH_DPP(v, 0x143 /*row_bcast:31*/, 0xc, false);
+    return v;
 }
 
-// Shared tail of the tile kernels: per-tile LPMD partials (wave DPP reduce -> LDS -> one plain
-// store per tile, no same-address global atomics) and compaction of the dense LDS counters into
-// the tile's scratch slice (block scan; rows come out sorted by position).
 template <int W, int B>
 __device__ __forceinline__ void tile_epilogue(const TileArgs &a, const uint32_t t, const int32_t T0,
                                               uint32_t *cnt, uint32_t (*red)[B / 64], uint32_t *wave_off,
@@ -136,12 +147,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, const uint32_t 
     uint32_t mine = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) mine += (c[q] + d[q] >= a.min_cov) ? 1u : 0u;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
+    const uint32_t incl = wave_scan_incl(mine);
     if (lane == 63) wave_off[wave + 1] = incl;
     __syncthreads();
     if (tid == 0) {
@@ -161,6 +167,31 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, const uint32_t 
     }
 }
 
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+// NB relative positions of a read with one load (global memory takes unaligned vector loads)
+template <typename RelT, int NB>
+__device__ __forceinline__ void load_rel(const RelT *__restrict__ rp, int32_t (&r)[NB]) {
+    if constexpr (sizeof(RelT) == 1) {
+#pragma unroll
+        for (int k8 = 0; k8 < NB / 8; ++k8) {
+            const u32x2_a1 x = *reinterpret_cast<const u32x2_a1 *>(rp + 8 * k8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { r[8 * k8 + k] = (int32_t)((x.x >> (8 * k)) & 0xffu); r[8 * k8 + 4 + k] = (int32_t)((x.y >> (8 * k)) & 0xffu); }
+        }
+    } else {
+#pragma unroll
+        for (int k8 = 0; k8 < NB / 8; ++k8) {
+            const u32x4_a2 x = *reinterpret_cast<const u32x4_a2 *>(rp + 8 * k8);
+            r[8 * k8] = (int32_t)(x.x & 0xffffu); r[8 * k8 + 1] = (int32_t)(x.x >> 16);
+            r[8 * k8 + 2] = (int32_t)(x.y & 0xffffu); r[8 * k8 + 3] = (int32_t)(x.y >> 16);
+            r[8 * k8 + 4] = (int32_t)(x.z & 0xffffu); r[8 * k8 + 5] = (int32_t)(x.z >> 16);
+            r[8 * k8 + 6] = (int32_t)(x.w & 0xffffu); r[8 * k8 + 7] = (int32_t)(x.w >> 16);
+        }
+    }
+}
+
 // Tile kernel.  W = reference positions per tile, B = threads per workgroup, NB = CpG calls of a
 // read held in registers (reads with more calls take the memory loop for the tail).
 //
@@ -170,7 +201,7 @@ __device__ __forceinline__ void tile_epilogue(const TileArgs &a, const uint32_t 
 // tiles are served by the same L2.
 template <int W, int B, int NB, typename RelT>
 __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[2 * W];  // [0,W): concordant, [W,2W): discordant
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[2 * W + B];  // [0,W): concordant, [W,2W): discordant, then one trash word per thread
     __shared__ uint32_t red[4][B / 64];
     __shared__ uint32_t wave_off[B / 64 + 1];
 
@@ -209,98 +240,117 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
         const bool pdr_ok = a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);
         if (!(lp_ok || pdr_ok) || n == 0) continue;
 
-        // all calls of the read in flight at once.  Slots k >= n are masked below, so the loads are
-        // unconditional from a per-read base (immediate offsets, no per-load address arithmetic); they
-        // may touch the NEXT reads' calls but must not run past the end of the array, which only the
-        // batch's last few reads can do: those take the clamped form (wave-uniform choice).
+        // All calls of the read in flight at once: two 16-byte loads from a per-read base (dword alignment
+        // is all global_load_dwordx4 needs) and one 8/16-byte load of the relative positions.  Slots k >= n
+        // read the NEXT reads' calls and are neutralised below; only the batch's last few reads could run
+        // past the end of the arrays, and those take the clamped form (wave-uniform choice).
         uint32_t v[NB];
         int32_t r[NB];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) r[k] = 0;
         const uint32_t *__restrict__ cp = a.cpg_pos + o0;
         const RelT *__restrict__ rp = rel + o0;
+        // (distances between live calls are < 2^16, so capping max_distance keeps dead-slot differences outside)
+        const int32_t maxd = min(a.max_dist, 1 << 20);
+        const bool any_lp = maxd >= a.min_dist && __any(lp_ok && n > 1);   // min > max: no pair can qualify (and the range trick below would wrap)
         if (!__any(o0 + (uint32_t)NB > a.n_cpgs)) {
 #pragma unroll
-            for (int k = 0; k < NB; ++k) v[k] = cp[k];
-            if (lp_ok) {
-#pragma unroll
-                for (int k = 0; k < NB; ++k) r[k] = (int32_t)rp[k];
+            for (int k4 = 0; k4 < NB / 4; ++k4) {
+                const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(cp + 4 * k4);
+                v[4 * k4] = x.x; v[4 * k4 + 1] = x.y; v[4 * k4 + 2] = x.z; v[4 * k4 + 3] = x.w;
             }
+            if (any_lp) load_rel<RelT, NB>(rp, r);
         } else {
 #pragma unroll
             for (int k = 0; k < NB; ++k) v[k] = cp[min((uint32_t)k, n - 1)];
-            if (lp_ok) {
+            if (any_lp) {
 #pragma unroll
                 for (int k = 0; k < NB; ++k) r[k] = (int32_t)rp[min((uint32_t)k, n - 1)];
             }
         }
-        // every call must lie in [start-1, start+max_span-1]: this is what makes the halo complete
-        // (checked here, on the calls themselves, instead of trusting read_end)
-        const uint32_t first = v[0] >> 31;
-        uint32_t disc = 0;
+        // Every instruction type issues from the same few waves here (profiles/r01_tile_variants.md: the
+        // kernel is issue-bound), and predicates that are AND-ed / OR-ed per slot become s_and_b64 /
+        // s_or_b64 / saveexec chains on the scalar unit.  So the liveness of a slot (k < n) is used ONCE,
+        // to neutralise dead slots, and everything after is plain integer arithmetic:
+        //   dead call word  = far position (never inside a tile) with the first call's state (concordant)
+        //   dead rel        = (k+1) << 24 (any difference involving it exceeds every max_distance)
+        // Span check (every call in [start-1, start+max_span-1] -- this is what makes the halo complete,
+        // checked on the calls themselves instead of trusting read_end): max over the live slots.
+        const uint32_t sm1 = (uint32_t)(s - 1);
+        const uint32_t dead_w = 0x7fffffffu | (v[0] & 0x80000000u);
+        const uint32_t n_lp = (lp_ok && n <= (uint32_t)NB) ? n : 0u;   // pairs evaluated from the registers
+        uint32_t acc = 0, xmax = (v[0] & 0x7fffffffu) - sm1;
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
+        for (int k = 1; k < NB; ++k) {
             const bool live = (uint32_t)k < n;
-            disc |= live ? ((v[k] >> 31) ^ first) : 0u;
-            bad |= (live && ((v[k] & 0x7fffffffu) - (uint32_t)(s - 1) > (uint32_t)a.max_span)) ? 1u : 0u;
+            const uint32_t x = (v[k] & 0x7fffffffu) - sm1;
+            xmax = max(xmax, live ? x : 0u);
+            v[k] = live ? v[k] : dead_w;
+            acc |= v[k] ^ v[0];
         }
+        if (any_lp) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) r[k] = ((uint32_t)k < n_lp) ? r[k] : (int32_t)((k + 1) << 24);
+        }
+        bad |= (xmax > (uint32_t)a.max_span) ? 1u : 0u;
+        uint32_t disc = acc >> 31;
         if (n > (uint32_t)NB) {
+            const uint32_t first = v[0] >> 31;
             for (uint32_t k = NB; k < n; ++k) {
                 const uint32_t x = a.cpg_pos[o0 + k];
                 disc |= (x >> 31) ^ first;
-                bad |= ((x & 0x7fffffffu) - (uint32_t)(s - 1) > (uint32_t)a.max_span) ? 1u : 0u;
+                bad |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
             }
         }
         // windowed pair counts (readutil.rs:166-224): pairs (j<k) with min <= rel_k - rel_j <= max.
-        // Ablation (profiles/r01_tile_variants.md) put the full 28-slot block at 38 % of the kernel.  The
-        // calls are sorted by relpos, so the distance at call-index gap g+1 is >= the distance at gap g:
+        // The calls are sorted by relpos, so the distance at call-index gap g+1 is >= the distance at gap g:
         // walk the pair matrix by diagonals g = 1, 2, .. and stop once NO lane of the wave has a pair
         // within max_distance on the current diagonal (wave-uniform break).
-        const bool lp_reg = lp_ok && n > 1 && n <= (uint32_t)NB;      // pairs evaluated from the registers
-        if (__any(lp_reg)) {
-            {
+        if (any_lp) {
+            const uint32_t span_ok = (uint32_t)(maxd - a.min_dist);
+            uint32_t lp_n = 0, lp_dd = 0;
 #pragma unroll
-                for (int g = 1; g < NB; ++g) {
-                    bool within = false;
+            for (int g = 1; g < NB; ++g) {
+                int32_t dmin = 0x7fffffff;
 #pragma unroll
-                    for (int k = g; k < NB; ++k) {
-                        const int32_t dist = r[k] - r[k - g];
-                        const bool le = lp_reg && ((uint32_t)k < n) && dist <= a.max_dist;
-                        const bool in = le && dist >= a.min_dist;
-                        const uint32_t diff = (v[k] ^ v[k - g]) >> 31;
-                        lp_c += in ? (diff ^ 1u) : 0u;
-                        lp_d += in ? diff : 0u;
-                        within |= le;
-                    }
-                    if (!__any(within)) break;
+                for (int k = g; k < NB; ++k) {
+                    const int32_t dist = r[k] - r[k - g];
+                    dmin = min(dmin, dist);
+                    const bool in = (uint32_t)(dist - a.min_dist) <= span_ok;      // min <= dist <= max (min <= max)
+                    lp_n += in ? 1u : 0u;
+                    lp_dd += (in ? (v[k] ^ v[k - g]) : 0u) >> 31;
                 }
+                if (!__any(dmin <= maxd)) break;
             }
+            lp_c += lp_n - lp_dd;
+            lp_d += lp_dd;
         }
         if (lp_ok && n > (uint32_t)NB) {   // a read with more than NB calls: memory loop (divergent, rare)
-            {
-                for (uint32_t k = 1; k < n; ++k) {
-                    const int32_t rk = (int32_t)rel[o0 + k];
-                    const uint32_t mk = a.cpg_pos[o0 + k] >> 31;
-                    for (uint32_t j = k; j-- > 0;) {
-                        const int32_t dist = rk - (int32_t)rel[o0 + j];
-                        if (dist > a.max_dist) break;          // readutil.rs:184 (anchors evicted)
-                        if (dist < a.min_dist) continue;       // readutil.rs:196
-                        if ((a.cpg_pos[o0 + j] >> 31) == mk) lp_c += 1; else lp_d += 1;
-                    }
+            for (uint32_t k = 1; k < n; ++k) {
+                const int32_t rk = (int32_t)rel[o0 + k];
+                const uint32_t mk = a.cpg_pos[o0 + k] >> 31;
+                for (uint32_t j = k; j-- > 0;) {
+                    const int32_t dist = rk - (int32_t)rel[o0 + j];
+                    if (dist > a.max_dist) break;          // readutil.rs:184 (anchors evicted)
+                    if (dist < a.min_dist) continue;       // readutil.rs:196
+                    if ((a.cpg_pos[o0 + j] >> 31) == mk) lp_c += 1; else lp_d += 1;
                 }
             }
         }
-        // scatter +1 to the tile's sites (pdr.rs:180-191)
-        if (pdr_ok) {
-            uint32_t *base = cnt + (disc ? W : 0);
+        // scatter +1 to the tile's sites (pdr.rs:180-191), branch-free: a slot that is dead, outside the tile
+        // or belongs to a read PDR skips adds into the thread's own trash word instead (no exec juggling)
+        {
+            const uint32_t wt = pdr_ok ? Wt : 0u;
+            const uint32_t dw = disc ? (uint32_t)W : 0u;
+            const uint32_t trash = (uint32_t)(2 * W + tid) - dw;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const uint32_t p = (v[k] & 0x7fffffffu) - (uint32_t)T0;
-                if ((uint32_t)k < n && p < Wt) atomicAdd(base + p, 1u);
+                const uint32_t pk = (v[k] & 0x7fffffffu) - (uint32_t)T0;
+                atomicAdd(cnt + ((pk < wt ? pk : trash) + dw), 1u);
             }
-            for (uint32_t k = NB; k < n; ++k) {
-                const uint32_t p = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)T0;
-                if (p < Wt) atomicAdd(base + p, 1u);
+            if (pdr_ok) {
+                for (uint32_t k = NB; k < n; ++k) {
+                    const uint32_t pk = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)T0;
+                    if (pk < Wt) atomicAdd(cnt + dw + pk, 1u);
+                }
             }
         }
     }
