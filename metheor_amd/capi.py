@@ -60,7 +60,8 @@ class mth_lpmd_pairs_params_t(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libmetheor_hip.so")
+    # METHEOR_HIP_LIB: another build of the same library (A/B timing of kernel variants on one box)
+    return os.environ.get("METHEOR_HIP_LIB") or os.path.join(_HERE, "libmetheor_hip.so")
 
 
 def lib():

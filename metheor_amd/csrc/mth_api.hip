@@ -154,7 +154,6 @@ int mth_ctx_create(int device_id, mth_ctx_t **out) {
         return MTH_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    if (const char *v = getenv("MTH_TILE_VARIANT")) { const int k = atoi(v); if (k >= 0 && k <= 6) ctx->tile_variant = k; }
     if (hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream) != hipSuccess) {
         mth_ctx_destroy(ctx);
         return MTH_ERR_HIP;

@@ -73,7 +73,6 @@ struct mth_ctx {
     uint64_t p_cap = 0, p_rows_bound = 0;
     std::vector<mth::BatchMeta> p_batches;
 
-    int tile_variant = 0;        // fastest measured (profiles/r01_tile_variants.md)        // v2 lane=read: 0: 4096/256  1: 2048/512  2: 2048/256  3: 1024/256 ; v3 wave-cooperative: 4: 4096/4w  5: 4096/8w  6: 2048/4w
     bool timing = false;
     std::vector<mth::TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;

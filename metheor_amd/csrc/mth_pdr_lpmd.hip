@@ -111,60 +111,70 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
-template <int W, int B>
-__device__ __forceinline__ void tile_epilogue(const TileArgs &a, const uint32_t t, const int32_t T0,
-                                              uint32_t *cnt, uint32_t (*red)[B / 64], uint32_t *wave_off,
-                                              uint32_t lp_c, uint32_t lp_d, uint32_t n_read,
-                                              uint32_t n_valid, uint32_t bad) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
-
-    // per-tile LPMD partials (wave DPP reduce -> LDS -> one plain store per tile)
-    if (a.want_lpmd) {
-        const uint32_t r0 = wave_sum(lp_c), r1 = wave_sum(lp_d), r2 = wave_sum(n_read), r3 = wave_sum(n_valid);
-        if (lane == 0) { red[0][wave] = r0; red[1][wave] = r1; red[2][wave] = r2; red[3][wave] = r3; }
-    }
+// LPMD per-tile partials: wave DPP reduce -> LDS -> one plain store per tile (no same-address global atomics)
+template <int B>
+__device__ __forceinline__ void tile_lpmd_partials(const TileArgs &a, const uint32_t t, uint32_t (*red)[B / 64],
+                                                   uint32_t lp_c, uint32_t lp_d, uint32_t n_read, uint32_t n_valid) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r0 = wave_sum(lp_c), r1 = wave_sum(lp_d), r2 = wave_sum(n_read), r3 = wave_sum(n_valid);
+    if (lane == 0) { red[0][wave] = r0; red[1][wave] = r1; red[2][wave] = r2; red[3][wave] = r3; }
     __syncthreads();
-    if (a.want_lpmd && tid < 4) {
+    if (tid < 4) {
         uint32_t s = 0;
         for (int w = 0; w < B / 64; ++w) s += red[tid][w];
         a.tile_lpmd[t * 4 + tid] = s;
     }
-    if (!a.want_pdr) { if (tid == 0) a.tile_cnt[t] = 0; return; }
+}
 
-    // compaction: thread owns PER consecutive positions; emit sites with coverage >= min_cov
-    constexpr int PER = W / B;
-    static_assert(PER % 4 == 0, "uint4 LDS reads");
-    uint32_t c[PER], d[PER];
+// Compaction of one pass: NPOS = W (packed) or W/2 (wide) positions starting at reference position P0; the
+// thread owns PER consecutive positions and emits those with coverage >= min_cov to scratch[out_base..].
+// Sites are sparse (a few % of the positions): the thread keeps a bit mask of its qualifying positions and then
+// loops over the set bits only, re-reading the counters from LDS (PER predicated store blocks cost PER exec
+// save/restore pairs per wave whether or not anything qualifies).  Returns the pass's row count.
+template <int W, int B, bool WIDE>
+__device__ __forceinline__ uint32_t tile_compact(const TileArgs &a, const uint32_t t, const int32_t P0,
+                                                 const uint32_t *cnt, uint32_t *wave_off, const uint32_t out_base) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NPOS = WIDE ? W / 2 : W;
+    constexpr int PER = NPOS / B;
+    static_assert(PER % 4 == 0 && PER <= 32, "uint4 LDS reads, 32-bit mask");
+    uint32_t qual = 0;
 #pragma unroll
     for (int q = 0; q < PER / 4; ++q) {
         const uint4 x = reinterpret_cast<const uint4 *>(cnt)[tid * (PER / 4) + q];
-        const uint4 y = reinterpret_cast<const uint4 *>(cnt + W)[tid * (PER / 4) + q];
-        c[4 * q] = x.x; c[4 * q + 1] = x.y; c[4 * q + 2] = x.z; c[4 * q + 3] = x.w;
-        d[4 * q] = y.x; d[4 * q + 1] = y.y; d[4 * q + 2] = y.z; d[4 * q + 3] = y.w;
+        uint4 cov;
+        if (WIDE) {
+            const uint4 y = reinterpret_cast<const uint4 *>(cnt + W / 2)[tid * (PER / 4) + q];
+            cov = make_uint4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        } else {
+            cov = make_uint4((x.x & 0xffffu) + (x.x >> 16), (x.y & 0xffffu) + (x.y >> 16), (x.z & 0xffffu) + (x.z >> 16),
+                             (x.w & 0xffffu) + (x.w >> 16));
+        }
+        qual |= (cov.x >= a.min_cov ? 1u : 0u) << (4 * q);
+        qual |= (cov.y >= a.min_cov ? 1u : 0u) << (4 * q + 1);
+        qual |= (cov.z >= a.min_cov ? 1u : 0u) << (4 * q + 2);
+        qual |= (cov.w >= a.min_cov ? 1u : 0u) << (4 * q + 3);
     }
-    uint32_t mine = 0;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) mine += (c[q] + d[q] >= a.min_cov) ? 1u : 0u;
+    const uint32_t mine = __builtin_popcount(qual);
     const uint32_t incl = wave_scan_incl(mine);
     if (lane == 63) wave_off[wave + 1] = incl;
     __syncthreads();
     if (tid == 0) {
         wave_off[0] = 0;
         for (int w = 1; w <= B / 64; ++w) wave_off[w] += wave_off[w - 1];
-        a.tile_cnt[t] = wave_off[B / 64];
     }
     __syncthreads();
-    uint32_t o = wave_off[wave] + incl - mine;
+    uint32_t o = out_base + wave_off[wave] + incl - mine;
     SiteRec *__restrict__ out = a.scratch + (size_t)t * W;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        if (c[q] + d[q] >= a.min_cov) {
-            SiteRec rr; rr.pos = T0 + tid * PER + q; rr.n_conc = c[q]; rr.n_disc = d[q]; rr.pad = 0;
-            out[o++] = rr;
-        }
+    while (qual) {
+        const uint32_t idx = (uint32_t)tid * PER + (uint32_t)__builtin_ctz(qual);
+        qual &= qual - 1;
+        SiteRec rr; rr.pos = P0 + (int32_t)idx; rr.pad = 0;
+        if (WIDE) { rr.n_conc = cnt[idx]; rr.n_disc = cnt[W / 2 + idx]; }
+        else { const uint32_t x = cnt[idx]; rr.n_conc = x & 0xffffu; rr.n_disc = x >> 16; }
+        out[o++] = rr;
     }
+    return wave_off[B / 64];
 }
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -192,37 +202,17 @@ __device__ __forceinline__ void load_rel(const RelT *__restrict__ rp, int32_t (&
     }
 }
 
-// Tile kernel.  W = reference positions per tile, B = threads per workgroup, NB = CpG calls of a
-// read held in registers (reads with more calls take the memory loop for the tail).
-//
-// Latency structure (what v1 got wrong: one dependent HBM round trip per call): per tile the
-// dependent chain is  idx -> read fields -> ALL calls of the read (NB independent loads in
-// flight) -> LDS atomics.  Blocks are mapped to tiles XCD-aware so the halo reads of neighbouring
-// tiles are served by the same L2.
-template <int W, int B, int NB, typename RelT>
-__global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[2 * W + B];  // [0,W): concordant, [W,2W): discordant, then one trash word per thread
-    __shared__ uint32_t red[4][B / 64];
-    __shared__ uint32_t wave_off[B / 64 + 1];
-
+// One pass of a tile over its candidate reads [lo, hi): LDS counters for the reference positions
+// [P0, P0 + Wp), then compaction.  do_lp: also the LPMD pair counts and read totals of the reads the tile owns
+// (first pass only).  Returns the number of rows the pass appended at scratch[out_base..].
+template <int W, int B, int NB, typename RelT, bool WIDE>
+__device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t t, const int32_t T0, const int32_t T1,
+                                              const int32_t P0, const uint32_t Wp, const uint32_t lo, const uint32_t hi,
+                                              const bool do_lp, const uint32_t out_base, uint32_t *cnt,
+                                              uint32_t (*red)[B / 64], uint32_t *wave_off) {
     const int tid = threadIdx.x;
-    // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
-    const uint32_t per_xcd = (ntiles + 7) / 8;
-    const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (t >= ntiles) return;
-    const int32_t T0 = a.region_beg + (int32_t)(t * W);
-    const int32_t T1 = min(T0 + W, a.region_end);
-    const uint32_t Wt = (uint32_t)(T1 - T0);
-
-    // candidate reads: start in [T0 - max_span + 1, T0 + W]  (a call sits in [start-1, end]).
-    // Both bounds are clamped to n_reads: a batch that failed validation in k_build_index (stale or
-    // partial index) then only ever touches in-bounds reads, and its rows are discarded because the
-    // getters report the error.  (An explicit load of the error flag here cost every tile a dependent
-    // round trip before its first useful load.)
-    const uint32_t lo = min(a.idx[(uint32_t)(T0 - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
-    const uint32_t hi = min(a.idx[((uint32_t)(T0 + W - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
     const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
-    for (int i = tid; i < 2 * W / 4; i += B)
+    for (int i = tid; i < W / 4; i += B)
         reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
@@ -234,8 +224,8 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
         const uint32_t n = o1 - o0;
         const bool owned = (s >= T0) && (s < T1);
         // lpmd.rs:176-179
-        const bool lp_ok = a.want_lpmd && owned && (mq >= a.lpmd_min_qual);
-        if (a.want_lpmd && owned) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
+        const bool lp_ok = do_lp && owned && (mq >= a.lpmd_min_qual);
+        if (do_lp && owned) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
         // pdr.rs:147-157
         const bool pdr_ok = a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);
         if (!(lp_ok || pdr_ok) || n == 0) continue;
@@ -292,7 +282,8 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
         }
         bad |= (xmax > (uint32_t)a.max_span) ? 1u : 0u;
         uint32_t disc = acc >> 31;
-        if (n > (uint32_t)NB) {
+        const bool any_long = __any(n > (uint32_t)NB);   // wave-uniform: the three tails below are rare
+        if (any_long && n > (uint32_t)NB) {
             const uint32_t first = v[0] >> 31;
             for (uint32_t k = NB; k < n; ++k) {
                 const uint32_t x = a.cpg_pos[o0 + k];
@@ -323,7 +314,7 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
             lp_c += lp_n - lp_dd;
             lp_d += lp_dd;
         }
-        if (lp_ok && n > (uint32_t)NB) {   // a read with more than NB calls: memory loop (divergent, rare)
+        if (any_long && lp_ok && n > (uint32_t)NB) {   // a read with more than NB calls: memory loop (divergent, rare)
             for (uint32_t k = 1; k < n; ++k) {
                 const int32_t rk = (int32_t)rel[o0 + k];
                 const uint32_t mk = a.cpg_pos[o0 + k] >> 31;
@@ -335,276 +326,78 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
                 }
             }
         }
-        // scatter +1 to the tile's sites (pdr.rs:180-191), branch-free: a slot that is dead, outside the tile
-        // or belongs to a read PDR skips adds into the thread's own trash word instead (no exec juggling)
+        // scatter +1 to the pass's sites (pdr.rs:180-191), branch-free: a slot that is dead, outside the pass's
+        // positions or belongs to a read PDR skips adds into the thread's own trash word instead (no exec juggling).
+        // Packed: one word per position, concordant count in the low half, discordant in the high half.
+        // Wide: concordant at [0, W/2), discordant at [W/2, W).
         {
-            const uint32_t wt = pdr_ok ? Wt : 0u;
-            const uint32_t dw = disc ? (uint32_t)W : 0u;
-            const uint32_t trash = (uint32_t)(2 * W + tid) - dw;
+            const uint32_t wt = pdr_ok ? Wp : 0u;
+            const uint32_t one = (!WIDE && disc) ? 0x10000u : 1u;
+            const uint32_t dw = (WIDE && disc) ? (uint32_t)(W / 2) : 0u;
+            const uint32_t trash = (uint32_t)(W + tid) - dw;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const uint32_t pk = (v[k] & 0x7fffffffu) - (uint32_t)T0;
-                atomicAdd(cnt + ((pk < wt ? pk : trash) + dw), 1u);
+                const uint32_t pk = (v[k] & 0x7fffffffu) - (uint32_t)P0;
+                atomicAdd(cnt + ((pk < wt ? pk : trash) + dw), one);
             }
-            if (pdr_ok) {
+            if (any_long && pdr_ok) {
                 for (uint32_t k = NB; k < n; ++k) {
-                    const uint32_t pk = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)T0;
-                    if (pk < Wt) atomicAdd(cnt + dw + pk, 1u);
+                    const uint32_t pk = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)P0;
+                    if (pk < Wp) atomicAdd(cnt + dw + pk, one);
                 }
             }
         }
     }
-    tile_epilogue<W, B>(a, t, T0, cnt, red, wave_off, lp_c, lp_d, n_read, n_valid, bad);
+    if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
+    if (do_lp) tile_lpmd_partials<B>(a, t, red, lp_c, lp_d, n_read, n_valid);
+    __syncthreads();
+    if (!a.want_pdr) return 0u;
+    return tile_compact<W, B, WIDE>(a, t, P0, cnt, wave_off, out_base);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Wave-cooperative tile kernel -- EXPERIMENTAL, NOT the default (select with MTH_TILE_VARIANT=4..6).
-// History: its first form (v3) gave every call its read with a 6-step cross-lane max-scan and measured
-// SLOWER than the lane = read kernel above (tile kernel 0.301 vs 0.237 ms, profiles/r01_tile_variants.md).
-// This form (v4) keeps the structure but finds segment heads with one ballot + count-leading-zeros.
-// Idea: the lane = read kernel pads every read to NB call slots and NB*(NB-1)/2 pair slots (rocprof:
-// ~1650 VALU wave-instructions per wave and tile, ~3 of 8 slots useful).  Here a wave takes a chunk of
-// up to 64 consecutive reads (lane = read for the 9 B/read record) and then walks the chunk's CONTIGUOUS
-// call range with lane = call: coalesced loads, no padding.
-//   read of a call   : each read lane drops (lane+1 | flags) at its first call in a per-wave LDS u16
-//                      table; a round loads the 64 entries, ballot(entry != 0) is the head mask, the
-//                      nearest head at or before lane t is 63 - clz(mask & low_bits(t)), its entry comes
-//                      with one bpermute; "distance to head" makes same-read tests a compare
-//   read concordance : a read is discordant iff two ADJACENT calls differ (readutil.rs:134-145) ->
-//                      one lane shift + a (rare) LDS atomic-or on the read's flag word
-//   LPMD pairs       : call k looks back over calls k-1, k-2, .. of the same read while the query
-//                      distance stays <= max (readutil.rs:166-224) -- lane shifts, work proportional
-//                      to the pairs that exist; rounds overlap by OV lanes so no carry is needed;
-//                      look-backs deeper than OV finish with a per-lane memory loop
-//   PDR scatter      : second walk over the calls held in registers, LDS atomic add on the dense
-//                      tile counters
-constexpr int WC_MAXC = 1024;  // calls per chunk covered by the per-wave head table
-constexpr int WC_OV = 8;       // context lanes per round (look-back reach without touching memory)
-constexpr int WC_RQ = 8;       // rounds whose calls stay in registers for the scatter walk
-
-template <int W, int NW, typename RelT, bool WANT_PDR, bool WANT_LPMD>
-__global__ __launch_bounds__(NW * 64) void k_pdr_lpmd_tile_wc(const TileArgs a, const uint32_t ntiles) {
-    constexpr int B = NW * 64;
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[2 * W];
+// Tile kernel.  W = reference positions per tile, B = threads per workgroup, NB = CpG calls of a
+// read held in registers (reads with more calls take the memory loop for the tail).
+//
+// Latency structure (what v1 got wrong: one dependent HBM round trip per call): per tile the
+// dependent chain is  idx -> read fields -> ALL calls of the read (NB independent loads in
+// flight) -> LDS atomics.  Blocks are mapped to tiles XCD-aware so the halo reads of neighbouring
+// tiles are served by the same L2.
+//
+// LDS: one 32-bit word per reference position (16 KiB per tile -> 8 waves per SIMD; with two words the LDS
+// capped residency at 4 and the issue-bound kernel ran 27 % slower, profiles/r01_tile_variants.md).  A position
+// is called at most once per candidate read, so while the tile has <= 65535 candidates both counts fit 16 bits
+// (packed).  Heavier tiles (deep amplicons) take two passes over their reads with 32-bit counters, each
+// covering half of the tile's positions -- same LDS footprint, no extra launch, exact.
+template <int W, int B, int NB, typename RelT>
+__global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[W + B];   // counters, then one trash word per thread
     __shared__ uint32_t red[4][B / 64];
     __shared__ uint32_t wave_off[B / 64 + 1];
-    __shared__ __attribute__((aligned(16))) uint16_t head_s[NW][WC_MAXC];  // 0 = not a first call, else (read lane + 1)
-    __shared__ uint32_t rinfo_s[NW][64];                                    // bit0 pdr_ok, bit1 lp_ok, bit2 discordant
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t t = blockIdx.x;
+    // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
+    const uint32_t per_xcd = (ntiles + 7) / 8;
+    const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= ntiles) return;
     const int32_t T0 = a.region_beg + (int32_t)(t * W);
     const int32_t T1 = min(T0 + W, a.region_end);
-    const uint32_t Wt = (uint32_t)(T1 - T0);
-    uint16_t *head = head_s[wave];
-    uint32_t *rinfo = rinfo_s[wave];
 
-    for (int i = tid; i < 2 * W / 4; i += B)
-        reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
-    // candidate reads: start in [T0 - max_span + 1, T0 + W].  idx is clamped so that a batch that
-    // failed validation (stale index) only ever produces in-bounds reads; its rows are discarded
-    // because the error flag is reported by the getters.
+    // candidate reads: start in [T0 - max_span + 1, T0 + W]  (a call sits in [start-1, end]).
+    // Both bounds are clamped to n_reads: a batch that failed validation in k_build_index (stale or
+    // partial index) then only ever touches in-bounds reads, and its rows are discarded because the
+    // getters report the error.  (An explicit load of the error flag here cost every tile a dependent
+    // round trip before its first useful load.)
     const uint32_t lo = min(a.idx[(uint32_t)(T0 - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
     const uint32_t hi = min(a.idx[((uint32_t)(T0 + W - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
-    const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
-    __syncthreads();
-
-    uint32_t lp_c = 0, lp_d = 0, n_read = 0, n_valid = 0, bad = 0;
-    const uint32_t span = hi > lo ? hi - lo : 0;
-    const uint32_t per = (span + NW - 1) / NW;
-    const uint32_t r_end = min(lo + (wave + 1) * per, hi);
-    for (uint32_t i0 = lo + wave * per; i0 < r_end;) {
-        // ---- read round: lane <-> read i0 + lane ------------------------------------------
-        const uint32_t i = i0 + lane;
-        const bool inb = i < r_end;
-        const uint32_t off0 = a.cpg_off[inb ? i : i0], off1 = a.cpg_off[(inb ? i : i0) + 1];
-        const int32_t s = a.read_start[inb ? i : i0];
-        const uint32_t mq = a.read_mapq[inb ? i : i0];
-        const uint32_t cbeg = __builtin_amdgcn_readfirstlane(off0);
-        // reads of the chunk: the longest prefix whose calls fit the head table
-        const unsigned long long fits = __ballot(inb && (off1 - cbeg <= (uint32_t)WC_MAXC));
-        const int nr = fits == ~0ull ? 64 : __builtin_ctzll(~fits);
-        if (nr == 0) {
-            // one read with more than WC_MAXC calls (only possible with 16-bit relpos): the wave
-            // walks its calls from memory, lane-strided
-            const uint32_t e1 = __builtin_amdgcn_readfirstlane(off1);
-            const int32_t s0 = __builtin_amdgcn_readfirstlane(s);
-            const uint32_t mq0 = __builtin_amdgcn_readfirstlane(mq);
-            const uint32_t n = e1 - cbeg;
-            const bool owned = (s0 >= T0) && (s0 < T1);
-            const bool lp_ok = WANT_LPMD && owned && (mq0 >= a.lpmd_min_qual);
-            const bool pdr_ok = WANT_PDR && (n >= a.min_cpgs) && (mq0 >= a.pdr_min_qual);
-            if (WANT_LPMD && owned && lane == 0) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
-            if (lp_ok || pdr_ok) {
-                uint32_t dsc = 0;
-                for (uint32_t c = cbeg + lane; c < e1; c += 64) {
-                    const uint32_t x = a.cpg_pos[c];
-                    bad |= ((x & 0x7fffffffu) - (uint32_t)(s0 - 1) > (uint32_t)a.max_span) ? 1u : 0u;
-                    if (c > cbeg) dsc |= (x ^ a.cpg_pos[c - 1]) >> 31;
-                    if (lp_ok) {
-                        const int32_t rk = (int32_t)rel[c];
-                        for (uint32_t j = c; j-- > cbeg;) {
-                            const int32_t dist = rk - (int32_t)rel[j];
-                            if (dist > a.max_dist) break;
-                            if (dist < a.min_dist) continue;
-                            if ((a.cpg_pos[j] >> 31) == (x >> 31)) lp_c += 1; else lp_d += 1;
-                        }
-                    }
-                }
-                const bool disc = __ballot(dsc != 0) != 0ull;
-                if (pdr_ok) {
-                    uint32_t *base = cnt + (disc ? W : 0);
-                    for (uint32_t c = cbeg + lane; c < e1; c += 64) {
-                        const uint32_t p = (a.cpg_pos[c] & 0x7fffffffu) - (uint32_t)T0;
-                        if (p < Wt) atomicAdd(base + p, 1u);
-                    }
-                }
-            }
-            i0 += 1;
-            continue;
-        }
-        const bool act = lane < nr;
-        const uint32_t cend = __builtin_amdgcn_readlane(off1, nr - 1);
-        const uint32_t n = off1 - off0;
-        const bool owned = act && (s >= T0) && (s < T1);
-        const bool lp_ok = WANT_LPMD && owned && (mq >= a.lpmd_min_qual);                      // lpmd.rs:176-179
-        const bool pdr_ok = WANT_PDR && act && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);  // pdr.rs:147-157
-        if (WANT_LPMD && owned) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
-        if (!__any((lp_ok || pdr_ok) && n > 0)) { i0 += nr; continue; }   // nothing to do (halo chunk)
-
-        // ---- publish the chunk's read table ------------------------------------------------
-        reinterpret_cast<uint4 *>(head)[lane] = make_uint4(0, 0, 0, 0);            // 2 x 64 x 16 B = WC_MAXC u16
-        reinterpret_cast<uint4 *>(head)[lane + 64] = make_uint4(0, 0, 0, 0);
-        rinfo[lane] = (pdr_ok ? 1u : 0u) | (lp_ok ? 2u : 0u);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (act && n > 0) head[off0 - cbeg] = (uint16_t)(lane + 1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- call rounds: lane <-> call, rounds overlap by WC_OV context lanes -----------------
-        // one round = 64 consecutive calls starting at `base`; returns the call word and its read id
-        uint32_t carry = 0;   // read id (lane+1) of the call just before the round's lane 0
-        auto call_round = [&](const uint32_t base, uint32_t &v_out, uint32_t &rid_out) {
-            const uint32_t c = base + lane;
-            const bool valid = (int32_t)(c - cbeg) >= 0 && c < cend;
-            const bool isnew = valid && lane >= WC_OV;    // lanes < WC_OV only give context
-            const uint32_t v = valid ? a.cpg_pos[c] : 0u;
-            const uint32_t rl = (valid && WANT_LPMD) ? (uint32_t)rel[c] : 0u;
-            const uint32_t h = valid ? (uint32_t)head[c - cbeg] : 0u;
-            // segment heads: one ballot, then count-leading-zeros on the heads at or before this lane
-            const unsigned long long hm = __ballot(h != 0u);
-            const unsigned long long below = hm & ((2ull << lane) - 1ull);
-            const int hp = below ? 63 - __builtin_clzll(below) : 0;
-            const uint32_t hv = __shfl(h, hp, 64);
-            const uint32_t rid = valid ? (below ? hv : carry) : 0u;
-            const uint32_t dh = below ? (uint32_t)(lane - hp) : 255u;       // lanes since the head (255: head before the round)
-            carry = __builtin_amdgcn_readlane(rid, 63 - WC_OV);   // read of the call before the next round's lane 0
-            const int rlane = rid ? (int)rid - 1 : 0;
-            const uint32_t m = v >> 31;
-            // every call must lie in [start-1, start-1+max_span] (halo completeness)
-            const int32_t sR = __shfl(s, rlane, 64);
-            bad |= (valid && ((v & 0x7fffffffu) - (uint32_t)(sR - 1) > (uint32_t)a.max_span)) ? 1u : 0u;
-            const uint32_t info = valid ? rinfo[rlane] : 0u;
-            const uint32_t pk = (m << 16) | (rl & 0xffffu);
-            // adjacent calls of one read that differ make the read discordant
-            const uint32_t p1 = __shfl_up(pk, 1, 64);
-            if (WANT_PDR) {
-                if (isnew && dh >= 1u && ((p1 >> 16) != m) && (info & 1u))
-                    atomicOr(&rinfo[rlane], 4u);
-            }
-            if (WANT_LPMD) {
-                const bool lpc = isnew && (info & 2u);
-                bool deeper = false;
-#pragma unroll
-                for (int d = 1; d <= WC_OV; ++d) {
-                    const uint32_t pd = d == 1 ? p1 : __shfl_up(pk, d, 64);
-                    const int32_t dist = (int32_t)rl - (int32_t)(pd & 0xffffu);
-                    const bool on = lpc && dh >= (uint32_t)d && dist <= a.max_dist;   // same read; readutil.rs:184
-                    if (!__any(on)) break;
-                    const bool in = on && dist >= a.min_dist;                         // readutil.rs:196
-                    const bool sm = (pd >> 16) == m;
-                    lp_c += (in && sm) ? 1u : 0u;
-                    lp_d += (in && !sm) ? 1u : 0u;
-                    if (d == WC_OV) deeper = on;
-                }
-                // look-backs that outran the register window (dense CpGs or a wide --max-distance)
-                if (__any(deeper)) {
-                    const uint32_t o0r = __shfl(off0, rlane, 64);
-                    if (deeper) {
-                        for (uint32_t j = c - WC_OV; j-- > o0r;) {
-                            const int32_t dist = (int32_t)rl - (int32_t)rel[j];
-                            if (dist > a.max_dist) break;
-                            if (dist < a.min_dist) continue;
-                            if ((a.cpg_pos[j] >> 31) == m) lp_c += 1; else lp_d += 1;
-                        }
-                    }
-                }
-            }
-            v_out = isnew ? v : 0u;
-            rid_out = isnew ? rid : 0u;
-        };
-        uint32_t vq[WC_RQ], rq[WC_RQ];   // statically indexed: stay in VGPRs
-        uint32_t base = cbeg - WC_OV;
-        bool more = true;                 // wave-uniform
-#pragma unroll
-        for (int k = 0; k < WC_RQ; ++k) {
-            vq[k] = 0u; rq[k] = 0u;
-            if (more) {
-                call_round(base, vq[k], rq[k]);
-                more = base + 64 < cend;
-                base += 64 - WC_OV;
-            }
-        }
-        const uint32_t tail_base = base;
-        const uint32_t tail_carry = carry;
-        while (more) {                    // chunks with more than WC_RQ rounds: nothing kept
-            uint32_t v_, r_;
-            call_round(base, v_, r_);
-            more = base + 64 < cend;
-            base += 64 - WC_OV;
-        }
-        // ---- scatter walk: +1 on the tile's dense counters (pdr.rs:180-191) ----------------------
-        if (WANT_PDR) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < WC_RQ; ++k) {
-                const uint32_t rid = rq[k];
-                if (rid) {
-                    const uint32_t info = rinfo[rid - 1];
-                    const uint32_t p = (vq[k] & 0x7fffffffu) - (uint32_t)T0;
-                    if ((info & 1u) && p < Wt) atomicAdd(cnt + ((info & 4u) ? W : 0) + p, 1u);
-                }
-            }
-            // rounds beyond the register window: re-derive the read of each call from the table
-            if (tail_base + WC_OV < cend) {
-                uint32_t cr = tail_carry;
-                for (uint32_t b2 = tail_base;; b2 += 64 - WC_OV) {
-                    const uint32_t c = b2 + lane;
-                    const bool valid = (int32_t)(c - cbeg) >= 0 && c < cend;
-                    const uint32_t h = valid ? (uint32_t)head[c - cbeg] : 0u;
-                    const unsigned long long hm = __ballot(h != 0u);
-                    const unsigned long long below = hm & ((2ull << lane) - 1ull);
-                    const int hp = below ? 63 - __builtin_clzll(below) : 0;
-                    const uint32_t hv = __shfl(h, hp, 64);
-                    const uint32_t rid = valid ? (below ? hv : cr) : 0u;
-                    cr = __builtin_amdgcn_readlane(rid, 63 - WC_OV);
-                    if (valid && lane >= WC_OV) {
-                        const uint32_t info = rinfo[rid - 1];
-                        const uint32_t p = (a.cpg_pos[c] & 0x7fffffffu) - (uint32_t)T0;
-                        if ((info & 1u) && p < Wt) atomicAdd(cnt + ((info & 4u) ? W : 0) + p, 1u);
-                    }
-                    if (b2 + 64 >= cend) break;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        i0 += nr;
+    uint32_t rows;
+    if (hi - lo <= 65535u) {
+        rows = tile_pass<W, B, NB, RelT, false>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
+    } else {
+        const int32_t Tm = min(T0 + W / 2, T1);
+        rows = tile_pass<W, B, NB, RelT, true>(a, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
+        __syncthreads();
+        rows += tile_pass<W, B, NB, RelT, true>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off);
     }
-    tile_epilogue<W, B>(a, t, T0, cnt, red, wave_off, lp_c, lp_d, n_read, n_valid, bad);
+    if (threadIdx.x == 0) a.tile_cnt[t] = rows;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -722,16 +515,6 @@ static void launch_tile(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
     hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT>), dim3(grid), dim3(B), 0, s, a, ntiles);
 }
 
-template <int W, int NW, typename RelT>
-static void launch_tile_wc(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
-    if (a.want_pdr && a.want_lpmd)
-        hipLaunchKernelGGL((k_pdr_lpmd_tile_wc<W, NW, RelT, true, true>), dim3(ntiles), dim3(NW * 64), 0, s, a, ntiles);
-    else if (a.want_pdr)
-        hipLaunchKernelGGL((k_pdr_lpmd_tile_wc<W, NW, RelT, true, false>), dim3(ntiles), dim3(NW * 64), 0, s, a, ntiles);
-    else
-        hipLaunchKernelGGL((k_pdr_lpmd_tile_wc<W, NW, RelT, false, true>), dim3(ntiles), dim3(NW * 64), 0, s, a, ntiles);
-}
-
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_params_t &p, const TileSink *sink) {
     hipStream_t s = ctx->stream;
     // where the compacted rows and their counters go: the PDR result columns by default, or a
@@ -742,8 +525,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     float *o_pdr = sink ? sink->pdr : ctx->out_pdr.as<float>();
     uint32_t *o_nc = sink ? sink->nc : ctx->out_nc.as<uint32_t>();
     uint32_t *o_nd = sink ? sink->nd : ctx->out_nd.as<uint32_t>();
-    const int variant = ctx->tile_variant;
-    const int tile_w = (variant == 0 || variant == 4 || variant == 5) ? 4096 : (variant == 3 ? 1024 : 2048);
+    constexpr int tile_w = 4096;
     const int64_t region_len = (int64_t)b.region_end - b.region_beg;
     const uint32_t ntiles = (uint32_t)((region_len + tile_w - 1) / tile_w);
     if (ntiles == 0) return MTH_OK;
@@ -781,15 +563,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     {
         LaunchTimer lt(ctx, K_TILE);
         const bool r8 = b.cpg_rel != nullptr;
-        switch (variant) {
-            case 0: r8 ? launch_tile<4096, 256, uint8_t>(a, ntiles, s) : launch_tile<4096, 256, uint16_t>(a, ntiles, s); break;
-            case 2: r8 ? launch_tile<2048, 256, uint8_t>(a, ntiles, s) : launch_tile<2048, 256, uint16_t>(a, ntiles, s); break;
-            case 3: r8 ? launch_tile<1024, 256, uint8_t>(a, ntiles, s) : launch_tile<1024, 256, uint16_t>(a, ntiles, s); break;
-            case 4: r8 ? launch_tile_wc<4096, 4, uint8_t>(a, ntiles, s) : launch_tile_wc<4096, 4, uint16_t>(a, ntiles, s); break;
-            case 5: r8 ? launch_tile_wc<4096, 8, uint8_t>(a, ntiles, s) : launch_tile_wc<4096, 8, uint16_t>(a, ntiles, s); break;
-            case 6: r8 ? launch_tile_wc<2048, 4, uint8_t>(a, ntiles, s) : launch_tile_wc<2048, 4, uint16_t>(a, ntiles, s); break;
-            default: r8 ? launch_tile<2048, 512, uint8_t>(a, ntiles, s) : launch_tile<2048, 512, uint16_t>(a, ntiles, s); break;
-        }
+        if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
     }
     {
         LaunchTimer lt(ctx, K_SCAN);

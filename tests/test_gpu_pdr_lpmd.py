@@ -156,6 +156,30 @@ def test_high_depth_site_and_u16_rel(eng):
     assert p["n_concordant"].max() + p["n_discordant"].max() > 10_000
 
 
+def test_deep_amplicon_wide_counters(eng):
+    """The tile keeps ONE 32-bit LDS word per position (two 16-bit counts) while it has <= 65535 candidate reads;
+    heavier tiles take two passes with 32-bit counters.  70 000 reads calling the same four CpGs (a deep
+    amplicon: per-site counts beyond 16 bits) plus a uniformly deep tile with > 65535 candidates."""
+    from metheor_amd import PdrLpmdParams, synth
+    rng = np.random.default_rng(81)
+    n = 70_000
+    start = np.sort(1000 + (np.arange(n) % 2)).astype(np.int32)
+    cpgs = np.array([1005, 1015, 1040, 1080], np.int32)
+    meth = rng.random((n, 4)) < np.where(rng.random((n, 1)) < 0.5, 0.9, 0.1)      # mostly concordant reads, some mixed
+    pos = (cpgs[None, :].astype(np.uint32) | (meth.astype(np.uint32) << 31)).reshape(-1)
+    rel = (cpgs[None, :] - start[:, None]).astype(np.uint8).reshape(-1)
+    amp = dict(tid=0, length=9_000, read_start=start, read_end=start + 99, read_mapq=np.full(n, 40, np.uint8),
+               read_fwd=np.ones(n, np.uint8), cpg_off=(np.arange(n + 1) * 4).astype(np.uint32), cpg_pos=pos, cpg_rel=rel)
+    deep = synth.make_contig(1, 7_000, 75_000, 0.04, rng)                          # ~1600x over 7 kbp: two heavy tiles
+    cs = [amp, deep]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    p = PdrLpmdParams(min_depth=10, min_cpgs=2, min_qual=10, min_distance=2, max_distance=40, lpmd_min_qual=10)
+    d, l = run_device(eng, cs, p)
+    check_against_oracle(d, l, reads, dict(min_depth=10, min_cpgs=2, min_qual=10), dict(min_distance=2, max_distance=40, min_qual=10))
+    amp_rows = d["tid"] == 0
+    assert amp_rows.sum() == 4 and ((d["n_concordant"] + d["n_discordant"])[amp_rows] == n).all()   # > 65535 per site
+
+
 def test_edge_cases(eng):
     from metheor_amd import Batch, MthError, PdrLpmdParams, synth
     z4 = np.zeros(0, np.int32)
