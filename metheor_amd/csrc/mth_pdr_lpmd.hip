@@ -132,7 +132,7 @@ __device__ __forceinline__ void tile_lpmd_partials(const TileArgs &a, const uint
 // loops over the set bits only, re-reading the counters from LDS (PER predicated store blocks cost PER exec
 // save/restore pairs per wave whether or not anything qualifies).  Returns the pass's row count.
 template <int W, int B, bool WIDE>
-__device__ __forceinline__ uint32_t tile_compact(const TileArgs &a, const uint32_t t, const int32_t P0,
+__device__ __forceinline__ uint32_t tile_compact(const TileArgs &a, const uint32_t t, const int32_t P0, const uint32_t Wp,
                                                  const uint32_t *cnt, uint32_t *wave_off, const uint32_t out_base) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NPOS = WIDE ? W / 2 : W;
@@ -154,6 +154,10 @@ __device__ __forceinline__ uint32_t tile_compact(const TileArgs &a, const uint32
         qual |= (cov.y >= a.min_cov ? 1u : 0u) << (4 * q + 1);
         qual |= (cov.z >= a.min_cov ? 1u : 0u) << (4 * q + 2);
         qual |= (cov.w >= a.min_cov ? 1u : 0u) << (4 * q + 3);
+    }
+    {   // only the pass's positions [0, Wp) exist (the last tile of a region is short)
+        const int32_t left = (int32_t)Wp - tid * PER;
+        qual &= left >= PER ? 0xffffffffu : (left > 0 ? (1u << left) - 1u : 0u);
     }
     const uint32_t mine = __builtin_popcount(qual);
     const uint32_t incl = wave_scan_incl(mine);
@@ -205,7 +209,7 @@ __device__ __forceinline__ void load_rel(const RelT *__restrict__ rp, int32_t (&
 // One pass of a tile over its candidate reads [lo, hi): LDS counters for the reference positions
 // [P0, P0 + Wp), then compaction.  do_lp: also the LPMD pair counts and read totals of the reads the tile owns
 // (first pass only).  Returns the number of rows the pass appended at scratch[out_base..].
-template <int W, int B, int NB, typename RelT, bool WIDE>
+template <int W, int B, int NB, typename RelT, bool WIDE, bool CLAMP>
 __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t t, const int32_t T0, const int32_t T1,
                                               const int32_t P0, const uint32_t Wp, const uint32_t lo, const uint32_t hi,
                                               const bool do_lp, const uint32_t out_base, uint32_t *cnt,
@@ -233,7 +237,8 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         // All calls of the read in flight at once: two 16-byte loads from a per-read base (dword alignment
         // is all global_load_dwordx4 needs) and one 8/16-byte load of the relative positions.  Slots k >= n
         // read the NEXT reads' calls and are neutralised below; only the batch's last few reads could run
-        // past the end of the arrays, and those take the clamped form (wave-uniform choice).
+        // past the end of the arrays: a tile that holds them runs the CLAMP instantiation (per-tile choice,
+        // so neither instantiation merges two load paths inside the loop).
         uint32_t v[NB];
         int32_t r[NB];
         const uint32_t *__restrict__ cp = a.cpg_pos + o0;
@@ -241,7 +246,7 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         // (distances between live calls are < 2^16, so capping max_distance keeps dead-slot differences outside)
         const int32_t maxd = min(a.max_dist, 1 << 20);
         const bool any_lp = maxd >= a.min_dist && __any(lp_ok && n > 1);   // min > max: no pair can qualify (and the range trick below would wrap)
-        if (!__any(o0 + (uint32_t)NB > a.n_cpgs)) {
+        if (!CLAMP) {
 #pragma unroll
             for (int k4 = 0; k4 < NB / 4; ++k4) {
                 const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(cp + 4 * k4);
@@ -260,12 +265,12 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         // kernel is issue-bound), and predicates that are AND-ed / OR-ed per slot become s_and_b64 /
         // s_or_b64 / saveexec chains on the scalar unit.  So the liveness of a slot (k < n) is used ONCE,
         // to neutralise dead slots, and everything after is plain integer arithmetic:
-        //   dead call word  = far position (never inside a tile) with the first call's state (concordant)
+        //   dead call word  = a position 2^28 bp past the tile with the first call's state (concordant)
         //   dead rel        = (k+1) << 24 (any difference involving it exceeds every max_distance)
         // Span check (every call in [start-1, start+max_span-1] -- this is what makes the halo complete,
         // checked on the calls themselves instead of trusting read_end): max over the live slots.
         const uint32_t sm1 = (uint32_t)(s - 1);
-        const uint32_t dead_w = 0x7fffffffu | (v[0] & 0x80000000u);
+        const uint32_t dead_w = (((uint32_t)T0 + (1u << 28)) & 0x7fffffffu) | (v[0] & 0x80000000u);   // 2^28 bp past the tile
         const uint32_t n_lp = (lp_ok && n <= (uint32_t)NB) ? n : 0u;   // pairs evaluated from the registers
         uint32_t acc = 0, xmax = (v[0] & 0x7fffffffu) - sm1;
 #pragma unroll
@@ -327,23 +332,41 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
             }
         }
         // scatter +1 to the pass's sites (pdr.rs:180-191), branch-free: a slot that is dead, outside the pass's
-        // positions or belongs to a read PDR skips adds into the thread's own trash word instead (no exec juggling).
-        // Packed: one word per position, concordant count in the low half, discordant in the high half.
-        // Wide: concordant at [0, W/2), discordant at [W/2, W).
-        {
-            const uint32_t wt = pdr_ok ? Wp : 0u;
-            const uint32_t one = (!WIDE && disc) ? 0x10000u : 1u;
-            const uint32_t dw = (WIDE && disc) ? (uint32_t)(W / 2) : 0u;
-            const uint32_t trash = (uint32_t)(W + tid) - dw;
+        // positions or belongs to a read PDR skips adds into a trash word instead (no exec juggling).
+        // Packed: one word per position, concordant count in the low half, discordant in the high half; the
+        // address is formed in byte units modulo 2^32 -- (word << 2) drops the state bit, candidates lie within
+        // W + max_span of the tile, dead words 2^28 bp away and PDR-skipped reads get a base shifted by 2^28 bp --
+        // and clamped with one min to the thread's trash word (3 VALU per slot).  Positions of the tile past
+        // the region end may collect adds that way; the compaction masks them.
+        // Wide: concordant at [0, W/2), discordant at [W/2, W); explicit range test.
+        if (!WIDE) {
+            const uint32_t one = disc ? 0x10000u : 1u;
+            const uint32_t base4 = ((uint32_t)P0 << 2) - (pdr_ok ? 0u : (1u << 30));
+            const uint32_t trash4 = (uint32_t)(W + tid) << 2;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const uint32_t pk = (v[k] & 0x7fffffffu) - (uint32_t)P0;
-                atomicAdd(cnt + ((pk < wt ? pk : trash) + dw), one);
+                const uint32_t a4 = min((v[k] << 2) - base4, trash4);
+                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt) + a4), one);
             }
             if (any_long && pdr_ok) {
                 for (uint32_t k = NB; k < n; ++k) {
                     const uint32_t pk = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)P0;
-                    if (pk < Wp) atomicAdd(cnt + dw + pk, one);
+                    if (pk < Wp) atomicAdd(cnt + pk, one);
+                }
+            }
+        } else {
+            const uint32_t wt = pdr_ok ? Wp : 0u;
+            const uint32_t dw = disc ? (uint32_t)(W / 2) : 0u;
+            const uint32_t trash = (uint32_t)(W + tid) - dw;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const uint32_t pk = (v[k] & 0x7fffffffu) - (uint32_t)P0;
+                atomicAdd(cnt + ((pk < wt ? pk : trash) + dw), 1u);
+            }
+            if (any_long && pdr_ok) {
+                for (uint32_t k = NB; k < n; ++k) {
+                    const uint32_t pk = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)P0;
+                    if (pk < Wp) atomicAdd(cnt + dw + pk, 1u);
                 }
             }
         }
@@ -352,7 +375,7 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
     if (do_lp) tile_lpmd_partials<B>(a, t, red, lp_c, lp_d, n_read, n_valid);
     __syncthreads();
     if (!a.want_pdr) return 0u;
-    return tile_compact<W, B, WIDE>(a, t, P0, cnt, wave_off, out_base);
+    return tile_compact<W, B, WIDE>(a, t, P0, Wp, cnt, wave_off, out_base);
 }
 
 // Tile kernel.  W = reference positions per tile, B = threads per workgroup, NB = CpG calls of a
@@ -390,12 +413,17 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
     const uint32_t hi = min(a.idx[((uint32_t)(T0 + W - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
     uint32_t rows;
     if (hi - lo <= 65535u) {
-        rows = tile_pass<W, B, NB, RelT, false>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
+        // only a tile that holds the batch's last reads can have a read whose NB-slot window runs past the arrays
+        const bool clamp = a.cpg_off[hi] + (uint32_t)NB > a.n_cpgs;   // cpg_off ascends: covers every read of [lo, hi)
+        if (!clamp)
+            rows = tile_pass<W, B, NB, RelT, false, false>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
+        else
+            rows = tile_pass<W, B, NB, RelT, false, true>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
     } else {
         const int32_t Tm = min(T0 + W / 2, T1);
-        rows = tile_pass<W, B, NB, RelT, true>(a, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
+        rows = tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
         __syncthreads();
-        rows += tile_pass<W, B, NB, RelT, true>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off);
+        rows += tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off);
     }
     if (threadIdx.x == 0) a.tile_cnt[t] = rows;
 }
