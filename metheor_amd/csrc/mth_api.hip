@@ -8,7 +8,7 @@
 
 namespace mth {
 
-static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_tile_scan", "k_gather",
+static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_gather",
                                           "k_quartet_bound", "k_quartet_insert", "k_quartet_emit",
                                           "k_mhl_walk", "k_mhl_walk_big", "k_mhl_emit", "k_pdr_walk",
                                           "k_fdrp_walk", "k_fdrp_emit", "k_pairs"};
@@ -167,7 +167,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->st_start, &ctx->st_end, &ctx->st_mapq, &ctx->st_fwd, &ctx->st_off, &ctx->st_pos,
-                      &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_base, &ctx->tile_lpmd, &ctx->scratch,
+                      &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_bucket, &ctx->scratch,
                       &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
                       &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
                       &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_aux, &ctx->w_flags,

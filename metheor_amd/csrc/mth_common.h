@@ -42,6 +42,6 @@ struct SiteRec {  // per-tile scratch row
     uint32_t n_conc, n_disc, pad;
 };
 
-enum KernelId { K_INDEX = 0, K_TILE, K_SCAN, K_GATHER, K_QBOUND, K_QINSERT, K_QEMIT, K_MHLWALK, K_MHLWALKBIG, K_MHLEMIT, K_PDRWALK, K_FDRPWALK, K_FDRPEMIT, K_PAIRS, K_NUM };
+enum KernelId { K_INDEX = 0, K_TILE, K_GATHER, K_QBOUND, K_QINSERT, K_QEMIT, K_MHLWALK, K_MHLWALKBIG, K_MHLEMIT, K_PDRWALK, K_FDRPWALK, K_FDRPEMIT, K_PAIRS, K_NUM };
 
 }  // namespace mth

@@ -41,7 +41,7 @@ struct mth_ctx {
     // staging for MTH_MEM_HOST batches
     mth::DevBuf st_start, st_end, st_mapq, st_fwd, st_off, st_pos, st_rel;
     // per-batch work buffers
-    mth::DevBuf idx, tile_cnt, tile_base, tile_lpmd, scratch, batch_cnt;
+    mth::DevBuf idx, tile_cnt, tile_bucket, scratch, batch_cnt;
     // results (PDR columns)
     mth::DevBuf out_pos, out_pdr, out_nc, out_nd;
     uint64_t out_cap = 0;        // rows

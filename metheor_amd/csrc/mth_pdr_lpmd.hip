@@ -14,8 +14,11 @@
 //                   neighbour tile).  LPMD pair counts are reduced per wave with DPP shuffles and
 //                   stored as per-tile partials (no same-address global atomics).  The tile's
 //                   non-empty sites are compacted with a block scan into a per-tile scratch slice.
-//   k_tile_scan     one workgroup: exclusive scan of per-tile site counts, LPMD partial reduce.
-//   k_gather        packs the scratch slices into the final sorted SoA and computes the f32 PDR.
+//   k_gather        one wave per tile: its output base = rows of the 256-tile buckets before it (summed by the
+//                   tile kernel with one atomic per tile) + rows of its bucket's earlier tiles; packs the scratch
+//                   slice into the final sorted SoA and computes the f32 PDR.  The last tile's wave commits the
+//                   batch totals (rows, LPMD counters) to DevState.  (A separate single-workgroup scan kernel
+//                   used to sit here: 15 us of latency per batch.)
 //
 // Roofline: integer streaming + LDS atomics, HBM-bound by design (no MFMA: there is no
 // contraction here).  Algorithmic bytes: 16 B/read + 5 B/CpG call in, 12 B/site out.
@@ -32,7 +35,8 @@ struct TileArgs {
     const uint32_t *idx;
     const DevState *st;
     uint32_t *tile_cnt;
-    uint32_t *tile_lpmd;   // 4 x u32 per tile
+    unsigned long long *bucket;   // per 256-tile bucket: [nbk] rows, then [nbk][4] LPMD partial sums
+    uint32_t nbk;
     SiteRec  *scratch;     // TILE_W rows per tile
     int32_t region_beg, region_end, idx_base, max_span;
     uint32_t n_reads, n_cpgs;
@@ -50,8 +54,14 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
                                                        uint32_t n_reads, int32_t idx_base,
                                                        uint32_t nq, int aligned16,
                                                        uint32_t *__restrict__ idx,
-                                                       DevState *__restrict__ st) {
-    const uint32_t i0 = (blockIdx.x * BLOCK + threadIdx.x) * 4u;
+                                                       DevState *__restrict__ st, DevState *__restrict__ cst,
+                                                       unsigned long long *__restrict__ bucket_sums, uint32_t n_bucket_words) {
+    // first kernel of a batch: its rows go after everything emitted so far, and the bucket sums start at zero
+    // (nothing else runs between the previous batch's last kernel and this one on the stream)
+    const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
+    if (gtid == 0) cst->cur_base = cst->n_sites;
+    for (uint32_t w = gtid; w < n_bucket_words; w += gridDim.x * BLOCK) bucket_sums[w] = 0ull;
+    const uint32_t i0 = gtid * 4u;
     if (i0 > n_reads) return;
     auto bucket = [&](int32_t s) -> int64_t {  // floor((s-base)/Q), -1 below the base
         const int64_t d = (int64_t)s - idx_base;
@@ -111,7 +121,9 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
-// LPMD per-tile partials: wave DPP reduce -> LDS -> one plain store per tile (no same-address global atomics)
+constexpr int TILE_BUCKET_SHIFT = 8;   // 256 tiles per bucket
+// LPMD per-tile partials: wave DPP reduce -> LDS -> one atomic per counter into the tile's bucket (256 tiles share
+// an address; the per-read counts never touch global memory)
 template <int B>
 __device__ __forceinline__ void tile_lpmd_partials(const TileArgs &a, const uint32_t t, uint32_t (*red)[B / 64],
                                                    uint32_t lp_c, uint32_t lp_d, uint32_t n_read, uint32_t n_valid) {
@@ -122,7 +134,7 @@ __device__ __forceinline__ void tile_lpmd_partials(const TileArgs &a, const uint
     if (tid < 4) {
         uint32_t s = 0;
         for (int w = 0; w < B / 64; ++w) s += red[tid][w];
-        a.tile_lpmd[t * 4 + tid] = s;
+        if (s) atomicAdd(a.bucket + a.nbk + (size_t)(t >> TILE_BUCKET_SHIFT) * 4 + tid, (unsigned long long)s);
     }
 }
 
@@ -425,114 +437,64 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
         __syncthreads();
         rows += tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off);
     }
-    if (threadIdx.x == 0) a.tile_cnt[t] = rows;
+    if (threadIdx.x == 0) {
+        a.tile_cnt[t] = rows;
+        if (rows) atomicAdd(a.bucket + (t >> TILE_BUCKET_SHIFT), (unsigned long long)rows);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// single workgroup: tile_base = exclusive scan(tile_cnt); LPMD partials -> DevState.
-// Chunks of 4096 tiles: each thread takes 4 consecutive tiles with one 16-byte load (tile_cnt is
-// hipMalloc-aligned), one block scan per chunk.  (History: 1024-tile chunks measured 0.0216 ms for
-// 14 312 tiles; a variant where each thread walked its own contiguous segment serially was slower.)
-__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *__restrict__ tile_cnt,
-                                                    const uint32_t *__restrict__ tile_lpmd,
-                                                    uint32_t ntiles, uint32_t *__restrict__ tile_base,
-                                                    uint32_t *__restrict__ batch_cnt, int want_lpmd,
-                                                    DevState *__restrict__ st) {
-    __shared__ uint32_t wsum[16 + 1];
-    __shared__ unsigned long long lsum[4][16];
-    __shared__ uint32_t running_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) running_s = 0;
-    unsigned long long acc[4] = {0, 0, 0, 0};
-    __syncthreads();
-    for (uint32_t b = 0; b < ntiles; b += 4096) {
-        const uint32_t i = b + 4u * tid;
-        uint32_t v[4] = {0, 0, 0, 0};
-        if (i + 4 <= ntiles) {
-            const uint4 x = *reinterpret_cast<const uint4 *>(tile_cnt + i);
-            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (i + k < ntiles) ? tile_cnt[i + k] : 0u;
+// One wave per tile.  base = cur_base + rows of the buckets before the tile's bucket + rows of the bucket's
+// earlier tiles (a few coalesced loads per lane, two wave reductions); then scratch -> final sorted SoA with
+// the reference's f32 PDR (pdr.rs:47-49).  The wave of the batch's last tile also commits the batch to
+// DevState: n_sites, the batch's row count, and the LPMD counters summed over the buckets.  Nobody in this
+// launch reads what it writes (cur_base is set by the next batch's k_build_index).
+// fin_only (LPMD-only passes): a single wave that only commits.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gather(const SiteRec *__restrict__ scratch,
+                                               const uint32_t *__restrict__ tile_cnt,
+                                               const unsigned long long *__restrict__ bucket, uint32_t nbk,
+                                               uint32_t ntiles, int fin_only, int want_lpmd,
+                                               DevState *__restrict__ st, uint32_t *__restrict__ batch_cnt,
+                                               uint32_t tile_w,
+                                               int32_t *__restrict__ out_pos, float *__restrict__ out_pdr,
+                                               uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
+    const uint32_t t = fin_only ? ntiles - 1 : blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t bk = t >> TILE_BUCKET_SHIFT;
+    uint32_t part = 0;                                  // rows of one batch fit 32 bits (<= region positions)
+    for (uint32_t b = lane; b < bk; b += 64) part += (uint32_t)bucket[b];
+    for (uint32_t u = (bk << TILE_BUCKET_SHIFT) + lane; u < t; u += 64) part += tile_cnt[u];
+    const uint32_t before = wave_sum(part);
+    const uint32_t n = tile_cnt[t];
+    const uint64_t cur = st->cur_base;
+    const uint64_t base = cur + before;
+    if (!fin_only) {
+        const SiteRec *__restrict__ src = scratch + (size_t)t * tile_w;
+        for (uint32_t j = lane; j < n; j += 64) {
+            const SiteRec r = src[j];
+            out_pos[base + j] = r.pos;
+            out_nc[base + j] = r.n_conc;
+            out_nd[base + j] = r.n_disc;
+            out_pdr[base + j] = (float)r.n_disc / ((float)r.n_conc + (float)r.n_disc);
         }
-        if (want_lpmd) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (i + k < ntiles) {
-                    const uint4 l = reinterpret_cast<const uint4 *>(tile_lpmd)[i + k];
-                    acc[0] += l.x; acc[1] += l.y; acc[2] += l.z; acc[3] += l.w;
-                }
-            }
-        }
-        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        if (lane == 63) wsum[wave + 1] = incl;
-        __syncthreads();
-        if (tid == 0) {
-            wsum[0] = running_s;
-            for (int w = 1; w <= 16; ++w) wsum[w] += wsum[w - 1];
-        }
-        __syncthreads();
-        uint32_t run = wsum[wave] + incl - mine;
-        if (i + 4 <= ntiles) {
-            uint4 o;
-            o.x = run; o.y = run + v[0]; o.z = o.y + v[1]; o.w = o.z + v[2];
-            *reinterpret_cast<uint4 *>(tile_base + i) = o;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { if (i + k < ntiles) tile_base[i + k] = run; run += v[k]; }
-        }
-        __syncthreads();
-        if (tid == 0) running_s = wsum[16];
-        __syncthreads();
+    }
+    if (t != ntiles - 1) return;
+    const uint32_t total = before + n;
+    if (lane == 0) {
+        st->n_sites = cur + total;
+        batch_cnt[st->n_batches] = total;
+        st->n_batches += 1;
     }
     if (want_lpmd) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            unsigned long long x = acc[k];
+            unsigned long long x = 0;
+            for (uint32_t b = lane; b < nbk; b += 64) x += bucket[nbk + (size_t)b * 4 + k];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-            if (lane == 0) lsum[k][wave] = x;
+            if (lane == 0) st->lpmd[k] += (long long)x;
         }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t total = running_s;
-        st->cur_base = st->n_sites;
-        st->n_sites += total;
-        batch_cnt[st->n_batches] = total;
-        st->n_batches += 1;
-    }
-    if (want_lpmd && tid < 4) {
-        unsigned long long s = 0;
-        for (int w = 0; w < 16; ++w) s += lsum[tid][w];
-        st->lpmd[tid] += (long long)s;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// pack per-tile scratch slices into the final SoA; pdr.rs:47-49 f32 expression
-__global__ __launch_bounds__(64) void k_gather(const SiteRec *__restrict__ scratch,
-                                               const uint32_t *__restrict__ tile_cnt,
-                                               const uint32_t *__restrict__ tile_base,
-                                               const DevState *__restrict__ st, uint32_t tile_w,
-                                               int32_t *__restrict__ out_pos, float *__restrict__ out_pdr,
-                                               uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
-    const uint32_t t = blockIdx.x;
-    const uint32_t n = tile_cnt[t];
-    const uint64_t base = st->cur_base + tile_base[t];
-    const SiteRec *__restrict__ src = scratch + (size_t)t * tile_w;
-    for (uint32_t j = threadIdx.x; j < n; j += 64) {
-        const SiteRec r = src[j];
-        out_pos[base + j] = r.pos;
-        out_nc[base + j] = r.n_conc;
-        out_nd[base + j] = r.n_disc;
-        out_pdr[base + j] = (float)r.n_disc / ((float)r.n_conc + (float)r.n_disc);
     }
 }
 
@@ -564,8 +526,8 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
 
     MTH_HIP(ctx, ctx->idx.reserve((size_t)(nq + 1) * 4, s));
     MTH_HIP(ctx, ctx->tile_cnt.reserve((size_t)ntiles * 4, s));
-    MTH_HIP(ctx, ctx->tile_base.reserve((size_t)ntiles * 4, s));
-    MTH_HIP(ctx, ctx->tile_lpmd.reserve((size_t)ntiles * 16, s));
+    const uint32_t nbk = (ntiles + (1u << TILE_BUCKET_SHIFT) - 1) >> TILE_BUCKET_SHIFT;
+    MTH_HIP(ctx, ctx->tile_bucket.reserve((size_t)nbk * 5 * sizeof(unsigned long long), s));
     if (p.want_pdr) MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * tile_w * sizeof(SiteRec), s));
 
     {
@@ -573,13 +535,13 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
         const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK - 1) / BLOCK;
         hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start,
                            b.n_reads, idx_base, nq, (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0),
-                           ctx->idx.as<uint32_t>(), ctx->d_state);
+                           ctx->idx.as<uint32_t>(), ctx->d_state, cst, ctx->tile_bucket.as<unsigned long long>(), nbk * 5u);
     }
     TileArgs a;
     a.read_start = b.read_start; a.read_mapq = b.read_mapq; a.cpg_off = b.cpg_off; a.cpg_pos = b.cpg_pos;
     a.cpg_rel = b.cpg_rel ? (const void *)b.cpg_rel : (const void *)b.cpg_rel16;
     a.idx = ctx->idx.as<uint32_t>(); a.st = ctx->d_state;
-    a.tile_cnt = ctx->tile_cnt.as<uint32_t>(); a.tile_lpmd = ctx->tile_lpmd.as<uint32_t>();
+    a.tile_cnt = ctx->tile_cnt.as<uint32_t>(); a.bucket = ctx->tile_bucket.as<unsigned long long>(); a.nbk = nbk;
     a.scratch = ctx->scratch.as<SiteRec>();
     a.region_beg = b.region_beg; a.region_end = b.region_end; a.idx_base = idx_base; a.max_span = b.max_span;
     a.n_reads = b.n_reads; a.n_cpgs = b.n_cpgs;
@@ -594,16 +556,10 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
         if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
     }
     {
-        LaunchTimer lt(ctx, K_SCAN);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, ctx->tile_cnt.as<uint32_t>(),
-                           ctx->tile_lpmd.as<uint32_t>(), ntiles, ctx->tile_base.as<uint32_t>(),
-                           bcnt, (int)p.want_lpmd, cst);
-    }
-    if (p.want_pdr) {
         LaunchTimer lt(ctx, K_GATHER);
-        hipLaunchKernelGGL(k_gather, dim3(ntiles), dim3(64), 0, s, ctx->scratch.as<SiteRec>(),
-                           ctx->tile_cnt.as<uint32_t>(), ctx->tile_base.as<uint32_t>(), cst,
-                           (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
+        hipLaunchKernelGGL(k_gather, dim3(p.want_pdr ? ntiles : 1u), dim3(64), 0, s, ctx->scratch.as<SiteRec>(),
+                           ctx->tile_cnt.as<uint32_t>(), ctx->tile_bucket.as<unsigned long long>(), nbk, ntiles,
+                           p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, bcnt, (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
     }
     MTH_HIP(ctx, hipGetLastError());
     return MTH_OK;
