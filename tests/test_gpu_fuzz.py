@@ -1,0 +1,114 @@
+"""GPU parity, randomised: many small seeded scenarios, every measure against the CPU oracle through the C ABI.
+
+The hand-built and fixture tests pin known semantics; this one looks for what nobody thought of.  Generators lean
+on the edges the kernels special-case: reads without CpGs, duplicate starts, low mapq, both strands (a reverse
+read's first call at start-1), calls dropped at random (a read that covers a site without calling it: flushes
+and re-opened sites), dense CpGs (more calls than registers), long reads (spans > 150 / > 200 bp), shallow and
+deep piles (reservoir sampling), random parameters, whole contigs and region slices.  Same bars as the
+per-measure tests (their check functions are reused): integers bit-exact, floats bit-exact or within 1e-6."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tests import test_gpu_fdrp as T_fdrp
+from tests import test_gpu_mhl as T_mhl
+from tests import test_gpu_pairs as T_pairs
+from tests import test_gpu_pdr_lpmd as T_pdr
+from tests import test_gpu_quartet as T_quartet
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import metheor_amd
+    e = metheor_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def drop_calls(c, rng, frac):
+    """remove a random subset of the CpG calls (mismatch / non-CpG context in the XM string)"""
+    if frac <= 0 or len(c["cpg_pos"]) == 0:
+        return c
+    keep = rng.random(len(c["cpg_pos"])) >= frac
+    cnt = np.diff(c["cpg_off"].astype(np.int64))
+    read_of = np.repeat(np.arange(len(cnt)), cnt)
+    new_cnt = np.bincount(read_of[keep], minlength=len(cnt))
+    off = np.zeros(len(cnt) + 1, np.int64)
+    np.cumsum(new_cnt, out=off[1:])
+    d = dict(c)
+    d["cpg_off"] = off.astype(np.uint32)
+    d["cpg_pos"] = c["cpg_pos"][keep]
+    d["cpg_rel"] = c["cpg_rel"][keep]
+    return d
+
+
+def scenario(seed):
+    from metheor_amd import synth
+    rng = np.random.default_rng(10_000 + seed)
+    n_contigs = int(rng.integers(1, 3))
+    read_len = int(rng.choice([36, 75, 100, 150, 150, 150, 200, 250]))
+    density = float(rng.choice([0.004, 0.02, 0.02, 0.05, 0.12, 0.3]))
+    cs = []
+    for tid in range(n_contigs):
+        length = int(rng.integers(2_000, 40_000))
+        n_reads = int(rng.integers(20, 4_000))
+        starts = None
+        mode = int(rng.integers(0, 4))
+        hi = max(length - read_len, 1)
+        if mode == 1:      # piles: a few start positions, many duplicates
+            spots = rng.integers(0, hi, size=int(rng.integers(1, 12)))
+            starts = np.sort(rng.choice(spots, size=n_reads) + rng.integers(0, 3, size=n_reads)).astype(np.int32)
+        elif mode == 2:    # one deep window inside a shallow background
+            w0 = int(rng.integers(0, hi))
+            starts = np.sort(np.concatenate([rng.integers(0, hi, size=n_reads // 3),
+                                             rng.integers(w0, min(w0 + 300, hi) + 1, size=n_reads - n_reads // 3)])).astype(np.int32)
+        c = synth.make_contig(tid, length, n_reads, density, rng, read_len=read_len,
+                              low_mapq_frac=float(rng.choice([0.0, 0.05, 0.4])), starts=starts)
+        cs.append(drop_calls(c, rng, float(rng.choice([0.0, 0.0, 0.1, 0.4]))))
+    regions = None
+    if rng.random() < 0.4:
+        from metheor_amd import shard
+        regions = [shard.plan_regions(c, int(rng.integers(2, 5))) for c in cs]
+    return rng, cs, regions, read_len
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_scenario_all_measures(eng, seed):
+    from metheor_amd import PdrLpmdParams, synth
+    rng, cs, regions, read_len = scenario(seed)
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    mq = int(rng.choice([0, 10, 10, 43]))
+
+    # PDR + LPMD (fused tile kernel for spans <= 150, exact site walk for the PDR half beyond)
+    pk = dict(min_depth=int(rng.choice([0, 1, 3, 10])), min_cpgs=int(rng.choice([0, 1, 2, 4, 9])), min_qual=mq)
+    lk = dict(min_distance=int(rng.choice([0, 1, 2, 5])), max_distance=int(rng.choice([1, 4, 16, 60, 300])), min_qual=mq)
+    p = PdrLpmdParams(min_distance=lk["min_distance"], max_distance=lk["max_distance"], lpmd_min_qual=mq, **pk)
+    d, l = T_pdr.run_device(eng, cs, p, regions=regions, rel16=bool(rng.integers(0, 2)))
+    T_pdr.check_against_oracle(d, l, reads, pk, lk)
+
+    # LPMD per-pair table
+    T_pairs.check(T_pairs.run_device(eng, cs, lk, regions=regions), reads, lk)
+
+    # ME / PM
+    qd = int(rng.choice([0, 2, 10]))
+    T_quartet.check(T_quartet.run_device(eng, cs, mq, qd, regions=regions), reads, mq, qd)
+
+    # MHL
+    mk = dict(min_depth=int(rng.choice([0, 1, 5, 10])), min_cpgs=int(rng.choice([1, 2, 4])), min_qual=mq)
+    T_mhl.check(T_mhl.run_device(eng, cs, mk, regions=regions), reads, mk)
+
+    # FDRP / qFDRP (a reverse read spanning >= 202 bp can index -1 in the reference and panics there: forward only then)
+    fcs, freads = cs, reads
+    if read_len > 200:
+        from tests import util
+        fcs = [util.subset_reads(c, c["read_fwd"] == 1) for c in cs]
+        freads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(fcs))
+    fk = dict(min_qual=mq, min_depth=int(rng.choice([0, 2, 10])), max_depth=int(rng.choice([2, 8, 40, 64])),
+              min_overlap=int(rng.choice([0, 1, 35, 120])), seed=int(rng.integers(0, 1 << 30)))
+    fregions = regions
+    if regions is not None and fcs is not cs:
+        from metheor_amd import shard
+        fregions = [[(b, e) for (b, e) in r] for r in regions]
+    T_fdrp.check(T_fdrp.run_device(eng, fcs, fk, regions=fregions), freads, fk)
