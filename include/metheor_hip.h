@@ -49,7 +49,8 @@ enum {
     MTH_ERR_REOPEN = -6,    /* reserved (was: flush re-open semantics not implemented; they are now) */
     MTH_ERR_RANGE = -7,     /* a CpG of an owned site lies outside what the batch declared */
     MTH_ERR_CAPACITY = -8,  /* an on-chip capacity was exceeded */
-    MTH_ERR_STATE = -9      /* call order violated */
+    MTH_ERR_STATE = -9,     /* call order violated */
+    MTH_ERR_FORMAT = -10    /* device record decode: malformed BAM record, or a record without XM:Z */
 };
 
 enum { MTH_MEM_HOST = 0, MTH_MEM_DEVICE = 1 };
@@ -194,6 +195,36 @@ int  mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdr
  * the segment the values come from; *n_rows always set, arrays may be NULL */
 int  mth_fdrp_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos, float *fdrp, float *qfdrp,
                     uint32_t *n_reads);
+
+/* ---- BAM record + XM decode on the device (the step before the hot path) ----------
+ * Replaces, per record, BismarkRead::new (readutil.rs:24-53: start/end = first/last aligned reference
+ * position) and get_cpgs (readutil.rs:323-345: XM z/Z at aligned query offsets, abspos for flags in
+ * {0,99,147} else abspos-1; insertions / soft clips skipped), i.e. what bamutil.rs:4-11's record
+ * iterator feeds every measure.  Input is the INFLATED BAM record stream (BGZF-decompressed bytes after
+ * the header) and the byte offset of each record (rec_off[i] points at record i's block_size field,
+ * rec_off[n_rec] = end of the last record); the walk over block_size fields stays on the host.  `mem`
+ * says where raw and rec_off live; append != 0 adds the records after those of the previous calls (a file
+ * streamed window by window), append == 0 starts over.  The decoded SoA stays in HBM, owned by the context:
+ * the arrays of mth_batch_t for ALL records so far, in file order (64-bit offsets, 16-bit relpos).  A record without XM:Z or a malformed record -> MTH_ERR_FORMAT (the reference panics,
+ * readutil.rs:46).  Not applied here: the --cpg-set filter (readutil.rs:87-95). */
+typedef struct {
+    uint64_t n_reads, n_cpgs;
+    const int32_t  *tid, *start, *end;   /* device pointers */
+    const uint8_t  *mapq, *fwd;
+    const uint64_t *cpg_off;             /* n_reads + 1 */
+    const uint32_t *cpg_pos;             /* abspos | methylated << 31 */
+    const uint16_t *cpg_rel;
+} mth_decoded_t;
+int  mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const uint64_t *rec_off, uint64_t n_rec,
+                        int mem, int append, mth_decoded_t *out);
+/* copy the decoded arrays to the host (any pointer may be NULL) */
+int  mth_decoded_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *start, int32_t *end, uint8_t *mapq, uint8_t *fwd,
+                       uint64_t *cpg_off, uint32_t *cpg_pos, uint16_t *cpg_rel);
+/* reads [read_beg, read_end) of the decoded stream -- ONE contig's reads (or a region slice of them) -- as a
+ * device-resident batch for the accumulate calls: 32-bit offsets rebased on the device, max_span reduced on
+ * the device.  Valid until the next mth_decoded_batch / mth_decode_records call. */
+int  mth_decoded_batch(mth_ctx_t *ctx, uint64_t read_beg, uint64_t read_end, int32_t tid, int32_t region_beg,
+                       int32_t region_end, mth_batch_t *batch);
 
 /* ---- measurement hooks (bench.py's roofline leg) -------------------------------------- */
 /* when enabled, every kernel launch is bracketed by hipEvents on the launch stream */

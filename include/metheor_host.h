@@ -32,7 +32,8 @@ enum {
     MTH_HOST_ERR_FORMAT = -102,   /* truncated or corrupt BAM */
     MTH_HOST_ERR_XM = -103,       /* a record has no XM:Z tag */
     MTH_HOST_ERR_CPGSET = -104,   /* --cpg-set file unreadable / unknown contig / bad number */
-    MTH_HOST_ERR_INVALID = -105
+    MTH_HOST_ERR_INVALID = -105,
+    MTH_HOST_ERR_CONSUMER = -106  /* the window consumer of mth_host_decode_stream returned non-zero */
 };
 
 /* open a BAM file and read its header */
@@ -47,6 +48,14 @@ int  mth_host_ref_tid(const mth_host_t *h, const char *name);   /* -1 if unknown
 /* Decode ALL remaining records of the file into one SoA held by the handle, in file order.
  * cpg_set_path may be NULL.  After success the arrays below are valid until close/decode. */
 int  mth_host_decode(mth_host_t *h, const char *cpg_set_path);
+/* Streaming alternative to mth_host_decode for a device-side record decode (mth_decode_records in metheor_hip.h):
+ * BGZF inflate (host threads) and the sequential walk over the records' block_size fields (bamutil.rs:4-11's
+ * record iterator), but NO record / XM parsing on the host.  The consumer is called once per inflated window
+ * (<= METHEOR_DECODE_WINDOW_MB, default 512 MiB) with the window's bytes and the byte offset of each complete
+ * record in it (rec_off[n_rec] = end of the last record; a record straddling two windows is carried into the
+ * next one).  buf / rec_off are only valid during the call.  A non-zero return aborts. */
+typedef int (*mth_host_window_cb)(void *user, const uint8_t *buf, const uint64_t *rec_off, uint64_t n_rec);
+int  mth_host_decode_stream(mth_host_t *h, mth_host_window_cb cb, void *user);
 int64_t mth_host_n_reads(const mth_host_t *h);
 int64_t mth_host_n_cpgs(const mth_host_t *h);
 const int32_t  *mth_host_read_tid(const mth_host_t *h);

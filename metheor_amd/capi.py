@@ -15,6 +15,7 @@ SYMBOLS = [
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
+    "mth_decode_records", "mth_decoded_fetch", "mth_decoded_batch",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -33,6 +34,12 @@ class mth_batch_t(C.Structure):
                 ("read_start", C.c_void_p), ("read_end", C.c_void_p), ("read_mapq", C.c_void_p),
                 ("read_fwd", C.c_void_p), ("cpg_off", C.c_void_p), ("cpg_pos", C.c_void_p),
                 ("cpg_rel", C.c_void_p), ("cpg_rel16", C.c_void_p)]
+
+
+class mth_decoded_t(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_cpgs", C.c_uint64), ("tid", C.c_void_p), ("start", C.c_void_p),
+                ("end", C.c_void_p), ("mapq", C.c_void_p), ("fwd", C.c_void_p), ("cpg_off", C.c_void_p),
+                ("cpg_pos", C.c_void_p), ("cpg_rel", C.c_void_p)]
 
 
 class mth_pdr_lpmd_params_t(C.Structure):
@@ -105,6 +112,9 @@ def lib():
         L.mth_fdrp_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 5
         L.mth_lpmd_pairs_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_lpmd_pairs_params_t)]
         L.mth_lpmd_pairs_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 6
+        L.mth_decode_records.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(mth_decoded_t)]
+        L.mth_decoded_fetch.argtypes = [vp] * 9
+        L.mth_decoded_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(mth_batch_t)]
         L.mth_timing_enable.argtypes = [vp, C.c_int]
         L.mth_timing_reset.argtypes = [vp]
         L.mth_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -125,6 +135,13 @@ class PdrLpmdParams:
 
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
+
+
+class DeviceBatch:
+    """an mth_batch_t filled in by the library (device pointers it owns)"""
+
+    def __init__(self):
+        self.c = mth_batch_t()
 
 
 class Batch:
@@ -298,6 +315,41 @@ class Engine:
         self._check(self.L.mth_lpmd_pairs_fetch(self.h, C.byref(n), *[out[x].ctypes.data_as(C.c_void_p) for x in
                                                                       ("tid", "pos1", "pos2", "lpmd", "n_concordant", "n_discordant")]))
         return out
+
+    # ---- device-side BAM record decode (mth_decode.hip) ----
+    def decode_records(self, raw, rec_off, append=False):
+        """raw: the inflated BAM record stream (numpy uint8 / bytes, or a torch CUDA uint8 tensor); rec_off: uint64
+        byte offsets of the records (n + 1).  The decoded SoA stays on the device; returns (n_reads, n_cpgs)."""
+        dev = _is_torch(raw)
+        if dev:
+            assert raw.is_cuda and raw.is_contiguous() and rec_off.is_cuda and rec_off.is_contiguous()
+            self._dec_keep = (raw, rec_off)
+            rp, op, nb, nr = raw.data_ptr(), rec_off.data_ptr(), raw.numel(), rec_off.numel() - 1
+        else:
+            raw = np.frombuffer(raw, np.uint8) if isinstance(raw, (bytes, bytearray, memoryview)) else np.ascontiguousarray(raw, np.uint8)
+            rec_off = np.ascontiguousarray(rec_off, np.uint64)
+            self._dec_keep = (raw, rec_off)
+            rp, op, nb, nr = raw.ctypes.data, rec_off.ctypes.data, raw.size, rec_off.size - 1
+        d = mth_decoded_t()
+        self._check(self.L.mth_decode_records(self.h, rp, nb, op, max(nr, 0), 1 if dev else 0, int(bool(append)), C.byref(d)))
+        self._decoded = d
+        return int(d.n_reads), int(d.n_cpgs)
+
+    def decoded_fetch(self):
+        d = self._decoded
+        nr, nc = int(d.n_reads), int(d.n_cpgs)
+        out = dict(tid=np.zeros(nr, np.int32), start=np.zeros(nr, np.int32), end=np.zeros(nr, np.int32),
+                   mapq=np.zeros(nr, np.uint8), fwd=np.zeros(nr, np.uint8), cpg_off=np.zeros(nr + 1, np.uint64),
+                   cpg_pos=np.zeros(nc, np.uint32), cpg_rel=np.zeros(nc, np.uint16))
+        self._check(self.L.mth_decoded_fetch(self.h, *[out[k].ctypes.data_as(C.c_void_p) for k in
+                                                       ("tid", "start", "end", "mapq", "fwd", "cpg_off", "cpg_pos", "cpg_rel")]))
+        return out
+
+    def decoded_batch(self, read_beg, read_end, tid, region_beg, region_end):
+        """device-resident batch over reads [read_beg, read_end) of the decoded stream (one contig)"""
+        b = DeviceBatch()
+        self._check(self.L.mth_decoded_batch(self.h, int(read_beg), int(read_end), int(tid), int(region_beg), int(region_end), C.byref(b.c)))
+        return b
 
     def timing_enable(self, on=True):
         self._check(self.L.mth_timing_enable(self.h, int(on)))

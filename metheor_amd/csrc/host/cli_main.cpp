@@ -210,6 +210,7 @@ struct Contig {
     size_t n_reads, n_cpgs;
     std::vector<uint32_t> off;
     int32_t max_span = 0;
+    uint64_t r0 = 0, r1 = 0;   // device-decoded input: the contig's reads in the decoded stream
     // owned copies (only when filtering was needed)
     std::vector<int32_t> o_start, o_end;
     std::vector<uint8_t> o_mapq;
@@ -220,6 +221,8 @@ struct Contig {
 struct Input {
     mth_host_t *h = nullptr;
     std::vector<Contig> contigs;
+    mth_ctx_t *ctx = nullptr;   // set when the records were decoded on the device (the batches live in its HBM)
+    bool device = false;
 };
 
 // METHEOR_TIMING=1: phase wall times on stderr (never stdout)
@@ -234,11 +237,84 @@ struct Phase {
     }
 };
 
+void check(mth_ctx_t *ctx, int rc) {
+    if (rc == MTH_OK) return;
+    std::string m = std::string("metheor (MI355X path): ") + mth_strerror(rc);
+    if (ctx && mth_last_error(ctx)[0]) m += std::string(" -- ") + mth_last_error(ctx);
+    die(m);
+}
+
+mth_ctx_t *make_ctx() {
+    Phase ph("device context");
+    mth_ctx_t *ctx = nullptr;
+    const char *dev = getenv("METHEOR_DEVICE");
+    const int rc = mth_ctx_create(dev ? atoi(dev) : 0, &ctx);
+    if (rc != MTH_OK) die(std::string("metheor (MI355X path): ") + mth_strerror(rc));
+    return ctx;
+}
+
+// Device-side record decode (mth_decode_records): the host inflates BGZF and walks the record boundaries, every
+// window goes to the GPU as raw bytes, and the SoA the measures read is built in HBM -- no record / XM parsing and
+// no SoA assembly on host threads.  Not used with --cpg-set (the filter is not on the device yet), with
+// METHEOR_HOST_DECODE=1, or when the file has records the batches cannot hold as they are (no contig, no aligned
+// base, contigs not grouped): those fall back to the host decoder below.
+struct StreamState { mth_ctx_t *ctx = nullptr; bool first = true; int rc = MTH_OK; };
+int window_to_device(void *user, const uint8_t *buf, const uint64_t *rec_off, uint64_t n_rec) {
+    StreamState *st = static_cast<StreamState *>(user);
+    mth_decoded_t d;
+    st->rc = mth_decode_records(st->ctx, buf, rec_off[n_rec], rec_off, n_rec, MTH_MEM_HOST, st->first ? 0 : 1, &d);
+    st->first = false;
+    return st->rc == MTH_OK ? 0 : 1;
+}
+
+bool load_on_device(Input &in) {
+    in.ctx = make_ctx();
+    StreamState st;
+    st.ctx = in.ctx;
+    {
+        Phase ph("  inflate + device record decode");
+        const int rc = mth_host_decode_stream(in.h, window_to_device, &st);
+        if (st.rc == MTH_ERR_FORMAT) {
+            const std::string m = mth_last_error(in.ctx);
+            if (m.find("XM") != std::string::npos) die("Error reading XM tag in BAM record. Make sure the reads are aligned using Bismark!");   // readutil.rs:46
+            die("Error reading BAM record. corrupt BAM record");
+        }
+        if (st.rc != MTH_OK) check(in.ctx, st.rc);
+        if (rc != 0) die(mth_host_last_error(in.h));
+        if (st.first) {   // no record at all: an empty decode
+            mth_decoded_t d;
+            check(in.ctx, mth_decode_records(in.ctx, nullptr, 0, nullptr, 0, MTH_MEM_HOST, 0, &d));
+        }
+    }
+    Phase ph2("  contig ranges");
+    mth_decoded_t d;
+    check(in.ctx, mth_decode_records(in.ctx, nullptr, 0, nullptr, 0, MTH_MEM_HOST, 1, &d));   // no new records: the current view
+    const uint64_t n = d.n_reads;
+    std::vector<int32_t> tid(n), st0(n);
+    check(in.ctx, mth_decoded_fetch(in.ctx, tid.data(), st0.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+    for (uint64_t i = 0; i < n;) {
+        uint64_t e = i;
+        while (e < n && tid[e] == tid[i]) { if (st0[e] < 0) return false; ++e; }
+        if (tid[i] < 0) return false;
+        for (const Contig &c : in.contigs) if (c.tid == tid[i]) return false;   // the host path reports it
+        in.contigs.emplace_back();
+        Contig &c = in.contigs.back();
+        c.tid = tid[i]; c.r0 = i; c.r1 = e; c.n_reads = (size_t)(e - i); c.n_cpgs = 0;
+        i = e;
+    }
+    in.device = true;
+    return true;
+}
+
 Input load(const std::string &path, const char *cpg_set) {
     Phase ph_all("load: open+decode+batch");
     Input in;
     char err[1024];
     if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) die(err);    // bamutil.rs:7-9
+    if (!cpg_set && !getenv("METHEOR_HOST_DECODE")) {
+        if (load_on_device(in)) return in;
+        in.contigs.clear();
+    }
     {
         Phase ph("  host decode (BGZF+BAM+XM)");
         if (mth_host_decode(in.h, cpg_set) != 0) die(mth_host_last_error(in.h));
@@ -285,25 +361,14 @@ Input load(const std::string &path, const char *cpg_set) {
     return in;
 }
 
-void check(mth_ctx_t *ctx, int rc) {
-    if (rc == MTH_OK) return;
-    std::string m = std::string("metheor (MI355X path): ") + mth_strerror(rc);
-    if (ctx && mth_last_error(ctx)[0]) m += std::string(" -- ") + mth_last_error(ctx);
-    die(m);
-}
-
-mth_ctx_t *make_ctx() {
-    Phase ph("device context");
-    mth_ctx_t *ctx = nullptr;
-    const char *dev = getenv("METHEOR_DEVICE");
-    const int rc = mth_ctx_create(dev ? atoi(dev) : 0, &ctx);
-    if (rc != MTH_OK) die(std::string("metheor (MI355X path): ") + mth_strerror(rc));
-    return ctx;
-}
-
 mth_batch_t make_batch(const Input &in, const Contig &c) {
     mth_batch_t b;
     memset(&b, 0, sizeof b);
+    if (in.device) {
+        const int64_t len = mth_host_ref_len(in.h, c.tid);
+        check(in.ctx, mth_decoded_batch(in.ctx, c.r0, c.r1, c.tid, 0, (int32_t)std::min<int64_t>(len, INT32_MAX), &b));
+        return b;
+    }
     b.tid = c.tid;
     b.region_beg = 0;
     const int64_t len = mth_host_ref_len(in.h, c.tid);
@@ -353,7 +418,7 @@ FILE *open_output(const std::string &path) {
 
 int run_pdr(const Args &a) {
     Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
-    mth_ctx_t *ctx = make_ctx();
+    mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_pdr_lpmd_params_t p;
     memset(&p, 0, sizeof p);
     p.pdr_min_depth = (uint32_t)a.n.at("min-depth");
@@ -390,7 +455,7 @@ int run_lpmd(const Args &a) {
     // lpmd.rs:161-164
     fprintf(stderr, "Computing subset-LPMD with parameters input=%s, min_distance=%d, max_distance=%d\n", input.c_str(), mind, maxd);
     Input in = load(input, a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
-    mth_ctx_t *ctx = make_ctx();
+    mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_pdr_lpmd_params_t p;
     memset(&p, 0, sizeof p);
     p.lpmd_min_qual = (uint8_t)a.n.at("min-qual");
@@ -438,7 +503,7 @@ int run_lpmd(const Args &a) {
 // chrom, pos1..pos4, value (me.rs:57-65).  The reference iterates a HashMap (random order).
 int run_quartet(const Args &a, bool want_me) {
     Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
-    mth_ctx_t *ctx = make_ctx();
+    mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_quartet_params_t p;
     p.min_qual = (uint8_t)a.n.at("min-qual");
     for (const Contig &c : in.contigs) {
@@ -469,7 +534,7 @@ int run_quartet(const Args &a, bool want_me) {
 // mhl.rs:101-133: chrom, pos, pos+2, mhl -- sorted by (tid,pos)
 int run_mhl(const Args &a) {
     Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
-    mth_ctx_t *ctx = make_ctx();
+    mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_mhl_params_t p;
     p.min_depth = (uint32_t)a.n.at("min-depth");
     p.min_cpgs = (uint32_t)std::min<int64_t>(a.n.at("min-cpgs"), UINT32_MAX);
@@ -498,7 +563,7 @@ int run_mhl(const Args &a) {
 // fdrp.rs:148-174 / qfdrp.rs:160-186: chrom, pos, pos+2, value -- sorted by (tid,pos)
 int run_fdrp(const Args &a, bool quantitative) {
     Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
-    mth_ctx_t *ctx = make_ctx();
+    mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_fdrp_params_t p;
     memset(&p, 0, sizeof p);
     p.min_qual = (uint8_t)a.n.at("min-qual");

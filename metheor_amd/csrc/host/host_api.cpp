@@ -120,6 +120,30 @@ int mth_host_decode(mth_host_t *h, const char *cpg_set_path) {
     return MTH_HOST_OK;
 }
 
+int mth_host_decode_stream(mth_host_t *h, mth_host_window_cb cb, void *user) {
+    if (!h || !cb) return MTH_HOST_ERR_INVALID;
+    h->tid.clear(); h->start.clear(); h->end.clear(); h->mapq.clear(); h->fwd.clear();
+    h->cpg_off.assign(1, 0); h->cpg_pos.clear(); h->cpg_rel.clear();
+    int nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) nthreads = 1;
+    if (nthreads > 128) nthreads = 128;
+    if (const char *e = getenv("METHEOR_THREADS")) { const int k = atoi(e); if (k >= 1 && k <= 1024) nthreads = k; }
+    int cb_rc = 0;
+    const WindowSink sink = [&](const uint8_t *buf, const uint64_t *rec_off, size_t n_rec, std::string &e) {
+        cb_rc = cb(user, buf, rec_off, (uint64_t)n_rec);
+        if (cb_rc != 0) { e = "window consumer failed"; return false; }
+        return true;
+    };
+    std::string err;
+    int kind = 0;
+    if (!parallel_decode(h->path, h->header_bytes, nullptr, nthreads, *h, err, kind, &sink)) {
+        if (cb_rc != 0) { h->last_error = "window consumer returned an error"; return MTH_HOST_ERR_CONSUMER; }
+        h->last_error = "Error reading BAM record. " + err;
+        return MTH_HOST_ERR_FORMAT;
+    }
+    return MTH_HOST_OK;
+}
+
 int64_t mth_host_n_reads(const mth_host_t *h) { return (int64_t)h->tid.size(); }
 int64_t mth_host_n_cpgs(const mth_host_t *h) { return (int64_t)h->cpg_pos.size(); }
 const int32_t *mth_host_read_tid(const mth_host_t *h) { return h->tid.data(); }

@@ -185,7 +185,7 @@ struct Stopwatch {   // METHEOR_TIMING=1: decoder phase totals on stderr
 }  // namespace
 
 bool parallel_decode(const std::string &path, size_t header_bytes, const std::unordered_set<uint64_t> *target,
-                     int nthreads, DecodedSoA &out, std::string &err, int &err_kind) {
+                     int nthreads, DecodedSoA &out, std::string &err, int &err_kind, const WindowSink *sink) {
     err_kind = 0;
     Stopwatch sw;
     const int fd = open(path.c_str(), O_RDONLY);
@@ -227,10 +227,11 @@ bool parallel_decode(const std::string &path, size_t header_bytes, const std::un
     nthreads = std::max(1, nthreads);
     Pool pool(nthreads);
     std::vector<Piece> pieces((size_t)nthreads);
-    std::unique_ptr<uint8_t[]> bufmem;      // not a vector: no zero-fill of hundreds of MB per window
+    // not a vector: no zero-fill of hundreds of MB per window
+    std::unique_ptr<uint8_t[]> bufmem;
     size_t bufcap = 0, buflen = 0;
     std::vector<uint8_t> carry;
-    std::vector<size_t> rec_off;
+    std::vector<uint64_t> rec_off;
     std::atomic<int> fail{0};
     size_t WINDOW = 512u << 20;
     if (const char *e = getenv("METHEOR_DECODE_WINDOW_MB")) { const long k = atol(e); if (k >= 1 && k <= 65536) WINDOW = (size_t)k << 20; }
@@ -313,6 +314,14 @@ bool parallel_decode(const std::string &path, size_t header_bytes, const std::un
         bi = be;
         skip = 0;
         sw.lap(2);
+        if (sink) {   // the records of this window go to the consumer (device decode) instead of the host threads
+            const size_t n_win = rec_off.size();
+            rec_off.push_back(p);
+            if (!(*sink)(buf, rec_off.data(), n_win, err)) { err_kind = err_kind ? err_kind : 3; return false; }
+            sw.lap(3);
+            if (bi >= blocks.size() && !carry.empty()) { err = "truncated BAM file"; err_kind = 1; return false; }
+            continue;
+        }
         // 4. decode
         const size_t nrec = rec_off.size();
         const int nt = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(1, nrec / 2048));

@@ -1,6 +1,7 @@
 // parallel_decode.h -- multi-threaded BGZF/BAM -> SoA decode (see parallel_decode.cpp)
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -15,9 +16,14 @@ struct DecodedSoA {
     std::vector<uint16_t> cpg_rel;
 };
 
+// Optional consumer of the inflated windows: called once per window with the window's bytes and the byte offsets of
+// its complete records (rec_off[n_rec] = end of the last one); when given, the host does NOT decode the records
+// itself (the device does, mth_decode_records).  Return false to abort (err is reported).
+using WindowSink = std::function<bool(const uint8_t *buf, const uint64_t *rec_off, size_t n_rec, std::string &err)>;
+
 // header_bytes: uncompressed size of the BAM header (records start right after it).
 // target: --cpg-set keys (tid << 32 | pos) or nullptr.  err_kind: 1 format/IO, 2 record without XM.
 bool parallel_decode(const std::string &path, size_t header_bytes, const std::unordered_set<uint64_t> *target,
-                     int nthreads, DecodedSoA &out, std::string &err, int &err_kind);
+                     int nthreads, DecodedSoA &out, std::string &err, int &err_kind, const WindowSink *sink = nullptr);
 
 }  // namespace mthh

@@ -42,6 +42,9 @@ struct mth_ctx {
     mth::DevBuf st_start, st_end, st_mapq, st_fwd, st_off, st_pos, st_rel;
     // per-batch work buffers
     mth::DevBuf idx, tile_cnt, tile_bucket, scratch, batch_cnt;
+    // device-side BAM record decode (mth_decode.hip): staged input, decoded SoA, scan scratch, one batch's 32-bit offsets
+    mth::DevBuf dec_raw, dec_recoff, dec_tid, dec_start, dec_end, dec_mapq, dec_fwd, dec_n, dec_off, dec_pos, dec_rel, dec_blk, dec_off32;
+    uint64_t dec_reads = 0, dec_cpgs = 0;
     // results (PDR columns)
     mth::DevBuf out_pos, out_pdr, out_nc, out_nd;
     uint64_t out_cap = 0;        // rows

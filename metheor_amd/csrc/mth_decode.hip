@@ -1,0 +1,347 @@
+// mth_decode.hip -- BAM record + XM decode on the device (the step before the hot path).
+//
+// Replaces, per record, BismarkRead::new + get_cpgs (readutil.rs:24-53, 323-345) as the host decoder
+// (csrc/host/parallel_decode.cpp) restates them: start/end = first/last reference position covered by an
+// M/=/X CIGAR run; a CpG call for every query offset q inside such a run whose XM character is z/Z, at
+// abspos (flags in {0,99,147}, readutil.rs:332) or abspos-1, methylated iff 'Z'; insertions and soft clips
+// advance the query only, deletions and skips the reference only.
+//
+// Input: the INFLATED record stream of a BAM file (what BGZF decompression yields after the header) plus the
+// byte offset of every record -- the walk over the block_size fields is inherently sequential and stays on the
+// host, where it overlaps the inflate.  One thread per record, two passes (count -> scan -> fill) because the
+// number of calls per read is only known after the XM scan; the outputs are the SoA arrays of mth_batch_t,
+// resident in HBM, ready for the measures without ever existing on the host.
+// Roofline: HBM/L2-bound byte parsing (each thread streams its own ~350-byte record; lanes touch different
+// cache lines, so the texture path, not the ALUs, is the limit); no MFMA.
+#include "mth_ctx.h"
+
+namespace mth {
+
+struct DecArgs {
+    const uint8_t *raw;
+    const uint64_t *off;          // n_rec + 1 byte offsets of the records (each starts with its block_size)
+    uint32_t n_rec;
+    int32_t *tid, *start, *end;
+    uint8_t *mapq, *fwd;
+    uint32_t *ncpg;               // pass 1 out
+    const unsigned long long *cpg_off;   // pass 2 in (exclusive scan of ncpg, n_rec + 1; global call indices)
+    uint32_t *cpg_pos;
+    uint16_t *cpg_rel;
+    uint32_t *err;                // DevState.err
+};
+
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+
+// aux fields until XM:Z (SAM spec 4.2.4); false = malformed or absent
+__device__ __forceinline__ bool dev_find_xm(const uint8_t *aux, uint32_t len, const uint8_t *&xm, uint32_t &xm_len) {
+    uint32_t o = 0;
+    while (o + 3 <= len) {
+        const uint8_t t0 = aux[o], t1 = aux[o + 1], ty = aux[o + 2];
+        o += 3;
+        switch (ty) {
+            case 'A': case 'c': case 'C': o += 1; break;
+            case 's': case 'S': o += 2; break;
+            case 'i': case 'I': case 'f': o += 4; break;
+            case 'Z': case 'H': {
+                const uint32_t b = o;
+                while (o < len && aux[o] != 0) ++o;
+                if (o >= len) return false;
+                if (ty == 'Z' && t0 == 'X' && t1 == 'M') { xm = aux + b; xm_len = o - b; return true; }
+                o += 1;
+                break;
+            }
+            case 'B': {
+                if (o + 5 > len) return false;
+                const uint8_t sub = aux[o];
+                const uint32_t cnt = ld_u32(aux + o + 1);
+                const uint32_t w = (sub == 'c' || sub == 'C') ? 1u : (sub == 's' || sub == 'S') ? 2u : 4u;
+                o += 5 + cnt * w;
+                break;
+            }
+            default: return false;
+        }
+    }
+    return false;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_decode(const DecArgs a) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_rec) return;
+    const uint64_t o0 = a.off[i], o1 = a.off[i + 1];
+    const uint8_t *p = a.raw + o0 + 4;                       // past block_size
+    const uint32_t len = (uint32_t)(o1 - o0 - 4);
+    bool bad = o1 < o0 + 4 + 32 || ld_u32(a.raw + o0) != len;
+    uint32_t n = 0;
+    int32_t tid = -1, first = -1, last = -1;
+    uint8_t mapq = 0, fwd = 0;
+    if (!bad) {
+        tid = (int32_t)ld_u32(p);
+        const int32_t pos = (int32_t)ld_u32(p + 4);
+        const uint32_t l_read_name = p[8], n_cigar = ld_u16(p + 12), l_seq = ld_u32(p + 16);
+        mapq = p[9];
+        const uint32_t flag = ld_u16(p + 14);
+        const uint64_t o_cigar = 32ull + l_read_name;
+        const uint64_t o_aux = o_cigar + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
+        const uint8_t *xm = nullptr;
+        uint32_t xm_len = 0;
+        if (o_aux > len) {
+            bad = true;
+        } else if (!dev_find_xm(p + o_aux, (uint32_t)(len - o_aux), xm, xm_len)) {
+            atomicOr(a.err, (uint32_t)ERRB_NOXM);                // readutil.rs:46: the reference panics without XM
+        } else {
+            const bool forward = flag == 0u || flag == 99u || flag == 147u;   // readutil.rs:332
+            fwd = forward ? 1 : 0;
+            int64_t r = pos;
+            uint32_t q = 0;
+            unsigned long long w = FILL ? a.cpg_off[i] : 0ull;
+            const uint8_t *cg = p + o_cigar;
+            for (uint32_t c = 0; c < n_cigar; ++c) {
+                const uint32_t cw = ld_u32(cg + 4 * c), op = cw & 15u, ln = cw >> 4;
+                if (op == 0 || op == 7 || op == 8) {                          // M = X: query and reference advance
+                    if (ln) { if (first < 0) first = (int32_t)r; last = (int32_t)(r + ln - 1); }
+                    const uint32_t qe = q + ln;
+                    for (; q < qe; ++q, ++r) {
+                        if (q >= xm_len) continue;
+                        const uint8_t ch = xm[q];
+                        if (ch != 'z' && ch != 'Z') continue;
+                        if (FILL) {
+                            const int32_t ap = forward ? (int32_t)r : (int32_t)(r - 1);
+                            a.cpg_pos[w] = ((uint32_t)ap & 0x7fffffffu) | (ch == 'Z' ? 0x80000000u : 0u);
+                            a.cpg_rel[w] = (uint16_t)q;
+                            ++w;
+                        }
+                        ++n;
+                    }
+                } else if (op == 1 || op == 4) {                              // I, S: query only
+                    q += ln;
+                } else if (op == 2 || op == 3) {                              // D, N: reference only
+                    r += ln;
+                }
+            }
+        }
+    }
+    if (bad) atomicOr(a.err, (uint32_t)ERRB_FORMAT);
+    if (!FILL) {
+        a.ncpg[i] = n;
+        a.tid[i] = tid; a.start[i] = first; a.end[i] = last; a.mapq[i] = mapq; a.fwd[i] = fwd;
+    }
+}
+
+// cpg_off = exclusive scan of ncpg (64-bit): per-block sums, a single-block scan of those, then each block adds
+constexpr int DS_PER = 8;   // records per thread
+__global__ __launch_bounds__(256) void k_dec_blocksum(const uint32_t *__restrict__ n, uint32_t n_rec, unsigned long long *__restrict__ blk) {
+    __shared__ unsigned long long ws[4];
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * DS_PER;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k = 0; k < DS_PER; ++k) s += (i0 + k < n_rec) ? n[i0 + k] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(1024) void k_dec_blockscan(unsigned long long *__restrict__ blk, uint32_t nblk, unsigned long long *__restrict__ total) {
+    __shared__ unsigned long long ws[17];
+    __shared__ unsigned long long run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) run = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < nblk; b += 1024) {
+        const unsigned long long v = (b + tid < nblk) ? blk[b + tid] : 0ull;
+        unsigned long long incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) ws[wave + 1] = incl;
+        __syncthreads();
+        if (tid == 0) { ws[0] = run; for (int w = 1; w <= 16; ++w) ws[w] += ws[w - 1]; }
+        __syncthreads();
+        if (b + tid < nblk) blk[b + tid] = ws[wave] + incl - v;
+        __syncthreads();
+        if (tid == 0) run = ws[16];
+        __syncthreads();
+    }
+    if (tid == 0) *total = run;
+}
+__global__ __launch_bounds__(256) void k_dec_offsets(const uint32_t *__restrict__ n, uint32_t n_rec, const unsigned long long *__restrict__ blk,
+                                                     unsigned long long base, unsigned long long *__restrict__ off) {
+    __shared__ unsigned long long ws[5];
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * DS_PER;
+    uint32_t v[DS_PER];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k = 0; k < DS_PER; ++k) { v[k] = (i0 + k < n_rec) ? n[i0 + k] : 0u; s += v[k]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) ws[wave + 1] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { ws[0] = base + blk[blockIdx.x]; for (int w = 1; w <= 4; ++w) ws[w] += ws[w - 1]; }
+    __syncthreads();
+    unsigned long long run = ws[wave] + incl - s;
+#pragma unroll
+    for (int k = 0; k < DS_PER; ++k) {
+        if (i0 + k < n_rec) off[i0 + k] = run;
+        run += v[k];
+    }
+    if (i0 < n_rec && i0 + DS_PER >= n_rec) off[n_rec] = run;     // the thread holding the last record closes the array
+}
+
+// a contiguous read range of ONE contig as a device-resident batch: 32-bit offsets rebased to the range's first call,
+// and the widest read (max_span) reduced on the device
+__global__ __launch_bounds__(256) void k_dec_rebase(const unsigned long long *__restrict__ off, uint64_t r0, uint32_t n_reads,
+                                                    const int32_t *__restrict__ start, const int32_t *__restrict__ end,
+                                                    uint32_t *__restrict__ off32, uint32_t *__restrict__ max_span) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long c0 = off[r0];
+    if (i <= n_reads) off32[i] = (uint32_t)(off[r0 + i] - c0);
+    uint32_t sp = 0;
+    if (i < n_reads) {
+        const int32_t s = start[r0 + i], e = end[r0 + i];
+        sp = (s >= 0 && e >= s) ? (uint32_t)(e - s + 1) : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sp = max(sp, (uint32_t)__shfl_down(sp, o, 64));
+    if ((threadIdx.x & 63) == 0 && sp) atomicMax(max_span, sp);
+}
+
+}  // namespace mth
+
+using namespace mth;
+
+extern "C" {
+
+int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const uint64_t *rec_off, uint64_t n_rec, int mem,
+                       int append, mth_decoded_t *out) {
+    if (!ctx || !out || (n_rec && (!raw || !rec_off))) return MTH_ERR_INVALID;
+    if (n_rec >= (1ull << 32) - 16) return fail(ctx, MTH_ERR_CAPACITY, "more than 2^32 records in one decode call: split the stream");
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (!append) { ctx->dec_reads = 0; ctx->dec_cpgs = 0; }
+    const uint8_t *d_raw = (const uint8_t *)raw;
+    const uint64_t *d_off = rec_off;
+    if (mem == MTH_MEM_HOST) {
+        MTH_HIP(ctx, ctx->dec_raw.reserve(n_bytes + 16, s));
+        MTH_HIP(ctx, ctx->dec_recoff.reserve((n_rec + 1) * 8, s));
+        if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->dec_raw.p, raw, n_bytes, hipMemcpyHostToDevice, s));
+        if (n_rec) MTH_HIP(ctx, hipMemcpyAsync(ctx->dec_recoff.p, rec_off, (n_rec + 1) * 8, hipMemcpyHostToDevice, s));
+        d_raw = ctx->dec_raw.as<uint8_t>(); d_off = ctx->dec_recoff.as<uint64_t>();
+    } else if (mem != MTH_MEM_DEVICE) {
+        return fail(ctx, MTH_ERR_INVALID, "mem");
+    }
+    // the SoA grows geometrically when windows are appended (a reallocation copies what is already decoded)
+    const size_t R0 = (size_t)ctx->dec_reads, C0 = (size_t)ctx->dec_cpgs, nr = (size_t)n_rec, R1 = R0 + nr;
+    auto grow = [&](DevBuf &b, size_t need, size_t used) -> hipError_t {
+        if (need <= b.cap) return hipSuccess;
+        return b.reserve(std::max(need, b.cap + b.cap / 2), s, used > 0, used);
+    };
+    MTH_HIP(ctx, grow(ctx->dec_tid, R1 * 4 + 4, R0 * 4));
+    MTH_HIP(ctx, grow(ctx->dec_start, R1 * 4 + 4, R0 * 4));
+    MTH_HIP(ctx, grow(ctx->dec_end, R1 * 4 + 4, R0 * 4));
+    MTH_HIP(ctx, grow(ctx->dec_mapq, R1 + 4, R0));
+    MTH_HIP(ctx, grow(ctx->dec_fwd, R1 + 4, R0));
+    MTH_HIP(ctx, grow(ctx->dec_off, (R1 + 1) * 8, R0 ? (R0 + 1) * 8 : 0));
+    MTH_HIP(ctx, ctx->dec_n.reserve(nr * 4 + 4, s));
+    const uint32_t nblk = (uint32_t)((nr + 256 * DS_PER - 1) / (256 * DS_PER));
+    MTH_HIP(ctx, ctx->dec_blk.reserve(((size_t)nblk + 2) * 8, s));
+    unsigned long long *d_total = ctx->dec_blk.as<unsigned long long>() + nblk;
+    DecArgs a{};
+    a.raw = d_raw; a.off = d_off; a.n_rec = (uint32_t)n_rec;
+    a.tid = ctx->dec_tid.as<int32_t>() + R0; a.start = ctx->dec_start.as<int32_t>() + R0; a.end = ctx->dec_end.as<int32_t>() + R0;
+    a.mapq = ctx->dec_mapq.as<uint8_t>() + R0; a.fwd = ctx->dec_fwd.as<uint8_t>() + R0; a.ncpg = ctx->dec_n.as<uint32_t>();
+    a.err = &ctx->d_state->err;
+    unsigned long long total = 0;
+    if (n_rec) {
+        const uint32_t grid = (uint32_t)((nr + 255) / 256);
+        {
+            LaunchTimer lt(ctx, K_DECODE);
+            hipLaunchKernelGGL((k_decode<false>), dim3(grid), dim3(256), 0, s, a);
+        }
+        hipLaunchKernelGGL(k_dec_blocksum, dim3(nblk), dim3(256), 0, s, a.ncpg, a.n_rec, ctx->dec_blk.as<unsigned long long>());
+        hipLaunchKernelGGL(k_dec_blockscan, dim3(1), dim3(1024), 0, s, ctx->dec_blk.as<unsigned long long>(), nblk, d_total);
+        hipLaunchKernelGGL(k_dec_offsets, dim3(nblk), dim3(256), 0, s, a.ncpg, a.n_rec, ctx->dec_blk.as<unsigned long long>(),
+                           (unsigned long long)C0, ctx->dec_off.as<unsigned long long>() + R0);
+        MTH_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
+        int rc = sync_and_check(ctx);          // also surfaces malformed records / a record without XM
+        if (rc) return rc;
+    } else if (R0 == 0) {
+        MTH_HIP(ctx, hipMemsetAsync(ctx->dec_off.p, 0, 8, s));
+    }
+    const size_t C1 = C0 + (size_t)total;
+    MTH_HIP(ctx, grow(ctx->dec_pos, C1 * 4 + 4, C0 * 4));
+    MTH_HIP(ctx, grow(ctx->dec_rel, C1 * 2 + 4, C0 * 2));
+    if (n_rec && total) {
+        a.cpg_off = ctx->dec_off.as<unsigned long long>() + R0;
+        a.cpg_pos = ctx->dec_pos.as<uint32_t>(); a.cpg_rel = ctx->dec_rel.as<uint16_t>();
+        LaunchTimer lt(ctx, K_DECODE);
+        hipLaunchKernelGGL((k_decode<true>), dim3((uint32_t)((nr + 255) / 256)), dim3(256), 0, s, a);
+    }
+    MTH_HIP(ctx, hipGetLastError());
+    if (mem == MTH_MEM_HOST) MTH_HIP(ctx, hipStreamSynchronize(s));   // the caller may reuse its buffers (and ours is restaged next call)
+    ctx->dec_reads = R1; ctx->dec_cpgs = C1;
+    out->n_reads = R1; out->n_cpgs = C1;
+    out->tid = ctx->dec_tid.as<int32_t>(); out->start = ctx->dec_start.as<int32_t>(); out->end = ctx->dec_end.as<int32_t>();
+    out->mapq = ctx->dec_mapq.as<uint8_t>(); out->fwd = ctx->dec_fwd.as<uint8_t>();
+    out->cpg_off = ctx->dec_off.as<uint64_t>(); out->cpg_pos = ctx->dec_pos.as<uint32_t>(); out->cpg_rel = ctx->dec_rel.as<uint16_t>();
+    return MTH_OK;
+}
+
+int mth_decoded_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *start, int32_t *end, uint8_t *mapq, uint8_t *fwd,
+                      uint64_t *cpg_off, uint32_t *cpg_pos, uint16_t *cpg_rel) {
+    if (!ctx) return MTH_ERR_INVALID;
+    int rc = sync_and_check(ctx);
+    if (rc) return rc;
+    const size_t nr = (size_t)ctx->dec_reads, nc = (size_t)ctx->dec_cpgs;
+    if (tid && nr) MTH_HIP(ctx, hipMemcpy(tid, ctx->dec_tid.p, nr * 4, hipMemcpyDeviceToHost));
+    if (start && nr) MTH_HIP(ctx, hipMemcpy(start, ctx->dec_start.p, nr * 4, hipMemcpyDeviceToHost));
+    if (end && nr) MTH_HIP(ctx, hipMemcpy(end, ctx->dec_end.p, nr * 4, hipMemcpyDeviceToHost));
+    if (mapq && nr) MTH_HIP(ctx, hipMemcpy(mapq, ctx->dec_mapq.p, nr, hipMemcpyDeviceToHost));
+    if (fwd && nr) MTH_HIP(ctx, hipMemcpy(fwd, ctx->dec_fwd.p, nr, hipMemcpyDeviceToHost));
+    if (cpg_off) MTH_HIP(ctx, hipMemcpy(cpg_off, ctx->dec_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost));
+    if (cpg_pos && nc) MTH_HIP(ctx, hipMemcpy(cpg_pos, ctx->dec_pos.p, nc * 4, hipMemcpyDeviceToHost));
+    if (cpg_rel && nc) MTH_HIP(ctx, hipMemcpy(cpg_rel, ctx->dec_rel.p, nc * 2, hipMemcpyDeviceToHost));
+    return MTH_OK;
+}
+
+int mth_decoded_batch(mth_ctx_t *ctx, uint64_t read_beg, uint64_t read_end, int32_t tid, int32_t region_beg, int32_t region_end,
+                      mth_batch_t *batch) {
+    if (!ctx || !batch || read_end < read_beg || read_end > ctx->dec_reads) return MTH_ERR_INVALID;
+    const uint64_t n = read_end - read_beg;
+    if (n >= (1ull << 32) - 1) return fail(ctx, MTH_ERR_CAPACITY, "batch of more than 2^32 reads");
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    MTH_HIP(ctx, ctx->dec_off32.reserve((size_t)(n + 1) * 4 + 16, s));
+    uint32_t *d_span = ctx->dec_off32.as<uint32_t>() + n + 1;
+    MTH_HIP(ctx, hipMemsetAsync(d_span, 0, 4, s));
+    hipLaunchKernelGGL(k_dec_rebase, dim3((uint32_t)((n + 1 + 255) / 256)), dim3(256), 0, s, ctx->dec_off.as<unsigned long long>(),
+                       read_beg, (uint32_t)n, ctx->dec_start.as<int32_t>(), ctx->dec_end.as<int32_t>(),
+                       ctx->dec_off32.as<uint32_t>(), d_span);
+    uint32_t span = 0;
+    unsigned long long c01[2] = {0, 0};
+    MTH_HIP(ctx, hipMemcpyAsync(&span, d_span, 4, hipMemcpyDeviceToHost, s));
+    MTH_HIP(ctx, hipMemcpyAsync(&c01[0], ctx->dec_off.as<unsigned long long>() + read_beg, 8, hipMemcpyDeviceToHost, s));
+    MTH_HIP(ctx, hipMemcpyAsync(&c01[1], ctx->dec_off.as<unsigned long long>() + read_end, 8, hipMemcpyDeviceToHost, s));
+    MTH_HIP(ctx, hipStreamSynchronize(s));
+    if (c01[1] - c01[0] >= (1ull << 32)) return fail(ctx, MTH_ERR_CAPACITY, "batch of more than 2^32 CpG calls: split the contig into regions");
+    mth_batch_t b{};
+    b.tid = tid; b.region_beg = region_beg; b.region_end = region_end; b.max_span = (int32_t)span;
+    b.n_reads = (uint32_t)n; b.n_cpgs = (uint32_t)(c01[1] - c01[0]); b.mem = MTH_MEM_DEVICE;
+    b.read_start = ctx->dec_start.as<int32_t>() + read_beg; b.read_end = ctx->dec_end.as<int32_t>() + read_beg;
+    b.read_mapq = ctx->dec_mapq.as<uint8_t>() + read_beg; b.read_fwd = ctx->dec_fwd.as<uint8_t>() + read_beg;
+    b.cpg_off = ctx->dec_off32.as<uint32_t>();
+    b.cpg_pos = ctx->dec_pos.as<uint32_t>() + c01[0];
+    b.cpg_rel = nullptr; b.cpg_rel16 = ctx->dec_rel.as<uint16_t>() + c01[0];
+    *batch = b;
+    return MTH_OK;
+}
+
+}  // extern "C"

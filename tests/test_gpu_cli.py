@@ -205,3 +205,62 @@ def test_unbuilt_parts_fail_loudly(tmp_path):
     bam = os.path.join("tests", "golden", "test1.bam")
     r = run("tag", "-i", bam, "-o", str(tmp_path / "o.sam"), "-g", "x.fa")
     assert r.returncode != 0 and "no device kernel yet" in r.stderr
+
+
+def run_env(env_extra, *args):
+    env = dict(os.environ)
+    env.update(env_extra)
+    return subprocess.run([EXE, *args], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+
+
+def test_device_decode_equals_host_decode(tmp_path):
+    """the default load path decodes the records on the GPU (mth_decode_records); METHEOR_HOST_DECODE=1 takes the host
+    decoder: same TSV bytes for every measure, on a file with indels / clips / both strands / three contigs"""
+    from tests.test_host_decode import _weird_records
+    rec = _weird_records()
+    # the CLI's batches need every read to have an aligned base and a contig: drop the one pure soft-clip record
+    keep = [i for i in range(len(rec)) if any((c & 15) in (0, 7, 8) and (c >> 4) > 0 for c in rec.cigars[i])]
+    rec = bamio.Records(rec.refs, rec.tid[keep], rec.pos[keep], rec.flag[keep], rec.mapq[keep], [rec.cigars[i] for i in keep],
+                        [rec.xms[i] for i in keep])
+    bam = str(tmp_path / "weird.bam")
+    bamio.write_bam(bam, rec)
+    for sub, extra in (("pdr", ["-d", "2", "-p", "1"]), ("lpmd", []), ("mhl", ["-d", "2", "-p", "1"]), ("me", ["-d", "1"]),
+                       ("pm", ["-d", "1"]), ("fdrp", ["-d", "2"]), ("qfdrp", ["-d", "2"])):
+        od, oh = tmp_path / ("d_%s.tsv" % sub), tmp_path / ("h_%s.tsv" % sub)
+        rd = run_env({"METHEOR_TIMING": "1"}, sub, "-i", bam, "-o", str(od), *extra)
+        rh = run_env({"METHEOR_TIMING": "1", "METHEOR_HOST_DECODE": "1"}, sub, "-i", bam, "-o", str(oh), *extra)
+        assert rd.returncode == 0 and rh.returncode == 0, (rd.stderr, rh.stderr)
+        assert "device record decode" in rd.stderr and "device record decode" not in rh.stderr
+        assert "host decode" in rh.stderr and "host decode" not in rd.stderr
+        a, b = od.read_text(), oh.read_text()
+        if sub in ("me", "pm"):      # unsorted HashMap output in the reference; ours is deterministic but compare as sets anyway
+            assert sorted(a.splitlines()) == sorted(b.splitlines())
+        else:
+            assert a == b
+        assert len(a.splitlines()) > 1 or sub == "lpmd"
+
+
+def test_device_decode_falls_back_for_reads_without_aligned_bases(tmp_path):
+    """a pure soft-clip record has no reference position (start = end = -1): the device batches cannot hold it, the CLI
+    silently takes the host decoder (which drops such reads from the batches) -- same result as forcing the host path"""
+    from tests.test_host_decode import _weird_records
+    rec = _weird_records()
+    bam = str(tmp_path / "weird.bam")
+    bamio.write_bam(bam, rec)
+    o1, o2 = tmp_path / "a.tsv", tmp_path / "b.tsv"
+    r1 = run_env({"METHEOR_TIMING": "1"}, "pdr", "-i", bam, "-o", str(o1), "-d", "2", "-p", "1")
+    r2 = run_env({"METHEOR_HOST_DECODE": "1"}, "pdr", "-i", bam, "-o", str(o2), "-d", "2", "-p", "1")
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+    assert "device record decode" in r1.stderr and "host decode" in r1.stderr      # tried the device, fell back
+    assert o1.read_text() == o2.read_text() and len(o1.read_text()) > 0
+
+
+def test_device_decode_reports_missing_xm(golden_dir, tmp_path):
+    """readutil.rs:46: a record without XM -> exit 101 and the reference's message, also through the device decoder"""
+    rec = bamio.read_bam(os.path.join(golden_dir, "test1.bam"))
+    rec.xms[3] = None
+    bam = str(tmp_path / "noxm.bam")
+    bamio.write_bam(bam, rec)
+    for env in ({}, {"METHEOR_HOST_DECODE": "1"}):
+        r = run_env(env, "pdr", "-i", bam, "-o", str(tmp_path / "o.tsv"))
+        assert r.returncode == 101 and "Error reading XM tag in BAM record" in r.stderr, r.stderr
