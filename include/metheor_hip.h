@@ -50,7 +50,8 @@ enum {
     MTH_ERR_RANGE = -7,     /* a CpG of an owned site lies outside what the batch declared */
     MTH_ERR_CAPACITY = -8,  /* an on-chip capacity was exceeded */
     MTH_ERR_STATE = -9,     /* call order violated */
-    MTH_ERR_FORMAT = -10    /* device record decode: malformed BAM record, or a record without XM:Z */
+    MTH_ERR_FORMAT = -10,   /* device decode: corrupt BGZF block, malformed BAM record, or a record without XM:Z */
+    MTH_ERR_UNALIGNED = -11 /* mth_bgzf_decode: a record straddles two BGZF blocks (decode via the host walk instead) */
 };
 
 enum { MTH_MEM_HOST = 0, MTH_MEM_DEVICE = 1 };
@@ -217,6 +218,19 @@ typedef struct {
 } mth_decoded_t;
 int  mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const uint64_t *rec_off, uint64_t n_rec,
                         int mem, int append, mth_decoded_t *out);
+/* The whole step on the device: BGZF inflate (one wave per block, RFC 1951 stored / fixed / dynamic blocks, checked
+ * against ISIZE), record boundaries (one thread per block; htslib-family writers never let a record straddle a BGZF
+ * block, which is verified -- MTH_ERR_UNALIGNED otherwise, nothing is appended then), record + XM decode as above.
+ * `file` = n_bytes of the BAM file in HOST memory covering the blocks; per block: coff = offset of its DEFLATE payload
+ * inside `file`, csize = payload bytes, isize = inflated bytes (blocks with isize 0 omitted); first_byte = offset in
+ * the inflated stream of these blocks where the records start (the header's uncompressed size for the first call,
+ * 0 afterwards).  Replaces bamutil.rs:4-11 (htslib's reader) + readutil.rs:24-53, 323-345 for a coordinate-sorted
+ * Bismark BAM.  CRC32 of the blocks is NOT verified on this path (the host reader does). */
+/* the inflate step alone: inflated bytes of the given blocks, concatenated, copied to dst_host (may be NULL); *n_out = size */
+int  mth_bgzf_inflate(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
+                      const uint32_t *isize, uint64_t n_blocks, void *dst_host, uint64_t *n_out);
+int  mth_bgzf_decode(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
+                     const uint32_t *isize, uint64_t n_blocks, uint64_t first_byte, int append, mth_decoded_t *out);
 /* copy the decoded arrays to the host (any pointer may be NULL) */
 int  mth_decoded_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *start, int32_t *end, uint8_t *mapq, uint8_t *fwd,
                        uint64_t *cpg_off, uint32_t *cpg_pos, uint16_t *cpg_rel);

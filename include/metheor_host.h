@@ -56,6 +56,18 @@ int  mth_host_decode(mth_host_t *h, const char *cpg_set_path);
  * next one).  buf / rec_off are only valid during the call.  A non-zero return aborts. */
 typedef int (*mth_host_window_cb)(void *user, const uint8_t *buf, const uint64_t *rec_off, uint64_t n_rec);
 int  mth_host_decode_stream(mth_host_t *h, mth_host_window_cb cb, void *user);
+/* For a consumer that inflates on its own (mth_bgzf_decode in metheor_hip.h): the file mapped read-only and the table
+ * of its BGZF blocks that hold data -- payload offset in the file, payload bytes, inflated bytes -- plus the
+ * uncompressed size of the BAM header (where the records start in the inflated stream).  Valid until close. */
+typedef struct {
+    const uint8_t  *file;
+    uint64_t        file_bytes;
+    const uint64_t *coff;
+    const uint32_t *csize, *isize;
+    uint64_t        n_blocks;
+    uint64_t        header_bytes;
+} mth_host_bgzf_t;
+int  mth_host_bgzf_blocks(mth_host_t *h, mth_host_bgzf_t *out);
 int64_t mth_host_n_reads(const mth_host_t *h);
 int64_t mth_host_n_cpgs(const mth_host_t *h);
 const int32_t  *mth_host_read_tid(const mth_host_t *h);

@@ -15,7 +15,7 @@ SYMBOLS = [
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
-    "mth_decode_records", "mth_decoded_fetch", "mth_decoded_batch",
+    "mth_decode_records", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_decoded_fetch", "mth_decoded_batch",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -113,6 +113,8 @@ def lib():
         L.mth_lpmd_pairs_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_lpmd_pairs_params_t)]
         L.mth_lpmd_pairs_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 6
         L.mth_decode_records.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(mth_decoded_t)]
+        L.mth_bgzf_inflate.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
+        L.mth_bgzf_decode.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(mth_decoded_t)]
         L.mth_decoded_fetch.argtypes = [vp] * 9
         L.mth_decoded_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(mth_batch_t)]
         L.mth_timing_enable.argtypes = [vp, C.c_int]
@@ -332,6 +334,28 @@ class Engine:
             rp, op, nb, nr = raw.ctypes.data, rec_off.ctypes.data, raw.size, rec_off.size - 1
         d = mth_decoded_t()
         self._check(self.L.mth_decode_records(self.h, rp, nb, op, max(nr, 0), 1 if dev else 0, int(bool(append)), C.byref(d)))
+        self._decoded = d
+        return int(d.n_reads), int(d.n_cpgs)
+
+    def bgzf_inflate(self, file_bytes, coff, csize, isize):
+        """inflate the given BGZF blocks on the device; returns the concatenated inflated bytes (numpy uint8)"""
+        fb = np.frombuffer(file_bytes, np.uint8) if isinstance(file_bytes, (bytes, bytearray, memoryview)) else np.ascontiguousarray(file_bytes, np.uint8)
+        coff = np.ascontiguousarray(coff, np.uint64); csize = np.ascontiguousarray(csize, np.uint32); isize = np.ascontiguousarray(isize, np.uint32)
+        out = np.zeros(int(isize.astype(np.uint64).sum()), np.uint8)
+        n = C.c_uint64(0)
+        self._check(self.L.mth_bgzf_inflate(self.h, fb.ctypes.data, fb.size, coff.ctypes.data, csize.ctypes.data, isize.ctypes.data,
+                                            len(coff), out.ctypes.data, C.byref(n)))
+        assert n.value == len(out)
+        return out
+
+    def bgzf_decode(self, file_bytes, coff, csize, isize, first_byte, append=False):
+        """file_bytes: the BAM file (bytes / uint8 array, host); coff/csize/isize: per-BGZF-block payload offset, payload
+        size, inflated size.  Inflate + record walk + decode on the device; returns (n_reads, n_cpgs)."""
+        fb = np.frombuffer(file_bytes, np.uint8) if isinstance(file_bytes, (bytes, bytearray, memoryview)) else np.ascontiguousarray(file_bytes, np.uint8)
+        coff = np.ascontiguousarray(coff, np.uint64); csize = np.ascontiguousarray(csize, np.uint32); isize = np.ascontiguousarray(isize, np.uint32)
+        d = mth_decoded_t()
+        self._check(self.L.mth_bgzf_decode(self.h, fb.ctypes.data, fb.size, coff.ctypes.data, csize.ctypes.data, isize.ctypes.data,
+                                           len(coff), int(first_byte), int(bool(append)), C.byref(d)))
         self._decoded = d
         return int(d.n_reads), int(d.n_cpgs)
 

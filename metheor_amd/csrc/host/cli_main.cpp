@@ -267,11 +267,51 @@ int window_to_device(void *user, const uint8_t *buf, const uint64_t *rec_off, ui
     return st->rc == MTH_OK ? 0 : 1;
 }
 
+// Whole load path on the device (mth_bgzf_decode): the file's bytes go to the GPU as they are, BGZF inflate, record
+// boundaries and record decode all happen there.  Needs every BGZF block to hold whole records (what htslib-family
+// writers produce); returns false -- with the context reset -- for a file where that does not hold.
+bool load_bgzf_on_device(Input &in) {
+    mth_host_bgzf_t bz;
+    if (mth_host_bgzf_blocks(in.h, &bz) != 0) die(mth_host_last_error(in.h));
+    Phase ph("  device inflate + walk + decode");
+    // chunks of whole blocks, <= ~1 GiB of file bytes each (bounds the staging buffers, not the decoded SoA)
+    size_t chunk = (size_t)1 << 30;
+    if (const char *e = getenv("METHEOR_DEVICE_CHUNK_MB")) { const long k = atol(e); if (k >= 1 && k <= 65536) chunk = (size_t)k << 20; }
+    bool first = true;
+    uint64_t hdr_left = bz.header_bytes;      // header bytes still ahead of the next chunk's inflated stream
+    for (uint64_t b0 = 0; b0 < bz.n_blocks || first;) {
+        uint64_t b1 = b0;
+        uint64_t ubytes = 0;
+        while (b1 < bz.n_blocks && (b1 == b0 || bz.coff[b1] + bz.csize[b1] - bz.coff[b0] <= chunk)) { ubytes += bz.isize[b1]; ++b1; }
+        std::vector<uint64_t> rel((size_t)(b1 - b0));
+        const uint64_t base = b1 > b0 ? bz.coff[b0] : 0;
+        for (uint64_t k = b0; k < b1; ++k) rel[(size_t)(k - b0)] = bz.coff[k] - base;
+        const uint64_t nbytes = b1 > b0 ? bz.coff[b1 - 1] + bz.csize[b1 - 1] - base : 0;
+        const uint64_t first_byte = std::min<uint64_t>(hdr_left, ubytes);
+        if (b1 > b0 && hdr_left > ubytes && b1 < bz.n_blocks) { hdr_left -= ubytes; b0 = b1; continue; }   // a chunk made of header only
+        mth_decoded_t d;
+        const int rc = mth_bgzf_decode(in.ctx, bz.file + base, nbytes, rel.data(), bz.csize + b0, bz.isize + b0, b1 - b0, first_byte, first ? 0 : 1, &d);
+        hdr_left -= first_byte;
+        if (rc == MTH_ERR_UNALIGNED) { check(in.ctx, mth_reset(in.ctx)); return false; }
+        if (rc == MTH_ERR_FORMAT) {
+            const std::string m = mth_last_error(in.ctx);
+            if (m.find("XM") != std::string::npos) die("Error reading XM tag in BAM record. Make sure the reads are aligned using Bismark!");   // readutil.rs:46
+            die("Error reading BAM record. corrupt BGZF block or BAM record");
+        }
+        check(in.ctx, rc);
+        first = false;
+        b0 = b1;
+        if (b1 >= bz.n_blocks) break;
+    }
+    return true;
+}
+
 bool load_on_device(Input &in) {
     in.ctx = make_ctx();
-    StreamState st;
-    st.ctx = in.ctx;
-    {
+    const bool on_device = !getenv("METHEOR_HOST_INFLATE") && load_bgzf_on_device(in);
+    if (!on_device) {
+        StreamState st;
+        st.ctx = in.ctx;
         Phase ph("  inflate + device record decode");
         const int rc = mth_host_decode_stream(in.h, window_to_device, &st);
         if (st.rc == MTH_ERR_FORMAT) {

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -33,6 +34,7 @@ struct mth_host : DecodedSoA {
     std::string path, last_error;
     std::unordered_map<std::string, int> name2tid;
     size_t header_bytes = 0;
+    std::unique_ptr<BgzfMap> bgzf;
 };
 
 namespace {
@@ -117,6 +119,20 @@ int mth_host_decode(mth_host_t *h, const char *cpg_set_path) {
         h->last_error = "Error reading BAM record. " + err;
         return MTH_HOST_ERR_FORMAT;
     }
+    return MTH_HOST_OK;
+}
+
+int mth_host_bgzf_blocks(mth_host_t *h, mth_host_bgzf_t *out) {
+    if (!h || !out) return MTH_HOST_ERR_INVALID;
+    if (!h->bgzf) {
+        std::unique_ptr<BgzfMap> m(new BgzfMap);
+        std::string err;
+        if (!bgzf_map(h->path, *m, err)) { h->last_error = "Error reading BAM record. " + err; return MTH_HOST_ERR_FORMAT; }
+        h->bgzf = std::move(m);
+    }
+    out->file = h->bgzf->file; out->file_bytes = h->bgzf->file_bytes;
+    out->coff = h->bgzf->coff.data(); out->csize = h->bgzf->csize.data(); out->isize = h->bgzf->isize.data();
+    out->n_blocks = h->bgzf->coff.size(); out->header_bytes = h->header_bytes;
     return MTH_HOST_OK;
 }
 

@@ -184,6 +184,41 @@ struct Stopwatch {   // METHEOR_TIMING=1: decoder phase totals on stderr
 };
 }  // namespace
 
+BgzfMap::~BgzfMap() { if (file && file_bytes) munmap(const_cast<uint8_t *>(file), file_bytes); }
+
+bool bgzf_map(const std::string &path, BgzfMap &out, std::string &err) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) { err = "cannot open " + path; return false; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); err = "cannot stat " + path; return false; }
+    const size_t fsz = (size_t)st.st_size;
+    const uint8_t *file = fsz ? static_cast<const uint8_t *>(mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0)) : nullptr;
+    close(fd);
+    if (fsz && file == MAP_FAILED) { err = "cannot mmap " + path; return false; }
+    out.file = file; out.file_bytes = fsz;
+    out.coff.clear(); out.csize.clear(); out.isize.clear();
+    size_t o = 0;
+    while (o < fsz) {
+        if (o + 18 > fsz || file[o] != 31 || file[o + 1] != 139 || file[o + 2] != 8 || !(file[o + 3] & 4)) { err = "not a BGZF file (bad block header)"; return false; }
+        const uint32_t xlen = read_u16(file + o + 10);
+        if (o + 12 + xlen > fsz) { err = "truncated BGZF block"; return false; }
+        int bsize = -1;
+        for (uint32_t e = 0; e + 4 <= xlen;) {
+            const uint8_t *x = file + o + 12 + e;
+            const uint32_t slen = read_u16(x + 2);
+            if (x[0] == 'B' && x[1] == 'C' && slen == 2 && e + 6 <= xlen) bsize = read_u16(x + 4);
+            e += 4 + slen;
+        }
+        if (bsize < 0) { err = "not a BGZF file (no BC subfield)"; return false; }
+        const size_t total = (size_t)bsize + 1;
+        if (total < 12 + xlen + 8 || o + total > fsz) { err = "truncated BGZF block"; return false; }
+        const uint32_t isize = read_u32(file + o + total - 4);
+        if (isize) { out.coff.push_back(o + 12 + xlen); out.csize.push_back((uint32_t)(total - 12 - xlen - 8)); out.isize.push_back(isize); }
+        o += total;
+    }
+    return true;
+}
+
 bool parallel_decode(const std::string &path, size_t header_bytes, const std::unordered_set<uint64_t> *target,
                      int nthreads, DecodedSoA &out, std::string &err, int &err_kind, const WindowSink *sink) {
     err_kind = 0;

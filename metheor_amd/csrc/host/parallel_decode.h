@@ -21,6 +21,17 @@ struct DecodedSoA {
 // itself (the device does, mth_decode_records).  Return false to abort (err is reported).
 using WindowSink = std::function<bool(const uint8_t *buf, const uint64_t *rec_off, size_t n_rec, std::string &err)>;
 
+// The file mapped read-only plus the table of its BGZF blocks that hold data (payload offset / payload size /
+// inflated size), for a consumer that inflates on its own (the device).  false + err for anything that is not BGZF.
+struct BgzfMap {
+    const uint8_t *file = nullptr;
+    size_t file_bytes = 0;
+    std::vector<uint64_t> coff;
+    std::vector<uint32_t> csize, isize;
+    ~BgzfMap();
+};
+bool bgzf_map(const std::string &path, BgzfMap &out, std::string &err);
+
 // header_bytes: uncompressed size of the BAM header (records start right after it).
 // target: --cpg-set keys (tid << 32 | pos) or nullptr.  err_kind: 1 format/IO, 2 record without XM.
 bool parallel_decode(const std::string &path, size_t header_bytes, const std::unordered_set<uint64_t> *target,

@@ -2,6 +2,8 @@
 // tooling: the SURVEY's "seeded synthetic Bismark BAM generator").  One contig, `read_len`M reads,
 // XM:Z strings with z/Z at the call offsets, random sequence and quality bytes so that the file
 // compresses like a real BAM.  Records are built and deflated (BGZF, zlib level 6) in parallel.
+// Block layout as htslib writes it (bgzf_flush_try before every record): a block holds whole records, at most
+// 0xff00 inflated bytes -- no record straddles two BGZF blocks.
 #include <zlib.h>
 
 #include <cstring>
@@ -16,11 +18,12 @@ namespace {
 void put32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
 void put16(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
 
-// append `n` uncompressed bytes as BGZF blocks (<= 60000 bytes each)
+constexpr size_t BGZF_BLOCK = 0xff00;   // htslib's BGZF_BLOCK_SIZE
+// append `n` uncompressed bytes as BGZF blocks (<= 0xff00 bytes each)
 void bgzf_append(std::vector<uint8_t> &out, const uint8_t *p, size_t n) {
     size_t o = 0;
     do {
-        const size_t take = std::min<size_t>(60000, n - o);
+        const size_t take = std::min<size_t>(BGZF_BLOCK, n - o);
         uint8_t comp[70000];
         z_stream zs;
         memset(&zs, 0, sizeof zs);
@@ -63,8 +66,8 @@ extern "C" int mth_host_write_synthetic_bam(const char *path, const char *contig
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t] {
         const int64_t r0 = n_reads * t / nthreads, r1 = n_reads * (t + 1) / nthreads;
-        std::vector<uint8_t> raw;
-        raw.reserve(1 << 22);
+        std::vector<uint8_t> raw;          // the block being filled (whole records)
+        raw.reserve(BGZF_BLOCK + 4096);
         std::vector<uint8_t> &out = parts[(size_t)t];
         uint64_t rs = seed ^ (0x51ed27ULL * (uint64_t)(t + 1));
         const uint32_t seqb = (uint32_t)(read_len + 1) / 2;
@@ -73,6 +76,7 @@ extern "C" int mth_host_write_synthetic_bam(const char *path, const char *contig
             const int ln = snprintf(name, sizeof name, "r%lld", (long long)i) + 1;
             const uint32_t aux_len = 4 + 3 + (uint32_t)read_len + 1 + 6;
             const uint32_t bs = 32 + (uint32_t)ln + 4 + seqb + (uint32_t)read_len + aux_len;
+            if (!raw.empty() && raw.size() + 4 + bs > BGZF_BLOCK) { bgzf_append(out, raw.data(), raw.size()); raw.clear(); }   // bgzf_flush_try
             put32(raw, bs); put32(raw, 0); put32(raw, (uint32_t)start[i]);
             raw.push_back((uint8_t)ln); raw.push_back(mapq[i]); put16(raw, 4680); put16(raw, 1);
             put16(raw, fwd[i] ? 0 : 16); put32(raw, (uint32_t)read_len); put32(raw, 0xffffffffu); put32(raw, 0xffffffffu); put32(raw, 0);
@@ -87,7 +91,6 @@ extern "C" int mth_host_write_synthetic_bam(const char *path, const char *contig
                 if (cpg_rel[c] < (uint32_t)read_len) raw[xo + cpg_rel[c]] = (cpg_pos[c] >> 31) ? 'Z' : 'z';
             raw.push_back(0);
             raw.insert(raw.end(), {'X', 'R', 'Z', 'C', 'T', 0});
-            if (raw.size() >= (1u << 22)) { bgzf_append(out, raw.data(), raw.size()); raw.clear(); }
         }
         if (!raw.empty()) bgzf_append(out, raw.data(), raw.size());
     });

@@ -45,6 +45,8 @@ struct mth_ctx {
     // device-side BAM record decode (mth_decode.hip): staged input, decoded SoA, scan scratch, one batch's 32-bit offsets
     mth::DevBuf dec_raw, dec_recoff, dec_tid, dec_start, dec_end, dec_mapq, dec_fwd, dec_n, dec_off, dec_pos, dec_rel, dec_blk, dec_off32;
     uint64_t dec_reads = 0, dec_cpgs = 0;
+    // device-side BGZF inflate + per-block record walk (mth_inflate.hip)
+    mth::DevBuf inf_file, inf_tab, inf_raw, inf_cnt, inf_base, inf_recoff;
     // results (PDR columns)
     mth::DevBuf out_pos, out_pdr, out_nc, out_nd;
     uint64_t out_cap = 0;        // rows
@@ -102,6 +104,10 @@ struct LaunchTimer {
 int sync_and_check(mth_ctx *ctx);   // stream sync + read DevState + map error bits
 // validate a caller batch and make it device-resident (MTH_MEM_HOST arrays go through the staging buffers)
 int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &dev);
+// mth_decode.hip: 64-bit exclusive scan of a u32 array (synchronises), and the record decode over device-resident input
+int scan_u32_to_u64(mth_ctx *ctx, const uint32_t *n, uint32_t count, unsigned long long base, unsigned long long *off,
+                    unsigned long long *total_host);
+int decode_core(mth_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_off, uint64_t n_rec, int append, mth_decoded_t *out);
 // implemented in mth_sites.hip: PDR with exact flush / re-open semantics (spans > 150 bp)
 int launch_pdr_exact(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p);
 // site discovery (tile pipeline into the private sink): positions called by >= 1 read with

@@ -220,24 +220,31 @@ using namespace mth;
 
 extern "C" {
 
-int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const uint64_t *rec_off, uint64_t n_rec, int mem,
-                       int append, mth_decoded_t *out) {
-    if (!ctx || !out || (n_rec && (!raw || !rec_off))) return MTH_ERR_INVALID;
-    if (n_rec >= (1ull << 32) - 16) return fail(ctx, MTH_ERR_CAPACITY, "more than 2^32 records in one decode call: split the stream");
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+}  // extern "C"
+
+namespace mth {
+
+// off[0..count] = base + exclusive scan of n[0..count) (64-bit); *total_host = sum.  Synchronises the stream and
+// surfaces pending device errors.
+int scan_u32_to_u64(mth_ctx *ctx, const uint32_t *n, uint32_t count, unsigned long long base, unsigned long long *off,
+                    unsigned long long *total_host) {
+    hipStream_t s = ctx->stream;
+    const uint32_t nblk = (uint32_t)(((size_t)count + 256 * DS_PER - 1) / (256 * DS_PER));
+    MTH_HIP(ctx, ctx->dec_blk.reserve(((size_t)nblk + 2) * 8, s));
+    unsigned long long *d_total = ctx->dec_blk.as<unsigned long long>() + nblk;
+    *total_host = 0;
+    if (count == 0) { MTH_HIP(ctx, hipMemcpyAsync(off, &base, 8, hipMemcpyHostToDevice, s)); return sync_and_check(ctx); }
+    hipLaunchKernelGGL(k_dec_blocksum, dim3(nblk), dim3(256), 0, s, n, count, ctx->dec_blk.as<unsigned long long>());
+    hipLaunchKernelGGL(k_dec_blockscan, dim3(1), dim3(1024), 0, s, ctx->dec_blk.as<unsigned long long>(), nblk, d_total);
+    hipLaunchKernelGGL(k_dec_offsets, dim3(nblk), dim3(256), 0, s, n, count, ctx->dec_blk.as<unsigned long long>(), base, off);
+    MTH_HIP(ctx, hipMemcpyAsync(total_host, d_total, 8, hipMemcpyDeviceToHost, s));
+    return sync_and_check(ctx);
+}
+
+// the decode proper: d_raw / d_off are device-resident
+int decode_core(mth_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_off, uint64_t n_rec, int append, mth_decoded_t *out) {
     hipStream_t s = ctx->stream;
     if (!append) { ctx->dec_reads = 0; ctx->dec_cpgs = 0; }
-    const uint8_t *d_raw = (const uint8_t *)raw;
-    const uint64_t *d_off = rec_off;
-    if (mem == MTH_MEM_HOST) {
-        MTH_HIP(ctx, ctx->dec_raw.reserve(n_bytes + 16, s));
-        MTH_HIP(ctx, ctx->dec_recoff.reserve((n_rec + 1) * 8, s));
-        if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->dec_raw.p, raw, n_bytes, hipMemcpyHostToDevice, s));
-        if (n_rec) MTH_HIP(ctx, hipMemcpyAsync(ctx->dec_recoff.p, rec_off, (n_rec + 1) * 8, hipMemcpyHostToDevice, s));
-        d_raw = ctx->dec_raw.as<uint8_t>(); d_off = ctx->dec_recoff.as<uint64_t>();
-    } else if (mem != MTH_MEM_DEVICE) {
-        return fail(ctx, MTH_ERR_INVALID, "mem");
-    }
     // the SoA grows geometrically when windows are appended (a reallocation copies what is already decoded)
     const size_t R0 = (size_t)ctx->dec_reads, C0 = (size_t)ctx->dec_cpgs, nr = (size_t)n_rec, R1 = R0 + nr;
     auto grow = [&](DevBuf &b, size_t need, size_t used) -> hipError_t {
@@ -251,9 +258,6 @@ int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const 
     MTH_HIP(ctx, grow(ctx->dec_fwd, R1 + 4, R0));
     MTH_HIP(ctx, grow(ctx->dec_off, (R1 + 1) * 8, R0 ? (R0 + 1) * 8 : 0));
     MTH_HIP(ctx, ctx->dec_n.reserve(nr * 4 + 4, s));
-    const uint32_t nblk = (uint32_t)((nr + 256 * DS_PER - 1) / (256 * DS_PER));
-    MTH_HIP(ctx, ctx->dec_blk.reserve(((size_t)nblk + 2) * 8, s));
-    unsigned long long *d_total = ctx->dec_blk.as<unsigned long long>() + nblk;
     DecArgs a{};
     a.raw = d_raw; a.off = d_off; a.n_rec = (uint32_t)n_rec;
     a.tid = ctx->dec_tid.as<int32_t>() + R0; a.start = ctx->dec_start.as<int32_t>() + R0; a.end = ctx->dec_end.as<int32_t>() + R0;
@@ -261,18 +265,12 @@ int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const 
     a.err = &ctx->d_state->err;
     unsigned long long total = 0;
     if (n_rec) {
-        const uint32_t grid = (uint32_t)((nr + 255) / 256);
         {
             LaunchTimer lt(ctx, K_DECODE);
-            hipLaunchKernelGGL((k_decode<false>), dim3(grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_decode<false>), dim3((uint32_t)((nr + 255) / 256)), dim3(256), 0, s, a);
         }
-        hipLaunchKernelGGL(k_dec_blocksum, dim3(nblk), dim3(256), 0, s, a.ncpg, a.n_rec, ctx->dec_blk.as<unsigned long long>());
-        hipLaunchKernelGGL(k_dec_blockscan, dim3(1), dim3(1024), 0, s, ctx->dec_blk.as<unsigned long long>(), nblk, d_total);
-        hipLaunchKernelGGL(k_dec_offsets, dim3(nblk), dim3(256), 0, s, a.ncpg, a.n_rec, ctx->dec_blk.as<unsigned long long>(),
-                           (unsigned long long)C0, ctx->dec_off.as<unsigned long long>() + R0);
-        MTH_HIP(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, s));
-        int rc = sync_and_check(ctx);          // also surfaces malformed records / a record without XM
-        if (rc) return rc;
+        int rc = scan_u32_to_u64(ctx, a.ncpg, a.n_rec, (unsigned long long)C0, ctx->dec_off.as<unsigned long long>() + R0, &total);
+        if (rc) return rc;                     // also surfaces malformed records / a record without XM
     } else if (R0 == 0) {
         MTH_HIP(ctx, hipMemsetAsync(ctx->dec_off.p, 0, 8, s));
     }
@@ -286,12 +284,38 @@ int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const 
         hipLaunchKernelGGL((k_decode<true>), dim3((uint32_t)((nr + 255) / 256)), dim3(256), 0, s, a);
     }
     MTH_HIP(ctx, hipGetLastError());
-    if (mem == MTH_MEM_HOST) MTH_HIP(ctx, hipStreamSynchronize(s));   // the caller may reuse its buffers (and ours is restaged next call)
     ctx->dec_reads = R1; ctx->dec_cpgs = C1;
     out->n_reads = R1; out->n_cpgs = C1;
     out->tid = ctx->dec_tid.as<int32_t>(); out->start = ctx->dec_start.as<int32_t>(); out->end = ctx->dec_end.as<int32_t>();
     out->mapq = ctx->dec_mapq.as<uint8_t>(); out->fwd = ctx->dec_fwd.as<uint8_t>();
     out->cpg_off = ctx->dec_off.as<uint64_t>(); out->cpg_pos = ctx->dec_pos.as<uint32_t>(); out->cpg_rel = ctx->dec_rel.as<uint16_t>();
+    return MTH_OK;
+}
+
+}  // namespace mth
+
+extern "C" {
+
+int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const uint64_t *rec_off, uint64_t n_rec, int mem,
+                       int append, mth_decoded_t *out) {
+    if (!ctx || !out || (n_rec && (!raw || !rec_off))) return MTH_ERR_INVALID;
+    if (n_rec >= (1ull << 32) - 16) return fail(ctx, MTH_ERR_CAPACITY, "more than 2^32 records in one decode call: split the stream");
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint8_t *d_raw = (const uint8_t *)raw;
+    const uint64_t *d_off = rec_off;
+    if (mem == MTH_MEM_HOST) {
+        MTH_HIP(ctx, ctx->dec_raw.reserve(n_bytes + 16, s));
+        MTH_HIP(ctx, ctx->dec_recoff.reserve((n_rec + 1) * 8, s));
+        if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->dec_raw.p, raw, n_bytes, hipMemcpyHostToDevice, s));
+        if (n_rec) MTH_HIP(ctx, hipMemcpyAsync(ctx->dec_recoff.p, rec_off, (n_rec + 1) * 8, hipMemcpyHostToDevice, s));
+        d_raw = ctx->dec_raw.as<uint8_t>(); d_off = ctx->dec_recoff.as<uint64_t>();
+    } else if (mem != MTH_MEM_DEVICE) {
+        return fail(ctx, MTH_ERR_INVALID, "mem");
+    }
+    const int rc = decode_core(ctx, d_raw, d_off, n_rec, append, out);
+    if (rc) return rc;
+    if (mem == MTH_MEM_HOST) MTH_HIP(ctx, hipStreamSynchronize(s));   // the caller may reuse its buffers (and ours is restaged next call)
     return MTH_OK;
 }
 

@@ -1,0 +1,360 @@
+// mth_inflate.hip -- BGZF (RFC 1951 DEFLATE) block inflate and per-block record walk on the device
+// (the step before the record decode; replaces bamutil.rs:4-11's htslib reader thread).
+//
+// BGZF = independent <= 64-KiB gzip members, each one raw DEFLATE stream: embarrassingly parallel across blocks,
+// strictly serial inside one.  Mapping: ONE WAVE per BGZF block.  The decoder state (bit buffer, input cursor,
+// output cursor) is wave-uniform, so the symbol loop is effectively one decoder per wave; the lanes are used for
+// what is parallel -- filling the Huffman lookup tables (lane = symbol) and copying matches (lane = byte).
+// Huffman decode: a direct lookup table on the low ROOT bits (codes are read LSB-first, so the index is the
+// bit-reversed code) for codes up to ROOT bits, canonical bit-by-bit decode (count / first-code walk) for the few
+// longer ones.  Output goes straight to HBM; back-references read it back (the window of a block is the block).
+// A block is checked against its ISIZE; any inconsistency sets ERRB_FORMAT.
+//
+// k_block_walk: BAM writers built on htslib flush the BGZF block before a record that would not fit, so records
+// never straddle blocks and every block starts at a record boundary: one thread per block follows the block_size
+// chain, counting / writing record offsets, and VERIFIES that the chain ends exactly at the block's end.  A file for
+// which that does not hold sets ERRB_UNALIGNED and the caller takes the host walk instead.
+#include "mth_ctx.h"
+
+namespace mth {
+
+constexpr int LROOT = 10, DROOT = 9;          // direct-lookup bits of the literal/length and distance tables
+struct InflArgs {
+    const uint8_t *file;                      // the compressed file, padded by >= 16 readable bytes
+    const uint64_t *coff;                     // per block: offset of the DEFLATE payload in the file
+    const uint32_t *csize, *isize;            // payload bytes / inflated bytes
+    const uint64_t *uoff;                     // offset of the block's output in the inflated stream
+    uint32_t n_blocks;
+    uint8_t *out;
+    uint32_t *err;
+};
+
+__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// one Huffman code: lens[0..n) -> direct table (entry = sym << 4 | len, 0 = not a short code) + canonical arrays
+struct Huff {
+    uint16_t *tab;        // 1 << root entries
+    uint16_t *sorted;     // symbols ordered by (length, symbol)
+    uint16_t *count;      // [16] codes per length
+    int root;
+    uint16_t *tmp;        // [32] builder scratch (next code / sorted offset per length)
+};
+
+// wave-cooperative build; returns false for an over-subscribed code (incomplete codes are accepted as zlib does for
+// the single-distance-code case; an unused entry decodes as an error later)
+__device__ bool huff_build(const Huff &h, const uint8_t *lens, int n, uint16_t *code_of /* scratch, n entries */) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 16) h.count[lane] = 0;
+    for (int i = lane; i < (1 << h.root); i += 64) h.tab[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {                  // canonical codes (RFC 1951 3.2.2); per-length arrays in LDS (dynamic indexing)
+        uint16_t *cnt = h.count, *next = h.tmp, *offs = h.tmp + 16;
+        for (int s = 0; s < n; ++s) cnt[lens[s]]++;
+        cnt[0] = 0;
+        int left = 1;
+        bool over = false;
+        for (int l = 1; l < 16; ++l) { left <<= 1; left -= cnt[l]; if (left < 0) over = true; }
+        uint32_t code = 0;
+        uint16_t o = 0;
+        next[0] = 0; offs[0] = 0;
+        for (int l = 1; l < 16; ++l) { code = (code + cnt[l - 1]) << 1; next[l] = (uint16_t)code; offs[l] = o; o += cnt[l]; }
+        for (int s = 0; s < n; ++s) {
+            const int l = lens[s];
+            if (l) { code_of[s] = next[l]++; h.sorted[offs[l]++] = (uint16_t)s; } else code_of[s] = 0;
+        }
+        cnt[0] = over ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (h.count[0]) return false;
+    // direct table: lane = symbol; a code of length l <= root owns every index whose low l bits are its reversal
+    for (int s = lane; s < n; s += 64) {
+        const int l = lens[s];
+        if (l == 0 || l > h.root) continue;
+        const uint32_t rev = __builtin_bitreverse32((uint32_t)code_of[s]) >> (32 - l);
+        const uint16_t e = (uint16_t)((s << 4) | l);
+        for (uint32_t k = rev; k < (1u << h.root); k += (1u << l)) h.tab[k] = e;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return true;
+}
+
+struct Bits {
+    const uint8_t *in, *end;     // end: first byte past the payload (reads may run a few bytes beyond: the file is padded)
+    uint64_t bb;
+    int bc;
+    __device__ __forceinline__ void refill() {
+        if (bc < 32) {
+            uint32_t w;
+            __builtin_memcpy(&w, in, 4);
+            bb |= (uint64_t)w << bc;
+            in += 4; bc += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(int n) { bb >>= n; bc -= n; }
+    __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = peek(n); drop(n); return v; }
+    // bytes consumed so far (whole bytes of the bit buffer given back)
+    __device__ __forceinline__ const uint8_t *cursor() const { return in - (bc >> 3); }
+};
+
+// decode one symbol; -1 on an invalid code
+__device__ __forceinline__ int huff_decode(const Huff &h, Bits &b) {
+    const uint32_t e = h.tab[b.peek(h.root)];
+    if (e) { b.drop((int)(e & 15u)); return (int)(e >> 4); }
+    // longer than root bits (or invalid): canonical walk, one bit at a time (RFC 1951 3.2.2; MSB of the code first)
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l < 16; ++l) {
+        code |= (int)b.take(1);
+        const int c = h.count[l];
+        if (code - c < first) return h.sorted[index + (code - first)];
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
+    __shared__ uint16_t s_ltab[1 << LROOT], s_dtab[1 << DROOT];
+    __shared__ uint16_t s_lsorted[288], s_dsorted[32], s_lcount[16], s_dcount[16], s_code[320];
+    __shared__ uint8_t s_lens[320];
+    __shared__ uint16_t s_tmp[32];
+    const uint32_t blk = blockIdx.x;
+    if (blk >= a.n_blocks) return;
+    const int lane = threadIdx.x;
+    uint8_t *const out0 = a.out + a.uoff[blk];
+    const uint32_t isize = a.isize[blk];
+    Bits b;
+    b.in = a.file + a.coff[blk]; b.end = b.in + a.csize[blk]; b.bb = 0; b.bc = 0;
+    const Huff HL{s_ltab, s_lsorted, s_lcount, LROOT, s_tmp}, HD{s_dtab, s_dsorted, s_dcount, DROOT, s_tmp};
+    uint32_t pos = 0;
+    bool bad = false, last = false;
+    while (!last && !bad) {
+        b.refill();
+        last = b.take(1) != 0;
+        const uint32_t type = b.take(2);
+        if (type == 0) {                                   // stored
+            b.drop(b.bc & 7);                              // to the byte boundary
+            const uint8_t *p = b.cursor();
+            const uint32_t len = (uint32_t)p[0] | ((uint32_t)p[1] << 8), nlen = (uint32_t)p[2] | ((uint32_t)p[3] << 8);
+            p += 4;
+            if ((len ^ nlen) != 0xffffu || pos + len > isize || p + len > b.end) { bad = true; break; }
+            for (uint32_t i = lane; i < len; i += 64) out0[pos + i] = p[i];
+            pos += len;
+            b.in = p + len; b.bb = 0; b.bc = 0;
+            continue;
+        }
+        if (type == 3) { bad = true; break; }
+        if (type == 1) {                                   // fixed codes (RFC 1951 3.2.6)
+            for (int s = lane; s < 288; s += 64) s_lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!huff_build(HL, s_lens, 288, s_code)) { bad = true; break; }
+            for (int s = lane; s < 30; s += 64) s_lens[s] = 5;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!huff_build(HD, s_lens, 30, s_code)) { bad = true; break; }
+        } else {                                           // dynamic codes (3.2.7)
+            b.refill();
+            const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
+            if (hlit > 286 || hdist > 30) { bad = true; break; }
+            if (lane < 19) s_lens[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int i = 0; i < hclen; ++i) {
+                b.refill();
+                const uint32_t v = b.take(3);
+                if (lane == 0) s_lens[c_clen_order[i]] = (uint8_t)v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the code-length code reuses the distance table's storage (root 7 <= DROOT)
+            const Huff HC{s_dtab, s_dsorted, s_dcount, 7, s_tmp};
+            if (!huff_build(HC, s_lens, 19, s_code)) { bad = true; break; }
+            int i = 0, prev = 0;
+            const int total = hlit + hdist;
+            while (i < total) {
+                b.refill();
+                const int sym = huff_decode(HC, b);
+                if (sym < 0) { bad = true; break; }
+                int rep = 1, val = sym;
+                if (sym == 16) { if (i == 0) { bad = true; break; } val = prev; rep = 3 + (int)b.take(2); }
+                else if (sym == 17) { val = 0; rep = 3 + (int)b.take(3); }
+                else if (sym == 18) { val = 0; rep = 11 + (int)b.take(7); }
+                if (i + rep > total) { bad = true; break; }
+                // lens of the literal/length code then of the distance code, one array (s_lens is 320 long)
+                for (int k = lane; k < rep; k += 64) s_lens[i + k] = (uint8_t)val;   // into a second region below
+                i += rep; prev = val;
+            }
+            if (bad) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (s_lens[256] == 0) { bad = true; break; }   // no end-of-block code
+            // the distance lengths follow the literal/length ones: build the distance code first (it lives in s_dtab,
+            // which the code-length code no longer needs), from a copy at the front of a scratch region
+            if (!huff_build(HD, s_lens + hlit, hdist, s_code)) { bad = true; break; }
+            if (!huff_build(HL, s_lens, hlit, s_code)) { bad = true; break; }
+        }
+        // ---- symbols ----
+        for (;;) {
+            b.refill();
+            const int sym = huff_decode(HL, b);
+            if (sym < 0) { bad = true; break; }
+            if (sym < 256) {
+                if (pos >= isize) { bad = true; break; }
+                if (lane == 0) out0[pos] = (uint8_t)sym;
+                ++pos;
+                continue;
+            }
+            if (sym == 256) break;
+            if (sym > 285) { bad = true; break; }
+            const int li = sym - 257;
+            const uint32_t len = c_len_base[li] + b.take(c_len_extra[li]);
+            b.refill();
+            const int ds = huff_decode(HD, b);
+            if (ds < 0 || ds > 29) { bad = true; break; }
+            const uint32_t dist = c_dist_base[ds] + b.take(c_dist_extra[ds]);
+            if (dist > pos || pos + len > isize) { bad = true; break; }
+            // the bytes written so far must be visible to the loads below (same wave, but loads and stores return
+            // out of order with respect to each other)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (dist >= len) {                              // no overlap: all lanes copy at once
+                for (uint32_t k = lane; k < len; k += 64) out0[pos + k] = out0[pos - dist + k];
+            } else {                                        // overlapping run: the source repeats with period dist
+                for (uint32_t k = lane; k < len; k += 64) out0[pos + k] = out0[pos - dist + (k % dist)];
+            }
+            pos += len;
+        }
+    }
+    if (!bad && (pos != isize || b.cursor() > b.end)) bad = true;
+    if (bad && lane == 0) atomicOr(a.err, (uint32_t)ERRB_FORMAT);
+}
+
+// ---- per-block record walk ------------------------------------------------------------------------------
+struct WalkBArgs {
+    const uint8_t *raw;            // inflated stream
+    const uint64_t *uoff;          // per block: offset of its bytes in raw
+    const uint32_t *isize;
+    uint32_t n_blocks;
+    uint64_t first_byte;           // records start here (end of the BAM header)
+    uint32_t *cnt;                 // pass 1: records per block
+    const unsigned long long *base;   // pass 2: exclusive scan of cnt
+    uint64_t *rec_off;             // pass 2: record offsets (+ closing offset written by the last block)
+    uint64_t total_bytes;
+    uint32_t *err;
+};
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_block_walk(const WalkBArgs a) {
+    const uint32_t blk = blockIdx.x * 256 + threadIdx.x;
+    if (blk >= a.n_blocks) return;
+    const uint64_t b0 = a.uoff[blk], b1 = b0 + a.isize[blk];
+    uint32_t n = 0;
+    if (b1 > a.first_byte) {
+        uint64_t p = b0 < a.first_byte ? a.first_byte : b0;
+        unsigned long long w = FILL ? a.base[blk] : 0ull;
+        while (p + 4 <= b1) {
+            uint32_t bs;
+            __builtin_memcpy(&bs, a.raw + p, 4);
+            if (bs < 32 || p + 4 + (uint64_t)bs > b1) break;
+            if (FILL) a.rec_off[w++] = p;
+            ++n;
+            p += 4 + (uint64_t)bs;
+        }
+        if (p != b1) atomicOr(a.err, (uint32_t)ERRB_UNALIGNED);      // a record straddles the block (or garbage)
+    }
+    if (!FILL) a.cnt[blk] = n;
+    if (FILL && blk == a.n_blocks - 1) a.rec_off[a.base[blk] + n] = a.total_bytes;
+}
+
+}  // namespace mth
+
+using namespace mth;
+
+// stage the file bytes + block table and launch the inflate; on return d_uoff / d_isize point at the device table
+static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
+                          const uint32_t *isize, uint64_t n_blocks, uint64_t &total, uint64_t *&d_uoff, uint32_t *&d_isize) {
+    if (n_blocks >= (1ull << 31)) return fail(ctx, MTH_ERR_CAPACITY, "too many BGZF blocks in one call: split the file");
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t nb = (size_t)n_blocks;
+    // output offsets of the blocks + validation of the table against the byte range given
+    std::vector<uint64_t> uoff(nb + 1, 0);
+    for (size_t i = 0; i < nb; ++i) {
+        if (coff[i] + (uint64_t)csize[i] > n_bytes || isize[i] > 65536u) return fail(ctx, MTH_ERR_INVALID, "BGZF block table does not fit the file bytes");
+        uoff[i + 1] = uoff[i] + isize[i];
+    }
+    total = uoff[nb];
+    // stage: compressed bytes (padded: the bit reader loads whole words), the table, the inflated stream
+    MTH_HIP(ctx, ctx->inf_file.reserve((size_t)n_bytes + 64, s));
+    MTH_HIP(ctx, ctx->inf_tab.reserve(nb * 24 + 64, s));
+    MTH_HIP(ctx, ctx->inf_raw.reserve((size_t)total + 64, s));
+    if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->inf_file.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, s));
+    MTH_HIP(ctx, hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file.p) + n_bytes, 0, 64, s));
+    uint8_t *tab = static_cast<uint8_t *>(ctx->inf_tab.p);
+    uint64_t *d_coff = reinterpret_cast<uint64_t *>(tab);
+    d_uoff = reinterpret_cast<uint64_t *>(tab + nb * 8);
+    uint32_t *d_csize = reinterpret_cast<uint32_t *>(tab + nb * 16);
+    d_isize = reinterpret_cast<uint32_t *>(tab + nb * 20);
+    if (nb) {
+        MTH_HIP(ctx, hipMemcpyAsync(d_coff, coff, nb * 8, hipMemcpyHostToDevice, s));
+        MTH_HIP(ctx, hipMemcpyAsync(d_uoff, uoff.data(), nb * 8, hipMemcpyHostToDevice, s));
+        MTH_HIP(ctx, hipMemcpyAsync(d_csize, csize, nb * 4, hipMemcpyHostToDevice, s));
+        MTH_HIP(ctx, hipMemcpyAsync(d_isize, isize, nb * 4, hipMemcpyHostToDevice, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));            // uoff is a local
+        InflArgs ia{};
+        ia.file = ctx->inf_file.as<uint8_t>(); ia.coff = d_coff; ia.csize = d_csize; ia.isize = d_isize; ia.uoff = d_uoff;
+        ia.n_blocks = (uint32_t)nb; ia.out = ctx->inf_raw.as<uint8_t>(); ia.err = &ctx->d_state->err;
+        LaunchTimer lt(ctx, K_INFLATE);
+        hipLaunchKernelGGL(k_inflate, dim3((uint32_t)nb), dim3(64), 0, s, ia);
+    }
+    return MTH_OK;
+}
+
+extern "C" {
+
+int mth_bgzf_inflate(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
+                     const uint32_t *isize, uint64_t n_blocks, void *dst_host, uint64_t *n_out) {
+    if (!ctx || (n_blocks && (!file || !coff || !csize || !isize))) return MTH_ERR_INVALID;
+    uint64_t total = 0, *d_uoff = nullptr;
+    uint32_t *d_isize = nullptr;
+    int rc = inflate_blocks(ctx, file, n_bytes, coff, csize, isize, n_blocks, total, d_uoff, d_isize);
+    if (rc) return rc;
+    if ((rc = sync_and_check(ctx))) return rc;
+    if (n_out) *n_out = total;
+    if (dst_host && total) MTH_HIP(ctx, hipMemcpy(dst_host, ctx->inf_raw.p, (size_t)total, hipMemcpyDeviceToHost));
+    return MTH_OK;
+}
+
+int mth_bgzf_decode(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
+                    const uint32_t *isize, uint64_t n_blocks, uint64_t first_byte, int append, mth_decoded_t *out) {
+    if (!ctx || !out || (n_blocks && (!file || !coff || !csize || !isize))) return MTH_ERR_INVALID;
+    uint64_t total = 0, *d_uoff = nullptr;
+    uint32_t *d_isize = nullptr;
+    int rc0 = inflate_blocks(ctx, file, n_bytes, coff, csize, isize, n_blocks, total, d_uoff, d_isize);
+    if (rc0) return rc0;
+    if (first_byte > total) return fail(ctx, MTH_ERR_INVALID, "first_byte beyond the inflated stream");
+    hipStream_t s = ctx->stream;
+    const size_t nb = (size_t)n_blocks;
+    uint64_t n_rec = 0;
+    if (nb) {
+        // record offsets: count per block -> scan -> fill (verifying that no record straddles a block)
+        MTH_HIP(ctx, ctx->inf_cnt.reserve(nb * 4 + 16, s));
+        MTH_HIP(ctx, ctx->inf_base.reserve((nb + 1) * 8 + 16, s));
+        WalkBArgs wa{};
+        wa.raw = ctx->inf_raw.as<uint8_t>(); wa.uoff = d_uoff; wa.isize = d_isize; wa.n_blocks = (uint32_t)nb;
+        wa.first_byte = first_byte; wa.cnt = ctx->inf_cnt.as<uint32_t>(); wa.total_bytes = total; wa.err = &ctx->d_state->err;
+        hipLaunchKernelGGL((k_block_walk<false>), dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, wa);
+        unsigned long long tot_rec = 0;
+        int rc = scan_u32_to_u64(ctx, wa.cnt, (uint32_t)nb, 0ull, ctx->inf_base.as<unsigned long long>(), &tot_rec);
+        if (rc) return rc;                       // (synchronises: inflate / walk errors surface here)
+        n_rec = tot_rec;
+        MTH_HIP(ctx, ctx->inf_recoff.reserve((size_t)(n_rec + 1) * 8 + 16, s));
+        wa.base = ctx->inf_base.as<unsigned long long>(); wa.rec_off = ctx->inf_recoff.as<uint64_t>();
+        hipLaunchKernelGGL((k_block_walk<true>), dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, s, wa);
+    }
+    return decode_core(ctx, ctx->inf_raw.as<uint8_t>(), ctx->inf_recoff.as<uint64_t>(), n_rec, append, out);
+}
+
+}  // extern "C"
