@@ -234,6 +234,11 @@ int  mth_bgzf_decode(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const u
 /* copy the decoded arrays to the host (any pointer may be NULL) */
 int  mth_decoded_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *start, int32_t *end, uint8_t *mapq, uint8_t *fwd,
                        uint64_t *cpg_off, uint32_t *cpg_pos, uint16_t *cpg_rel);
+/* the decoded stream as runs of equal tid, in file order (a coordinate-sorted file has one run per contig): up to `cap`
+ * runs are returned, *n_runs is the true number; *flags bit0 = some read has no aligned base (start < 0), bit1 = some
+ * record has no contig (tid < 0) -- such records cannot enter a batch as they are */
+int  mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *read_beg, uint64_t *read_end,
+                         uint32_t *n_runs, uint32_t *flags);
 /* reads [read_beg, read_end) of the decoded stream -- ONE contig's reads (or a region slice of them) -- as a
  * device-resident batch for the accumulate calls: 32-bit offsets rebased on the device, max_span reduced on
  * the device.  Valid until the next mth_decoded_batch / mth_decode_records call. */

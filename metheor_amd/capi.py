@@ -15,7 +15,7 @@ SYMBOLS = [
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
-    "mth_decode_records", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_decoded_fetch", "mth_decoded_batch",
+    "mth_decode_records", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -116,6 +116,7 @@ def lib():
         L.mth_bgzf_inflate.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
         L.mth_bgzf_decode.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(mth_decoded_t)]
         L.mth_decoded_fetch.argtypes = [vp] * 9
+        L.mth_decoded_contigs.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.mth_decoded_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(mth_batch_t)]
         L.mth_timing_enable.argtypes = [vp, C.c_int]
         L.mth_timing_reset.argtypes = [vp]
@@ -368,6 +369,14 @@ class Engine:
         self._check(self.L.mth_decoded_fetch(self.h, *[out[k].ctypes.data_as(C.c_void_p) for k in
                                                        ("tid", "start", "end", "mapq", "fwd", "cpg_off", "cpg_pos", "cpg_rel")]))
         return out
+
+    def decoded_contigs(self, cap=65536):
+        """runs of equal tid in the decoded stream: (tids, read_beg, read_end, flags)"""
+        tids, beg, end = np.zeros(cap, np.int32), np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+        n, fl = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.L.mth_decoded_contigs(self.h, cap, tids.ctypes.data, beg.ctypes.data, end.ctypes.data, C.byref(n), C.byref(fl)))
+        k = min(n.value, cap)
+        return tids[:k], beg[:k], end[:k], fl.value
 
     def decoded_batch(self, read_beg, read_end, tid, region_beg, region_end):
         """device-resident batch over reads [read_beg, read_end) of the decoded stream (one contig)"""

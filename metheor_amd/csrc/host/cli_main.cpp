@@ -327,20 +327,18 @@ bool load_on_device(Input &in) {
         }
     }
     Phase ph2("  contig ranges");
-    mth_decoded_t d;
-    check(in.ctx, mth_decode_records(in.ctx, nullptr, 0, nullptr, 0, MTH_MEM_HOST, 1, &d));   // no new records: the current view
-    const uint64_t n = d.n_reads;
-    std::vector<int32_t> tid(n), st0(n);
-    check(in.ctx, mth_decoded_fetch(in.ctx, tid.data(), st0.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
-    for (uint64_t i = 0; i < n;) {
-        uint64_t e = i;
-        while (e < n && tid[e] == tid[i]) { if (st0[e] < 0) return false; ++e; }
-        if (tid[i] < 0) return false;
-        for (const Contig &c : in.contigs) if (c.tid == tid[i]) return false;   // the host path reports it
+    // one run of equal tid per contig in a coordinate-sorted file; anything else the batches cannot hold as it is
+    const uint32_t cap = (uint32_t)std::max(1, mth_host_n_refs(in.h)) + 1;
+    std::vector<int32_t> tids(cap);
+    std::vector<uint64_t> rb(cap), re(cap);
+    uint32_t n_runs = 0, flags = 0;
+    check(in.ctx, mth_decoded_contigs(in.ctx, cap, tids.data(), rb.data(), re.data(), &n_runs, &flags));
+    if (flags || n_runs > cap) return false;                       // unaligned / contig-less records, or contigs not grouped
+    for (uint32_t k = 0; k < n_runs; ++k) {
+        for (const Contig &c : in.contigs) if (c.tid == tids[k]) return false;   // the host path reports it
         in.contigs.emplace_back();
         Contig &c = in.contigs.back();
-        c.tid = tid[i]; c.r0 = i; c.r1 = e; c.n_reads = (size_t)(e - i); c.n_cpgs = 0;
-        i = e;
+        c.tid = tids[k]; c.r0 = rb[k]; c.r1 = re[k]; c.n_reads = (size_t)(re[k] - rb[k]); c.n_cpgs = 0;
     }
     in.device = true;
     return true;

@@ -13,6 +13,8 @@
 // resident in HBM, ready for the measures without ever existing on the host.
 // Roofline: HBM/L2-bound byte parsing (each thread streams its own ~350-byte record; lanes touch different
 // cache lines, so the texture path, not the ALUs, is the limit); no MFMA.
+#include <algorithm>
+
 #include "mth_ctx.h"
 
 namespace mth {
@@ -214,6 +216,23 @@ __global__ __launch_bounds__(256) void k_dec_rebase(const unsigned long long *__
     if ((threadIdx.x & 63) == 0 && sp) atomicMax(max_span, sp);
 }
 
+// contig runs of the decoded stream: every i where tid changes opens a run (appended through an atomic counter, sorted by
+// the host -- there are only as many runs as contigs); flags: bit0 a read without aligned base (start < 0), bit1 a record
+// without contig (tid < 0)
+__global__ __launch_bounds__(256) void k_dec_contigs(const int32_t *__restrict__ tid, const int32_t *__restrict__ start, uint64_t n,
+                                                     uint32_t cap, uint32_t *__restrict__ count, uint64_t *__restrict__ run_beg,
+                                                     int32_t *__restrict__ run_tid, uint32_t *__restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t t = tid[i];
+    uint32_t f = (start[i] < 0 ? 1u : 0u) | (t < 0 ? 2u : 0u);
+    if (f) atomicOr(flags, f);
+    if (i == 0 || tid[i - 1] != t) {
+        const uint32_t k = atomicAdd(count, 1u);
+        if (k < cap) { run_beg[k] = i; run_tid[k] = t; }
+    }
+}
+
 }  // namespace mth
 
 using namespace mth;
@@ -316,6 +335,43 @@ int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const 
     const int rc = decode_core(ctx, d_raw, d_off, n_rec, append, out);
     if (rc) return rc;
     if (mem == MTH_MEM_HOST) MTH_HIP(ctx, hipStreamSynchronize(s));   // the caller may reuse its buffers (and ours is restaged next call)
+    return MTH_OK;
+}
+
+int mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *read_beg, uint64_t *read_end, uint32_t *n_runs,
+                        uint32_t *flags) {
+    if (!ctx || !n_runs || !flags || (cap && (!tids || !read_beg || !read_end))) return MTH_ERR_INVALID;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = ctx->dec_reads;
+    *n_runs = 0; *flags = 0;
+    if (n == 0) return MTH_OK;
+    MTH_HIP(ctx, ctx->dec_runs.reserve((size_t)cap * 12 + 64, s));
+    uint8_t *base = static_cast<uint8_t *>(ctx->dec_runs.p);
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(base);                 // [0] count, [1] flags
+    uint64_t *d_beg = reinterpret_cast<uint64_t *>(base + 16);
+    int32_t *d_tid = reinterpret_cast<int32_t *>(base + 16 + (size_t)cap * 8);
+    MTH_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, s));
+    hipLaunchKernelGGL(k_dec_contigs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, ctx->dec_tid.as<int32_t>(),
+                       ctx->dec_start.as<int32_t>(), n, cap, d_cnt, d_beg, d_tid, d_cnt + 1);
+    uint32_t hc[2] = {0, 0};
+    MTH_HIP(ctx, hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, s));
+    MTH_HIP(ctx, hipStreamSynchronize(s));
+    *n_runs = hc[0]; *flags = hc[1];
+    const uint32_t k = std::min(hc[0], cap);
+    if (k) {
+        std::vector<uint64_t> hb(k);
+        std::vector<int32_t> ht(k);
+        MTH_HIP(ctx, hipMemcpy(hb.data(), d_beg, (size_t)k * 8, hipMemcpyDeviceToHost));
+        MTH_HIP(ctx, hipMemcpy(ht.data(), d_tid, (size_t)k * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> ord(k);
+        for (uint32_t i = 0; i < k; ++i) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return hb[x] < hb[y]; });
+        for (uint32_t i = 0; i < k; ++i) {
+            tids[i] = ht[ord[i]]; read_beg[i] = hb[ord[i]];
+            read_end[i] = (i + 1 < k) ? hb[ord[i + 1]] : (hc[0] <= cap ? n : hb[ord[i]]);
+        }
+    }
     return MTH_OK;
 }
 
