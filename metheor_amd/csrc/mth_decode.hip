@@ -26,6 +26,7 @@ struct DecArgs {
     int32_t *tid, *start, *end;
     uint8_t *mapq, *fwd;
     uint32_t *ncpg;               // pass 1 out
+    uint2 *xm_loc;                // pass 1 out / pass 2 in: {offset of the XM string from the record core, its length}
     const unsigned long long *cpg_off;   // pass 2 in (exclusive scan of ncpg, n_rec + 1; global call indices)
     uint32_t *cpg_pos;
     uint16_t *cpg_rel;
@@ -47,7 +48,15 @@ __device__ __forceinline__ bool dev_find_xm(const uint8_t *aux, uint32_t len, co
             case 'i': case 'I': case 'f': o += 4; break;
             case 'Z': case 'H': {
                 const uint32_t b = o;
-                while (o < len && aux[o] != 0) ++o;
+                // NUL search four bytes at a time (global memory takes unaligned dword loads), bytewise at the very end
+                for (;;) {
+                    if (o >= len) return false;
+                    if (o + 4 > len) { if (aux[o] == 0) break; ++o; continue; }
+                    const uint32_t w = ld_u32(aux + o);
+                    const uint32_t z = (w - 0x01010101u) & ~w & 0x80808080u;
+                    if (z) { o += (uint32_t)(__builtin_ctz(z) >> 3); break; }
+                    o += 4;
+                }
                 if (o >= len) return false;
                 if (ty == 'Z' && t0 == 'X' && t1 == 'M') { xm = aux + b; xm_len = o - b; return true; }
                 o += 1;
@@ -88,34 +97,55 @@ __global__ __launch_bounds__(256) void k_decode(const DecArgs a) {
         const uint64_t o_aux = o_cigar + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + l_seq;
         const uint8_t *xm = nullptr;
         uint32_t xm_len = 0;
+        bool have_xm = false;
         if (o_aux > len) {
             bad = true;
-        } else if (!dev_find_xm(p + o_aux, (uint32_t)(len - o_aux), xm, xm_len)) {
-            atomicOr(a.err, (uint32_t)ERRB_NOXM);                // readutil.rs:46: the reference panics without XM
+        } else if (FILL) {                                       // found by the count pass
+            const uint2 loc = a.xm_loc[i];
+            xm = p + loc.x; xm_len = loc.y; have_xm = loc.x != 0u;
         } else {
+            have_xm = dev_find_xm(p + o_aux, (uint32_t)(len - o_aux), xm, xm_len);
+            a.xm_loc[i] = have_xm ? make_uint2((uint32_t)(xm - p), xm_len) : make_uint2(0u, 0u);
+            if (!have_xm) atomicOr(a.err, (uint32_t)ERRB_NOXM);   // readutil.rs:46: the reference panics without XM
+        }
+        if (!bad && have_xm) {
             const bool forward = flag == 0u || flag == 99u || flag == 147u;   // readutil.rs:332
             fwd = forward ? 1 : 0;
             int64_t r = pos;
             uint32_t q = 0;
             unsigned long long w = FILL ? a.cpg_off[i] : 0ull;
             const uint8_t *cg = p + o_cigar;
+            auto call = [&](const uint32_t qq, const int64_t rr, const uint8_t ch) {
+                if (FILL) {
+                    const int32_t ap = forward ? (int32_t)rr : (int32_t)(rr - 1);
+                    a.cpg_pos[w] = ((uint32_t)ap & 0x7fffffffu) | (ch == 'Z' ? 0x80000000u : 0u);
+                    a.cpg_rel[w] = (uint16_t)qq;
+                    ++w;
+                }
+                ++n;
+            };
             for (uint32_t c = 0; c < n_cigar; ++c) {
                 const uint32_t cw = ld_u32(cg + 4 * c), op = cw & 15u, ln = cw >> 4;
                 if (op == 0 || op == 7 || op == 8) {                          // M = X: query and reference advance
                     if (ln) { if (first < 0) first = (int32_t)r; last = (int32_t)(r + ln - 1); }
-                    const uint32_t qe = q + ln;
-                    for (; q < qe; ++q, ++r) {
-                        if (q >= xm_len) continue;
-                        const uint8_t ch = xm[q];
-                        if (ch != 'z' && ch != 'Z') continue;
-                        if (FILL) {
-                            const int32_t ap = forward ? (int32_t)r : (int32_t)(r - 1);
-                            a.cpg_pos[w] = ((uint32_t)ap & 0x7fffffffu) | (ch == 'Z' ? 0x80000000u : 0u);
-                            a.cpg_rel[w] = (uint16_t)q;
-                            ++w;
+                    const uint32_t qe = min(q + ln, xm_len);                   // (XM shorter than the query: nothing beyond it)
+                    uint32_t qq = q;
+                    // four XM characters per load; a word without z / Z (most of them) is skipped at once
+                    for (; qq + 4 <= qe; qq += 4) {
+                        const uint32_t x = ld_u32(xm + qq) | 0x20202020u;      // 'Z' -> 'z'
+                        const uint32_t y = x ^ 0x7a7a7a7au;                    // a zero byte where the character is z / Z
+                        if (((y - 0x01010101u) & ~y & 0x80808080u) == 0u) continue;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint8_t ch = xm[qq + k];
+                            if (ch == 'z' || ch == 'Z') call(qq + k, r + (qq + k - q), ch);
                         }
-                        ++n;
                     }
+                    for (; qq < qe; ++qq) {
+                        const uint8_t ch = xm[qq];
+                        if (ch == 'z' || ch == 'Z') call(qq, r + (qq - q), ch);
+                    }
+                    q += ln; r += ln;
                 } else if (op == 1 || op == 4) {                              // I, S: query only
                     q += ln;
                 } else if (op == 2 || op == 3) {                              // D, N: reference only
@@ -277,10 +307,11 @@ int decode_core(mth_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_off, uint6
     MTH_HIP(ctx, grow(ctx->dec_fwd, R1 + 4, R0));
     MTH_HIP(ctx, grow(ctx->dec_off, (R1 + 1) * 8, R0 ? (R0 + 1) * 8 : 0));
     MTH_HIP(ctx, ctx->dec_n.reserve(nr * 4 + 4, s));
+    MTH_HIP(ctx, ctx->dec_xm.reserve(nr * 8 + 8, s));
     DecArgs a{};
     a.raw = d_raw; a.off = d_off; a.n_rec = (uint32_t)n_rec;
     a.tid = ctx->dec_tid.as<int32_t>() + R0; a.start = ctx->dec_start.as<int32_t>() + R0; a.end = ctx->dec_end.as<int32_t>() + R0;
-    a.mapq = ctx->dec_mapq.as<uint8_t>() + R0; a.fwd = ctx->dec_fwd.as<uint8_t>() + R0; a.ncpg = ctx->dec_n.as<uint32_t>();
+    a.mapq = ctx->dec_mapq.as<uint8_t>() + R0; a.fwd = ctx->dec_fwd.as<uint8_t>() + R0; a.ncpg = ctx->dec_n.as<uint32_t>(); a.xm_loc = ctx->dec_xm.as<uint2>();
     a.err = &ctx->d_state->err;
     unsigned long long total = 0;
     if (n_rec) {
