@@ -8,12 +8,13 @@
 //   k_build_index   one thread per read: a linear index "first read starting at or after q*256 bp"
 //                   (reads are coordinate sorted) + sortedness validation.
 //   k_pdr_lpmd_tile one 256-thread workgroup per 4096-bp tile of the contig.  The tile's site
-//                   accumulators are DENSE in LDS (2 x u32 per reference position, 32 KiB), so the
-//                   scatter is an LDS atomic and HBM only sees the streamed SoA.  Reads that can
-//                   touch the tile are found through the index (halo reads are re-read by the
-//                   neighbour tile).  LPMD pair counts are reduced per wave with DPP shuffles and
-//                   stored as per-tile partials (no same-address global atomics).  The tile's
-//                   non-empty sites are compacted with a block scan into a per-tile scratch slice.
+//                   accumulators are DENSE in LDS (one 32-bit word per reference position holding both
+//                   16-bit counts, 16 KiB; tiles with > 65535 candidate reads run two half-tile passes with
+//                   32-bit counters), so the scatter is an LDS atomic and HBM only sees the streamed SoA.
+//                   Reads that can touch the tile are found through the index (halo reads are re-read by
+//                   the neighbour tile).  LPMD pair counts are reduced per wave with DPP and added to
+//                   per-256-tile bucket sums (one atomic per counter and tile).  The tile's qualifying
+//                   sites are compacted (bit mask + DPP scan) into a per-tile scratch slice.
 //   k_gather        one wave per tile: its output base = rows of the 256-tile buckets before it (summed by the
 //                   tile kernel with one atomic per tile) + rows of its bucket's earlier tiles; packs the scratch
 //                   slice into the final sorted SoA and computes the f32 PDR.  The last tile's wave commits the

@@ -336,8 +336,8 @@ def test_dense_cpg_chunks(eng):
 
 
 def test_long_reads_lpmd_only(eng):
-    """6-kbp reads with > 1024 calls each (16-bit relpos): the LPMD-only launch of the tile kernel
-    (and, under MTH_TILE_VARIANT=4..6, the wave-cooperative kernel's single-read memory path)"""
+    """6-kbp reads with > 1024 calls each (16-bit relpos): the LPMD-only launch of the tile kernel and its
+    memory loop for reads with more calls than the 8 register slots"""
     from metheor_amd import PdrLpmdParams, synth
     rng = np.random.default_rng(22)
     c = synth.make_contig(0, 400_000, 600, 0.3, rng, read_len=6000)
