@@ -207,7 +207,7 @@ int  mth_fdrp_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos
  * says where raw and rec_off live; append != 0 adds the records after those of the previous calls (a file
  * streamed window by window), append == 0 starts over.  The decoded SoA stays in HBM, owned by the context:
  * the arrays of mth_batch_t for ALL records so far, in file order (64-bit offsets, 16-bit relpos).  A record without XM:Z or a malformed record -> MTH_ERR_FORMAT (the reference panics,
- * readutil.rs:46).  Not applied here: the --cpg-set filter (readutil.rs:87-95). */
+ * readutil.rs:46).  The --cpg-set filter (filter_isin, readutil.rs:87-95) is applied when set, see below. */
 typedef struct {
     uint64_t n_reads, n_cpgs;
     const int32_t  *tid, *start, *end;   /* device pointers */
@@ -226,6 +226,11 @@ int  mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const
  * the inflated stream of these blocks where the records start (the header's uncompressed size for the first call,
  * 0 afterwards).  Replaces bamutil.rs:4-11 (htslib's reader) + readutil.rs:24-53, 323-345 for a coordinate-sorted
  * Bismark BAM.  CRC32 of the blocks is NOT verified on this path (the host reader does). */
+/* --cpg-set (get_target_cpgs / filter_isin, readutil.rs:347-374, 87-95): keep only the calls whose (tid, pos) is in the set;
+ * relpos of the kept calls is unchanged.  keys_sorted = strictly ascending (uint64)tid << 32 | pos, host memory.
+ * enabled != 0 with n_keys == 0 is the empty set (every call dropped, as HashSet::contains on an empty set);
+ * enabled == 0 removes the filter.  Applies to the following mth_decode_records / mth_bgzf_decode calls. */
+int  mth_decode_set_cpg_filter(mth_ctx_t *ctx, const uint64_t *keys_sorted, uint64_t n_keys, int enabled);
 /* the inflate step alone: inflated bytes of the given blocks, concatenated, copied to dst_host (may be NULL); *n_out = size */
 int  mth_bgzf_inflate(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
                       const uint32_t *isize, uint64_t n_blocks, void *dst_host, uint64_t *n_out);

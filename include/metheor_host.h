@@ -56,6 +56,9 @@ int  mth_host_decode(mth_host_t *h, const char *cpg_set_path);
  * next one).  buf / rec_off are only valid during the call.  A non-zero return aborts. */
 typedef int (*mth_host_window_cb)(void *user, const uint8_t *buf, const uint64_t *rec_off, uint64_t n_rec);
 int  mth_host_decode_stream(mth_host_t *h, mth_host_window_cb cb, void *user);
+/* The --cpg-set BED file (readutil.rs:347-374: col0 chrom -- must be in the header --, col1 start) as strictly ascending keys
+ * (uint64)tid << 32 | start, for mth_decode_set_cpg_filter.  Same errors as mth_host_decode's cpg_set_path.  Valid until close. */
+int  mth_host_cpg_set_keys(mth_host_t *h, const char *cpg_set_path, const uint64_t **keys, uint64_t *n_keys);
 /* For a consumer that inflates on its own (mth_bgzf_decode in metheor_hip.h): the file mapped read-only and the table
  * of its BGZF blocks that hold data -- payload offset in the file, payload bytes, inflated bytes -- plus the
  * uncompressed size of the BAM header (where the records start in the inflated stream).  Valid until close. */

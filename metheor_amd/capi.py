@@ -15,7 +15,7 @@ SYMBOLS = [
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
-    "mth_decode_records", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch",
+    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -113,6 +113,7 @@ def lib():
         L.mth_lpmd_pairs_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_lpmd_pairs_params_t)]
         L.mth_lpmd_pairs_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 6
         L.mth_decode_records.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(mth_decoded_t)]
+        L.mth_decode_set_cpg_filter.argtypes = [vp, vp, C.c_uint64, C.c_int]
         L.mth_bgzf_inflate.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
         L.mth_bgzf_decode.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(mth_decoded_t)]
         L.mth_decoded_fetch.argtypes = [vp] * 9
@@ -369,6 +370,14 @@ class Engine:
         self._check(self.L.mth_decoded_fetch(self.h, *[out[k].ctypes.data_as(C.c_void_p) for k in
                                                        ("tid", "start", "end", "mapq", "fwd", "cpg_off", "cpg_pos", "cpg_rel")]))
         return out
+
+    def decode_set_cpg_filter(self, sites):
+        """sites: iterable of (tid, pos) or None (no filter); an empty iterable filters every call"""
+        if sites is None:
+            self._check(self.L.mth_decode_set_cpg_filter(self.h, None, 0, 0))
+            return
+        keys = np.array(sorted({(int(t) << 32) | (int(p) & 0xffffffff) for t, p in sites}), np.uint64)
+        self._check(self.L.mth_decode_set_cpg_filter(self.h, keys.ctypes.data if len(keys) else None, len(keys), 1))
 
     def decoded_contigs(self, cap=65536):
         """runs of equal tid in the decoded stream: (tids, read_beg, read_end, flags)"""

@@ -256,7 +256,7 @@ mth_ctx_t *make_ctx() {
 
 // Device-side record decode (mth_decode_records): the host inflates BGZF and walks the record boundaries, every
 // window goes to the GPU as raw bytes, and the SoA the measures read is built in HBM -- no record / XM parsing and
-// no SoA assembly on host threads.  Not used with --cpg-set (the filter is not on the device yet), with
+// no SoA assembly on host threads (--cpg-set is applied by the decode kernel).  Not used with
 // METHEOR_HOST_DECODE=1, or when the file has records the batches cannot hold as they are (no contig, no aligned
 // base, contigs not grouped): those fall back to the host decoder below.
 struct StreamState { mth_ctx_t *ctx = nullptr; bool first = true; int rc = MTH_OK; };
@@ -307,8 +307,12 @@ bool load_bgzf_on_device(Input &in) {
     return true;
 }
 
-bool load_on_device(Input &in) {
+bool load_on_device(Input &in, const char *cpg_set) {
+    const uint64_t *keys = nullptr;
+    uint64_t n_keys = 0;
+    if (cpg_set && mth_host_cpg_set_keys(in.h, cpg_set, &keys, &n_keys) != 0) die(mth_host_last_error(in.h));   // readutil.rs:356
     in.ctx = make_ctx();
+    if (cpg_set) check(in.ctx, mth_decode_set_cpg_filter(in.ctx, keys, n_keys, 1));
     const bool on_device = !getenv("METHEOR_HOST_INFLATE") && load_bgzf_on_device(in);
     if (!on_device) {
         StreamState st;
@@ -350,8 +354,8 @@ Input load(const std::string &path, const char *cpg_set) {
     Input in;
     char err[1024];
     if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) die(err);    // bamutil.rs:7-9
-    if (!cpg_set && !getenv("METHEOR_HOST_DECODE")) {
-        if (load_on_device(in)) return in;
+    if (!getenv("METHEOR_HOST_DECODE")) {
+        if (load_on_device(in, cpg_set)) return in;
         in.contigs.clear();
     }
     {

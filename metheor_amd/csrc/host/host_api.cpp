@@ -35,6 +35,7 @@ struct mth_host : DecodedSoA {
     std::unordered_map<std::string, int> name2tid;
     size_t header_bytes = 0;
     std::unique_ptr<BgzfMap> bgzf;
+    std::vector<uint64_t> cpg_keys;
 };
 
 namespace {
@@ -42,6 +43,28 @@ namespace {
 inline uint64_t site_key(int32_t tid, int32_t pos) { return ((uint64_t)(uint32_t)tid << 32) | (uint32_t)pos; }
 
 }  // namespace
+
+// readutil.rs:347-374 get_target_cpgs: tab-split lines, col0 chrom (must be in the header), col1 start; HashSet<CpGPosition>
+static int read_cpg_set(mth_host *h, const char *cpg_set_path, std::unordered_set<uint64_t> &target) {
+    std::ifstream f(cpg_set_path);
+    if (!f) { h->last_error = "Could not read target CpG file."; return MTH_HOST_ERR_CPGSET; }
+    std::string line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        const size_t t1 = line.find('\t');
+        if (t1 == std::string::npos) { h->last_error = "malformed --cpg-set line (needs chrom<TAB>start): " + line; return MTH_HOST_ERR_CPGSET; }
+        const size_t t2 = line.find('\t', t1 + 1);
+        const std::string chrom = line.substr(0, t1);
+        const std::string num = line.substr(t1 + 1, t2 == std::string::npos ? std::string::npos : t2 - t1 - 1);
+        int32_t pos = 0;
+        const auto r = std::from_chars(num.data(), num.data() + num.size(), pos);
+        if (r.ec != std::errc() || r.ptr != num.data() + num.size()) { h->last_error = "bad start in --cpg-set: " + line; return MTH_HOST_ERR_CPGSET; }
+        const auto it = h->name2tid.find(chrom);
+        if (it == h->name2tid.end()) { h->last_error = "unknown contig in --cpg-set: " + chrom; return MTH_HOST_ERR_CPGSET; }
+        target.insert(site_key(it->second, pos));
+    }
+    return MTH_HOST_OK;
+}
 
 extern "C" {
 
@@ -82,28 +105,11 @@ int mth_host_decode(mth_host_t *h, const char *cpg_set_path) {
     h->tid.clear(); h->start.clear(); h->end.clear(); h->mapq.clear(); h->fwd.clear();
     h->cpg_off.assign(1, 0); h->cpg_pos.clear(); h->cpg_rel.clear();
 
-    // readutil.rs:347-374 get_target_cpgs: tab-split lines, col0 chrom (must be in the header),
-    // col1 start; HashSet<CpGPosition>
     bool have_set = false;
     std::unordered_set<uint64_t> target;
     if (cpg_set_path) {
-        std::ifstream f(cpg_set_path);
-        if (!f) { h->last_error = "Could not read target CpG file."; return MTH_HOST_ERR_CPGSET; }
-        std::string line;
-        while (std::getline(f, line)) {
-            if (!line.empty() && line.back() == '\r') line.pop_back();
-            const size_t t1 = line.find('\t');
-            if (t1 == std::string::npos) { h->last_error = "malformed --cpg-set line (needs chrom<TAB>start): " + line; return MTH_HOST_ERR_CPGSET; }
-            const size_t t2 = line.find('\t', t1 + 1);
-            const std::string chrom = line.substr(0, t1);
-            const std::string num = line.substr(t1 + 1, t2 == std::string::npos ? std::string::npos : t2 - t1 - 1);
-            int32_t pos = 0;
-            const auto r = std::from_chars(num.data(), num.data() + num.size(), pos);
-            if (r.ec != std::errc() || r.ptr != num.data() + num.size()) { h->last_error = "bad start in --cpg-set: " + line; return MTH_HOST_ERR_CPGSET; }
-            const auto it = h->name2tid.find(chrom);
-            if (it == h->name2tid.end()) { h->last_error = "unknown contig in --cpg-set: " + chrom; return MTH_HOST_ERR_CPGSET; }
-            target.insert(site_key(it->second, pos));
-        }
+        const int rc = read_cpg_set(h, cpg_set_path, target);
+        if (rc) return rc;
         have_set = true;
     }
 
@@ -119,6 +125,17 @@ int mth_host_decode(mth_host_t *h, const char *cpg_set_path) {
         h->last_error = "Error reading BAM record. " + err;
         return MTH_HOST_ERR_FORMAT;
     }
+    return MTH_HOST_OK;
+}
+
+int mth_host_cpg_set_keys(mth_host_t *h, const char *cpg_set_path, const uint64_t **keys, uint64_t *n_keys) {
+    if (!h || !cpg_set_path || !keys || !n_keys) return MTH_HOST_ERR_INVALID;
+    std::unordered_set<uint64_t> target;
+    const int rc = read_cpg_set(h, cpg_set_path, target);
+    if (rc) return rc;
+    h->cpg_keys.assign(target.begin(), target.end());
+    std::sort(h->cpg_keys.begin(), h->cpg_keys.end());
+    *keys = h->cpg_keys.data(); *n_keys = h->cpg_keys.size();
     return MTH_HOST_OK;
 }
 

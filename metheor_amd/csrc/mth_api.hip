@@ -173,7 +173,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->st_start, &ctx->st_end, &ctx->st_mapq, &ctx->st_fwd, &ctx->st_off, &ctx->st_pos,
                       &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_bucket, &ctx->scratch, &ctx->dec_raw, &ctx->dec_recoff, &ctx->dec_tid, &ctx->dec_start, &ctx->dec_end,
-                      &ctx->dec_mapq, &ctx->dec_fwd, &ctx->dec_n, &ctx->dec_off, &ctx->dec_pos, &ctx->dec_rel, &ctx->dec_blk, &ctx->dec_off32, &ctx->dec_runs, &ctx->dec_xm,
+                      &ctx->dec_mapq, &ctx->dec_fwd, &ctx->dec_n, &ctx->dec_off, &ctx->dec_pos, &ctx->dec_rel, &ctx->dec_blk, &ctx->dec_off32, &ctx->dec_runs, &ctx->dec_xm, &ctx->dec_filter,
                       &ctx->inf_file, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff,
                       &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
                       &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,

@@ -43,7 +43,9 @@ struct mth_ctx {
     // per-batch work buffers
     mth::DevBuf idx, tile_cnt, tile_bucket, scratch, batch_cnt;
     // device-side BAM record decode (mth_decode.hip): staged input, decoded SoA, scan scratch, one batch's 32-bit offsets
-    mth::DevBuf dec_raw, dec_recoff, dec_tid, dec_start, dec_end, dec_mapq, dec_fwd, dec_n, dec_off, dec_pos, dec_rel, dec_blk, dec_off32, dec_runs, dec_xm;
+    mth::DevBuf dec_raw, dec_recoff, dec_tid, dec_start, dec_end, dec_mapq, dec_fwd, dec_n, dec_off, dec_pos, dec_rel, dec_blk, dec_off32, dec_runs, dec_xm, dec_filter;
+    bool dec_filter_on = false;
+    uint64_t dec_filter_n = 0;
     uint64_t dec_reads = 0, dec_cpgs = 0;
     // device-side BGZF inflate + per-block record walk (mth_inflate.hip)
     mth::DevBuf inf_file, inf_tab, inf_raw, inf_cnt, inf_base, inf_recoff;

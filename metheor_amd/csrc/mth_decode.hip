@@ -31,6 +31,8 @@ struct DecArgs {
     uint32_t *cpg_pos;
     uint16_t *cpg_rel;
     uint32_t *err;                // DevState.err
+    const unsigned long long *filt;   // --cpg-set: sorted keys tid << 32 | pos, or nullptr (no filter)
+    uint64_t n_filt;
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -76,6 +78,16 @@ __device__ __forceinline__ bool dev_find_xm(const uint8_t *aux, uint32_t len, co
     return false;
 }
 
+// filter_isin (readutil.rs:87-95): is (tid, pos) in the sorted key array ?
+__device__ __forceinline__ bool in_cpg_set(const unsigned long long *__restrict__ keys, uint64_t n, unsigned long long key) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && keys[lo] == key;
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_decode(const DecArgs a) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -116,8 +128,10 @@ __global__ __launch_bounds__(256) void k_decode(const DecArgs a) {
             unsigned long long w = FILL ? a.cpg_off[i] : 0ull;
             const uint8_t *cg = p + o_cigar;
             auto call = [&](const uint32_t qq, const int64_t rr, const uint8_t ch) {
+                const int32_t ap = forward ? (int32_t)rr : (int32_t)(rr - 1);
+                // --cpg-set: calls outside the set are dropped, relpos of the kept ones unchanged (readutil.rs:87-95)
+                if (a.filt && !in_cpg_set(a.filt, a.n_filt, ((unsigned long long)(uint32_t)tid << 32) | (uint32_t)ap)) return;
                 if (FILL) {
-                    const int32_t ap = forward ? (int32_t)rr : (int32_t)(rr - 1);
                     a.cpg_pos[w] = ((uint32_t)ap & 0x7fffffffu) | (ch == 'Z' ? 0x80000000u : 0u);
                     a.cpg_rel[w] = (uint16_t)qq;
                     ++w;
@@ -313,6 +327,8 @@ int decode_core(mth_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_off, uint6
     a.tid = ctx->dec_tid.as<int32_t>() + R0; a.start = ctx->dec_start.as<int32_t>() + R0; a.end = ctx->dec_end.as<int32_t>() + R0;
     a.mapq = ctx->dec_mapq.as<uint8_t>() + R0; a.fwd = ctx->dec_fwd.as<uint8_t>() + R0; a.ncpg = ctx->dec_n.as<uint32_t>(); a.xm_loc = ctx->dec_xm.as<uint2>();
     a.err = &ctx->d_state->err;
+    a.filt = ctx->dec_filter_on ? ctx->dec_filter.as<unsigned long long>() : nullptr; a.n_filt = ctx->dec_filter_n;
+    if (ctx->dec_filter_on && ctx->dec_filter_n == 0) a.filt = reinterpret_cast<const unsigned long long *>(ctx->d_state);   // empty set: drops every call
     unsigned long long total = 0;
     if (n_rec) {
         {
@@ -366,6 +382,21 @@ int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const 
     const int rc = decode_core(ctx, d_raw, d_off, n_rec, append, out);
     if (rc) return rc;
     if (mem == MTH_MEM_HOST) MTH_HIP(ctx, hipStreamSynchronize(s));   // the caller may reuse its buffers (and ours is restaged next call)
+    return MTH_OK;
+}
+
+int mth_decode_set_cpg_filter(mth_ctx_t *ctx, const uint64_t *keys_sorted, uint64_t n_keys, int enabled) {
+    if (!ctx || (enabled && n_keys && !keys_sorted)) return MTH_ERR_INVALID;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->dec_filter_on = enabled != 0;
+    ctx->dec_filter_n = enabled ? n_keys : 0;
+    if (enabled && n_keys) {
+        for (uint64_t i = 1; i < n_keys; ++i)
+            if (keys_sorted[i - 1] >= keys_sorted[i]) return fail(ctx, MTH_ERR_INVALID, "cpg-set keys must be strictly ascending");
+        MTH_HIP(ctx, ctx->dec_filter.reserve((size_t)n_keys * 8, ctx->stream));
+        MTH_HIP(ctx, hipMemcpyAsync(ctx->dec_filter.p, keys_sorted, (size_t)n_keys * 8, hipMemcpyHostToDevice, ctx->stream));
+        MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return MTH_OK;
 }
 

@@ -133,3 +133,30 @@ def test_decode_to_measures_on_device(eng, tmp_path):
         r0, r1 = int(np.searchsorted(tids, t, "left")), int(np.searchsorted(tids, t, "right"))
         eng.pdr_lpmd_accumulate(eng.decoded_batch(r0, r1, t, 0, length), PdrLpmdParams(**kw))
     T_pdr.check_against_oracle(eng.pdr_fetch(), eng.lpmd_global(), reads, kw, dict())
+
+
+def test_cpg_set_filter_on_device(eng, tmp_path):
+    """--cpg-set (filter_isin, readutil.rs:87-95) applied by the decode kernel: same SoA as the oracle's filtered decode,
+    relpos preserved; an empty set drops every call; removing the filter restores the full decode"""
+    rec = _weird_records()
+    p = str(tmp_path / "weird.bam")
+    bamio.write_bam(p, rec)
+    refs, body, offs = record_stream(p)
+    full = pyoracle.Reads.decode(rec).soa()
+    pos = full["cpg_pos"] & 0x7fffffff
+    tid_of_call = np.repeat(full["tid"], np.diff(full["cpg_off"]).astype(np.int64))
+    pick = np.random.default_rng(3).random(len(pos)) < 0.3
+    sites = sorted(set(zip(tid_of_call[pick].tolist(), pos[pick].tolist())))
+    try:
+        eng.decode_set_cpg_filter(sites)
+        eng.decode_records(body, offs)
+        got = eng.decoded_fetch()
+        same_soa(got, pyoracle.Reads.decode(rec, cpg_set=sites).soa())
+        assert 0 < len(got["cpg_pos"]) < len(full["cpg_pos"]) and got["cpg_rel"].max() > 10
+        eng.decode_set_cpg_filter([])
+        eng.decode_records(body, offs)
+        assert len(eng.decoded_fetch()["cpg_pos"]) == 0
+    finally:
+        eng.decode_set_cpg_filter(None)
+    eng.decode_records(body, offs)
+    same_soa(eng.decoded_fetch(), full)
