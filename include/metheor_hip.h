@@ -225,13 +225,15 @@ int  mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const
  * inside `file`, csize = payload bytes, isize = inflated bytes (blocks with isize 0 omitted); first_byte = offset in
  * the inflated stream of these blocks where the records start (the header's uncompressed size for the first call,
  * 0 afterwards).  Replaces bamutil.rs:4-11 (htslib's reader) + readutil.rs:24-53, 323-345 for a coordinate-sorted
- * Bismark BAM.  CRC32 of the blocks is NOT verified on this path (the host reader does). */
+ * Bismark BAM.  Every inflated block is checked against its ISIZE and its CRC32 (as htslib does); a mismatch is
+ * MTH_ERR_FORMAT. */
 /* --cpg-set (get_target_cpgs / filter_isin, readutil.rs:347-374, 87-95): keep only the calls whose (tid, pos) is in the set;
  * relpos of the kept calls is unchanged.  keys_sorted = strictly ascending (uint64)tid << 32 | pos, host memory.
  * enabled != 0 with n_keys == 0 is the empty set (every call dropped, as HashSet::contains on an empty set);
  * enabled == 0 removes the filter.  Applies to the following mth_decode_records / mth_bgzf_decode calls. */
 int  mth_decode_set_cpg_filter(mth_ctx_t *ctx, const uint64_t *keys_sorted, uint64_t n_keys, int enabled);
-/* the inflate step alone: inflated bytes of the given blocks, concatenated, copied to dst_host (may be NULL); *n_out = size */
+/* the inflate step alone: inflated bytes of the given blocks, concatenated, copied to dst_host (may be NULL); *n_out = size.
+ * The 4 bytes after each payload (the gzip trailer's CRC32) must lie inside the file bytes given: they are verified. */
 int  mth_bgzf_inflate(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
                       const uint32_t *isize, uint64_t n_blocks, void *dst_host, uint64_t *n_out);
 int  mth_bgzf_decode(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,

@@ -287,7 +287,7 @@ bool load_bgzf_on_device(Input &in) {
         std::vector<uint64_t> rel((size_t)(b1 - b0));
         const uint64_t base = b1 > b0 ? bz.coff[b0] : 0;
         for (uint64_t k = b0; k < b1; ++k) rel[(size_t)(k - b0)] = bz.coff[k] - base;
-        const uint64_t nbytes = b1 > b0 ? bz.coff[b1 - 1] + bz.csize[b1 - 1] - base : 0;
+        const uint64_t nbytes = b1 > b0 ? bz.coff[b1 - 1] + bz.csize[b1 - 1] + 8 - base : 0;   // incl. the last block's CRC32 + ISIZE trailer
         const uint64_t first_byte = std::min<uint64_t>(hdr_left, ubytes);
         if (b1 > b0 && hdr_left > ubytes && b1 < bz.n_blocks) { hdr_left -= ubytes; b0 = b1; continue; }   // a chunk made of header only
         mth_decoded_t d;

@@ -11,7 +11,7 @@ namespace mth {
 static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_gather",
                                           "k_quartet_bound", "k_quartet_insert", "k_quartet_emit",
                                           "k_mhl_walk", "k_mhl_walk_big", "k_mhl_emit", "k_pdr_walk",
-                                          "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_decode", "k_inflate"};
+                                          "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_decode", "k_inflate", "k_crc32"};
 
 int fail(mth_ctx *ctx, int status, const char *what, hipError_t e) {
     if (ctx) {
@@ -72,7 +72,8 @@ int sync_and_check(mth_ctx *ctx) {
     if (e & ERRB_SPAN) return fail(ctx, MTH_ERR_SPAN, "a read spans more reference bases than batch.max_span");
     if (e & ERRB_RANGE) return fail(ctx, MTH_ERR_RANGE, "CpG position outside the declared range");
     if (e & ERRB_CAPACITY) return fail(ctx, MTH_ERR_CAPACITY, "on-chip capacity exceeded");
-    if (e & ERRB_FORMAT) return fail(ctx, MTH_ERR_FORMAT, "malformed BAM record (block_size / field lengths inconsistent)");
+    if (e & ERRB_CRC) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block (CRC32 mismatch)");
+    if (e & ERRB_FORMAT) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block or malformed BAM record (DEFLATE / ISIZE / block_size / field lengths inconsistent)");
     if (e & ERRB_NOXM) return fail(ctx, MTH_ERR_FORMAT, "a record has no XM:Z tag (the reference panics: Error reading XM tag)");
     if (e & ERRB_UNALIGNED) return fail(ctx, MTH_ERR_UNALIGNED, "a BAM record straddles two BGZF blocks: the per-block device walk does not apply (use the host walk)");
     return MTH_OK;
@@ -174,7 +175,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     for (DevBuf *b : {&ctx->st_start, &ctx->st_end, &ctx->st_mapq, &ctx->st_fwd, &ctx->st_off, &ctx->st_pos,
                       &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_bucket, &ctx->scratch, &ctx->dec_raw, &ctx->dec_recoff, &ctx->dec_tid, &ctx->dec_start, &ctx->dec_end,
                       &ctx->dec_mapq, &ctx->dec_fwd, &ctx->dec_n, &ctx->dec_off, &ctx->dec_pos, &ctx->dec_rel, &ctx->dec_blk, &ctx->dec_off32, &ctx->dec_runs, &ctx->dec_xm, &ctx->dec_filter,
-                      &ctx->inf_file, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff,
+                      &ctx->inf_file, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff, &ctx->crc_mat,
                       &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
                       &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
                       &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_aux, &ctx->w_flags,

@@ -26,6 +26,7 @@ enum : uint32_t {
     ERRB_CAPACITY = 1u << 3,
     ERRB_FORMAT = 1u << 5,     // device record decode: malformed BAM record
     ERRB_NOXM = 1u << 6,       // device record decode: record without XM:Z
+    ERRB_CRC = 1u << 8,        // device inflate: CRC32 of an inflated BGZF block does not match its trailer
     ERRB_UNALIGNED = 1u << 7,  // device record walk: a record straddles two BGZF blocks (take the host walk)
 };
 
@@ -45,6 +46,6 @@ struct SiteRec {  // per-tile scratch row
     uint32_t n_conc, n_disc, pad;
 };
 
-enum KernelId { K_INDEX = 0, K_TILE, K_GATHER, K_QBOUND, K_QINSERT, K_QEMIT, K_MHLWALK, K_MHLWALKBIG, K_MHLEMIT, K_PDRWALK, K_FDRPWALK, K_FDRPEMIT, K_PAIRS, K_DECODE, K_INFLATE, K_NUM };
+enum KernelId { K_INDEX = 0, K_TILE, K_GATHER, K_QBOUND, K_QINSERT, K_QEMIT, K_MHLWALK, K_MHLWALKBIG, K_MHLEMIT, K_PDRWALK, K_FDRPWALK, K_FDRPEMIT, K_PAIRS, K_DECODE, K_INFLATE, K_CRC, K_NUM };
 
 }  // namespace mth

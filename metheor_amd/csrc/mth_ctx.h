@@ -48,7 +48,7 @@ struct mth_ctx {
     uint64_t dec_filter_n = 0;
     uint64_t dec_reads = 0, dec_cpgs = 0;
     // device-side BGZF inflate + per-block record walk (mth_inflate.hip)
-    mth::DevBuf inf_file, inf_tab, inf_raw, inf_cnt, inf_base, inf_recoff;
+    mth::DevBuf inf_file, inf_tab, inf_raw, inf_cnt, inf_base, inf_recoff, crc_mat;
     // results (PDR columns)
     mth::DevBuf out_pos, out_pdr, out_nc, out_nd;
     uint64_t out_cap = 0;        // rows

@@ -232,6 +232,78 @@ __global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
     if (bad && lane == 0) atomicOr(a.err, (uint32_t)ERRB_FORMAT);
 }
 
+
+// ---- CRC32 of the inflated blocks (gzip trailer; htslib and the host reader verify it, so does this path) ----------
+// One wave per block.  Raw CRC (init 0, no final xor) is linear and ignores leading zeros, so the block is cut into 64
+// chunks of 1 KiB aligned to its END (the first chunks of a short block are empty); lane = chunk, slicing-by-4 table
+// CRC from LDS tables, then a 6-level tree R(A||B) = shift_|B|(R(A)) ^ R(B) with precomputed GF(2) operators for
+// "append 2^k zero bytes" (crc_mat[k][32]).  The standard CRC is ~(R0(data) ^ shift_L(0xffffffff)).
+struct CrcArgs {
+    const uint8_t *raw;             // inflated stream
+    const uint8_t *file;            // compressed file (the stored CRC follows each payload)
+    const uint64_t *coff, *uoff;
+    const uint32_t *csize, *isize;
+    const uint32_t *mat;            // [17][32]: operator for 2^k zero bytes, k = 0..16
+    uint32_t n_blocks;
+    uint32_t *err;
+};
+__device__ __forceinline__ uint32_t gf2_apply(const uint32_t *__restrict__ m, uint32_t v) {
+    uint32_t s = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) s ^= ((v >> i) & 1u) ? m[i] : 0u;
+    return s;
+}
+__global__ __launch_bounds__(64) void k_crc32(const CrcArgs a) {
+    __shared__ uint32_t tab[4][256];          // slicing-by-4: tab[j][b] = CRC of byte b followed by j zero bytes
+    __shared__ uint32_t smat[17 * 32];
+    const uint32_t blk = blockIdx.x;
+    if (blk >= a.n_blocks) return;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = (uint32_t)i;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+        tab[0][i] = c;
+    }
+    for (int i = lane; i < 17 * 32; i += 64) smat[i] = a.mat[i];
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) {
+        const uint32_t c1 = (tab[0][i] >> 8) ^ tab[0][tab[0][i] & 0xffu];
+        const uint32_t c2 = (c1 >> 8) ^ tab[0][c1 & 0xffu];
+        tab[1][i] = c1; tab[2][i] = c2; tab[3][i] = (c2 >> 8) ^ tab[0][c2 & 0xffu];
+    }
+    __syncthreads();
+    const uint32_t L = a.isize[blk];
+    const uint8_t *p = a.raw + a.uoff[blk];
+    const int64_t beg = (int64_t)L - (int64_t)(64 - lane) * 1024;
+    uint32_t c = 0;
+    int64_t i = beg < 0 ? 0 : beg;
+    const int64_t end = beg + 1024;                          // <= 0 for the empty leading chunks of a short block
+    for (; i < end && ((end - i) & 3); ++i) c = tab[0][(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    for (; i < end; i += 4) {                                // four bytes per step: one load, four independent lookups
+        uint32_t w;
+        __builtin_memcpy(&w, p + i, 4);
+        c ^= w;
+        c = tab[3][c & 0xffu] ^ tab[2][(c >> 8) & 0xffu] ^ tab[1][(c >> 16) & 0xffu] ^ tab[0][c >> 24];
+    }
+    // tree: at level k lanes are grouped in runs of 2^(k+1); the left half's CRC is shifted by the right half's length
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)c, 1 << k, 64);
+        const bool right = (lane >> k) & 1;                      // this lane holds the right half of its pair
+        const uint32_t left_crc = right ? other : c, right_crc = right ? c : other;
+        c = gf2_apply(smat + (10 + k) * 32, left_crc) ^ right_crc;   // right half is 1024 << k bytes long
+    }
+    if (lane == 0) {
+        uint32_t init = 0xffffffffu;                              // shift_L(0xffffffff): binary decomposition of L
+        for (int k = 0; k < 17; ++k) if ((L >> k) & 1u) init = gf2_apply(smat + k * 32, init);
+        const uint32_t crc = ~(c ^ init);
+        uint32_t want;
+        __builtin_memcpy(&want, a.file + a.coff[blk] + a.csize[blk], 4);
+        if (crc != want) atomicOr(a.err, (uint32_t)ERRB_CRC);
+    }
+}
+
 // ---- per-block record walk ------------------------------------------------------------------------------
 struct WalkBArgs {
     const uint8_t *raw;            // inflated stream
@@ -272,6 +344,18 @@ __global__ __launch_bounds__(256) void k_block_walk(const WalkBArgs a) {
 
 using namespace mth;
 
+// GF(2) operators for appending 2^k zero bytes to a raw CRC-32 (zlib's crc32_combine construction)
+static void crc_zero_operators(uint32_t (*mat)[32]) {
+    auto times = [](const uint32_t *m, uint32_t v) { uint32_t s = 0; for (int i = 0; v; v >>= 1, ++i) if (v & 1u) s ^= m[i]; return s; };
+    uint32_t bit[32], t[32];
+    bit[0] = 0xedb88320u;                               // one zero BIT
+    for (int n = 1; n < 32; ++n) bit[n] = 1u << (n - 1);
+    auto square = [&](uint32_t *dst, const uint32_t *src) { for (int n = 0; n < 32; ++n) dst[n] = times(src, src[n]); };
+    square(t, bit); square(bit, t); square(t, bit);     // 2, 4, 8 bits: t = one zero byte
+    for (int n = 0; n < 32; ++n) mat[0][n] = t[n];
+    for (int k = 1; k < 17; ++k) square(mat[k], mat[k - 1]);
+}
+
 // stage the file bytes + block table and launch the inflate; on return d_uoff / d_isize point at the device table
 static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
                           const uint32_t *isize, uint64_t n_blocks, uint64_t &total, uint64_t *&d_uoff, uint32_t *&d_isize) {
@@ -306,8 +390,24 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
         InflArgs ia{};
         ia.file = ctx->inf_file.as<uint8_t>(); ia.coff = d_coff; ia.csize = d_csize; ia.isize = d_isize; ia.uoff = d_uoff;
         ia.n_blocks = (uint32_t)nb; ia.out = ctx->inf_raw.as<uint8_t>(); ia.err = &ctx->d_state->err;
-        LaunchTimer lt(ctx, K_INFLATE);
-        hipLaunchKernelGGL(k_inflate, dim3((uint32_t)nb), dim3(64), 0, s, ia);
+        {
+            LaunchTimer lt(ctx, K_INFLATE);
+            hipLaunchKernelGGL(k_inflate, dim3((uint32_t)nb), dim3(64), 0, s, ia);
+        }
+        // CRC32 of every inflated block against the gzip trailer (the 4 bytes after the payload)
+        if (!ctx->crc_mat.p) {
+            uint32_t mat[17][32];
+            crc_zero_operators(mat);
+            MTH_HIP(ctx, ctx->crc_mat.reserve(sizeof mat, s));
+            MTH_HIP(ctx, hipMemcpy(ctx->crc_mat.p, mat, sizeof mat, hipMemcpyHostToDevice));
+        }
+        for (size_t i = 0; i < nb; ++i)
+            if (coff[i] + (uint64_t)csize[i] + 4 > n_bytes) return fail(ctx, MTH_ERR_INVALID, "BGZF block table: the CRC trailer of a block lies outside the file bytes");
+        CrcArgs ca{};
+        ca.raw = ctx->inf_raw.as<uint8_t>(); ca.file = ctx->inf_file.as<uint8_t>(); ca.coff = d_coff; ca.uoff = d_uoff;
+        ca.csize = d_csize; ca.isize = d_isize; ca.mat = ctx->crc_mat.as<uint32_t>(); ca.n_blocks = (uint32_t)nb; ca.err = &ctx->d_state->err;
+        LaunchTimer lt(ctx, K_CRC);
+        hipLaunchKernelGGL(k_crc32, dim3((uint32_t)nb), dim3(64), 0, s, ca);
     }
     return MTH_OK;
 }

@@ -22,13 +22,14 @@ def eng():
 
 
 def deflate_blocks(chunks, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
-    """raw DEFLATE payloads of the chunks, concatenated -> (file bytes, coff, csize, isize)"""
+    """raw DEFLATE payloads of the chunks, each followed by the gzip trailer (CRC32, ISIZE), concatenated
+    -> (file bytes, coff, csize, isize)"""
     out, coff, csize, isize = bytearray(), [], [], []
     for c in chunks:
         co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
         z = co.compress(bytes(c)) + co.flush()
         coff.append(len(out)); csize.append(len(z)); isize.append(len(c))
-        out += z
+        out += z + struct.pack("<II", zlib.crc32(bytes(c)) & 0xffffffff, len(c))
     return bytes(out), np.array(coff, np.uint64), np.array(csize, np.uint32), np.array(isize, np.uint32)
 
 
@@ -77,6 +78,16 @@ def test_corrupt_payload_is_reported(eng):
         eng.bgzf_inflate(fb, coff, csize, wrong)
     eng.reset()
     assert eng.bgzf_inflate(fb, coff, csize, isize).tobytes() == data
+    # a flipped DATA byte inside a stored block: the DEFLATE stream and ISIZE stay valid, only the CRC32 catches it
+    rnd = np.random.default_rng(8).integers(0, 256, size=50_000, dtype=np.uint8).tobytes()
+    fb0, c0, s0, i0 = deflate_blocks([rnd, b"tail" * 100], 0)
+    bad0 = bytearray(fb0)
+    bad0[1000] ^= 0x01
+    with pytest.raises(MthError) as e:
+        eng.bgzf_inflate(bytes(bad0), c0, s0, i0)
+    assert e.value.status == -10 and "CRC32" in str(e.value)
+    eng.reset()
+    assert eng.bgzf_inflate(fb0, c0, s0, i0).tobytes() == rnd + b"tail" * 100
 
 
 def block_table(path):
