@@ -218,15 +218,6 @@ typedef struct {
 } mth_decoded_t;
 int  mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const uint64_t *rec_off, uint64_t n_rec,
                         int mem, int append, mth_decoded_t *out);
-/* The whole step on the device: BGZF inflate (one wave per block, RFC 1951 stored / fixed / dynamic blocks, checked
- * against ISIZE), record boundaries (one thread per block; htslib-family writers never let a record straddle a BGZF
- * block, which is verified -- MTH_ERR_UNALIGNED otherwise, nothing is appended then), record + XM decode as above.
- * `file` = n_bytes of the BAM file in HOST memory covering the blocks; per block: coff = offset of its DEFLATE payload
- * inside `file`, csize = payload bytes, isize = inflated bytes (blocks with isize 0 omitted); first_byte = offset in
- * the inflated stream of these blocks where the records start (the header's uncompressed size for the first call,
- * 0 afterwards).  Replaces bamutil.rs:4-11 (htslib's reader) + readutil.rs:24-53, 323-345 for a coordinate-sorted
- * Bismark BAM.  Every inflated block is checked against its ISIZE and its CRC32 (as htslib does); a mismatch is
- * MTH_ERR_FORMAT. */
 /* --cpg-set (get_target_cpgs / filter_isin, readutil.rs:347-374, 87-95): keep only the calls whose (tid, pos) is in the set;
  * relpos of the kept calls is unchanged.  keys_sorted = strictly ascending (uint64)tid << 32 | pos, host memory.
  * enabled != 0 with n_keys == 0 is the empty set (every call dropped, as HashSet::contains on an empty set);
@@ -236,6 +227,15 @@ int  mth_decode_set_cpg_filter(mth_ctx_t *ctx, const uint64_t *keys_sorted, uint
  * The 4 bytes after each payload (the gzip trailer's CRC32) must lie inside the file bytes given: they are verified. */
 int  mth_bgzf_inflate(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
                       const uint32_t *isize, uint64_t n_blocks, void *dst_host, uint64_t *n_out);
+/* The whole step on the device: BGZF inflate (one wave per block, RFC 1951 stored / fixed / dynamic blocks, checked
+ * against ISIZE), record boundaries (one thread per block; htslib-family writers never let a record straddle a BGZF
+ * block, which is verified -- MTH_ERR_UNALIGNED otherwise, nothing is appended then), record + XM decode as above.
+ * `file` = n_bytes of the BAM file in HOST memory covering the blocks; per block: coff = offset of its DEFLATE payload
+ * inside `file`, csize = payload bytes, isize = inflated bytes (blocks with isize 0 omitted); first_byte = offset in
+ * the inflated stream of these blocks where the records start (the header's uncompressed size for the first call,
+ * 0 afterwards).  Replaces bamutil.rs:4-11 (htslib's reader) + readutil.rs:24-53, 323-345 for a coordinate-sorted
+ * Bismark BAM.  Every inflated block is checked against its ISIZE and its CRC32 (as htslib does); a mismatch is
+ * MTH_ERR_FORMAT. */
 int  mth_bgzf_decode(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
                      const uint32_t *isize, uint64_t n_blocks, uint64_t first_byte, int append, mth_decoded_t *out);
 /* copy the decoded arrays to the host (any pointer may be NULL) */
