@@ -160,3 +160,41 @@ def test_straddling_records_are_refused(eng, tmp_path):
         eng.bgzf_decode(fb, coff, csize, isize, hbytes)
     assert e.value.status == -11
     eng.reset()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_mixed_blocks(eng, seed):
+    """many blocks in ONE call, each with its own random size, content model, zlib level and strategy (stored / fixed /
+    dynamic mixed; short and long codes; literal-only and match-only blocks) -- byte-identical to the input"""
+    rng = np.random.default_rng(7000 + seed)
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]
+    out, coff, csize, isize, want = bytearray(), [], [], [], []
+    for _ in range(150):
+        n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 258, 259, 4096, 65279, 65280])) if rng.random() < 0.3 else int(rng.integers(1, 65281))
+        kind = int(rng.integers(0, 7))
+        if kind == 0:
+            c = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        elif kind == 1:
+            c = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=n, p=[0.3, 0.2, 0.2, 0.29, 0.01]).tobytes()
+        elif kind == 2:                                   # runs of random length and byte
+            parts = []
+            while sum(map(len, parts)) < n:
+                parts.append(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 700)))
+            c = b"".join(parts)[:n]
+        elif kind == 3:                                   # repeats at assorted distances (1 .. 32767)
+            base = rng.integers(0, 256, size=int(rng.integers(1, 40000)), dtype=np.uint8).tobytes()
+            c = (base * (n // len(base) + 1))[:n]
+        elif kind == 4:                                   # heavily skewed alphabet: code lengths up to 15
+            p = 0.5 ** np.arange(1, 41); p /= p.sum()
+            c = rng.choice(np.arange(40, dtype=np.uint8), size=n, p=p).tobytes()
+        elif kind == 5:
+            c = (b"XM:Z:" + b"." * 40 + b"z..Z" + b"\0" + bytes(rng.integers(33, 74, size=30, dtype=np.uint8))) * (n // 80 + 1)
+            c = c[:n]
+        else:
+            c = bytes(n)
+        co = zlib.compressobj(int(rng.choice([0, 1, 4, 6, 9])), zlib.DEFLATED, -15, int(rng.integers(1, 10)), int(rng.choice(strategies)))
+        z = co.compress(c) + co.flush()
+        coff.append(len(out)); csize.append(len(z)); isize.append(len(c)); want.append(c)
+        out += z + struct.pack("<II", zlib.crc32(c) & 0xffffffff, len(c)) + bytes(int(rng.integers(0, 5)))   # arbitrary payload alignment
+    got = eng.bgzf_inflate(bytes(out), np.array(coff, np.uint64), np.array(csize, np.uint32), np.array(isize, np.uint32)).tobytes()
+    assert got == b"".join(want)
