@@ -2,7 +2,7 @@
 """bench.py -- M reads/s of the fused PDR+LPMD hot path on MI355X (BASELINE.json metric).
 
 A "step" is one complete pass of the hot path over one resident batch: reset -> linear index ->
-tile accumulate (PDR site counters + LPMD pair counts) -> scan -> gather (sorted rows + f32 PDR)
+tile accumulate (PDR site counters + LPMD pair counts) -> gather (sorted rows + f32 PDR, batch totals)
 [-> RCCL all-reduce of the 4 LPMD counters when N > 1].  Workload at every N: BASELINE config 2,
 "S-chr19-10M" (10 M synthetic 150-bp reads on a 58.6-Mbp contig) PER GPU -- weak scaling, the
 contig/region sharding of SURVEY 8(e): rank r owns contig r; per-site rows are disjoint by
