@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
             if (sym < 0) { bad = true; break; }
             if (sym < 256) {
                 if (pos >= isize) { bad = true; break; }
-                if (lane == 0) out0[pos] = (uint8_t)sym;
+                out0[pos] = (uint8_t)sym;          // every lane, same address, same value: no exec-mask juggling for lane 0
                 ++pos;
                 continue;
             }
