@@ -245,6 +245,27 @@ void check(mth_ctx_t *ctx, int rc) {
     die(m);
 }
 
+// HIP initialisation takes 70-140 ms: on the device load path it runs on its own thread while the main thread opens the
+// file, parses --cpg-set and builds the BGZF block table.  Errors are reported by whoever joins (file errors first).
+struct CtxFuture {
+    std::thread th;
+    mth_ctx_t *ctx = nullptr;
+    int rc = MTH_OK;
+    void start() {
+        th = std::thread([this] {
+            Phase ph("device context (overlapped)");
+            const char *dev = getenv("METHEOR_DEVICE");
+            rc = mth_ctx_create(dev ? atoi(dev) : 0, &ctx);
+        });
+    }
+    void wait() { if (th.joinable()) th.join(); }
+    mth_ctx_t *get() {
+        wait();
+        if (rc != MTH_OK) die(std::string("metheor (MI355X path): ") + mth_strerror(rc));
+        return ctx;
+    }
+};
+
 mth_ctx_t *make_ctx() {
     Phase ph("device context");
     mth_ctx_t *ctx = nullptr;
@@ -307,11 +328,15 @@ bool load_bgzf_on_device(Input &in) {
     return true;
 }
 
-bool load_on_device(Input &in, const char *cpg_set) {
+bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
     const uint64_t *keys = nullptr;
     uint64_t n_keys = 0;
-    if (cpg_set && mth_host_cpg_set_keys(in.h, cpg_set, &keys, &n_keys) != 0) die(mth_host_last_error(in.h));   // readutil.rs:356
-    in.ctx = make_ctx();
+    if (cpg_set && mth_host_cpg_set_keys(in.h, cpg_set, &keys, &n_keys) != 0) { cf.wait(); die(mth_host_last_error(in.h)); }   // readutil.rs:356
+    {
+        mth_host_bgzf_t bz;                      // builds (and caches) the block table while the context is being created
+        if (!getenv("METHEOR_HOST_INFLATE") && mth_host_bgzf_blocks(in.h, &bz) != 0) { cf.wait(); die(mth_host_last_error(in.h)); }
+    }
+    in.ctx = cf.get();
     if (cpg_set) check(in.ctx, mth_decode_set_cpg_filter(in.ctx, keys, n_keys, 1));
     const bool on_device = !getenv("METHEOR_HOST_INFLATE") && load_bgzf_on_device(in);
     if (!on_device) {
@@ -353,9 +378,12 @@ Input load(const std::string &path, const char *cpg_set) {
     Phase ph_all("load: open+decode+batch");
     Input in;
     char err[1024];
-    if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) die(err);    // bamutil.rs:7-9
-    if (!getenv("METHEOR_HOST_DECODE")) {
-        if (load_on_device(in, cpg_set)) return in;
+    const bool try_device = !getenv("METHEOR_HOST_DECODE");
+    CtxFuture cf;
+    if (try_device) cf.start();
+    if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) { cf.wait(); die(err); }    // bamutil.rs:7-9
+    if (try_device) {
+        if (load_on_device(in, cpg_set, cf)) return in;
         in.contigs.clear();
     }
     {

@@ -4,7 +4,7 @@ python tools/e2e_repeat.py <bam> <sub> <reps> NAME=VAL[,NAME=VAL] ..."""
 import os, statistics, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 bam, sub, reps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-exe = os.path.join(ROOT, "metheor_amd", "metheor")
+exe = os.environ.get("METHEOR_EXE") or os.path.join(ROOT, "metheor_amd", "metheor")
 for spec in sys.argv[4:]:
     env = dict(os.environ)
     if spec != "-":
