@@ -121,11 +121,11 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             unsigned long long mC = 0, mA = 0, mM = 0;
             bool compact = false;
             // (halo reads of a region slice call positions outside the region; those are not in the site list)
-            if (!win_check && c - 200 >= a.region_beg && c + 200 < a.region_end) {
+            if (!win_check && (int64_t)c - 200 >= a.region_beg && (int64_t)c + 200 < a.region_end) {
                 const uint32_t j0 = (j >= 32u) ? min(j - 32u, n_sites > 64u ? n_sites - 64u : 0u) : 0u;
                 const int32_t sp = (j0 + (uint32_t)lane < n_sites) ? a.site_pos[j0 + lane] : 0x7fffffff;
                 const int32_t sp_lo = __builtin_amdgcn_readlane(sp, 0), sp_hi = __builtin_amdgcn_readlane(sp, 63);
-                compact = (j0 == 0u || sp_lo < c - 200) && sp_hi > c + 200;       // absent sites read as +inf
+                compact = (j0 == 0u || sp_lo < c - 200) && (int64_t)sp_hi > (int64_t)c + 200;       // absent sites read as +inf
                 if (compact) {
                     const uint32_t rel = (uint32_t)(sp - (c - FD_WIN));
                     if (rel <= 2u * FD_WIN) bit_of[rel] = (uint8_t)lane;

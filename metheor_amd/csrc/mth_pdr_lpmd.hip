@@ -415,15 +415,16 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
     const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= ntiles) return;
     const int32_t T0 = a.region_beg + (int32_t)(t * W);
-    const int32_t T1 = min(T0 + W, a.region_end);
+    // (T0 + W can exceed INT32_MAX on a contig of ~2^31 bp: bounds in 64-bit / unsigned arithmetic)
+    const int32_t T1 = (int32_t)min((int64_t)T0 + W, (int64_t)a.region_end);
 
     // candidate reads: start in [T0 - max_span + 1, T0 + W]  (a call sits in [start-1, end]).
     // Both bounds are clamped to n_reads: a batch that failed validation in k_build_index (stale or
     // partial index) then only ever touches in-bounds reads, and its rows are discarded because the
     // getters report the error.  (An explicit load of the error flag here cost every tile a dependent
     // round trip before its first useful load.)
-    const uint32_t lo = min(a.idx[(uint32_t)(T0 - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
-    const uint32_t hi = min(a.idx[((uint32_t)(T0 + W - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+    const uint32_t lo = min(a.idx[((uint32_t)T0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
+    const uint32_t hi = min(a.idx[(((uint32_t)T0 + (uint32_t)W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
     uint32_t rows;
     if (hi - lo <= 65535u) {
         // only a tile that holds the batch's last reads can have a read whose NB-slot window runs past the arrays
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
         else
             rows = tile_pass<W, B, NB, RelT, false, true>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
     } else {
-        const int32_t Tm = min(T0 + W / 2, T1);
+        const int32_t Tm = (int32_t)min((int64_t)T0 + W / 2, (int64_t)T1);
         rows = tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
         __syncthreads();
         rows += tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off);

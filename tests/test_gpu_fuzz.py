@@ -112,3 +112,41 @@ def test_random_scenario_all_measures(eng, seed):
         from metheor_amd import shard
         fregions = [[(b, e) for (b, e) in r] for r in regions]
     T_fdrp.check(T_fdrp.run_device(eng, fcs, fk, regions=fregions), freads, fk)
+
+
+def shift_contig(c, off):
+    """the same reads on a contig whose coordinates start `off` bp further right"""
+    d = dict(c)
+    d["read_start"] = (c["read_start"].astype(np.int64) + off).astype(np.int32)
+    d["read_end"] = (c["read_end"].astype(np.int64) + off).astype(np.int32)
+    pos = (c["cpg_pos"] & np.uint32(0x7fffffff)).astype(np.int64) + off
+    d["cpg_pos"] = (pos.astype(np.uint32) | (c["cpg_pos"] & np.uint32(0x80000000))).astype(np.uint32)
+    d["length"] = int(c["length"] + off)
+    return d
+
+
+@pytest.mark.parametrize("seed,top", [(3, 2**31 - 1), (7, 2**31 - 1), (11, 2**30 + 5000), (12, 2**30 - 3000), (21, 2**29 + 77)])
+def test_high_coordinates(eng, seed, top):
+    """positions up to the top of the int32 range (and around 2^30 / 2^29, where the packed LDS addressing of the tile
+    kernel wraps by design): every measure on a region slice [length - span, length) of a contig that long"""
+    from metheor_amd import PdrLpmdParams, synth
+    rng, cs, _, read_len = scenario(seed)
+    c = cs[0]
+    off = top - c["length"]
+    hc = shift_contig(c, off)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(hc))
+    region = [[(off - 1000, hc["length"])]]          # the batch is a region far from 0 (the index origin sits just below it)
+    mq = 10
+    pk = dict(min_depth=2, min_cpgs=1, min_qual=mq)
+    lk = dict(min_distance=1, max_distance=40, min_qual=mq)
+    p = PdrLpmdParams(min_distance=1, max_distance=40, lpmd_min_qual=mq, **pk)
+    d, l = T_pdr.run_device(eng, [hc], p, regions=region)
+    T_pdr.check_against_oracle(d, l, reads, pk, lk)
+    assert len(d["pos"]) == 0 or int(d["pos"].max()) > top - c["length"]
+    T_pairs.check(T_pairs.run_device(eng, [hc], lk, regions=region), reads, lk)
+    T_quartet.check(T_quartet.run_device(eng, [hc], mq, 1, regions=region), reads, mq, 1)
+    mk = dict(min_depth=1, min_cpgs=1, min_qual=mq)
+    T_mhl.check(T_mhl.run_device(eng, [hc], mk, regions=region), reads, mk)
+    if read_len <= 200:
+        fk = dict(min_qual=mq, min_depth=2, max_depth=40, min_overlap=10, seed=1)
+        T_fdrp.check(T_fdrp.run_device(eng, [hc], fk, regions=region), reads, fk)
