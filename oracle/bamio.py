@@ -174,7 +174,8 @@ def write_bam(path, rec, seq_len=None, realistic=False, seed=0):
         aux = b""
         if rec.xms[i] is not None:
             assert b"\0" not in rec.xms[i], "XM:Z value must not contain NUL (record %d)" % i
-            aux += b"NMC\x00" + b"XMZ" + rec.xms[i] + b"\0" + b"XRZCT\0"
+            pre, post = rec.aux_extra[i] if getattr(rec, "aux_extra", None) else (b"NMC\x00", b"XRZCT\0")
+            aux += pre + b"XMZ" + rec.xms[i] + b"\0" + post        # aux_extra: other tags before / after XM (tests of the aux scanners)
         body = struct.pack("<iiBBHHHiiii", int(rec.tid[i]), int(rec.pos[i]), len(name), int(rec.mapq[i]), 4680,
                            len(cig), int(rec.flag[i]), qlen, -1, -1, 0)
         if realistic:

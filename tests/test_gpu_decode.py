@@ -160,3 +160,16 @@ def test_cpg_set_filter_on_device(eng, tmp_path):
         eng.decode_set_cpg_filter(None)
     eng.decode_records(body, offs)
     same_soa(eng.decoded_fetch(), full)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_aux_fields(eng, tmp_path, seed):
+    """aux fields of every BAM type (A c C s S i I f Z H, B arrays) before and after XM:Z: the device aux scanner steps over them"""
+    from tests.test_host_decode import random_aux_fields
+    rec = _weird_records()
+    rec.aux_extra = random_aux_fields(np.random.default_rng(500 + seed), len(rec))
+    p = str(tmp_path / "aux.bam")
+    bamio.write_bam(p, rec)
+    refs, body, offs = record_stream(p)
+    eng.decode_records(body, offs)
+    same_soa(eng.decoded_fetch(), pyoracle.Reads.decode(rec).soa())

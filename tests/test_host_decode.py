@@ -212,3 +212,45 @@ def test_fast_synthetic_writer_round_trip(tmp_path):
     same_soa(f.decode(), want)
     same_soa(pyoracle.Reads.decode(bamio.read_bam(p)).soa(), want)
     assert os.path.getsize(p) > 40_000 * 100        # realistic compression (> 100 B/read)
+
+
+def random_aux_fields(rng, n):
+    """n (before, after) byte strings of random BAM aux fields of every type -- A c C s S i I f Z H and B arrays of every
+    subtype -- none of them tagged XM (SAM spec 4.2.4); the decoders must step over them to find XM:Z"""
+    import struct
+
+    def field():
+        tag = bytes(rng.choice(np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWYZ", np.uint8), size=2))     # no 'X' first letter: never XM
+        t = rng.choice(list("AcCsSiIfZHB"))
+        if t == "A":
+            return tag + b"A" + bytes([int(rng.integers(33, 127))])
+        if t in "cC":
+            return tag + t.encode() + bytes([int(rng.integers(0, 256))])
+        if t in "sS":
+            return tag + t.encode() + struct.pack("<H", int(rng.integers(0, 65536)))
+        if t in "iI":
+            return tag + t.encode() + struct.pack("<I", int(rng.integers(0, 2**32)))
+        if t == "f":
+            return tag + b"f" + struct.pack("<f", float(rng.normal()))
+        if t == "Z":      # strings that look like XM strings, of lengths around the 4-byte scan granularity
+            return tag + b"Z" + bytes(rng.choice(np.frombuffer(b"zZ.xhXHMZ:", np.uint8), size=int(rng.integers(0, 40)))) + b"\0"
+        if t == "H":
+            return tag + b"H" + b"".join(b"%02X" % int(v) for v in rng.integers(0, 256, size=int(rng.integers(0, 9)))) + b"\0"
+        sub = rng.choice(list("cCsSiIf"))
+        cnt = int(rng.integers(0, 12))
+        w = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
+        return tag + b"B" + sub.encode() + struct.pack("<i", cnt) + bytes(rng.integers(0, 256, size=cnt * w, dtype=np.uint8))
+
+    return [(b"".join(field() for _ in range(int(rng.integers(0, 5)))), b"".join(field() for _ in range(int(rng.integers(0, 4)))))
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_aux_fields(tmp_path, seed):
+    rec = _weird_records()
+    rec.aux_extra = random_aux_fields(np.random.default_rng(500 + seed), len(rec))
+    p = str(tmp_path / "aux.bam")
+    bamio.write_bam(p, rec)
+    want = pyoracle.Reads.decode(rec).soa()
+    same_soa(hostapi.BamFile(p).decode(), want)
+    same_soa(pyoracle.Reads.decode(bamio.read_bam(p)).soa(), want)      # (the oracle's own loader steps over them too)
