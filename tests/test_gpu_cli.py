@@ -264,3 +264,62 @@ def test_device_decode_reports_missing_xm(golden_dir, tmp_path):
     for env in ({}, {"METHEOR_HOST_DECODE": "1"}):
         r = run_env(env, "pdr", "-i", bam, "-o", str(tmp_path / "o.tsv"))
         assert r.returncode == 101 and "Error reading XM tag in BAM record" in r.stderr, r.stderr
+
+
+def reblock_aligned(src, dst):
+    """rewrite a BAM so that every BGZF block holds whole records (what htslib writes): the header in blocks of its own,
+    then records packed greedily into <= 0xff00-byte blocks"""
+    import gzip
+    import struct
+    raw = gzip.decompress(open(src, "rb").read())
+    l_text, = struct.unpack_from("<i", raw, 4)
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, o); o += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, o); o += 8 + l_name
+    with open(dst, "wb") as fh:
+        for k in range(0, o, 0xff00):
+            fh.write(bamio._bgzf_block(raw[k:min(k + 0xff00, o)]))
+        blk = bytearray()
+        while o < len(raw):
+            bs, = struct.unpack_from("<i", raw, o)
+            r = raw[o:o + 4 + bs]
+            if blk and len(blk) + len(r) > 0xff00:
+                fh.write(bamio._bgzf_block(bytes(blk))); blk = bytearray()
+            blk += r
+            o += 4 + bs
+        if blk:
+            fh.write(bamio._bgzf_block(bytes(blk)))
+        fh.write(bamio._bgzf_block(b""))
+
+
+def test_device_inflate_path_large_header_many_contigs(tmp_path):
+    """record-aligned BAM, 3 000 contigs in the header (it spans several BGZF blocks), reads on a few of them with empty
+    contigs in between: the whole load path on the device (inflate + walk + decode), every measure's TSV == host-decoder TSV,
+    PDR also against the oracle's text"""
+    from metheor_amd import synth
+    rng = np.random.default_rng(31)
+    n_ref = 3000
+    refs = [("ctg%04d_with_a_rather_long_name" % i, 50_000 + i) for i in range(n_ref)]
+    used = [5, 6, 1200, 2999]
+    tid, pos, flag, mapq, cig, xms = [], [], [], [], [], []
+    for t in used:
+        c = synth.make_contig(t, refs[t][1], 3000, 0.04, rng)
+        r = util.contig_to_records(c, refs[t][0])
+        tid += [t] * len(r); pos += r.pos.tolist(); flag += r.flag.tolist(); mapq += r.mapq.tolist(); cig += r.cigars; xms += r.xms
+    rec = bamio.Records(refs, tid, pos, flag, mapq, cig, xms)
+    raw_bam, bam = str(tmp_path / "u.bam"), str(tmp_path / "a.bam")
+    bamio.write_bam(raw_bam, rec)
+    reblock_aligned(raw_bam, bam)
+    reads = pyoracle.Reads.decode(rec)
+    o = tmp_path / "o.tsv"
+    r = run_env({"METHEOR_TIMING": "1"}, "pdr", "-i", bam, "-o", str(o), "-d", "3", "-p", "1")
+    assert r.returncode == 0, r.stderr
+    assert "device inflate + walk + decode" in r.stderr and "host decode" not in r.stderr and "inflate + device record decode" not in r.stderr
+    assert o.read_text() == util.oracle_tsv_pdr(reads, [n for n, _ in refs], min_depth=3, min_cpgs=1)
+    for sub, extra in (("lpmd", []), ("mhl", ["-d", "3", "-p", "1"]), ("me", ["-d", "2"]), ("fdrp", ["-d", "3"]), ("qfdrp", ["-d", "3"])):
+        od, oh = tmp_path / ("d_%s.tsv" % sub), tmp_path / ("h_%s.tsv" % sub)
+        rd = run_env({}, sub, "-i", bam, "-o", str(od), *extra)
+        rh = run_env({"METHEOR_HOST_DECODE": "1"}, sub, "-i", bam, "-o", str(oh), *extra)
+        assert rd.returncode == 0 and rh.returncode == 0, (rd.stderr, rh.stderr)
+        assert sorted(od.read_text().splitlines()) == sorted(oh.read_text().splitlines()) and (sub == "lpmd" or len(od.read_text()) > 100)
