@@ -42,13 +42,14 @@ __global__ __launch_bounds__(256) void k_quartet_bound(const uint32_t *__restric
     if (threadIdx.x == 0) atomicAdd(out, ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
+constexpr uint32_t QPROBE_MAX = 1024;
 __global__ __launch_bounds__(256) void k_quartet_insert(const uint32_t *__restrict__ cpg_off,
                                                         const uint32_t *__restrict__ cpg_pos,
                                                         const uint8_t *__restrict__ mapq, uint32_t n_reads,
                                                         uint8_t min_qual, int32_t region_beg, int32_t region_end,
                                                         unsigned long long *__restrict__ keys,
                                                         uint32_t *__restrict__ hist, unsigned long long mask,
-                                                        DevState *__restrict__ st) {
+                                                        unsigned long long *__restrict__ overflow, DevState *__restrict__ st) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_reads) return;
     const uint32_t o0 = cpg_off[i], o1 = cpg_off[i + 1];
@@ -67,12 +68,17 @@ __global__ __launch_bounds__(256) void k_quartet_insert(const uint32_t *__restri
             } else {
                 const uint32_t pat = ((a >> 31) << 3) | ((b >> 31) << 2) | ((c >> 31) << 1) | (d >> 31);
                 unsigned long long h = qhash(key) & mask;
-                for (;;) {
+                // The table is sized for the DISTINCT quartets one expects (half the instances), not for the instances:
+                // a bounded probe, and a flag that makes the host redo the pass with a larger table, keep that safe.
+                uint32_t probes = 0;
+                bool placed = false;
+                while (probes++ < QPROBE_MAX) {
                     const unsigned long long cur = atomicCAS(&keys[h], QKEY_EMPTY, key);
-                    if (cur == QKEY_EMPTY || cur == key) break;
+                    if (cur == QKEY_EMPTY || cur == key) { placed = true; break; }
                     h = (h + 1) & mask;
                 }
-                atomicAdd(&hist[h * 16 + pat], 1u);         // me.rs:121-125
+                if (placed) atomicAdd(&hist[h * 16 + pat], 1u);         // me.rs:121-125
+                else *overflow = 1ull;
             }
         }
         a = b; b = c; c = d;
@@ -198,17 +204,30 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
     unsigned long long bound = 0;
     MTH_HIP(ctx, hipMemcpyAsync(&bound, qs, sizeof bound, hipMemcpyDeviceToHost, s));
     MTH_HIP(ctx, hipStreamSynchronize(s));                            // table is sized exactly: one sync per batch
+    // Table size: `bound` counts quartet INSTANCES; at sequencing depth D there are ~D instances per distinct quartet, and
+    // the table is cleared and scanned once per batch (72 B per slot), so it starts at bound / 2 slots (load <= 50 % as
+    // soon as D >= 4) and is redone 4x larger if an insert ran out of probes -- at 2 x bound slots that cannot happen.
     unsigned long long n_slots = 1024;
-    while (n_slots < 2 * bound) n_slots <<= 1;
-    MTH_HIP(ctx, ctx->q_keys.reserve(n_slots * 8, s));
-    MTH_HIP(ctx, ctx->q_hist.reserve(n_slots * 64, s));
-    MTH_HIP(ctx, hipMemsetAsync(ctx->q_keys.p, 0xFF, n_slots * 8, s));
-    MTH_HIP(ctx, hipMemsetAsync(ctx->q_hist.p, 0, n_slots * 64, s));
-    if (d.n_reads) {
-        LaunchTimer lt(ctx, K_QINSERT);
-        hipLaunchKernelGGL(k_quartet_insert, dim3((d.n_reads + 255) / 256), dim3(256), 0, s, d.cpg_off, d.cpg_pos,
-                           d.read_mapq, d.n_reads, params->min_qual, d.region_beg, d.region_end,
-                           ctx->q_keys.as<unsigned long long>(), ctx->q_hist.as<uint32_t>(), n_slots - 1, ctx->d_state);
+    while (n_slots < bound / 2) n_slots <<= 1;
+    if (const char *e = getenv("MTH_QUARTET_SLOTS_MIN")) { const unsigned long long k = strtoull(e, nullptr, 10); if (k >= 16) { n_slots = 16; while (n_slots < k) n_slots <<= 1; } }   // tests: force the retry
+    for (;;) {
+        MTH_HIP(ctx, ctx->q_keys.reserve(n_slots * 8, s));
+        MTH_HIP(ctx, ctx->q_hist.reserve(n_slots * 64, s));
+        MTH_HIP(ctx, hipMemsetAsync(ctx->q_keys.p, 0xFF, n_slots * 8, s));
+        MTH_HIP(ctx, hipMemsetAsync(ctx->q_hist.p, 0, n_slots * 64, s));
+        MTH_HIP(ctx, hipMemsetAsync(qs + 3, 0, sizeof(unsigned long long), s));
+        if (!d.n_reads) break;
+        {
+            LaunchTimer lt(ctx, K_QINSERT);
+            hipLaunchKernelGGL(k_quartet_insert, dim3((d.n_reads + 255) / 256), dim3(256), 0, s, d.cpg_off, d.cpg_pos,
+                               d.read_mapq, d.n_reads, params->min_qual, d.region_beg, d.region_end,
+                               ctx->q_keys.as<unsigned long long>(), ctx->q_hist.as<uint32_t>(), n_slots - 1, qs + 3, ctx->d_state);
+        }
+        unsigned long long ovf = 0;
+        MTH_HIP(ctx, hipMemcpyAsync(&ovf, qs + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));
+        if (!ovf) break;
+        n_slots <<= 2;
     }
     // distinct quartets <= bound: grow the row buffers (keeping earlier batches) before emitting
     const uint64_t need = ctx->q_rows_bound + bound;

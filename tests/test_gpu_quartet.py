@@ -132,3 +132,16 @@ def test_wide_quartet_is_refused(eng):
         eng.quartet_fetch(0)
     assert e.value.status == -8
     eng.reset()
+
+
+def test_table_overflow_retry(eng, monkeypatch):
+    """the quartet table starts smaller than the number of quartet instances; an insert that runs out of probes makes the
+    pass start over with a 4x larger table -- forced here by starting from 16 slots"""
+    from metheor_amd import synth
+    c = synth.make_contig(0, 200_000, 30_000, 0.05, np.random.default_rng(77))
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    monkeypatch.setenv("MTH_QUARTET_SLOTS_MIN", "16")
+    d = run_device(eng, [c], 10, 2)
+    monkeypatch.delenv("MTH_QUARTET_SLOTS_MIN")
+    assert len(d["tid"]) > 2000
+    check(d, reads, 10, 2)
