@@ -36,6 +36,7 @@ struct PairArgs {
     int32_t region_beg, region_end, min_dist, max_dist;
     uint32_t n_reads;
     uint8_t min_qual;
+    unsigned long long *overflow;   // set when an insert ran out of probes
 };
 
 // COUNT: only count the updates (table sizing); otherwise insert them
@@ -59,12 +60,16 @@ __global__ __launch_bounds__(256) void k_pairs(const PairArgs a) {
                 if (COUNT) { mine += 1; continue; }
                 const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 32) | (wk & 0x7fffffffu);
                 unsigned long long h = phash(key) & a.mask;
-                for (;;) {
+                // table sized for the distinct pairs one expects, not for the updates: bounded probe + redo flag (as mth_quartet.hip)
+                uint32_t probes = 0;
+                bool placed = false;
+                while (probes++ < 1024u) {
                     const unsigned long long cur = atomicCAS(&a.keys[h], PKEY_EMPTY, key);
-                    if (cur == PKEY_EMPTY || cur == key) break;
+                    if (cur == PKEY_EMPTY || cur == key) { placed = true; break; }
                     h = (h + 1) & a.mask;
                 }
-                atomicAdd(&a.cnt[h * 2 + (((wj ^ wk) >> 31) ? 1 : 0)], 1u);  // lpmd.rs:79-86
+                if (placed) atomicAdd(&a.cnt[h * 2 + (((wj ^ wk) >> 31) ? 1 : 0)], 1u);  // lpmd.rs:79-86
+                else *a.overflow = 1ull;
             }
         }
     }
@@ -145,7 +150,7 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
     PairArgs a;
     a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
     a.cpg_rel = d.cpg_rel ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
-    a.keys = nullptr; a.cnt = nullptr; a.n_updates = ps; a.mask = 0;
+    a.keys = nullptr; a.cnt = nullptr; a.n_updates = ps; a.mask = 0; a.overflow = ps + 3;
     a.region_beg = d.region_beg; a.region_end = d.region_end; a.min_dist = params->min_distance; a.max_dist = params->max_distance;
     a.n_reads = d.n_reads; a.min_qual = params->min_qual;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)d.n_reads + 255) / 256 + 1, 8192);
@@ -158,17 +163,28 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
     unsigned long long bound = 0;
     MTH_HIP(ctx, hipMemcpyAsync(&bound, ps, sizeof bound, hipMemcpyDeviceToHost, s));
     MTH_HIP(ctx, hipStreamSynchronize(s));                            // exact table sizing: one sync per batch
+    // `bound` counts pair UPDATES; at depth D there are ~D per distinct pair, and the table is cleared and scanned once per
+    // batch: start at bound / 2 slots and redo 4x larger if an insert ran out of probes (cannot happen at 2 x bound)
     unsigned long long n_slots = 1024;
-    while (n_slots < 2 * bound) n_slots <<= 1;
-    MTH_HIP(ctx, ctx->p_keys.reserve(n_slots * 8, s));
-    MTH_HIP(ctx, ctx->p_cnt.reserve(n_slots * 8, s));
-    MTH_HIP(ctx, hipMemsetAsync(ctx->p_keys.p, 0xFF, n_slots * 8, s));
-    MTH_HIP(ctx, hipMemsetAsync(ctx->p_cnt.p, 0, n_slots * 8, s));
-    a.keys = ctx->p_keys.as<unsigned long long>(); a.cnt = ctx->p_cnt.as<uint32_t>(); a.mask = n_slots - 1;
-    {
-        LaunchTimer lt(ctx, K_PAIRS);
-        if (r8) hipLaunchKernelGGL((k_pairs<uint8_t, false>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_pairs<uint16_t, false>), dim3(grid), dim3(256), 0, s, a);
+    while (n_slots < bound / 2) n_slots <<= 1;
+    if (const char *e = getenv("MTH_PAIRS_SLOTS_MIN")) { const unsigned long long k = strtoull(e, nullptr, 10); if (k >= 16) { n_slots = 16; while (n_slots < k) n_slots <<= 1; } }   // tests: force the retry
+    for (;;) {
+        MTH_HIP(ctx, ctx->p_keys.reserve(n_slots * 8, s));
+        MTH_HIP(ctx, ctx->p_cnt.reserve(n_slots * 8, s));
+        MTH_HIP(ctx, hipMemsetAsync(ctx->p_keys.p, 0xFF, n_slots * 8, s));
+        MTH_HIP(ctx, hipMemsetAsync(ctx->p_cnt.p, 0, n_slots * 8, s));
+        MTH_HIP(ctx, hipMemsetAsync(ps + 3, 0, sizeof(unsigned long long), s));
+        a.keys = ctx->p_keys.as<unsigned long long>(); a.cnt = ctx->p_cnt.as<uint32_t>(); a.mask = n_slots - 1; a.overflow = ps + 3;
+        {
+            LaunchTimer lt(ctx, K_PAIRS);
+            if (r8) hipLaunchKernelGGL((k_pairs<uint8_t, false>), dim3(grid), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_pairs<uint16_t, false>), dim3(grid), dim3(256), 0, s, a);
+        }
+        unsigned long long ovf = 0;
+        MTH_HIP(ctx, hipMemcpyAsync(&ovf, ps + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));
+        if (!ovf) break;
+        n_slots <<= 2;
     }
     const uint64_t need = ctx->p_rows_bound + bound;
     if (need > ctx->p_cap) {

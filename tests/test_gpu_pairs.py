@@ -86,3 +86,16 @@ def test_synthetic_multi_contig_and_region_split(eng):
         eng.pdr_lpmd_accumulate(util.device_batch(c), PdrLpmdParams(want_pdr=False))
     g = eng.lpmd_global()
     assert int(d["n_concordant"].sum()) == g["n_concordant"] and int(d["n_discordant"].sum()) == g["n_discordant"]
+
+
+def test_table_overflow_retry(eng, monkeypatch):
+    """the pairs table starts smaller than the number of pair updates; running out of probes redoes the pass 4x larger
+    (forced by starting from 16 slots)"""
+    from metheor_amd import synth
+    c = synth.make_contig(0, 200_000, 30_000, 0.05, np.random.default_rng(78))
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    kw = dict(min_distance=2, max_distance=40, min_qual=10)
+    monkeypatch.setenv("MTH_PAIRS_SLOTS_MIN", "16")
+    d = run_device(eng, [c], kw)
+    monkeypatch.delenv("MTH_PAIRS_SLOTS_MIN")
+    assert check(d, reads, kw) > 2000
