@@ -57,7 +57,8 @@ struct mth_ctx {
     size_t batch_cnt_cap = 0;
 
     // ME / PM (mth_quartet.hip): hash table of the batch in flight + appended result rows
-    mth::DevBuf q_state, q_keys, q_hist, q_blk, q_batch_rows;
+    mth::DevBuf q_state, q_keys, q_hist, q_blk, q_batch_rows, q_batch_heavy0, q_tflag, q_tile_row0, q_tile_rows;
+    std::vector<uint64_t> q_tile_ofs;      // per batch: tiles of all batches up to and including it
     mth::DevBuf q_pos, q_cnt, q_me, q_pm, q_depth;
     uint64_t q_cap = 0, q_rows_bound = 0;
     std::vector<mth::BatchMeta> q_batches;
@@ -124,6 +125,7 @@ struct TileSink {
     uint32_t *nc, *nd;
     uint32_t *batch_cnt;
 };
+int build_read_index(mth_ctx *ctx, const mth_batch_t &dev_batch, int tile_w, int32_t &idx_base, uint32_t &ntiles);
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p,
                     const TileSink *sink = nullptr);
 

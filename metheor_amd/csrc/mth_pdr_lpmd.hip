@@ -507,6 +507,24 @@ static void launch_tile(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
     hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT>), dim3(grid), dim3(B), 0, s, a, ntiles);
 }
 
+// the linear read index alone (for kernels that find a tile's candidate reads without running the PDR/LPMD pass):
+// idx lives in ctx->idx; same origin and quantum as launch_pdr_lpmd builds
+int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &idx_base, uint32_t &ntiles) {
+    hipStream_t s = ctx->stream;
+    const int64_t region_len = (int64_t)b.region_end - b.region_beg;
+    ntiles = (uint32_t)((region_len + tile_w - 1) / tile_w);
+    const int32_t ext = ((b.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
+    idx_base = b.region_beg - ext;
+    const uint32_t nq = (uint32_t)(((int64_t)ntiles * tile_w + ext) >> IDX_QSHIFT) + 2;
+    MTH_HIP(ctx, ctx->idx.reserve((size_t)(nq + 1) * 4, s));
+    LaunchTimer lt(ctx, K_INDEX);
+    const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, idx_base, nq,
+                       (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0), ctx->idx.as<uint32_t>(), ctx->d_state,
+                       ctx->d_state, (unsigned long long *)nullptr, 0u);   // cur_base is rewritten by the next PDR batch's own index build
+    return MTH_OK;
+}
+
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_params_t &p, const TileSink *sink) {
     hipStream_t s = ctx->stream;
     // where the compacted rows and their counters go: the PDR result columns by default, or a

@@ -6,34 +6,68 @@
 // (me = -0.25 * sum_{c>0} p*log2(p)), pm.rs:42-51 (pm = 1 - sum p*p), p = c as f32 / total as f32,
 // bins visited 0..15 in order; min_depth is applied when rows are written (me.rs:82).
 //
-// Device design: at WGBS CpG density a 150-bp read yields ~0.35 quartets, so the update stream is
-// small and sparse: a global open-addressing table (64-bit key CAS, then one L2 atomic add on the
+// Device design.  A quartet is owned by the position of its first CpG, so -- as for the per-site counters of PDR -- the
+// 8192-bp tile that contains p1 sees ALL updates of its quartets: k_quartet_tile keeps a 512-slot hash table in LDS
+// (64-bit key, sixteen 16-bit bins packed in 8 words), fed by the tile's candidate reads (linear read index), and emits
+// its rows straight from LDS (one global atomic per tile to claim the output range).  The first version sent every
+// update to a global table: 6 M CAS + 6 M adds through L2 per 10 M reads were what it spent its time on.  Tiles that do
+// not fit (> 65535 candidate reads: 16-bit bins; more distinct quartets than the table holds) are flagged and take
+// that global path, restricted to their quartets: a global open-addressing table (64-bit key CAS, then one L2 atomic add on the
 // bin) sized from an exact counting pre-pass.  Key = p1 (31 bits) | three position deltas (11 bits
 // each): consecutive CpGs of one read further than 2047 bp apart are refused (MTH_ERR_CAPACITY).
 // A quartet is owned by the batch whose region contains p1 (same rule as sites), so region / contig
-// sharding needs no exchange.  Rows are emitted in slot order (deterministic; the reference's order
-// is HashMap-random, compare as sets).
+// sharding needs no exchange.  Each tile sorts its rows in LDS and the fetch walks the tiles in order, so rows come out
+// sorted by (tid, p1..p4); rows of tiles that took the global path follow in table order (the reference's order is
+// HashMap-random, compare as sets).
 #include "mth_ctx.h"
 #include "mth_scan.h"
 
 namespace mth {
 
 constexpr unsigned long long QKEY_EMPTY = ~0ull;
+// tile kernel: reference positions per tile, LDS table slots, threads.  Measured on S-chr19-10M (profiles/r01_quartet_tile.md):
+// wider tiles re-read fewer halo reads and clear LDS less often, a smaller table lets more tiles share a CU (25 KB each).
+constexpr int QT_W = 8192, QT_S = 512, QT_B = 256;
+constexpr int Q_STATE_WORDS = 8;
+constexpr uint32_t QT_RANK_MAX = 192;          // up to this many quartets in a tile: rank sort; above: bitonic network
 
 __device__ __forceinline__ unsigned long long qhash(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
 
+// slot of a key in the tile kernel's LDS table: two 32-bit multiplies (the 64-bit mixer above costs ~30 VALU)
+__device__ __forceinline__ uint32_t qslot(unsigned long long key) {
+    uint32_t h = (uint32_t)(key >> 33) * 0x9E3779B1u ^ (uint32_t)key * 0x85EBCA6Bu;
+    h ^= h >> 15;
+    return h & (QT_S - 1);
+}
+
 // upper bound of the number of (read, window) updates: sum over passing reads of max(0, n - 3)
+// (+ the span check the tile kernel's candidate ranges rely on: a read longer than max_span could be missed)
 __global__ __launch_bounds__(256) void k_quartet_bound(const uint32_t *__restrict__ cpg_off,
-                                                       const uint8_t *__restrict__ mapq, uint32_t n_reads,
-                                                       uint8_t min_qual, unsigned long long *__restrict__ out) {
+                                                       const uint32_t *__restrict__ cpg_pos,
+                                                       const uint8_t *__restrict__ mapq,
+                                                       const int32_t *__restrict__ read_start, int32_t max_span,
+                                                       uint32_t n_reads, uint8_t min_qual,
+                                                       unsigned long long *__restrict__ out, DevState *__restrict__ st) {
+    // first kernel of a batch: [4] = rows before the batch, [5] = tiles left to the global path (nothing else is in flight)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[4] = out[1]; out[5] = 0; }
     unsigned long long acc = 0;
+    uint32_t bad = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_reads; i += gridDim.x * 256) {
-        const uint32_t n = cpg_off[i + 1] - cpg_off[i];
-        if (n >= 4 && mapq[i] >= min_qual) acc += n - 3;
+        const uint32_t o0 = cpg_off[i], o1 = cpg_off[i + 1], n = o1 - o0;
+        if (n >= 4 && mapq[i] >= min_qual) {
+            acc += n - 3;
+            // first and last CpG within [start - 1, start - 1 + max_span] (a reverse read's first call may sit one base
+            // before its start, readutil.rs:338; same rule as the PDR tile kernel): unsigned, so a call further left is
+            // caught as well (the windows' deltas are checked to be 1..2047 at insert time: the calls in between are ordered)
+            const uint32_t sm1 = (uint32_t)read_start[i] - 1u;
+            bad |= ((cpg_pos[o0] & 0x7fffffffu) - sm1 > (uint32_t)max_span) ? 1u : 0u;
+            bad |= ((cpg_pos[o1 - 1] & 0x7fffffffu) - sm1 > (uint32_t)max_span) ? 1u : 0u;
+        }
     }
+    if (bad) atomicOr(&st->err, (uint32_t)ERRB_SPAN);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     __shared__ unsigned long long ws[4];
@@ -49,7 +83,8 @@ __global__ __launch_bounds__(256) void k_quartet_insert(const uint32_t *__restri
                                                         uint8_t min_qual, int32_t region_beg, int32_t region_end,
                                                         unsigned long long *__restrict__ keys,
                                                         uint32_t *__restrict__ hist, unsigned long long mask,
-                                                        unsigned long long *__restrict__ overflow, DevState *__restrict__ st) {
+                                                        unsigned long long *__restrict__ overflow, DevState *__restrict__ st,
+                                                        const uint32_t *__restrict__ tile_flag /* nullptr: every quartet */) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_reads) return;
     const uint32_t o0 = cpg_off[i], o1 = cpg_off[i + 1];
@@ -58,7 +93,7 @@ __global__ __launch_bounds__(256) void k_quartet_insert(const uint32_t *__restri
     for (uint32_t k = o0 + 3; k < o1; ++k) {                // readutil.rs:105-129
         const uint32_t d = cpg_pos[k];
         const int32_t p1 = (int32_t)(a & 0x7fffffffu);
-        if (p1 >= region_beg && p1 < region_end) {
+        if (p1 >= region_beg && p1 < region_end && (!tile_flag || tile_flag[(uint32_t)(p1 - region_beg) / QT_W])) {
             const uint32_t d2 = (b & 0x7fffffffu) - (a & 0x7fffffffu), d3 = (c & 0x7fffffffu) - (b & 0x7fffffffu),
                            d4 = (d & 0x7fffffffu) - (c & 0x7fffffffu);
             const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 33) | ((unsigned long long)d2 << 22) |
@@ -178,6 +213,178 @@ __global__ __launch_bounds__(256) void k_quartet_emit(const unsigned long long *
     }
 }
 
+
+// ---- tile kernel ---------------------------------------------------------------------------------------------------
+struct QTileArgs {
+    const uint8_t  *read_mapq;
+    const uint32_t *cpg_off, *cpg_pos, *idx;
+    int32_t region_beg, region_end, idx_base, max_span;
+    uint32_t n_reads;
+    uint8_t min_qual, force_heavy;            // force_heavy: tests send every tile down the global path
+    unsigned long long *row_total;            // rows emitted so far (all batches): the tile claims its range with one atomic
+    unsigned long long *n_heavy;              // tiles left to the global path
+    uint32_t *tile_flag;                      // per tile of the batch: 1 = left to the global path
+    unsigned long long *tile_row0;            // per tile: first row of its range ...
+    uint32_t *tile_rows;                      // ... and its length (the fetch walks tiles in order: rows come out sorted)
+    int32_t *out_pos; uint32_t *out_cnt; float *out_me, *out_pm; uint32_t *out_depth;
+    DevState *st;
+};
+__global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
+    __shared__ unsigned long long keys[QT_S];  // the hash table ...
+    __shared__ unsigned long long skey[QT_S];  // ... and its keys once more, compacted and sorted
+    __shared__ uint16_t sslot[QT_S];           // slot of compacted key r
+    __shared__ uint32_t bins[QT_S * 8];        // bin 2w in the low half of word w, bin 2w+1 in the high half
+    __shared__ uint32_t s_heavy, ws[QT_B / 64 + 1];
+    __shared__ unsigned long long s_row0;
+    const int tid = threadIdx.x;
+    const uint32_t t = blockIdx.x;
+    const int32_t T0 = a.region_beg + (int32_t)(t * QT_W);
+    const int32_t T1 = (int32_t)min((int64_t)T0 + QT_W, (int64_t)a.region_end);
+    // candidate reads: a read with a CpG at p1 >= T0 starts after T0 - max_span and not after T1 - 1
+    const uint32_t lo = min(a.idx[((uint32_t)T0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
+    const uint32_t hi = min(a.idx[(((uint32_t)T0 + (uint32_t)QT_W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+    if (lo >= hi) {                                             // nothing starts here: no LDS work at all
+        if (tid == 0) { a.tile_flag[t] = 0u; a.tile_rows[t] = 0u; a.tile_row0[t] = 0ull; }
+        return;
+    }
+    for (int i = tid; i < QT_S; i += QT_B) keys[i] = QKEY_EMPTY;
+    for (int i = tid; i < QT_S * 8; i += QT_B) bins[i] = 0;
+    if (tid == 0) s_heavy = (hi - lo > 65535u || a.force_heavy) ? 1u : 0u;      // a bin counts at most one update per candidate read
+    __syncthreads();
+    if (!s_heavy) {
+        for (uint32_t i = lo + tid; i < hi; i += QT_B) {
+            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+            if (o1 - o0 < 4 || a.read_mapq[i] < a.min_qual) continue;      // readutil.rs:101, me.rs:115
+            uint32_t x = a.cpg_pos[o0], y = a.cpg_pos[o0 + 1], z = a.cpg_pos[o0 + 2];
+            for (uint32_t k = o0 + 3; k < o1; ++k) {                        // readutil.rs:105-129
+                const uint32_t w = a.cpg_pos[k];
+                const int32_t p1 = (int32_t)(x & 0x7fffffffu);
+                if (p1 >= T0 && p1 < T1) {
+                    const uint32_t d2 = (y & 0x7fffffffu) - (x & 0x7fffffffu), d3 = (z & 0x7fffffffu) - (y & 0x7fffffffu),
+                                   d4 = (w & 0x7fffffffu) - (z & 0x7fffffffu);
+                    const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 33) | ((unsigned long long)d2 << 22) |
+                                                   ((unsigned long long)d3 << 11) | (unsigned long long)d4;
+                    if (d2 - 1u >= 2047u || d3 - 1u >= 2047u || d4 - 1u >= 2047u || key == QKEY_EMPTY) {
+                        atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);
+                    } else {
+                        const uint32_t pat = ((x >> 31) << 3) | ((y >> 31) << 2) | ((z >> 31) << 1) | (w >> 31);
+                        uint32_t h = qslot(key), probes = 0;
+                        bool placed = false;
+                        while (probes++ < (uint32_t)QT_S) {
+                            const unsigned long long cur = atomicCAS(&keys[h], QKEY_EMPTY, key);
+                            if (cur == QKEY_EMPTY || cur == key) { placed = true; break; }
+                            h = (h + 1) & (QT_S - 1);
+                        }
+                        if (placed) atomicAdd(&bins[h * 8 + (pat >> 1)], (pat & 1u) ? 0x10000u : 1u);      // me.rs:121-125
+                        else s_heavy = 1u;                                   // more distinct quartets than slots
+                    }
+                }
+                x = y; y = z; z = w;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_heavy) {                                      // block-uniform: the whole tile goes to the global path
+        if (tid == 0) { a.tile_flag[t] = 1u; a.tile_rows[t] = 0u; a.tile_row0[t] = 0ull; atomicAdd(a.n_heavy, 1ull); }
+        return;
+    }
+    // compact the occupied slots (each thread owns 4) ...
+    static_assert(QT_S % QT_B == 0, "each thread owns QT_S / QT_B slots");
+    constexpr int PER = QT_S / QT_B;
+    unsigned long long kk[PER];
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { kk[k] = keys[tid * PER + k]; m += kk[k] != QKEY_EMPTY ? 1u : 0u; }
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t incl = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) ws[wave + 1] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        ws[0] = 0;
+        for (int w = 1; w <= QT_B / 64; ++w) ws[w] += ws[w - 1];
+        const uint32_t n_all = ws[QT_B / 64];
+        a.tile_flag[t] = 0u; a.tile_rows[t] = n_all;
+        s_row0 = n_all ? atomicAdd(a.row_total, (unsigned long long)n_all) : 0ull;
+        a.tile_row0[t] = s_row0;
+    }
+    __syncthreads();
+    const uint32_t n = ws[QT_B / 64];
+    if (n == 0) return;
+    {
+        uint32_t o = ws[wave] + incl - m;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) if (kk[k] != QKEY_EMPTY) { skey[o] = kk[k]; sslot[o] = (uint16_t)(tid * PER + k); ++o; }
+    }
+    auto emit_row = [&](unsigned long long key, uint32_t h, uint32_t r) {
+        const unsigned long long o = s_row0 + r;
+        const int32_t p1 = (int32_t)(key >> 33);
+        const int32_t p2 = p1 + (int32_t)((key >> 22) & 2047u), p3 = p2 + (int32_t)((key >> 11) & 2047u),
+                      p4 = p3 + (int32_t)(key & 2047u);
+        reinterpret_cast<int4 *>(a.out_pos)[o] = make_int4(p1, p2, p3, p4);
+        uint32_t c[16];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const uint32_t v = bins[h * 8 + w];
+            c[2 * w] = v & 0xffffu; c[2 * w + 1] = v >> 16;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            reinterpret_cast<uint4 *>(a.out_cnt + o * 16)[q] = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+        float me, pm;
+        uint32_t total;
+        quartet_values(c, me, pm, total);
+        a.out_me[o] = me; a.out_pm[o] = pm; a.out_depth[o] = total;
+    };
+    // rows go out sorted by key = (p1, d2, d3, d4) = (p1, p2, p3, p4) order
+    if (n <= QT_RANK_MAX) {
+        // few keys (the usual case): thread j counts the keys below compacted key j -- no barriers, LDS broadcast reads
+        __syncthreads();
+        for (uint32_t j = tid; j < n; j += QT_B) {
+            const unsigned long long key = skey[j];
+            uint32_t r = 0;
+            for (uint32_t i = 0; i < n; ++i) r += skey[i] < key ? 1u : 0u;
+            emit_row(key, sslot[j], r);
+        }
+        return;
+    }
+    uint32_t P = 2;
+    while (P < n) P <<= 1;
+    for (uint32_t i = n + tid; i < P; i += QT_B) skey[i] = QKEY_EMPTY;      // pads sort to the end
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {                                  // bitonic network over P = pow2 >= n keys
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < P; i += QT_B) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long u = skey[i], v = skey[l];
+                    const bool up = (i & k) == 0;
+                    if ((u > v) == up) { skey[i] = v; skey[l] = u; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t r = tid; r < n; r += QT_B) {
+        const unsigned long long key = skey[r];
+        uint32_t h = qslot(key);
+        while (keys[h] != key) h = (h + 1) & (QT_S - 1);
+        emit_row(key, h, r);
+    }
+}
+
+// bookkeeping around a batch.  qs: [0] bound [1] total rows [2] first row of the global path's rows [3] overflow flag
+// [4] rows before the batch [5] tiles left to the global path
+__global__ void k_quartet_end(const unsigned long long *qs, uint32_t *batch_rows, unsigned long long *batch_heavy0,
+                              uint32_t batch_idx, int ran_global) {
+    batch_rows[batch_idx] = (uint32_t)(qs[1] - qs[4]);
+    batch_heavy0[batch_idx] = ran_global ? qs[2] : qs[1];
+}
+
 }  // namespace mth
 
 using namespace mth;
@@ -191,44 +398,19 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
     if (rc) return rc;
     hipStream_t s = ctx->stream;
     if (!ctx->q_state.p) {
-        MTH_HIP(ctx, ctx->q_state.reserve(4 * sizeof(unsigned long long), s));
-        MTH_HIP(ctx, hipMemsetAsync(ctx->q_state.p, 0, 4 * sizeof(unsigned long long), s));
+        MTH_HIP(ctx, ctx->q_state.reserve(Q_STATE_WORDS * sizeof(unsigned long long), s));
+        MTH_HIP(ctx, hipMemsetAsync(ctx->q_state.p, 0, Q_STATE_WORDS * sizeof(unsigned long long), s));
     }
-    unsigned long long *qs = ctx->q_state.as<unsigned long long>();   // [0] bound [1] total rows [2] base of the batch
+    unsigned long long *qs = ctx->q_state.as<unsigned long long>();   // words: see k_quartet_end
     MTH_HIP(ctx, hipMemsetAsync(qs, 0, sizeof(unsigned long long), s));
-    if (d.n_reads) {
+    {   // also with no reads: it opens the batch (k_quartet_end closes it)
         LaunchTimer lt(ctx, K_QBOUND);
-        hipLaunchKernelGGL(k_quartet_bound, dim3(1024), dim3(256), 0, s, d.cpg_off, d.read_mapq, d.n_reads,
-                           params->min_qual, qs);
+        hipLaunchKernelGGL(k_quartet_bound, dim3(1024), dim3(256), 0, s, d.cpg_off, d.cpg_pos, d.read_mapq, d.read_start,
+                           d.max_span, d.n_reads, params->min_qual, qs, ctx->d_state);
     }
     unsigned long long bound = 0;
     MTH_HIP(ctx, hipMemcpyAsync(&bound, qs, sizeof bound, hipMemcpyDeviceToHost, s));
-    MTH_HIP(ctx, hipStreamSynchronize(s));                            // table is sized exactly: one sync per batch
-    // Table size: `bound` counts quartet INSTANCES; at sequencing depth D there are ~D instances per distinct quartet, and
-    // the table is cleared and scanned once per batch (72 B per slot), so it starts at bound / 2 slots (load <= 50 % as
-    // soon as D >= 4) and is redone 4x larger if an insert ran out of probes -- at 2 x bound slots that cannot happen.
-    unsigned long long n_slots = 1024;
-    while (n_slots < bound / 2) n_slots <<= 1;
-    if (const char *e = getenv("MTH_QUARTET_SLOTS_MIN")) { const unsigned long long k = strtoull(e, nullptr, 10); if (k >= 16) { n_slots = 16; while (n_slots < k) n_slots <<= 1; } }   // tests: force the retry
-    for (;;) {
-        MTH_HIP(ctx, ctx->q_keys.reserve(n_slots * 8, s));
-        MTH_HIP(ctx, ctx->q_hist.reserve(n_slots * 64, s));
-        MTH_HIP(ctx, hipMemsetAsync(ctx->q_keys.p, 0xFF, n_slots * 8, s));
-        MTH_HIP(ctx, hipMemsetAsync(ctx->q_hist.p, 0, n_slots * 64, s));
-        MTH_HIP(ctx, hipMemsetAsync(qs + 3, 0, sizeof(unsigned long long), s));
-        if (!d.n_reads) break;
-        {
-            LaunchTimer lt(ctx, K_QINSERT);
-            hipLaunchKernelGGL(k_quartet_insert, dim3((d.n_reads + 255) / 256), dim3(256), 0, s, d.cpg_off, d.cpg_pos,
-                               d.read_mapq, d.n_reads, params->min_qual, d.region_beg, d.region_end,
-                               ctx->q_keys.as<unsigned long long>(), ctx->q_hist.as<uint32_t>(), n_slots - 1, qs + 3, ctx->d_state);
-        }
-        unsigned long long ovf = 0;
-        MTH_HIP(ctx, hipMemcpyAsync(&ovf, qs + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
-        MTH_HIP(ctx, hipStreamSynchronize(s));
-        if (!ovf) break;
-        n_slots <<= 2;
-    }
+    MTH_HIP(ctx, hipStreamSynchronize(s));                            // the row buffers are sized exactly: one sync per batch
     // distinct quartets <= bound: grow the row buffers (keeping earlier batches) before emitting
     const uint64_t need = ctx->q_rows_bound + bound;
     if (need > ctx->q_cap) {
@@ -242,22 +424,83 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
         ctx->q_cap = ncap;
     }
     ctx->q_rows_bound = need;
-    const uint32_t nblk = (uint32_t)((n_slots + 256 * QE_PER - 1) / (256 * QE_PER));
-    MTH_HIP(ctx, ctx->q_blk.reserve((size_t)nblk * 4, s));
-    MTH_HIP(ctx, ctx->q_batch_rows.reserve((ctx->q_batches.size() + 1) * 4, s, true, ctx->q_batches.size() * 4));
-    {
-        LaunchTimer lt(ctx, K_QEMIT);
-        hipLaunchKernelGGL(k_quartet_blockcount, dim3(nblk), dim3(256), 0, s, ctx->q_keys.as<unsigned long long>(),
-                           n_slots, ctx->q_blk.as<uint32_t>());
-        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->q_blk.as<uint32_t>(), nblk, qs + 1, qs + 2,
-                           ctx->q_batch_rows.as<uint32_t>(), (uint32_t)ctx->q_batches.size());
-        hipLaunchKernelGGL(k_quartet_emit, dim3(nblk), dim3(256), 0, s, ctx->q_keys.as<unsigned long long>(),
-                           ctx->q_hist.as<uint32_t>(), n_slots, ctx->q_blk.as<uint32_t>(), qs + 2,
-                           ctx->q_pos.as<int32_t>(), ctx->q_cnt.as<uint32_t>(), ctx->q_me.as<float>(),
-                           ctx->q_pm.as<float>(), ctx->q_depth.as<uint32_t>());
+    const uint32_t batch_idx = (uint32_t)ctx->q_batches.size();
+    MTH_HIP(ctx, ctx->q_batch_rows.reserve((size_t)(batch_idx + 1) * 4, s, true, (size_t)batch_idx * 4));
+    MTH_HIP(ctx, ctx->q_batch_heavy0.reserve((size_t)(batch_idx + 1) * 8, s, true, (size_t)batch_idx * 8));
+    const int64_t region_len = (int64_t)d.region_end - d.region_beg;
+    const uint64_t tiles_before = ctx->q_tile_ofs.empty() ? 0 : ctx->q_tile_ofs.back();
+    const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + QT_W - 1) / QT_W) : 0u;
+    int ran_global = 0;
+    if (ntiles) {
+        int32_t idx_base = 0;
+        uint32_t nt = 0;
+        rc = build_read_index(ctx, d, QT_W, idx_base, nt);
+        if (rc) return rc;
+        MTH_HIP(ctx, ctx->q_tflag.reserve((size_t)ntiles * 4, s));
+        MTH_HIP(ctx, ctx->q_tile_row0.reserve((tiles_before + ntiles) * 8, s, true, tiles_before * 8));
+        MTH_HIP(ctx, ctx->q_tile_rows.reserve((tiles_before + ntiles) * 4, s, true, tiles_before * 4));
+        QTileArgs a;
+        a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos; a.idx = ctx->idx.as<uint32_t>();
+        a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
+        a.n_reads = d.n_reads; a.min_qual = params->min_qual;
+        a.force_heavy = getenv("MTH_QUARTET_FORCE_GLOBAL") ? 1 : 0;
+        a.row_total = qs + 1; a.n_heavy = qs + 5; a.tile_flag = ctx->q_tflag.as<uint32_t>();
+        a.tile_row0 = ctx->q_tile_row0.as<unsigned long long>() + tiles_before;
+        a.tile_rows = ctx->q_tile_rows.as<uint32_t>() + tiles_before;
+        a.out_pos = ctx->q_pos.as<int32_t>(); a.out_cnt = ctx->q_cnt.as<uint32_t>(); a.out_me = ctx->q_me.as<float>();
+        a.out_pm = ctx->q_pm.as<float>(); a.out_depth = ctx->q_depth.as<uint32_t>(); a.st = ctx->d_state;
+        {
+            LaunchTimer lt(ctx, K_QTILE);
+            hipLaunchKernelGGL(k_quartet_tile, dim3(ntiles), dim3(QT_B), 0, s, a);
+        }
+        unsigned long long n_heavy = 0;
+        MTH_HIP(ctx, hipMemcpyAsync(&n_heavy, qs + 5, sizeof n_heavy, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));
+        if (n_heavy) {
+            // The tiles the LDS table could not hold: the global table, for their quartets only.  Its size: `bound` counts
+            // quartet INSTANCES of the whole batch; bound / 2 slots to start with, redone 4x larger if an insert ran out of
+            // probes -- at 2 x bound slots that cannot happen.
+            ran_global = 1;
+            unsigned long long n_slots = 1024;
+            while (n_slots < bound / 2) n_slots <<= 1;
+            if (const char *e = getenv("MTH_QUARTET_SLOTS_MIN")) { const unsigned long long k = strtoull(e, nullptr, 10); if (k >= 16) { n_slots = 16; while (n_slots < k) n_slots <<= 1; } }   // tests: force the retry
+            for (;;) {
+                MTH_HIP(ctx, ctx->q_keys.reserve(n_slots * 8, s));
+                MTH_HIP(ctx, ctx->q_hist.reserve(n_slots * 64, s));
+                MTH_HIP(ctx, hipMemsetAsync(ctx->q_keys.p, 0xFF, n_slots * 8, s));
+                MTH_HIP(ctx, hipMemsetAsync(ctx->q_hist.p, 0, n_slots * 64, s));
+                MTH_HIP(ctx, hipMemsetAsync(qs + 3, 0, sizeof(unsigned long long), s));
+                {
+                    LaunchTimer lt(ctx, K_QINSERT);
+                    hipLaunchKernelGGL(k_quartet_insert, dim3((d.n_reads + 255) / 256), dim3(256), 0, s, d.cpg_off, d.cpg_pos,
+                                       d.read_mapq, d.n_reads, params->min_qual, d.region_beg, d.region_end,
+                                       ctx->q_keys.as<unsigned long long>(), ctx->q_hist.as<uint32_t>(), n_slots - 1, qs + 3,
+                                       ctx->d_state, (const uint32_t *)ctx->q_tflag.as<uint32_t>());
+                }
+                unsigned long long ovf = 0;
+                MTH_HIP(ctx, hipMemcpyAsync(&ovf, qs + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
+                MTH_HIP(ctx, hipStreamSynchronize(s));
+                if (!ovf) break;
+                n_slots <<= 2;
+            }
+            const uint32_t nblk = (uint32_t)((n_slots + 256 * QE_PER - 1) / (256 * QE_PER));
+            MTH_HIP(ctx, ctx->q_blk.reserve((size_t)nblk * 4, s));
+            LaunchTimer lt(ctx, K_QEMIT);
+            hipLaunchKernelGGL(k_quartet_blockcount, dim3(nblk), dim3(256), 0, s, ctx->q_keys.as<unsigned long long>(),
+                               n_slots, ctx->q_blk.as<uint32_t>());
+            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->q_blk.as<uint32_t>(), nblk, qs + 1, qs + 2,
+                               ctx->q_batch_rows.as<uint32_t>(), batch_idx);
+            hipLaunchKernelGGL(k_quartet_emit, dim3(nblk), dim3(256), 0, s, ctx->q_keys.as<unsigned long long>(),
+                               ctx->q_hist.as<uint32_t>(), n_slots, ctx->q_blk.as<uint32_t>(), qs + 2,
+                               ctx->q_pos.as<int32_t>(), ctx->q_cnt.as<uint32_t>(), ctx->q_me.as<float>(),
+                               ctx->q_pm.as<float>(), ctx->q_depth.as<uint32_t>());
+        }
     }
+    hipLaunchKernelGGL(k_quartet_end, dim3(1), dim3(1), 0, s, (const unsigned long long *)qs, ctx->q_batch_rows.as<uint32_t>(),
+                       ctx->q_batch_heavy0.as<unsigned long long>(), batch_idx, ran_global);
     MTH_HIP(ctx, hipGetLastError());
     ctx->q_batches.push_back(BatchMeta{batch->tid});
+    ctx->q_tile_ofs.push_back(tiles_before + ntiles);
     return MTH_OK;
 }
 
@@ -287,17 +530,32 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
         if (me) MTH_HIP(ctx, hipMemcpy(hme.data(), ctx->q_me.p, total * 4, hipMemcpyDeviceToHost));
         if (pm) MTH_HIP(ctx, hipMemcpy(hpm.data(), ctx->q_pm.p, total * 4, hipMemcpyDeviceToHost));
     }
-    uint64_t o = 0, i = 0;
+    // Row order: per batch, the tiles in position order (each tile's rows are sorted by (p1..p4)), then the rows of the
+    // tiles that took the global path (table order).  The reference's order is HashMap-random.
+    const uint64_t n_tiles = ctx->q_tile_ofs.empty() ? 0 : ctx->q_tile_ofs.back();
+    std::vector<unsigned long long> trow0(n_tiles), heavy0(rows.size());
+    std::vector<uint32_t> trows(n_tiles);
+    if (n_tiles) {
+        MTH_HIP(ctx, hipMemcpy(trow0.data(), ctx->q_tile_row0.p, n_tiles * 8, hipMemcpyDeviceToHost));
+        MTH_HIP(ctx, hipMemcpy(trows.data(), ctx->q_tile_rows.p, n_tiles * 4, hipMemcpyDeviceToHost));
+    }
+    if (!rows.empty()) MTH_HIP(ctx, hipMemcpy(heavy0.data(), ctx->q_batch_heavy0.p, rows.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t o = 0, batch_end = 0;
+    auto put = [&](int32_t t_id, uint64_t i) {
+        if (depth[i] < min_depth) return;
+        if (tid) tid[o] = t_id;
+        if (pos4) memcpy(pos4 + o * 4, hp.data() + i * 4, 16);
+        if (counts16) memcpy(counts16 + o * 16, hc.data() + i * 16, 64);
+        if (me) me[o] = hme[i];
+        if (pm) pm[o] = hpm[i];
+        ++o;
+    };
     for (size_t b = 0; b < rows.size(); ++b) {
-        for (uint32_t j = 0; j < rows[b]; ++j, ++i) {
-            if (depth[i] < min_depth) continue;
-            if (tid) tid[o] = ctx->q_batches[b].tid;
-            if (pos4) memcpy(pos4 + o * 4, hp.data() + i * 4, 16);
-            if (counts16) memcpy(counts16 + o * 16, hc.data() + i * 16, 64);
-            if (me) me[o] = hme[i];
-            if (pm) pm[o] = hpm[i];
-            ++o;
-        }
+        batch_end += rows[b];
+        const int32_t t_id = ctx->q_batches[b].tid;
+        for (uint64_t t = b ? ctx->q_tile_ofs[b - 1] : 0; t < ctx->q_tile_ofs[b]; ++t)
+            for (uint32_t j = 0; j < trows[t]; ++j) put(t_id, trow0[t] + j);
+        for (uint64_t i = heavy0[b]; i < batch_end; ++i) put(t_id, i);
     }
     return MTH_OK;
 }

@@ -141,7 +141,106 @@ def test_table_overflow_retry(eng, monkeypatch):
     c = synth.make_contig(0, 200_000, 30_000, 0.05, np.random.default_rng(77))
     reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
     monkeypatch.setenv("MTH_QUARTET_SLOTS_MIN", "16")
+    monkeypatch.setenv("MTH_QUARTET_FORCE_GLOBAL", "1")        # the global table only serves tiles the LDS table refused
     d = run_device(eng, [c], 10, 2)
     monkeypatch.delenv("MTH_QUARTET_SLOTS_MIN")
+    monkeypatch.delenv("MTH_QUARTET_FORCE_GLOBAL")
     assert len(d["tid"]) > 2000
     check(d, reads, 10, 2)
+
+
+def test_rows_come_out_sorted(eng):
+    """tile path: rows are ordered by (tid, pos1..pos4) without any host sort (tiles in order, each sorted in LDS)"""
+    from metheor_amd import synth
+    rng = np.random.default_rng(5)
+    cs = [synth.make_contig(0, 300_000, 60_000, 0.04, rng), synth.make_contig(1, 150_000, 30_000, 0.015, rng)]   # bitonic / rank sort
+    d = run_device(eng, cs, 10, 0)
+    order = np.lexsort((d["pos"][:, 3], d["pos"][:, 2], d["pos"][:, 1], d["pos"][:, 0], d["tid"]))
+    assert len(order) > 5000 and (order == np.arange(len(order))).all()
+    check(d, pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs)), 10, 0)
+
+
+def test_global_path_for_every_tile(eng, monkeypatch):
+    """every tile sent down the global-table path gives the same rows as the tile path"""
+    from metheor_amd import shard, synth
+    rng = np.random.default_rng(6)
+    cs = [synth.make_contig(0, 300_000, 50_000, 0.05, rng), synth.make_contig(1, 100_000, 20_000, 0.2, rng)]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    monkeypatch.setenv("MTH_QUARTET_FORCE_GLOBAL", "1")
+    d = run_device(eng, cs, 10, 3, regions=[shard.plan_regions(cs[0], 3), [(0, cs[1]["length"])]])
+    monkeypatch.delenv("MTH_QUARTET_FORCE_GLOBAL")
+    check(d, reads, 10, 3)
+    assert len(d["tid"]) > 3000
+
+
+def _reads_over(sites, starts, span, rng, p_meth=0.5):
+    """reads [s, s+span) over a sorted site list: SoA dict in the synth contig layout"""
+    lo = np.searchsorted(sites, starts)
+    hi = np.searchsorted(sites, starts + span)
+    n = (hi - lo).astype(np.uint32)
+    off = np.zeros(len(starts) + 1, np.uint32)
+    np.cumsum(n, out=off[1:])
+    idx = np.repeat(lo - off[:-1].astype(np.int64), n) + np.arange(off[-1])
+    pos = sites[idx].astype(np.uint32)
+    meth = rng.random(len(pos)) < p_meth
+    rel = (pos.astype(np.int64) - np.repeat(starts, n)).astype(np.uint8)
+    return off, pos | (meth.astype(np.uint32) << 31), rel
+
+
+def _contig(tid, length, starts, span, off, pos, rel, rng):
+    n = len(starts)
+    return {"tid": tid, "length": length, "read_start": starts.astype(np.int32),
+            "read_end": (starts + span - 1).astype(np.int32), "read_mapq": rng.integers(0, 60, n).astype(np.uint8),
+            "read_fwd": np.ones(n, np.uint8), "cpg_off": off, "cpg_pos": pos, "cpg_rel": rel}
+
+
+def test_dense_tile_overflows_the_lds_table(eng):
+    """a CpG every 2 bp: ~2000 distinct quartets start in one 4096-bp tile, more than the LDS table holds -> that tile
+    (and only that one) takes the global path; the sparse tiles around it stay on the tile path"""
+    from metheor_amd import synth
+    rng = np.random.default_rng(8)
+    dense = np.arange(8192, 8192 + 4096, 2)
+    sparse = np.sort(rng.choice(np.r_[0:8192, 12288:60000], 1500, replace=False))
+    sites = np.sort(np.r_[dense, sparse]).astype(np.int64)
+    starts = np.sort(rng.integers(0, 60000 - 100, 20000)).astype(np.int64)
+    off, pos, rel = _reads_over(sites, starts, 100, rng)
+    c = _contig(0, 60000, starts, 100, off, pos, rel, rng)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    d = run_device(eng, [c], 10, 0)
+    check(d, reads, 10, 0)
+    p1 = d["pos"][:, 0]
+    assert ((p1 >= 8192) & (p1 < 12288)).sum() > 1024
+    # the heavy tile's rows come last (table order); everything before them is sorted
+    first_heavy = int(np.argmax((p1 >= 8192) & (p1 < 12288)))
+    head = d["pos"][:first_heavy]
+    assert (np.lexsort((head[:, 3], head[:, 2], head[:, 1], head[:, 0])) == np.arange(len(head))).all()
+
+
+def test_deep_tile_exceeds_16bit_bins(eng):
+    """> 65535 candidate reads over one tile (deep amplicon): 16-bit bins would wrap, the tile takes the global path"""
+    from metheor_amd import synth
+    rng = np.random.default_rng(9)
+    sites = np.array([5000, 5010, 5020, 5030, 5040, 9000, 9004, 9010, 9100, 9150], np.int64)
+    starts = np.sort(np.r_[np.full(70_000, 4990), rng.integers(8950, 9000, 3000)]).astype(np.int64)
+    off, pos, rel = _reads_over(sites, starts, 120, rng)
+    c = _contig(0, 20000, starts, 120, off, pos, rel, rng)
+    c["read_mapq"][:] = 40
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    d = run_device(eng, [c], 10, 0)
+    check(d, reads, 10, 0)
+    assert d["cnt"].sum(axis=1).max() == 70_000
+
+
+def test_span_violation_is_refused(eng):
+    """max_span smaller than a read's CpG extent: the tile path's candidate ranges would miss it -> MTH_ERR_SPAN"""
+    from metheor_amd import Batch, MthError
+    st = np.array([100], np.int32)
+    pos = np.array([100, 120, 140, 400], np.uint32)
+    b = Batch(0, 0, 100_000, st, st + 300, np.array([42], np.uint8), np.array([0, 4], np.uint32), pos,
+              np.array([0, 20, 40, 300], np.uint16), max_span=150)
+    eng.reset()
+    eng.quartet_accumulate(b)
+    with pytest.raises(MthError) as e:
+        eng.quartet_fetch(0)
+    assert e.value.status == -5
+    eng.reset()
