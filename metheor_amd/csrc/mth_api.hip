@@ -11,7 +11,7 @@ namespace mth {
 static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_gather",
                                           "k_quartet_bound", "k_quartet_tile", "k_quartet_insert", "k_quartet_emit",
                                           "k_mhl_walk", "k_mhl_walk_big", "k_mhl_emit", "k_pdr_walk",
-                                          "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_decode", "k_inflate", "k_crc32"};
+                                          "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_pairs_tile", "k_decode", "k_inflate", "k_crc32"};
 
 int fail(mth_ctx *ctx, int status, const char *what, hipError_t e) {
     if (ctx) {
@@ -181,7 +181,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
                       &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_aux, &ctx->w_flags,
                       &ctx->w_blk, &ctx->m_state, &ctx->m_pos, &ctx->m_val, &ctx->m_cov, &ctx->m_batch_rows,
                       &ctx->f_state, &ctx->f_pos, &ctx->f_val, &ctx->f_qval, &ctx->f_n, &ctx->f_batch_rows,
-                      &ctx->p_state, &ctx->p_keys, &ctx->p_cnt, &ctx->p_out_key, &ctx->p_out_cnt, &ctx->p_batch_rows})
+                      &ctx->p_state, &ctx->p_keys, &ctx->p_cnt, &ctx->p_out_key, &ctx->p_out_cnt, &ctx->p_batch_rows, &ctx->p_tflag, &ctx->p_tile_row0, &ctx->p_tile_rows})
         b->release();
     for (auto &t : ctx->timed) { (void)hipEventDestroy(t.beg); (void)hipEventDestroy(t.end); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -220,9 +220,9 @@ int mth_reset(mth_ctx_t *ctx) {
     if (ctx->f_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->f_state.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
     ctx->f_batches.clear();
     ctx->f_rows_bound = 0;
-    if (ctx->p_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->p_state.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
-    ctx->p_batches.clear();
-    ctx->p_rows_bound = 0;
+    if (ctx->p_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->p_state.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    ctx->p_meta.clear();
+    ctx->p_rows = 0;
     return MTH_OK;
 }
 

@@ -77,9 +77,11 @@ struct mth_ctx {
     std::vector<mth::BatchMeta> f_batches;
 
     // LPMD per-pair table (mth_pairs.hip)
-    mth::DevBuf p_state, p_keys, p_cnt, p_out_key, p_out_cnt, p_batch_rows;
-    uint64_t p_cap = 0, p_rows_bound = 0;
-    std::vector<mth::BatchMeta> p_batches;
+    mth::DevBuf p_state, p_keys, p_cnt, p_out_key, p_out_cnt, p_batch_rows, p_tflag, p_tile_row0, p_tile_rows;
+    uint64_t p_cap = 0, p_rows = 0;        // row capacity of p_out_*, rows in use (known exactly: one sync per batch)
+    double p_rows_per_cpg = 0.1;           // output sizing of the next batch
+    struct PairBatch { int32_t tid; uint64_t rows, heavy0, tile_end; };   // heavy0: first row of the global path's rows
+    std::vector<PairBatch> p_meta;
 
     bool timing = false;
     std::vector<mth::TimedLaunch> timed;

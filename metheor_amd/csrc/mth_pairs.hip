@@ -5,10 +5,19 @@
 // min_distance <= relpos_j - relpos_i <= max_distance: key (abspos_i, abspos_j), +1 concordant or
 // discordant.  Rows sorted by key; per-pair lpmd = n_d as f32 / (n_c as f32 + n_d as f32) (lpmd.rs:111).
 //
-// Device: global open-addressing table (key = pos1 << 32 | pos2, two u32 counters), sized from an
-// exact counting pre-pass; a pair is owned by the batch whose region contains pos1 (halo reads
-// included), so region / contig sharding needs no merge.  The reference sorts at print time; rows are
-// sorted by key on the host in mth_lpmd_pairs_fetch (optional secondary output, not a hot kernel).
+// Device: a pair is owned by the position of its first CpG, so the 8192-bp tile holding pos1 sees every update of its
+// pairs (the ownership argument of the PDR tile kernel and of mth_quartet.hip).  k_pairs_tile: one workgroup per tile,
+// candidate reads from the linear read index, a 2048-slot table in LDS -- one 64-bit word per slot: key = (pos1 - tile
+// start) << 19 | (pos2 - pos1) in the high half, the two 16-bit counters in the low half, so sorting the words sorts the
+// pairs -- compacted and sorted in LDS, rows written straight to the output (one global atomic per tile claims the
+// range).  The fetch walks the tiles in order: rows come out sorted as lpmd.rs:94 wants them, with no sort.
+// The row buffer is sized from the rows-per-CpG of earlier batches; a batch that does not fit is redone once with the
+// exact size (the kernel reports it) -- there is no counting pre-pass.
+// Tiles the LDS table cannot hold (> 65535 candidate reads: 16-bit counters; > 2048 distinct pairs; pos2 - pos1 >= 2^19)
+// are flagged and take the first version's path for their pairs only: a global open-addressing table (key = pos1 << 32 |
+// pos2, two u32 counters) sized from a counting pre-pass; their rows follow the batch's sorted rows and the fetch then
+// sorts that contig's rows on the host.  A pair is owned by the batch whose region contains pos1 (halo reads
+// included), so region / contig sharding needs no merge.
 #include <algorithm>
 #include <numeric>
 
@@ -37,7 +46,12 @@ struct PairArgs {
     uint32_t n_reads;
     uint8_t min_qual;
     unsigned long long *overflow;   // set when an insert ran out of probes
+    const uint32_t *tile_flag;      // nullptr: every pair; else only pairs whose pos1 lies in a flagged tile
 };
+
+constexpr int PT_W = 8192, PT_S = 2048, PT_B = 256;     // tile kernel: positions per tile, LDS slots, threads
+constexpr uint32_t PT_RANK_MAX = 192;                    // up to this many pairs in a tile: rank sort; above: bitonic network
+constexpr int P_STATE_WORDS = 8;
 
 // COUNT: only count the updates (table sizing); otherwise insert them
 template <typename RelT, bool COUNT>
@@ -57,6 +71,7 @@ __global__ __launch_bounds__(256) void k_pairs(const PairArgs a) {
                 const uint32_t wj = a.cpg_pos[j];
                 const int32_t p1 = (int32_t)(wj & 0x7fffffffu);
                 if (p1 < a.region_beg || p1 >= a.region_end) continue;     // owned by the region of pos1
+                if (a.tile_flag && !a.tile_flag[(uint32_t)(p1 - a.region_beg) / PT_W]) continue;
                 if (COUNT) { mine += 1; continue; }
                 const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 32) | (wk & 0x7fffffffu);
                 unsigned long long h = phash(key) & a.mask;
@@ -129,6 +144,161 @@ __global__ __launch_bounds__(256) void k_pairs_emit(const unsigned long long *__
     }
 }
 
+
+// ---- tile kernel ---------------------------------------------------------------------------------------------------
+struct PTileArgs {
+    const int32_t  *read_start;
+    const uint8_t  *read_mapq;
+    const uint32_t *cpg_off, *cpg_pos, *idx;
+    const void     *cpg_rel;
+    int32_t region_beg, region_end, idx_base, max_span, min_dist, max_dist;
+    uint32_t n_reads;
+    uint8_t min_qual, force_heavy;            // force_heavy: tests send every tile down the global path
+    unsigned long long *row_total;            // rows so far (all batches): the tile claims its range with one atomic
+    unsigned long long row_cap;               // rows the output holds; a range beyond it is claimed but not written ...
+    unsigned long long *unfit;                // ... and reported here (the host redoes the batch with the exact size)
+    unsigned long long *n_heavy;              // tiles left to the global path
+    uint32_t *tile_flag;                      // per tile of the batch: 1 = left to the global path
+    unsigned long long *tile_row0;            // per tile: first row of its range ...
+    uint32_t *tile_rows;                      // ... and its length
+    unsigned long long *out_key; uint32_t *out_cnt;
+    DevState *st;
+};
+template <typename RelT>
+__global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
+    // slot h: tab[2h] = counters (concordant | discordant << 16), tab[2h+1] = key; as a 64-bit word key is the high half
+    __shared__ unsigned long long tab64[PT_S];
+    __shared__ uint32_t s_heavy, ws[PT_B / 64 + 1];
+    __shared__ unsigned long long s_row0;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(tab64);
+    const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
+    const int tid = threadIdx.x;
+    const uint32_t t = blockIdx.x;
+    const int32_t T0 = a.region_beg + (int32_t)(t * PT_W);
+    const int32_t T1 = (int32_t)min((int64_t)T0 + PT_W, (int64_t)a.region_end);
+    const uint32_t lo = min(a.idx[((uint32_t)T0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
+    const uint32_t hi = min(a.idx[(((uint32_t)T0 + (uint32_t)PT_W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+    if (lo >= hi) {
+        if (tid == 0) { a.tile_flag[t] = 0u; a.tile_rows[t] = 0u; a.tile_row0[t] = 0ull; }
+        return;
+    }
+    for (int i = tid; i < PT_S; i += PT_B) tab64[i] = 0xffffffff00000000ull;
+    if (tid == 0) s_heavy = (hi - lo > 65535u || a.force_heavy) ? 1u : 0u;   // a counter takes at most one update per read
+    __syncthreads();
+    if (!s_heavy) {
+        uint32_t bad = 0;
+        for (uint32_t i = lo + tid; i < hi; i += PT_B) {
+            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+            if (o1 - o0 < 2 || a.read_mapq[i] < a.min_qual) continue;          // lpmd.rs:177
+            // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (rule of the PDR tile kernel)
+            const uint32_t sm1 = (uint32_t)a.read_start[i] - 1u;
+            bad |= ((a.cpg_pos[o0] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+            bad |= ((a.cpg_pos[o1 - 1] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+            for (uint32_t k = o0 + 1; k < o1; ++k) {
+                const int32_t rk = (int32_t)rel[k];
+                const uint32_t wk = a.cpg_pos[k];
+                for (uint32_t j = k; j-- > o0;) {
+                    const int32_t dist = rk - (int32_t)rel[j];
+                    if (dist > a.max_dist) break;                              // readutil.rs:184
+                    if (dist < a.min_dist) continue;                           // readutil.rs:196
+                    const uint32_t wj = a.cpg_pos[j];
+                    const int32_t p1 = (int32_t)(wj & 0x7fffffffu);
+                    if (p1 < T0 || p1 >= T1) continue;                         // owned by the tile of pos1
+                    const uint32_t delta = (wk & 0x7fffffffu) - (uint32_t)p1;
+                    if (delta >= (1u << 19) - 1u) { s_heavy = 1u; continue; }  // does not fit the 32-bit key (also: calls out of order)
+                    const uint32_t key = ((uint32_t)(p1 - T0) << 19) | delta;
+                    uint32_t h = (key * 0x9E3779B1u) >> (32 - 11), probes = 0;
+                    static_assert(PT_S == 1 << 11, "slot hash takes the top 11 bits");
+                    bool placed = false;
+                    while (probes++ < (uint32_t)PT_S) {
+                        const uint32_t cur = atomicCAS(&tab[2 * h + 1], 0xffffffffu, key);
+                        if (cur == 0xffffffffu || cur == key) { placed = true; break; }
+                        h = (h + 1) & (PT_S - 1);
+                    }
+                    if (placed) atomicAdd(&tab[2 * h], ((wj ^ wk) >> 31) ? 0x10000u : 1u);    // lpmd.rs:79-86
+                    else s_heavy = 1u;                                          // more distinct pairs than slots
+                }
+            }
+        }
+        if (bad) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
+    }
+    __syncthreads();
+    if (s_heavy) {                                      // block-uniform: the whole tile goes to the global path
+        if (tid == 0) { a.tile_flag[t] = 1u; a.tile_rows[t] = 0u; a.tile_row0[t] = 0ull; atomicAdd(a.n_heavy, 1ull); }
+        return;
+    }
+    // compact the occupied slots in place (each thread owns PER consecutive slots) ...
+    constexpr int PER = PT_S / PT_B;
+    unsigned long long kk[PER];
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { kk[k] = tab64[tid * PER + k]; m += (kk[k] >> 32) != 0xffffffffull ? 1u : 0u; }
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t incl = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) ws[wave + 1] = incl;
+    __syncthreads();                                    // every slot is in registers now: the table can be overwritten
+    if (tid == 0) {
+        ws[0] = 0;
+        for (int w = 1; w <= PT_B / 64; ++w) ws[w] += ws[w - 1];
+        const uint32_t n_all = ws[PT_B / 64];
+        a.tile_flag[t] = 0u; a.tile_rows[t] = n_all;
+        s_row0 = n_all ? atomicAdd(a.row_total, (unsigned long long)n_all) : 0ull;
+        a.tile_row0[t] = s_row0;
+        if (n_all && s_row0 + n_all > a.row_cap) atomicAdd(a.unfit, 1ull);
+    }
+    __syncthreads();
+    const uint32_t n = ws[PT_B / 64];
+    if (n == 0 || s_row0 + n > a.row_cap) return;       // block-uniform
+    {
+        uint32_t o = ws[wave] + incl - m;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) if ((kk[k] >> 32) != 0xffffffffull) tab64[o++] = kk[k];
+    }
+    auto emit_row = [&](unsigned long long w, uint32_t r) {
+        const unsigned long long o = s_row0 + r;
+        const uint32_t key = (uint32_t)(w >> 32), c = (uint32_t)w;
+        const uint32_t p1 = (uint32_t)T0 + (key >> 19), p2 = p1 + (key & ((1u << 19) - 1u));
+        a.out_key[o] = ((unsigned long long)p1 << 32) | p2;
+        reinterpret_cast<uint2 *>(a.out_cnt)[o] = make_uint2(c & 0xffffu, c >> 16);
+    };
+    __syncthreads();
+    if (n <= PT_RANK_MAX) {                             // few pairs (the usual case): thread j ranks compacted word j
+        for (uint32_t j = tid; j < n; j += PT_B) {
+            const unsigned long long w = tab64[j];
+            uint32_t r = 0;
+            for (uint32_t i = 0; i < n; ++i) r += tab64[i] < w ? 1u : 0u;   // keys are distinct: the high halves decide
+            emit_row(w, r);
+        }
+        return;
+    }
+    uint32_t P = 2;
+    while (P < n) P <<= 1;
+    for (uint32_t i = n + tid; i < P; i += PT_B) tab64[i] = ~0ull;             // pads sort to the end
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {                                    // bitonic network over P = pow2 >= n words
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < P; i += PT_B) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long u = tab64[i], v = tab64[l];
+                    const bool up = (i & k) == 0;
+                    if ((u > v) == up) { tab64[i] = v; tab64[l] = u; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t r = tid; r < n; r += PT_B) emit_row(tab64[r], r);
+}
+
+// restart of a batch whose rows did not fit: back to the row count before it
+__global__ void k_pairs_rewind(unsigned long long *ps, unsigned long long rows_before) { ps[1] = rows_before; ps[5] = 0; ps[6] = 0; }
+
 }  // namespace mth
 
 using namespace mth;
@@ -142,71 +312,128 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
     if (rc) return rc;
     hipStream_t s = ctx->stream;
     if (!ctx->p_state.p) {
-        MTH_HIP(ctx, ctx->p_state.reserve(4 * sizeof(unsigned long long), s));
-        MTH_HIP(ctx, hipMemsetAsync(ctx->p_state.p, 0, 4 * sizeof(unsigned long long), s));
+        MTH_HIP(ctx, ctx->p_state.reserve(P_STATE_WORDS * sizeof(unsigned long long), s));
+        MTH_HIP(ctx, hipMemsetAsync(ctx->p_state.p, 0, P_STATE_WORDS * sizeof(unsigned long long), s));
     }
-    unsigned long long *ps = ctx->p_state.as<unsigned long long>();   // [0] updates of the batch [1] total rows [2] base
-    MTH_HIP(ctx, hipMemsetAsync(ps, 0, sizeof(unsigned long long), s));
-    PairArgs a;
-    a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
-    a.cpg_rel = d.cpg_rel ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
-    a.keys = nullptr; a.cnt = nullptr; a.n_updates = ps; a.mask = 0; a.overflow = ps + 3;
-    a.region_beg = d.region_beg; a.region_end = d.region_end; a.min_dist = params->min_distance; a.max_dist = params->max_distance;
-    a.n_reads = d.n_reads; a.min_qual = params->min_qual;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)d.n_reads + 255) / 256 + 1, 8192);
+    // [0] updates (counting pass of the global path) [1] total rows [2] first row of the global path's rows
+    // [3] its overflow flag [5] tiles left to the global path [6] tiles whose rows did not fit the output
+    unsigned long long *ps = ctx->p_state.as<unsigned long long>();
+    const int64_t region_len = (int64_t)d.region_end - d.region_beg;
+    const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + PT_W - 1) / PT_W) : 0u;
+    const uint64_t tiles_before = ctx->p_meta.empty() ? 0 : ctx->p_meta.back().tile_end;
+    const uint64_t rows_before = ctx->p_rows;
+    mth_ctx::PairBatch meta{batch->tid, 0, rows_before, tiles_before + ntiles};
+    if (!ntiles) { ctx->p_meta.push_back(meta); return MTH_OK; }
     const bool r8 = d.cpg_rel != nullptr;
-    {
-        LaunchTimer lt(ctx, K_PAIRS);
-        if (r8) hipLaunchKernelGGL((k_pairs<uint8_t, true>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_pairs<uint16_t, true>), dim3(grid), dim3(256), 0, s, a);
+    int32_t idx_base = 0;
+    uint32_t nt = 0;
+    rc = build_read_index(ctx, d, PT_W, idx_base, nt);
+    if (rc) return rc;
+    MTH_HIP(ctx, ctx->p_tflag.reserve((size_t)ntiles * 4, s));
+    MTH_HIP(ctx, ctx->p_tile_row0.reserve((tiles_before + ntiles) * 8, s, true, tiles_before * 8));
+    MTH_HIP(ctx, ctx->p_tile_rows.reserve((tiles_before + ntiles) * 4, s, true, tiles_before * 4));
+    // output size: rows per CpG call of the batches so far (first batch: a guess); the kernel reports the exact need
+    uint64_t want = rows_before + (uint64_t)((double)d.n_cpgs * ctx->p_rows_per_cpg * 1.25) + 4096;
+    if (const char *e = getenv("MTH_PAIRS_ROWS_MIN")) want = rows_before + strtoull(e, nullptr, 10);   // tests: force the redo
+    unsigned long long st[P_STATE_WORDS];
+    for (int attempt = 0;; ++attempt) {
+        if (want > ctx->p_cap) {
+            MTH_HIP(ctx, ctx->p_out_key.reserve(want * 8, s, true, rows_before * 8));
+            MTH_HIP(ctx, ctx->p_out_cnt.reserve(want * 8, s, true, rows_before * 8));
+            ctx->p_cap = want;
+        }
+        hipLaunchKernelGGL(k_pairs_rewind, dim3(1), dim3(1), 0, s, ps, (unsigned long long)rows_before);
+        PTileArgs a;
+        a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
+        a.idx = ctx->idx.as<uint32_t>(); a.cpg_rel = r8 ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
+        a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
+        a.min_dist = params->min_distance; a.max_dist = params->max_distance; a.n_reads = d.n_reads;
+        a.min_qual = params->min_qual; a.force_heavy = getenv("MTH_PAIRS_FORCE_GLOBAL") ? 1 : 0;
+        a.row_total = ps + 1; a.row_cap = ctx->p_cap; a.unfit = ps + 6; a.n_heavy = ps + 5;
+        a.tile_flag = ctx->p_tflag.as<uint32_t>();
+        a.tile_row0 = ctx->p_tile_row0.as<unsigned long long>() + tiles_before;
+        a.tile_rows = ctx->p_tile_rows.as<uint32_t>() + tiles_before;
+        a.out_key = ctx->p_out_key.as<unsigned long long>(); a.out_cnt = ctx->p_out_cnt.as<uint32_t>(); a.st = ctx->d_state;
+        {
+            LaunchTimer lt(ctx, K_PAIRSTILE);
+            if (r8) hipLaunchKernelGGL(k_pairs_tile<uint8_t>, dim3(ntiles), dim3(PT_B), 0, s, a);
+            else hipLaunchKernelGGL(k_pairs_tile<uint16_t>, dim3(ntiles), dim3(PT_B), 0, s, a);
+        }
+        MTH_HIP(ctx, hipMemcpyAsync(st, ps, sizeof st, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));            // one sync per batch: rows, flagged tiles, fit
+        if (!st[6]) break;
+        if (attempt) return fail(ctx, MTH_ERR_STATE, "pairs: rows did not fit an exactly sized output");
+        want = st[1];                                     // every tile claimed its range: this is the exact size
     }
-    unsigned long long bound = 0;
-    MTH_HIP(ctx, hipMemcpyAsync(&bound, ps, sizeof bound, hipMemcpyDeviceToHost, s));
-    MTH_HIP(ctx, hipStreamSynchronize(s));                            // exact table sizing: one sync per batch
-    // `bound` counts pair UPDATES; at depth D there are ~D per distinct pair, and the table is cleared and scanned once per
-    // batch: start at bound / 2 slots and redo 4x larger if an insert ran out of probes (cannot happen at 2 x bound)
-    unsigned long long n_slots = 1024;
-    while (n_slots < bound / 2) n_slots <<= 1;
-    if (const char *e = getenv("MTH_PAIRS_SLOTS_MIN")) { const unsigned long long k = strtoull(e, nullptr, 10); if (k >= 16) { n_slots = 16; while (n_slots < k) n_slots <<= 1; } }   // tests: force the retry
-    for (;;) {
-        MTH_HIP(ctx, ctx->p_keys.reserve(n_slots * 8, s));
-        MTH_HIP(ctx, ctx->p_cnt.reserve(n_slots * 8, s));
-        MTH_HIP(ctx, hipMemsetAsync(ctx->p_keys.p, 0xFF, n_slots * 8, s));
-        MTH_HIP(ctx, hipMemsetAsync(ctx->p_cnt.p, 0, n_slots * 8, s));
-        MTH_HIP(ctx, hipMemsetAsync(ps + 3, 0, sizeof(unsigned long long), s));
-        a.keys = ctx->p_keys.as<unsigned long long>(); a.cnt = ctx->p_cnt.as<uint32_t>(); a.mask = n_slots - 1; a.overflow = ps + 3;
+    uint64_t total = st[1];
+    meta.heavy0 = total;
+    if (st[5]) {
+        // The tiles the LDS table could not hold: the global table, for their pairs only.
+        PairArgs g;
+        g.read_mapq = d.read_mapq; g.cpg_off = d.cpg_off; g.cpg_pos = d.cpg_pos;
+        g.cpg_rel = r8 ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
+        g.keys = nullptr; g.cnt = nullptr; g.n_updates = ps; g.mask = 0; g.overflow = ps + 3;
+        g.region_beg = d.region_beg; g.region_end = d.region_end; g.min_dist = params->min_distance; g.max_dist = params->max_distance;
+        g.n_reads = d.n_reads; g.min_qual = params->min_qual; g.tile_flag = ctx->p_tflag.as<uint32_t>();
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)d.n_reads + 255) / 256 + 1, 8192);
+        MTH_HIP(ctx, hipMemsetAsync(ps, 0, sizeof(unsigned long long), s));
         {
             LaunchTimer lt(ctx, K_PAIRS);
-            if (r8) hipLaunchKernelGGL((k_pairs<uint8_t, false>), dim3(grid), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((k_pairs<uint16_t, false>), dim3(grid), dim3(256), 0, s, a);
+            if (r8) hipLaunchKernelGGL((k_pairs<uint8_t, true>), dim3(grid), dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((k_pairs<uint16_t, true>), dim3(grid), dim3(256), 0, s, g);
         }
-        unsigned long long ovf = 0;
-        MTH_HIP(ctx, hipMemcpyAsync(&ovf, ps + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
+        unsigned long long bound = 0;
+        MTH_HIP(ctx, hipMemcpyAsync(&bound, ps, sizeof bound, hipMemcpyDeviceToHost, s));
         MTH_HIP(ctx, hipStreamSynchronize(s));
-        if (!ovf) break;
-        n_slots <<= 2;
+        // `bound` counts pair UPDATES; at depth D there are ~D per distinct pair, and the table is cleared and scanned once per
+        // batch: start at bound / 2 slots and redo 4x larger if an insert ran out of probes (cannot happen at 2 x bound)
+        unsigned long long n_slots = 1024;
+        while (n_slots < bound / 2) n_slots <<= 1;
+        if (const char *e = getenv("MTH_PAIRS_SLOTS_MIN")) { const unsigned long long k = strtoull(e, nullptr, 10); if (k >= 16) { n_slots = 16; while (n_slots < k) n_slots <<= 1; } }   // tests: force the retry
+        for (;;) {
+            MTH_HIP(ctx, ctx->p_keys.reserve(n_slots * 8, s));
+            MTH_HIP(ctx, ctx->p_cnt.reserve(n_slots * 8, s));
+            MTH_HIP(ctx, hipMemsetAsync(ctx->p_keys.p, 0xFF, n_slots * 8, s));
+            MTH_HIP(ctx, hipMemsetAsync(ctx->p_cnt.p, 0, n_slots * 8, s));
+            MTH_HIP(ctx, hipMemsetAsync(ps + 3, 0, sizeof(unsigned long long), s));
+            g.keys = ctx->p_keys.as<unsigned long long>(); g.cnt = ctx->p_cnt.as<uint32_t>(); g.mask = n_slots - 1;
+            {
+                LaunchTimer lt(ctx, K_PAIRS);
+                if (r8) hipLaunchKernelGGL((k_pairs<uint8_t, false>), dim3(grid), dim3(256), 0, s, g);
+                else hipLaunchKernelGGL((k_pairs<uint16_t, false>), dim3(grid), dim3(256), 0, s, g);
+            }
+            unsigned long long ovf = 0;
+            MTH_HIP(ctx, hipMemcpyAsync(&ovf, ps + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
+            MTH_HIP(ctx, hipStreamSynchronize(s));
+            if (!ovf) break;
+            n_slots <<= 2;
+        }
+        const uint64_t need = total + bound;              // distinct pairs <= updates
+        if (need > ctx->p_cap) {
+            MTH_HIP(ctx, ctx->p_out_key.reserve(need * 8, s, true, total * 8));
+            MTH_HIP(ctx, ctx->p_out_cnt.reserve(need * 8, s, true, total * 8));
+            ctx->p_cap = need;
+        }
+        const uint32_t nblk = (uint32_t)((n_slots + 256 * SCAN_PER - 1) / (256 * SCAN_PER));
+        MTH_HIP(ctx, ctx->w_blk.reserve((size_t)nblk * 4, s));
+        MTH_HIP(ctx, ctx->p_batch_rows.reserve(4, s));
+        hipLaunchKernelGGL(k_pairs_blockcount, dim3(nblk), dim3(256), 0, s, ctx->p_keys.as<unsigned long long>(), n_slots,
+                           ctx->w_blk.as<uint32_t>());
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk, ps + 1, ps + 2,
+                           ctx->p_batch_rows.as<uint32_t>(), 0u);
+        hipLaunchKernelGGL(k_pairs_emit, dim3(nblk), dim3(256), 0, s, ctx->p_keys.as<unsigned long long>(), ctx->p_cnt.as<uint32_t>(),
+                           n_slots, ctx->w_blk.as<uint32_t>(), ps + 2, ctx->p_out_key.as<unsigned long long>(),
+                           ctx->p_out_cnt.as<uint32_t>());
+        unsigned long long t2 = 0;
+        MTH_HIP(ctx, hipMemcpyAsync(&t2, ps + 1, sizeof t2, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));
+        total = t2;
     }
-    const uint64_t need = ctx->p_rows_bound + bound;
-    if (need > ctx->p_cap) {
-        const uint64_t ncap = need + need / 4 + 1024, used = ctx->p_rows_bound;
-        MTH_HIP(ctx, ctx->p_out_key.reserve(ncap * 8, s, true, used * 8));
-        MTH_HIP(ctx, ctx->p_out_cnt.reserve(ncap * 8, s, true, used * 8));
-        ctx->p_cap = ncap;
-    }
-    ctx->p_rows_bound = need;
-    const uint32_t nblk = (uint32_t)((n_slots + 256 * SCAN_PER - 1) / (256 * SCAN_PER));
-    MTH_HIP(ctx, ctx->w_blk.reserve((size_t)nblk * 4, s));
-    const size_t nb = ctx->p_batches.size();
-    MTH_HIP(ctx, ctx->p_batch_rows.reserve((nb + 1) * 4, s, true, nb * 4));
-    hipLaunchKernelGGL(k_pairs_blockcount, dim3(nblk), dim3(256), 0, s, ctx->p_keys.as<unsigned long long>(), n_slots,
-                       ctx->w_blk.as<uint32_t>());
-    hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk, ps + 1, ps + 2,
-                       ctx->p_batch_rows.as<uint32_t>(), (uint32_t)nb);
-    hipLaunchKernelGGL(k_pairs_emit, dim3(nblk), dim3(256), 0, s, ctx->p_keys.as<unsigned long long>(), ctx->p_cnt.as<uint32_t>(),
-                       n_slots, ctx->w_blk.as<uint32_t>(), ps + 2, ctx->p_out_key.as<unsigned long long>(),
-                       ctx->p_out_cnt.as<uint32_t>());
     MTH_HIP(ctx, hipGetLastError());
-    ctx->p_batches.push_back(BatchMeta{batch->tid});
+    meta.rows = total - rows_before;
+    ctx->p_rows = total;
+    if (d.n_cpgs) ctx->p_rows_per_cpg = std::max(ctx->p_rows_per_cpg * 0.5, (double)meta.rows / (double)d.n_cpgs);
+    ctx->p_meta.push_back(meta);
     return MTH_OK;
 }
 
@@ -216,29 +443,43 @@ int mth_lpmd_pairs_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t
     if (!ctx) return MTH_ERR_INVALID;
     int rc = sync_and_check(ctx);
     if (rc) return rc;
-    unsigned long long ps[3] = {0, 0, 0};
-    if (ctx->p_state.p) MTH_HIP(ctx, hipMemcpy(ps, ctx->p_state.p, sizeof ps, hipMemcpyDeviceToHost));
-    const uint64_t n = ps[1];
+    const uint64_t n = ctx->p_rows;
     if (n_rows) *n_rows = n;
     if (n == 0 || (!tid && !pos1 && !pos2 && !lpmd && !n_concordant && !n_discordant)) return MTH_OK;
     std::vector<unsigned long long> key(n);
-    std::vector<uint32_t> cnt(2 * n), rows(ctx->p_batches.size());
+    std::vector<uint32_t> cnt(2 * n);
     MTH_HIP(ctx, hipMemcpy(key.data(), ctx->p_out_key.p, n * 8, hipMemcpyDeviceToHost));
     MTH_HIP(ctx, hipMemcpy(cnt.data(), ctx->p_out_cnt.p, n * 8, hipMemcpyDeviceToHost));
-    if (!rows.empty()) MTH_HIP(ctx, hipMemcpy(rows.data(), ctx->p_batch_rows.p, rows.size() * 4, hipMemcpyDeviceToHost));
-    // sort within runs of batches that share a tid (lpmd.rs:94: pairs.sort()); batches arrive tid-ordered
-    std::vector<uint64_t> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    uint64_t o = 0;
-    for (size_t b = 0; b < rows.size();) {
+    const uint64_t n_tiles = ctx->p_meta.empty() ? 0 : ctx->p_meta.back().tile_end;
+    std::vector<unsigned long long> trow0(n_tiles);
+    std::vector<uint32_t> trows(n_tiles);
+    if (n_tiles) {
+        MTH_HIP(ctx, hipMemcpy(trow0.data(), ctx->p_tile_row0.p, n_tiles * 8, hipMemcpyDeviceToHost));
+        MTH_HIP(ctx, hipMemcpy(trows.data(), ctx->p_tile_rows.p, n_tiles * 4, hipMemcpyDeviceToHost));
+    }
+    // lpmd.rs:94 (pairs.sort()): the tiles in position order give sorted rows; only a run of batches of one contig that
+    // holds rows of the global path is sorted here (batches arrive tid-ordered)
+    std::vector<uint64_t> order;
+    order.reserve(n);
+    uint64_t batch_end = 0;
+    const size_t nb = ctx->p_meta.size();
+    for (size_t b = 0; b < nb;) {
         size_t e = b;
-        uint64_t cntrows = 0;
-        while (e < rows.size() && ctx->p_batches[e].tid == ctx->p_batches[b].tid) { cntrows += rows[e]; ++e; }
-        std::sort(order.begin() + o, order.begin() + o + cntrows, [&](uint64_t x, uint64_t y) { return key[x] < key[y]; });
-        for (uint64_t r = 0; r < cntrows; ++r) if (tid) tid[o + r] = ctx->p_batches[b].tid;
-        o += cntrows;
+        const size_t run0 = order.size();
+        bool unsorted = false;
+        while (e < nb && ctx->p_meta[e].tid == ctx->p_meta[b].tid) {
+            const auto &mb = ctx->p_meta[e];
+            batch_end += mb.rows;
+            for (uint64_t t = e ? ctx->p_meta[e - 1].tile_end : 0; t < mb.tile_end; ++t)
+                for (uint32_t j = 0; j < trows[t]; ++j) order.push_back(trow0[t] + j);
+            for (uint64_t i = mb.heavy0; i < batch_end; ++i) { order.push_back(i); unsorted = true; }
+            ++e;
+        }
+        if (unsorted) std::sort(order.begin() + run0, order.end(), [&](uint64_t x, uint64_t y) { return key[x] < key[y]; });
+        if (tid) for (size_t r = run0; r < order.size(); ++r) tid[r] = ctx->p_meta[b].tid;
         b = e;
     }
+    if (order.size() != n) return fail(ctx, MTH_ERR_STATE, "pairs: tile ranges do not add up to the row count");
     for (uint64_t r = 0; r < n; ++r) {
         const uint64_t x = order[r];
         const uint32_t c = cnt[2 * x], dd = cnt[2 * x + 1];

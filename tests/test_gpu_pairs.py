@@ -96,6 +96,60 @@ def test_table_overflow_retry(eng, monkeypatch):
     reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
     kw = dict(min_distance=2, max_distance=40, min_qual=10)
     monkeypatch.setenv("MTH_PAIRS_SLOTS_MIN", "16")
+    monkeypatch.setenv("MTH_PAIRS_FORCE_GLOBAL", "1")          # the global table only serves tiles the LDS table refused
     d = run_device(eng, [c], kw)
     monkeypatch.delenv("MTH_PAIRS_SLOTS_MIN")
+    monkeypatch.delenv("MTH_PAIRS_FORCE_GLOBAL")
     assert check(d, reads, kw) > 2000
+
+
+def test_output_redo_when_rows_do_not_fit(eng, monkeypatch):
+    """the row buffer is sized from a guess; a batch that needs more is redone once with the exact size the kernel reports"""
+    from metheor_amd import shard, synth
+    rng = np.random.default_rng(79)
+    cs = [synth.make_contig(0, 300_000, 50_000, 0.04, rng), synth.make_contig(1, 200_000, 30_000, 0.04, rng)]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    kw = dict(min_distance=2, max_distance=30, min_qual=10)
+    monkeypatch.setenv("MTH_PAIRS_ROWS_MIN", "100")
+    d = run_device(eng, cs, kw, regions=[shard.plan_regions(cs[0], 3), [(0, cs[1]["length"])]])
+    monkeypatch.delenv("MTH_PAIRS_ROWS_MIN")
+    assert check(d, reads, kw) > 10000
+
+
+def test_global_path_for_every_tile(eng, monkeypatch):
+    from metheor_amd import shard, synth
+    rng = np.random.default_rng(80)
+    cs = [synth.make_contig(0, 300_000, 50_000, 0.04, rng), synth.make_contig(1, 200_000, 30_000, 0.04, rng)]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    kw = dict(min_distance=2, max_distance=16, min_qual=10)
+    monkeypatch.setenv("MTH_PAIRS_FORCE_GLOBAL", "1")
+    d = run_device(eng, cs, kw, regions=[shard.plan_regions(cs[0], 3), [(0, cs[1]["length"])]])
+    monkeypatch.delenv("MTH_PAIRS_FORCE_GLOBAL")
+    assert check(d, reads, kw) > 5000
+
+
+def test_dense_and_wide_window_overflow_the_lds_table(eng):
+    """density 0.2 with a 100-bp window: > 2048 distinct pairs per 8192-bp tile in the dense contig -> those tiles take the
+    global path, the sparse contig stays on the tile path; rows still come out in the reference's sorted order"""
+    from metheor_amd import synth
+    rng = np.random.default_rng(81)
+    cs = [synth.make_contig(0, 100_000, 20_000, 0.2, rng), synth.make_contig(1, 200_000, 30_000, 0.01, rng)]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    kw = dict(min_distance=2, max_distance=100, min_qual=10)
+    assert check(run_device(eng, cs, kw), reads, kw) > 50000
+
+
+def test_deep_tile_exceeds_16bit_counters(eng):
+    from metheor_amd import synth
+    from tests.test_gpu_quartet import _contig, _reads_over
+    rng = np.random.default_rng(82)
+    sites = np.array([5000, 5004, 5010, 5030, 5040, 9000, 9004, 9010, 9100, 9150], np.int64)
+    starts = np.sort(np.r_[np.full(70_000, 4990), rng.integers(8950, 9000, 3000)]).astype(np.int64)
+    off, pos, rel = _reads_over(sites, starts, 120, rng)
+    c = _contig(0, 20000, starts, 120, off, pos, rel, rng)
+    c["read_mapq"][:] = 40
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    kw = dict(min_distance=2, max_distance=16, min_qual=10)
+    d = run_device(eng, [c], kw)
+    check(d, reads, kw)
+    assert int((d["n_concordant"] + d["n_discordant"]).max()) == 70_000
