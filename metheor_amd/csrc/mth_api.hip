@@ -177,7 +177,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
                       &ctx->dec_mapq, &ctx->dec_fwd, &ctx->dec_n, &ctx->dec_off, &ctx->dec_pos, &ctx->dec_rel, &ctx->dec_blk, &ctx->dec_off32, &ctx->dec_runs, &ctx->dec_xm, &ctx->dec_filter,
                       &ctx->inf_file, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff, &ctx->crc_mat,
                       &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
-                      &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_batch_heavy0, &ctx->q_tflag, &ctx->q_tile_row0, &ctx->q_tile_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
+                      &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_tflag, &ctx->q_tile_row0, &ctx->q_tile_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
                       &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_aux, &ctx->w_flags,
                       &ctx->w_blk, &ctx->m_state, &ctx->m_pos, &ctx->m_val, &ctx->m_cov, &ctx->m_batch_rows,
                       &ctx->f_state, &ctx->f_pos, &ctx->f_val, &ctx->f_qval, &ctx->f_n, &ctx->f_batch_rows,
@@ -211,9 +211,8 @@ int mth_reset(mth_ctx_t *ctx) {
     ctx->batches.clear();
     ctx->out_bound = 0;
     if (ctx->q_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->q_state.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
-    ctx->q_batches.clear();
-    ctx->q_tile_ofs.clear();
-    ctx->q_rows_bound = 0;
+    ctx->q_meta.clear();
+    ctx->q_rows = 0;
     if (ctx->m_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->m_state.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
     ctx->m_batches.clear();
     ctx->m_rows_bound = 0;

@@ -57,11 +57,14 @@ struct mth_ctx {
     size_t batch_cnt_cap = 0;
 
     // ME / PM (mth_quartet.hip): hash table of the batch in flight + appended result rows
-    mth::DevBuf q_state, q_keys, q_hist, q_blk, q_batch_rows, q_batch_heavy0, q_tflag, q_tile_row0, q_tile_rows;
-    std::vector<uint64_t> q_tile_ofs;      // per batch: tiles of all batches up to and including it
+    mth::DevBuf q_state, q_keys, q_hist, q_blk, q_batch_rows, q_tflag, q_tile_row0, q_tile_rows;
+    // a batch of the tile-kernel measures (quartets, pairs): heavy0 = first row of the global path's rows, tile_end = tiles of
+    // all batches up to and including it
+    struct TileBatch { int32_t tid; uint64_t rows, heavy0, tile_end; };
+    std::vector<TileBatch> q_meta;
+    double q_rows_per_cpg = 0.15;          // output sizing of the next batch
     mth::DevBuf q_pos, q_cnt, q_me, q_pm, q_depth;
-    uint64_t q_cap = 0, q_rows_bound = 0;
-    std::vector<mth::BatchMeta> q_batches;
+    uint64_t q_cap = 0, q_rows = 0;        // row capacity, rows in use (known exactly: one sync per batch)
 
     // site-walk measures (mth_sites.hip): discovery sink, per-candidate work arrays, MHL result rows
     mth::DevState *d_state2 = nullptr;
@@ -80,8 +83,7 @@ struct mth_ctx {
     mth::DevBuf p_state, p_keys, p_cnt, p_out_key, p_out_cnt, p_batch_rows, p_tflag, p_tile_row0, p_tile_rows;
     uint64_t p_cap = 0, p_rows = 0;        // row capacity of p_out_*, rows in use (known exactly: one sync per batch)
     double p_rows_per_cpg = 0.1;           // output sizing of the next batch
-    struct PairBatch { int32_t tid; uint64_t rows, heavy0, tile_end; };   // heavy0: first row of the global path's rows
-    std::vector<PairBatch> p_meta;
+    std::vector<TileBatch> p_meta;
 
     bool timing = false;
     std::vector<mth::TimedLaunch> timed;

@@ -322,7 +322,7 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
     const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + PT_W - 1) / PT_W) : 0u;
     const uint64_t tiles_before = ctx->p_meta.empty() ? 0 : ctx->p_meta.back().tile_end;
     const uint64_t rows_before = ctx->p_rows;
-    mth_ctx::PairBatch meta{batch->tid, 0, rows_before, tiles_before + ntiles};
+    mth_ctx::TileBatch meta{batch->tid, 0, rows_before, tiles_before + ntiles};
     if (!ntiles) { ctx->p_meta.push_back(meta); return MTH_OK; }
     const bool r8 = d.cpg_rel != nullptr;
     int32_t idx_base = 0;

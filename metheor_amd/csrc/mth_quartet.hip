@@ -19,6 +19,8 @@
 // sharding needs no exchange.  Each tile sorts its rows in LDS and the fetch walks the tiles in order, so rows come out
 // sorted by (tid, p1..p4); rows of tiles that took the global path follow in table order (the reference's order is
 // HashMap-random, compare as sets).
+#include <algorithm>
+
 #include "mth_ctx.h"
 #include "mth_scan.h"
 
@@ -43,31 +45,15 @@ __device__ __forceinline__ uint32_t qslot(unsigned long long key) {
     return h & (QT_S - 1);
 }
 
-// upper bound of the number of (read, window) updates: sum over passing reads of max(0, n - 3)
-// (+ the span check the tile kernel's candidate ranges rely on: a read longer than max_span could be missed)
+// global path: upper bound of the number of (read, window) updates: sum over passing reads of max(0, n - 3)
 __global__ __launch_bounds__(256) void k_quartet_bound(const uint32_t *__restrict__ cpg_off,
-                                                       const uint32_t *__restrict__ cpg_pos,
-                                                       const uint8_t *__restrict__ mapq,
-                                                       const int32_t *__restrict__ read_start, int32_t max_span,
-                                                       uint32_t n_reads, uint8_t min_qual,
-                                                       unsigned long long *__restrict__ out, DevState *__restrict__ st) {
-    // first kernel of a batch: [4] = rows before the batch, [5] = tiles left to the global path (nothing else is in flight)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { out[4] = out[1]; out[5] = 0; }
+                                                       const uint8_t *__restrict__ mapq, uint32_t n_reads,
+                                                       uint8_t min_qual, unsigned long long *__restrict__ out) {
     unsigned long long acc = 0;
-    uint32_t bad = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_reads; i += gridDim.x * 256) {
-        const uint32_t o0 = cpg_off[i], o1 = cpg_off[i + 1], n = o1 - o0;
-        if (n >= 4 && mapq[i] >= min_qual) {
-            acc += n - 3;
-            // first and last CpG within [start - 1, start - 1 + max_span] (a reverse read's first call may sit one base
-            // before its start, readutil.rs:338; same rule as the PDR tile kernel): unsigned, so a call further left is
-            // caught as well (the windows' deltas are checked to be 1..2047 at insert time: the calls in between are ordered)
-            const uint32_t sm1 = (uint32_t)read_start[i] - 1u;
-            bad |= ((cpg_pos[o0] & 0x7fffffffu) - sm1 > (uint32_t)max_span) ? 1u : 0u;
-            bad |= ((cpg_pos[o1 - 1] & 0x7fffffffu) - sm1 > (uint32_t)max_span) ? 1u : 0u;
-        }
+        const uint32_t n = cpg_off[i + 1] - cpg_off[i];
+        if (n >= 4 && mapq[i] >= min_qual) acc += n - 3;
     }
-    if (bad) atomicOr(&st->err, (uint32_t)ERRB_SPAN);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     __shared__ unsigned long long ws[4];
@@ -216,12 +202,15 @@ __global__ __launch_bounds__(256) void k_quartet_emit(const unsigned long long *
 
 // ---- tile kernel ---------------------------------------------------------------------------------------------------
 struct QTileArgs {
+    const int32_t  *read_start;
     const uint8_t  *read_mapq;
     const uint32_t *cpg_off, *cpg_pos, *idx;
     int32_t region_beg, region_end, idx_base, max_span;
     uint32_t n_reads;
     uint8_t min_qual, force_heavy;            // force_heavy: tests send every tile down the global path
     unsigned long long *row_total;            // rows emitted so far (all batches): the tile claims its range with one atomic
+    unsigned long long row_cap;               // rows the output holds; a range beyond it is claimed but not written ...
+    unsigned long long *unfit;                // ... and reported here (the host redoes the batch with the exact size)
     unsigned long long *n_heavy;              // tiles left to the global path
     uint32_t *tile_flag;                      // per tile of the batch: 1 = left to the global path
     unsigned long long *tile_row0;            // per tile: first row of its range ...
@@ -252,10 +241,17 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
     if (tid == 0) s_heavy = (hi - lo > 65535u || a.force_heavy) ? 1u : 0u;      // a bin counts at most one update per candidate read
     __syncthreads();
     if (!s_heavy) {
+        uint32_t bad = 0;
         for (uint32_t i = lo + tid; i < hi; i += QT_B) {
             const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
             if (o1 - o0 < 4 || a.read_mapq[i] < a.min_qual) continue;      // readutil.rs:101, me.rs:115
             uint32_t x = a.cpg_pos[o0], y = a.cpg_pos[o0 + 1], z = a.cpg_pos[o0 + 2];
+            // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (a reverse read's first call may
+            // sit one base before its start, readutil.rs:338; rule of the PDR tile kernel).  Unsigned: a call further left is
+            // caught too; the windows' deltas are checked to be 1..2047 below, so the calls in between are ordered.
+            const uint32_t sm1 = (uint32_t)a.read_start[i] - 1u;
+            bad |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+            bad |= ((a.cpg_pos[o1 - 1] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
             for (uint32_t k = o0 + 3; k < o1; ++k) {                        // readutil.rs:105-129
                 const uint32_t w = a.cpg_pos[k];
                 const int32_t p1 = (int32_t)(x & 0x7fffffffu);
@@ -282,6 +278,7 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
                 x = y; y = z; z = w;
             }
         }
+        if (bad) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
     }
     __syncthreads();
     if (s_heavy) {                                      // block-uniform: the whole tile goes to the global path
@@ -311,10 +308,11 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
         a.tile_flag[t] = 0u; a.tile_rows[t] = n_all;
         s_row0 = n_all ? atomicAdd(a.row_total, (unsigned long long)n_all) : 0ull;
         a.tile_row0[t] = s_row0;
+        if (n_all && s_row0 + n_all > a.row_cap) atomicAdd(a.unfit, 1ull);
     }
     __syncthreads();
     const uint32_t n = ws[QT_B / 64];
-    if (n == 0) return;
+    if (n == 0 || s_row0 + n > a.row_cap) return;      // block-uniform
     {
         uint32_t o = ws[wave] + incl - m;
 #pragma unroll
@@ -377,13 +375,8 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
     }
 }
 
-// bookkeeping around a batch.  qs: [0] bound [1] total rows [2] first row of the global path's rows [3] overflow flag
-// [4] rows before the batch [5] tiles left to the global path
-__global__ void k_quartet_end(const unsigned long long *qs, uint32_t *batch_rows, unsigned long long *batch_heavy0,
-                              uint32_t batch_idx, int ran_global) {
-    batch_rows[batch_idx] = (uint32_t)(qs[1] - qs[4]);
-    batch_heavy0[batch_idx] = ran_global ? qs[2] : qs[1];
-}
+// (re)start of a batch: back to the row count before it
+__global__ void k_quartet_rewind(unsigned long long *qs, unsigned long long rows_before) { qs[1] = rows_before; qs[5] = 0; qs[6] = 0; }
 
 }  // namespace mth
 
@@ -401,50 +394,48 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
         MTH_HIP(ctx, ctx->q_state.reserve(Q_STATE_WORDS * sizeof(unsigned long long), s));
         MTH_HIP(ctx, hipMemsetAsync(ctx->q_state.p, 0, Q_STATE_WORDS * sizeof(unsigned long long), s));
     }
-    unsigned long long *qs = ctx->q_state.as<unsigned long long>();   // words: see k_quartet_end
-    MTH_HIP(ctx, hipMemsetAsync(qs, 0, sizeof(unsigned long long), s));
-    {   // also with no reads: it opens the batch (k_quartet_end closes it)
-        LaunchTimer lt(ctx, K_QBOUND);
-        hipLaunchKernelGGL(k_quartet_bound, dim3(1024), dim3(256), 0, s, d.cpg_off, d.cpg_pos, d.read_mapq, d.read_start,
-                           d.max_span, d.n_reads, params->min_qual, qs, ctx->d_state);
-    }
-    unsigned long long bound = 0;
-    MTH_HIP(ctx, hipMemcpyAsync(&bound, qs, sizeof bound, hipMemcpyDeviceToHost, s));
-    MTH_HIP(ctx, hipStreamSynchronize(s));                            // the row buffers are sized exactly: one sync per batch
-    // distinct quartets <= bound: grow the row buffers (keeping earlier batches) before emitting
-    const uint64_t need = ctx->q_rows_bound + bound;
-    if (need > ctx->q_cap) {
-        uint64_t ncap = need + need / 4 + 1024;
-        const uint64_t used = ctx->q_rows_bound;   // upper bound of rows in use: copy that many
-        MTH_HIP(ctx, ctx->q_pos.reserve(ncap * 16, s, true, used * 16));
-        MTH_HIP(ctx, ctx->q_cnt.reserve(ncap * 64, s, true, used * 64));
-        MTH_HIP(ctx, ctx->q_me.reserve(ncap * 4, s, true, used * 4));
-        MTH_HIP(ctx, ctx->q_pm.reserve(ncap * 4, s, true, used * 4));
-        MTH_HIP(ctx, ctx->q_depth.reserve(ncap * 4, s, true, used * 4));
-        ctx->q_cap = ncap;
-    }
-    ctx->q_rows_bound = need;
-    const uint32_t batch_idx = (uint32_t)ctx->q_batches.size();
-    MTH_HIP(ctx, ctx->q_batch_rows.reserve((size_t)(batch_idx + 1) * 4, s, true, (size_t)batch_idx * 4));
-    MTH_HIP(ctx, ctx->q_batch_heavy0.reserve((size_t)(batch_idx + 1) * 8, s, true, (size_t)batch_idx * 8));
+    // [0] updates (counting pass of the global path) [1] total rows [2] first row of the global path's rows
+    // [3] its overflow flag [5] tiles left to the global path [6] tiles whose rows did not fit the output
+    unsigned long long *qs = ctx->q_state.as<unsigned long long>();
     const int64_t region_len = (int64_t)d.region_end - d.region_beg;
-    const uint64_t tiles_before = ctx->q_tile_ofs.empty() ? 0 : ctx->q_tile_ofs.back();
     const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + QT_W - 1) / QT_W) : 0u;
-    int ran_global = 0;
-    if (ntiles) {
-        int32_t idx_base = 0;
-        uint32_t nt = 0;
-        rc = build_read_index(ctx, d, QT_W, idx_base, nt);
-        if (rc) return rc;
-        MTH_HIP(ctx, ctx->q_tflag.reserve((size_t)ntiles * 4, s));
-        MTH_HIP(ctx, ctx->q_tile_row0.reserve((tiles_before + ntiles) * 8, s, true, tiles_before * 8));
-        MTH_HIP(ctx, ctx->q_tile_rows.reserve((tiles_before + ntiles) * 4, s, true, tiles_before * 4));
+    const uint64_t tiles_before = ctx->q_meta.empty() ? 0 : ctx->q_meta.back().tile_end;
+    const uint64_t rows_before = ctx->q_rows;
+    mth_ctx::TileBatch meta{batch->tid, 0, rows_before, tiles_before + ntiles};
+    if (!ntiles) { ctx->q_meta.push_back(meta); return MTH_OK; }
+    auto grow_rows = [&](uint64_t cap, uint64_t used) -> hipError_t {      // keeps the rows of earlier batches
+        hipError_t e;
+        if ((e = ctx->q_pos.reserve(cap * 16, s, true, used * 16)) != hipSuccess) return e;
+        if ((e = ctx->q_cnt.reserve(cap * 64, s, true, used * 64)) != hipSuccess) return e;
+        if ((e = ctx->q_me.reserve(cap * 4, s, true, used * 4)) != hipSuccess) return e;
+        if ((e = ctx->q_pm.reserve(cap * 4, s, true, used * 4)) != hipSuccess) return e;
+        if ((e = ctx->q_depth.reserve(cap * 4, s, true, used * 4)) != hipSuccess) return e;
+        ctx->q_cap = cap;
+        return hipSuccess;
+    };
+    int32_t idx_base = 0;
+    uint32_t nt = 0;
+    rc = build_read_index(ctx, d, QT_W, idx_base, nt);
+    if (rc) return rc;
+    MTH_HIP(ctx, ctx->q_tflag.reserve((size_t)ntiles * 4, s));
+    MTH_HIP(ctx, ctx->q_tile_row0.reserve((tiles_before + ntiles) * 8, s, true, tiles_before * 8));
+    MTH_HIP(ctx, ctx->q_tile_rows.reserve((tiles_before + ntiles) * 4, s, true, tiles_before * 4));
+    // output size: rows per CpG call of the batches so far (first batch: a guess); the kernel reports the exact need --
+    // there is no counting pre-pass
+    uint64_t want = rows_before + (uint64_t)((double)d.n_cpgs * ctx->q_rows_per_cpg * 1.25) + 4096;
+    if (const char *e = getenv("MTH_QUARTET_ROWS_MIN")) want = rows_before + strtoull(e, nullptr, 10);   // tests: force the redo
+    unsigned long long st[Q_STATE_WORDS];
+    for (int attempt = 0;; ++attempt) {
+        if (want > ctx->q_cap) MTH_HIP(ctx, grow_rows(want, rows_before));
+        hipLaunchKernelGGL(k_quartet_rewind, dim3(1), dim3(1), 0, s, qs, (unsigned long long)rows_before);
         QTileArgs a;
-        a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos; a.idx = ctx->idx.as<uint32_t>();
+        a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
+        a.idx = ctx->idx.as<uint32_t>();
         a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
         a.n_reads = d.n_reads; a.min_qual = params->min_qual;
         a.force_heavy = getenv("MTH_QUARTET_FORCE_GLOBAL") ? 1 : 0;
-        a.row_total = qs + 1; a.n_heavy = qs + 5; a.tile_flag = ctx->q_tflag.as<uint32_t>();
+        a.row_total = qs + 1; a.row_cap = ctx->q_cap; a.unfit = qs + 6; a.n_heavy = qs + 5;
+        a.tile_flag = ctx->q_tflag.as<uint32_t>();
         a.tile_row0 = ctx->q_tile_row0.as<unsigned long long>() + tiles_before;
         a.tile_rows = ctx->q_tile_rows.as<uint32_t>() + tiles_before;
         a.out_pos = ctx->q_pos.as<int32_t>(); a.out_cnt = ctx->q_cnt.as<uint32_t>(); a.out_me = ctx->q_me.as<float>();
@@ -453,54 +444,74 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
             LaunchTimer lt(ctx, K_QTILE);
             hipLaunchKernelGGL(k_quartet_tile, dim3(ntiles), dim3(QT_B), 0, s, a);
         }
-        unsigned long long n_heavy = 0;
-        MTH_HIP(ctx, hipMemcpyAsync(&n_heavy, qs + 5, sizeof n_heavy, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipMemcpyAsync(st, qs, sizeof st, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));            // one sync per batch: rows, flagged tiles, fit
+        if (!st[6]) break;
+        if (attempt) return fail(ctx, MTH_ERR_STATE, "quartets: rows did not fit an exactly sized output");
+        want = st[1];                                     // every tile claimed its range: this is the exact size
+    }
+    uint64_t total = st[1];
+    meta.heavy0 = total;
+    if (st[5]) {
+        // The tiles the LDS table could not hold: the global table, for their quartets only.  Its size: `bound` counts
+        // quartet INSTANCES of the whole batch; bound / 2 slots to start with, redone 4x larger if an insert ran out of
+        // probes -- at 2 x bound slots that cannot happen.
+        MTH_HIP(ctx, hipMemsetAsync(qs, 0, sizeof(unsigned long long), s));
+        {
+            LaunchTimer lt(ctx, K_QBOUND);
+            hipLaunchKernelGGL(k_quartet_bound, dim3(1024), dim3(256), 0, s, d.cpg_off, d.read_mapq, d.n_reads,
+                               params->min_qual, qs);
+        }
+        unsigned long long bound = 0;
+        MTH_HIP(ctx, hipMemcpyAsync(&bound, qs, sizeof bound, hipMemcpyDeviceToHost, s));
         MTH_HIP(ctx, hipStreamSynchronize(s));
-        if (n_heavy) {
-            // The tiles the LDS table could not hold: the global table, for their quartets only.  Its size: `bound` counts
-            // quartet INSTANCES of the whole batch; bound / 2 slots to start with, redone 4x larger if an insert ran out of
-            // probes -- at 2 x bound slots that cannot happen.
-            ran_global = 1;
-            unsigned long long n_slots = 1024;
-            while (n_slots < bound / 2) n_slots <<= 1;
-            if (const char *e = getenv("MTH_QUARTET_SLOTS_MIN")) { const unsigned long long k = strtoull(e, nullptr, 10); if (k >= 16) { n_slots = 16; while (n_slots < k) n_slots <<= 1; } }   // tests: force the retry
-            for (;;) {
-                MTH_HIP(ctx, ctx->q_keys.reserve(n_slots * 8, s));
-                MTH_HIP(ctx, ctx->q_hist.reserve(n_slots * 64, s));
-                MTH_HIP(ctx, hipMemsetAsync(ctx->q_keys.p, 0xFF, n_slots * 8, s));
-                MTH_HIP(ctx, hipMemsetAsync(ctx->q_hist.p, 0, n_slots * 64, s));
-                MTH_HIP(ctx, hipMemsetAsync(qs + 3, 0, sizeof(unsigned long long), s));
-                {
-                    LaunchTimer lt(ctx, K_QINSERT);
-                    hipLaunchKernelGGL(k_quartet_insert, dim3((d.n_reads + 255) / 256), dim3(256), 0, s, d.cpg_off, d.cpg_pos,
-                                       d.read_mapq, d.n_reads, params->min_qual, d.region_beg, d.region_end,
-                                       ctx->q_keys.as<unsigned long long>(), ctx->q_hist.as<uint32_t>(), n_slots - 1, qs + 3,
-                                       ctx->d_state, (const uint32_t *)ctx->q_tflag.as<uint32_t>());
-                }
-                unsigned long long ovf = 0;
-                MTH_HIP(ctx, hipMemcpyAsync(&ovf, qs + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
-                MTH_HIP(ctx, hipStreamSynchronize(s));
-                if (!ovf) break;
-                n_slots <<= 2;
+        unsigned long long n_slots = 1024;
+        while (n_slots < bound / 2) n_slots <<= 1;
+        if (const char *e = getenv("MTH_QUARTET_SLOTS_MIN")) { const unsigned long long k = strtoull(e, nullptr, 10); if (k >= 16) { n_slots = 16; while (n_slots < k) n_slots <<= 1; } }   // tests: force the retry
+        for (;;) {
+            MTH_HIP(ctx, ctx->q_keys.reserve(n_slots * 8, s));
+            MTH_HIP(ctx, ctx->q_hist.reserve(n_slots * 64, s));
+            MTH_HIP(ctx, hipMemsetAsync(ctx->q_keys.p, 0xFF, n_slots * 8, s));
+            MTH_HIP(ctx, hipMemsetAsync(ctx->q_hist.p, 0, n_slots * 64, s));
+            MTH_HIP(ctx, hipMemsetAsync(qs + 3, 0, sizeof(unsigned long long), s));
+            {
+                LaunchTimer lt(ctx, K_QINSERT);
+                hipLaunchKernelGGL(k_quartet_insert, dim3((d.n_reads + 255) / 256), dim3(256), 0, s, d.cpg_off, d.cpg_pos,
+                                   d.read_mapq, d.n_reads, params->min_qual, d.region_beg, d.region_end,
+                                   ctx->q_keys.as<unsigned long long>(), ctx->q_hist.as<uint32_t>(), n_slots - 1, qs + 3,
+                                   ctx->d_state, (const uint32_t *)ctx->q_tflag.as<uint32_t>());
             }
-            const uint32_t nblk = (uint32_t)((n_slots + 256 * QE_PER - 1) / (256 * QE_PER));
-            MTH_HIP(ctx, ctx->q_blk.reserve((size_t)nblk * 4, s));
+            unsigned long long ovf = 0;
+            MTH_HIP(ctx, hipMemcpyAsync(&ovf, qs + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
+            MTH_HIP(ctx, hipStreamSynchronize(s));
+            if (!ovf) break;
+            n_slots <<= 2;
+        }
+        if (total + bound > ctx->q_cap) MTH_HIP(ctx, grow_rows(total + bound, total));     // distinct quartets <= instances
+        const uint32_t nblk = (uint32_t)((n_slots + 256 * QE_PER - 1) / (256 * QE_PER));
+        MTH_HIP(ctx, ctx->q_blk.reserve((size_t)nblk * 4, s));
+        MTH_HIP(ctx, ctx->q_batch_rows.reserve(4, s));
+        {
             LaunchTimer lt(ctx, K_QEMIT);
             hipLaunchKernelGGL(k_quartet_blockcount, dim3(nblk), dim3(256), 0, s, ctx->q_keys.as<unsigned long long>(),
                                n_slots, ctx->q_blk.as<uint32_t>());
             hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->q_blk.as<uint32_t>(), nblk, qs + 1, qs + 2,
-                               ctx->q_batch_rows.as<uint32_t>(), batch_idx);
+                               ctx->q_batch_rows.as<uint32_t>(), 0u);
             hipLaunchKernelGGL(k_quartet_emit, dim3(nblk), dim3(256), 0, s, ctx->q_keys.as<unsigned long long>(),
                                ctx->q_hist.as<uint32_t>(), n_slots, ctx->q_blk.as<uint32_t>(), qs + 2,
                                ctx->q_pos.as<int32_t>(), ctx->q_cnt.as<uint32_t>(), ctx->q_me.as<float>(),
                                ctx->q_pm.as<float>(), ctx->q_depth.as<uint32_t>());
         }
+        unsigned long long t2 = 0;
+        MTH_HIP(ctx, hipMemcpyAsync(&t2, qs + 1, sizeof t2, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));
+        total = t2;
     }
-    hipLaunchKernelGGL(k_quartet_end, dim3(1), dim3(1), 0, s, (const unsigned long long *)qs, ctx->q_batch_rows.as<uint32_t>(),
-                       ctx->q_batch_heavy0.as<unsigned long long>(), batch_idx, ran_global);
     MTH_HIP(ctx, hipGetLastError());
-    ctx->q_batches.push_back(BatchMeta{batch->tid});
-    ctx->q_tile_ofs.push_back(tiles_before + ntiles);
+    meta.rows = total - rows_before;
+    ctx->q_rows = total;
+    if (d.n_cpgs) ctx->q_rows_per_cpg = std::max(ctx->q_rows_per_cpg * 0.5, (double)meta.rows / (double)d.n_cpgs);
+    ctx->q_meta.push_back(meta);
     return MTH_OK;
 }
 
@@ -511,12 +522,9 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
     if (!ctx) return MTH_ERR_INVALID;
     int rc = sync_and_check(ctx);
     if (rc) return rc;
-    unsigned long long qs[3] = {0, 0, 0};
-    if (ctx->q_state.p) MTH_HIP(ctx, hipMemcpy(qs, ctx->q_state.p, sizeof qs, hipMemcpyDeviceToHost));
-    const uint64_t total = qs[1];
-    std::vector<uint32_t> depth(total), rows(ctx->q_batches.size());
+    const uint64_t total = ctx->q_rows;
+    std::vector<uint32_t> depth(total);
     if (total) MTH_HIP(ctx, hipMemcpy(depth.data(), ctx->q_depth.p, total * 4, hipMemcpyDeviceToHost));
-    if (!rows.empty()) MTH_HIP(ctx, hipMemcpy(rows.data(), ctx->q_batch_rows.p, rows.size() * 4, hipMemcpyDeviceToHost));
     uint64_t n = 0;
     for (uint64_t i = 0; i < total; ++i) n += depth[i] >= min_depth ? 1 : 0;
     if (n_rows) *n_rows = n;
@@ -532,14 +540,13 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
     }
     // Row order: per batch, the tiles in position order (each tile's rows are sorted by (p1..p4)), then the rows of the
     // tiles that took the global path (table order).  The reference's order is HashMap-random.
-    const uint64_t n_tiles = ctx->q_tile_ofs.empty() ? 0 : ctx->q_tile_ofs.back();
-    std::vector<unsigned long long> trow0(n_tiles), heavy0(rows.size());
+    const uint64_t n_tiles = ctx->q_meta.empty() ? 0 : ctx->q_meta.back().tile_end;
+    std::vector<unsigned long long> trow0(n_tiles);
     std::vector<uint32_t> trows(n_tiles);
     if (n_tiles) {
         MTH_HIP(ctx, hipMemcpy(trow0.data(), ctx->q_tile_row0.p, n_tiles * 8, hipMemcpyDeviceToHost));
         MTH_HIP(ctx, hipMemcpy(trows.data(), ctx->q_tile_rows.p, n_tiles * 4, hipMemcpyDeviceToHost));
     }
-    if (!rows.empty()) MTH_HIP(ctx, hipMemcpy(heavy0.data(), ctx->q_batch_heavy0.p, rows.size() * 8, hipMemcpyDeviceToHost));
     uint64_t o = 0, batch_end = 0;
     auto put = [&](int32_t t_id, uint64_t i) {
         if (depth[i] < min_depth) return;
@@ -550,12 +557,12 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
         if (pm) pm[o] = hpm[i];
         ++o;
     };
-    for (size_t b = 0; b < rows.size(); ++b) {
-        batch_end += rows[b];
-        const int32_t t_id = ctx->q_batches[b].tid;
-        for (uint64_t t = b ? ctx->q_tile_ofs[b - 1] : 0; t < ctx->q_tile_ofs[b]; ++t)
-            for (uint32_t j = 0; j < trows[t]; ++j) put(t_id, trow0[t] + j);
-        for (uint64_t i = heavy0[b]; i < batch_end; ++i) put(t_id, i);
+    for (size_t b = 0; b < ctx->q_meta.size(); ++b) {
+        const auto &mb = ctx->q_meta[b];
+        batch_end += mb.rows;
+        for (uint64_t t = b ? ctx->q_meta[b - 1].tile_end : 0; t < mb.tile_end; ++t)
+            for (uint32_t j = 0; j < trows[t]; ++j) put(mb.tid, trow0[t] + j);
+        for (uint64_t i = mb.heavy0; i < batch_end; ++i) put(mb.tid, i);
     }
     return MTH_OK;
 }

@@ -244,3 +244,16 @@ def test_span_violation_is_refused(eng):
         eng.quartet_fetch(0)
     assert e.value.status == -5
     eng.reset()
+
+
+def test_output_redo_when_rows_do_not_fit(eng, monkeypatch):
+    """the row buffers are sized from a guess; a batch that needs more is redone once with the exact size the kernel reports"""
+    from metheor_amd import shard, synth
+    rng = np.random.default_rng(10)
+    cs = [synth.make_contig(0, 300_000, 50_000, 0.04, rng), synth.make_contig(1, 200_000, 30_000, 0.04, rng)]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    monkeypatch.setenv("MTH_QUARTET_ROWS_MIN", "100")
+    d = run_device(eng, cs, 10, 0, regions=[shard.plan_regions(cs[0], 3), [(0, cs[1]["length"])]])
+    monkeypatch.delenv("MTH_QUARTET_ROWS_MIN")
+    check(d, reads, 10, 0)
+    assert len(d["tid"]) > 10000
