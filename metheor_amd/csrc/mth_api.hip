@@ -155,7 +155,8 @@ int mth_ctx_create(int device_id, mth_ctx_t **out) {
     ctx->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->d_state, sizeof(DevState)) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_words, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         mth_ctx_destroy(ctx);
         return MTH_ERR_HIP;
     }
@@ -188,6 +189,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->d_state2) (void)hipFree(ctx->d_state2);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->h_words) (void)hipHostFree(ctx->h_words);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -37,6 +37,7 @@ struct mth_ctx {
 
     mth::DevState *d_state = nullptr;   // device
     mth::DevState *h_state = nullptr;   // pinned host mirror
+    unsigned long long *h_words = nullptr;   // 16 pinned words: per-batch read-backs of the tile-kernel measures
 
     // staging for MTH_MEM_HOST batches
     mth::DevBuf st_start, st_end, st_mapq, st_fwd, st_off, st_pos, st_rel;

@@ -5,15 +5,16 @@
 // min_distance <= relpos_j - relpos_i <= max_distance: key (abspos_i, abspos_j), +1 concordant or
 // discordant.  Rows sorted by key; per-pair lpmd = n_d as f32 / (n_c as f32 + n_d as f32) (lpmd.rs:111).
 //
-// Device: a pair is owned by the position of its first CpG, so the 8192-bp tile holding pos1 sees every update of its
+// Device: a pair is owned by the position of its first CpG, so the tile (8192 / 16384 / 32768 bp, by the batch's call
+// density) holding pos1 sees every update of its
 // pairs (the ownership argument of the PDR tile kernel and of mth_quartet.hip).  k_pairs_tile: one workgroup per tile,
 // candidate reads from the linear read index, a 2048-slot table in LDS -- one 64-bit word per slot: key = (pos1 - tile
-// start) << 19 | (pos2 - pos1) in the high half, the two 16-bit counters in the low half, so sorting the words sorts the
-// pairs -- compacted and sorted in LDS, rows written straight to the output (one global atomic per tile claims the
+// start) << (32 - log2 W) | (pos2 - pos1) in the high half, the two 16-bit counters in the low half, so sorting the words sorts the
+// pairs -- bucket-sorted in place in LDS, rows written straight to the output (one global atomic per tile claims the
 // range).  The fetch walks the tiles in order: rows come out sorted as lpmd.rs:94 wants them, with no sort.
 // The row buffer is sized from the rows-per-CpG of earlier batches; a batch that does not fit is redone once with the
 // exact size (the kernel reports it) -- there is no counting pre-pass.
-// Tiles the LDS table cannot hold (> 65535 candidate reads: 16-bit counters; > 2048 distinct pairs; pos2 - pos1 >= 2^19)
+// Tiles the LDS table cannot hold (> 65535 candidate reads: 16-bit counters; > 2048 distinct pairs; pos2 - pos1 >= 2^(32 - log2 W))
 // are flagged and take the first version's path for their pairs only: a global open-addressing table (key = pos1 << 32 |
 // pos2, two u32 counters) sized from a counting pre-pass; their rows follow the batch's sorted rows and the fetch then
 // sorts that contig's rows on the host.  A pair is owned by the batch whose region contains pos1 (halo reads
@@ -47,10 +48,11 @@ struct PairArgs {
     uint8_t min_qual;
     unsigned long long *overflow;   // set when an insert ran out of probes
     const uint32_t *tile_flag;      // nullptr: every pair; else only pairs whose pos1 lies in a flagged tile
+    int tile_shift;                 // log2 of the tile width the flags were made with
 };
 
-constexpr int PT_W = 8192, PT_S = 2048, PT_B = 256;     // tile kernel: positions per tile, LDS slots, threads
-constexpr uint32_t PT_RANK_MAX = 192;                    // up to this many pairs in a tile: rank sort; above: bitonic network
+constexpr int PT_S = 2048, PT_B = 256, PT_U = 4, PT_CHUNK = 1024, PT_GRID = 8192;   // tile kernel: LDS slots, threads, reads per thread and round (the tile
+                                                   // width is a template parameter: 8192 / 16384 / 32768, chosen per batch)
 constexpr int P_STATE_WORDS = 8;
 
 // COUNT: only count the updates (table sizing); otherwise insert them
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void k_pairs(const PairArgs a) {
                 const uint32_t wj = a.cpg_pos[j];
                 const int32_t p1 = (int32_t)(wj & 0x7fffffffu);
                 if (p1 < a.region_beg || p1 >= a.region_end) continue;     // owned by the region of pos1
-                if (a.tile_flag && !a.tile_flag[(uint32_t)(p1 - a.region_beg) / PT_W]) continue;
+                if (a.tile_flag && !a.tile_flag[(uint32_t)(p1 - a.region_beg) >> a.tile_shift]) continue;
                 if (COUNT) { mine += 1; continue; }
                 const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 32) | (wk & 0x7fffffffu);
                 unsigned long long h = phash(key) & a.mask;
@@ -152,9 +154,9 @@ struct PTileArgs {
     const uint32_t *cpg_off, *cpg_pos, *idx;
     const void     *cpg_rel;
     int32_t region_beg, region_end, idx_base, max_span, min_dist, max_dist;
-    uint32_t n_reads;
+    uint32_t n_reads, ntiles;
     uint8_t min_qual, force_heavy;            // force_heavy: tests send every tile down the global path
-    unsigned long long *row_total;            // rows so far (all batches): the tile claims its range with one atomic
+    unsigned long long *row_total;            // rows claimed so far (all batches, gaps included)
     unsigned long long row_cap;               // rows the output holds; a range beyond it is claimed but not written ...
     unsigned long long *unfit;                // ... and reported here (the host redoes the batch with the exact size)
     unsigned long long *n_heavy;              // tiles left to the global path
@@ -164,36 +166,64 @@ struct PTileArgs {
     unsigned long long *out_key; uint32_t *out_cnt;
     DevState *st;
 };
-template <typename RelT>
+template <typename RelT, int PT_SHIFT>
 __global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
+    constexpr int PT_W = 1 << PT_SHIFT;
+    constexpr int DBITS = 32 - PT_SHIFT;              // key = (pos1 - tile start) << DBITS | (pos2 - pos1)
     // slot h: tab[2h] = counters (concordant | discordant << 16), tab[2h+1] = key; as a 64-bit word key is the high half
     __shared__ unsigned long long tab64[PT_S];
     __shared__ uint32_t s_heavy, ws[PT_B / 64 + 1];
+    __shared__ uint32_t bcnt[PT_B], bbase[PT_B];        // bucket sort: words per bucket, first rank of the bucket
     __shared__ unsigned long long s_row0;
     uint32_t *tab = reinterpret_cast<uint32_t *>(tab64);
     const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
+    __shared__ unsigned long long s_chunk_pos, s_chunk_end;   // rows claimed from the global counter, handed out tile by tile
     const int tid = threadIdx.x;
-    const uint32_t t = blockIdx.x;
+    if (tid == 0) { s_chunk_pos = 0; s_chunk_end = 0; }
+    // Persistent workgroups: each takes tiles t, t + grid, ... and claims output rows for several tiles at once.  (One claim
+    // per tile was the kernel's floor on sparse WGBS: same-address returning atomics serialise at ~12 ns each, and a
+    // human genome is 378 k tiles.)  The unused tail of a chunk stays a gap; the fetch walks per-tile ranges.
+    for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    __syncthreads();                                    // the previous tile's rows have left LDS
     const int32_t T0 = a.region_beg + (int32_t)(t * PT_W);
     const int32_t T1 = (int32_t)min((int64_t)T0 + PT_W, (int64_t)a.region_end);
     const uint32_t lo = min(a.idx[((uint32_t)T0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
     const uint32_t hi = min(a.idx[(((uint32_t)T0 + (uint32_t)PT_W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
     if (lo >= hi) {
         if (tid == 0) { a.tile_flag[t] = 0u; a.tile_rows[t] = 0u; a.tile_row0[t] = 0ull; }
-        return;
+        continue;
     }
     for (int i = tid; i < PT_S; i += PT_B) tab64[i] = 0xffffffff00000000ull;
+    bcnt[tid] = 0;
     if (tid == 0) s_heavy = (hi - lo > 65535u || a.force_heavy) ? 1u : 0u;   // a counter takes at most one update per read
     __syncthreads();
     if (!s_heavy) {
         uint32_t bad = 0;
-        for (uint32_t i = lo + tid; i < hi; i += PT_B) {
-            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
-            if (o1 - o0 < 2 || a.read_mapq[i] < a.min_qual) continue;          // lpmd.rs:177
+        // PT_U reads per thread and round, their fields requested before any of them is used (see mth_quartet.hip)
+        for (uint32_t b0 = lo; b0 < hi; b0 += PT_B * PT_U) {
+          uint32_t o0s[PT_U], o1s[PT_U], fs[PT_U], ls[PT_U];
+          int32_t st[PT_U];
+          bool ok[PT_U];
+#pragma unroll
+          for (int u = 0; u < PT_U; ++u) {
+              const uint32_t i = b0 + (uint32_t)u * PT_B + tid, ii = min(i, hi - 1);
+              o0s[u] = a.cpg_off[ii]; o1s[u] = a.cpg_off[ii + 1];
+              ok[u] = i < hi && a.read_mapq[ii] >= a.min_qual;                 // lpmd.rs:177
+              st[u] = a.read_start[ii];
+          }
+#pragma unroll
+          for (int u = 0; u < PT_U; ++u) {
+              ok[u] = ok[u] && o1s[u] - o0s[u] >= 2;
+              if (ok[u]) { fs[u] = a.cpg_pos[o0s[u]]; ls[u] = a.cpg_pos[o1s[u] - 1]; }
+          }
+#pragma unroll
+          for (int u = 0; u < PT_U; ++u) {
+            if (!ok[u]) continue;
+            const uint32_t o0 = o0s[u], o1 = o1s[u];
             // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (rule of the PDR tile kernel)
-            const uint32_t sm1 = (uint32_t)a.read_start[i] - 1u;
-            bad |= ((a.cpg_pos[o0] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
-            bad |= ((a.cpg_pos[o1 - 1] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+            const uint32_t sm1 = (uint32_t)st[u] - 1u;
+            bad |= ((fs[u] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+            bad |= ((ls[u] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
             for (uint32_t k = o0 + 1; k < o1; ++k) {
                 const int32_t rk = (int32_t)rel[k];
                 const uint32_t wk = a.cpg_pos[k];
@@ -205,8 +235,8 @@ __global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
                     const int32_t p1 = (int32_t)(wj & 0x7fffffffu);
                     if (p1 < T0 || p1 >= T1) continue;                         // owned by the tile of pos1
                     const uint32_t delta = (wk & 0x7fffffffu) - (uint32_t)p1;
-                    if (delta >= (1u << 19) - 1u) { s_heavy = 1u; continue; }  // does not fit the 32-bit key (also: calls out of order)
-                    const uint32_t key = ((uint32_t)(p1 - T0) << 19) | delta;
+                    if (delta >= (1u << DBITS) - 1u) { s_heavy = 1u; continue; }  // does not fit the 32-bit key (also: calls out of order)
+                    const uint32_t key = ((uint32_t)(p1 - T0) << DBITS) | delta;
                     uint32_t h = (key * 0x9E3779B1u) >> (32 - 11), probes = 0;
                     static_assert(PT_S == 1 << 11, "slot hash takes the top 11 bits");
                     bool placed = false;
@@ -219,21 +249,31 @@ __global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
                     else s_heavy = 1u;                                          // more distinct pairs than slots
                 }
             }
+          }
         }
         if (bad) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
     }
     __syncthreads();
     if (s_heavy) {                                      // block-uniform: the whole tile goes to the global path
         if (tid == 0) { a.tile_flag[t] = 1u; a.tile_rows[t] = 0u; a.tile_row0[t] = 0ull; atomicAdd(a.n_heavy, 1ull); }
-        return;
+        continue;
     }
-    // compact the occupied slots in place (each thread owns PER consecutive slots) ...
+    // Rows go out sorted by key.  Bucket sort on the key's top 8 bits (= 256 position ranges of the tile): every thread
+    // holds its PER slots in registers, so the table is rebuilt in place in bucket order; a word's final rank = start of
+    // its bucket + the words of that bucket below it (a few).
+    static_assert(PT_S % PT_B == 0 && PT_B == 256, "each thread owns PT_S / PT_B slots and one bucket");
     constexpr int PER = PT_S / PT_B;
     unsigned long long kk[PER];
-    uint32_t m = 0;
+    uint32_t pib[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { kk[k] = tab64[tid * PER + k]; m += (kk[k] >> 32) != 0xffffffffull ? 1u : 0u; }
+    for (int k = 0; k < PER; ++k) {
+        kk[k] = tab64[tid * PER + k];
+        pib[k] = 0;
+        if ((kk[k] >> 32) != 0xffffffffull) pib[k] = atomicAdd(&bcnt[(uint32_t)(kk[k] >> 56)], 1u);
+    }
+    __syncthreads();                                    // every slot is in registers now: the table can be overwritten
     const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t m = bcnt[tid];
     uint32_t incl = m;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -241,59 +281,46 @@ __global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
         if (lane >= o) incl += up;
     }
     if (lane == 63) ws[wave + 1] = incl;
-    __syncthreads();                                    // every slot is in registers now: the table can be overwritten
+    __syncthreads();
     if (tid == 0) {
         ws[0] = 0;
         for (int w = 1; w <= PT_B / 64; ++w) ws[w] += ws[w - 1];
         const uint32_t n_all = ws[PT_B / 64];
         a.tile_flag[t] = 0u; a.tile_rows[t] = n_all;
-        s_row0 = n_all ? atomicAdd(a.row_total, (unsigned long long)n_all) : 0ull;
+        if (n_all && s_chunk_pos + n_all > s_chunk_end) {       // next chunk (what is left of the old one stays unused)
+            // enough for this workgroup's remaining tiles if they are like this one, at most PT_CHUNK rows: the gaps stay
+            // small next to the rows (a single-tile workgroup claims exactly its rows)
+            const unsigned long long left = (unsigned long long)((a.ntiles - 1u - t) / gridDim.x + 1u);
+            const unsigned long long claim = max((unsigned long long)n_all, min((unsigned long long)n_all * left, (unsigned long long)PT_CHUNK));
+            s_chunk_pos = atomicAdd(a.row_total, claim);
+            s_chunk_end = s_chunk_pos + claim;
+            if (s_chunk_end > a.row_cap) atomicAdd(a.unfit, 1ull);
+        }
+        s_row0 = s_chunk_pos;
+        s_chunk_pos += n_all;
         a.tile_row0[t] = s_row0;
-        if (n_all && s_row0 + n_all > a.row_cap) atomicAdd(a.unfit, 1ull);
     }
     __syncthreads();
     const uint32_t n = ws[PT_B / 64];
-    if (n == 0 || s_row0 + n > a.row_cap) return;       // block-uniform
-    {
-        uint32_t o = ws[wave] + incl - m;
+    if (n == 0 || s_row0 + n > a.row_cap) continue;       // block-uniform
+    bbase[tid] = ws[wave] + incl - m;
+    __syncthreads();
 #pragma unroll
-        for (int k = 0; k < PER; ++k) if ((kk[k] >> 32) != 0xffffffffull) tab64[o++] = kk[k];
-    }
-    auto emit_row = [&](unsigned long long w, uint32_t r) {
+    for (int k = 0; k < PER; ++k)
+        if ((kk[k] >> 32) != 0xffffffffull) tab64[bbase[(uint32_t)(kk[k] >> 56)] + pib[k]] = kk[k];
+    __syncthreads();
+    for (uint32_t j = tid; j < n; j += PT_B) {
+        const unsigned long long w = tab64[j];
+        const uint32_t bk = (uint32_t)(w >> 56), b0 = bbase[bk], b1 = b0 + bcnt[bk];
+        uint32_t r = b0;
+        for (uint32_t i = b0; i < b1; ++i) r += tab64[i] < w ? 1u : 0u;     // keys are distinct: the high halves decide
         const unsigned long long o = s_row0 + r;
         const uint32_t key = (uint32_t)(w >> 32), c = (uint32_t)w;
-        const uint32_t p1 = (uint32_t)T0 + (key >> 19), p2 = p1 + (key & ((1u << 19) - 1u));
+        const uint32_t p1 = (uint32_t)T0 + (key >> DBITS), p2 = p1 + (key & ((1u << DBITS) - 1u));
         a.out_key[o] = ((unsigned long long)p1 << 32) | p2;
         reinterpret_cast<uint2 *>(a.out_cnt)[o] = make_uint2(c & 0xffffu, c >> 16);
-    };
-    __syncthreads();
-    if (n <= PT_RANK_MAX) {                             // few pairs (the usual case): thread j ranks compacted word j
-        for (uint32_t j = tid; j < n; j += PT_B) {
-            const unsigned long long w = tab64[j];
-            uint32_t r = 0;
-            for (uint32_t i = 0; i < n; ++i) r += tab64[i] < w ? 1u : 0u;   // keys are distinct: the high halves decide
-            emit_row(w, r);
-        }
-        return;
     }
-    uint32_t P = 2;
-    while (P < n) P <<= 1;
-    for (uint32_t i = n + tid; i < P; i += PT_B) tab64[i] = ~0ull;             // pads sort to the end
-    __syncthreads();
-    for (uint32_t k = 2; k <= P; k <<= 1) {                                    // bitonic network over P = pow2 >= n words
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < P; i += PT_B) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const unsigned long long u = tab64[i], v = tab64[l];
-                    const bool up = (i & k) == 0;
-                    if ((u > v) == up) { tab64[i] = v; tab64[l] = u; }
-                }
-            }
-            __syncthreads();
-        }
     }
-    for (uint32_t r = tid; r < n; r += PT_B) emit_row(tab64[r], r);
 }
 
 // restart of a batch whose rows did not fit: back to the row count before it
@@ -319,6 +346,18 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
     // [3] its overflow flag [5] tiles left to the global path [6] tiles whose rows did not fit the output
     unsigned long long *ps = ctx->p_state.as<unsigned long long>();
     const int64_t region_len = (int64_t)d.region_end - d.region_beg;
+    // Tile width (see mth_quartet.hip): distinct pairs per tile ~ sites per tile x sites per pair window
+    int tile_shift = 13;
+    if (d.n_reads && region_len > 0) {
+        const double sites_per_bp = (double)d.n_cpgs / (double)d.n_reads / (double)std::max(d.max_span, 1);
+        const double reads_per_bp = (double)d.n_reads / (double)region_len;
+        const double window = std::max(1.0, (double)std::min<int64_t>((int64_t)params->max_distance - std::max(params->min_distance, 0) + 1, d.max_span));
+        while (tile_shift < 15 && sites_per_bp * (double)(2 << tile_shift) * std::max(1.0, sites_per_bp * window) <= 0.3 * PT_S &&
+               reads_per_bp * (double)((2 << tile_shift) + d.max_span + 2 * IDX_Q) <= 30000.0)
+            ++tile_shift;
+    }
+    if (const char *e = getenv("MTH_PAIRS_TILE_SHIFT")) tile_shift = std::min(15, std::max(13, atoi(e)));   // tests / tuning
+    const int PT_W = 1 << tile_shift;
     const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + PT_W - 1) / PT_W) : 0u;
     const uint64_t tiles_before = ctx->p_meta.empty() ? 0 : ctx->p_meta.back().tile_end;
     const uint64_t rows_before = ctx->p_rows;
@@ -335,7 +374,7 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
     // output size: rows per CpG call of the batches so far (first batch: a guess); the kernel reports the exact need
     uint64_t want = rows_before + (uint64_t)((double)d.n_cpgs * ctx->p_rows_per_cpg * 1.25) + 4096;
     if (const char *e = getenv("MTH_PAIRS_ROWS_MIN")) want = rows_before + strtoull(e, nullptr, 10);   // tests: force the redo
-    unsigned long long st[P_STATE_WORDS];
+    unsigned long long *st = ctx->h_words;     // pinned: the read-back does not go through a staging copy
     for (int attempt = 0;; ++attempt) {
         if (want > ctx->p_cap) {
             MTH_HIP(ctx, ctx->p_out_key.reserve(want * 8, s, true, rows_before * 8));
@@ -347,7 +386,7 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
         a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
         a.idx = ctx->idx.as<uint32_t>(); a.cpg_rel = r8 ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
         a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
-        a.min_dist = params->min_distance; a.max_dist = params->max_distance; a.n_reads = d.n_reads;
+        a.min_dist = params->min_distance; a.max_dist = params->max_distance; a.n_reads = d.n_reads; a.ntiles = ntiles;
         a.min_qual = params->min_qual; a.force_heavy = getenv("MTH_PAIRS_FORCE_GLOBAL") ? 1 : 0;
         a.row_total = ps + 1; a.row_cap = ctx->p_cap; a.unfit = ps + 6; a.n_heavy = ps + 5;
         a.tile_flag = ctx->p_tflag.as<uint32_t>();
@@ -356,10 +395,18 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
         a.out_key = ctx->p_out_key.as<unsigned long long>(); a.out_cnt = ctx->p_out_cnt.as<uint32_t>(); a.st = ctx->d_state;
         {
             LaunchTimer lt(ctx, K_PAIRSTILE);
-            if (r8) hipLaunchKernelGGL(k_pairs_tile<uint8_t>, dim3(ntiles), dim3(PT_B), 0, s, a);
-            else hipLaunchKernelGGL(k_pairs_tile<uint16_t>, dim3(ntiles), dim3(PT_B), 0, s, a);
+            if (tile_shift == 13) {
+                if (r8) hipLaunchKernelGGL((k_pairs_tile<uint8_t, 13>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
+                else hipLaunchKernelGGL((k_pairs_tile<uint16_t, 13>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
+            } else if (tile_shift == 14) {
+                if (r8) hipLaunchKernelGGL((k_pairs_tile<uint8_t, 14>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
+                else hipLaunchKernelGGL((k_pairs_tile<uint16_t, 14>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
+            } else {
+                if (r8) hipLaunchKernelGGL((k_pairs_tile<uint8_t, 15>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
+                else hipLaunchKernelGGL((k_pairs_tile<uint16_t, 15>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
+            }
         }
-        MTH_HIP(ctx, hipMemcpyAsync(st, ps, sizeof st, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipMemcpyAsync(st, ps, P_STATE_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         MTH_HIP(ctx, hipStreamSynchronize(s));            // one sync per batch: rows, flagged tiles, fit
         if (!st[6]) break;
         if (attempt) return fail(ctx, MTH_ERR_STATE, "pairs: rows did not fit an exactly sized output");
@@ -374,7 +421,7 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
         g.cpg_rel = r8 ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
         g.keys = nullptr; g.cnt = nullptr; g.n_updates = ps; g.mask = 0; g.overflow = ps + 3;
         g.region_beg = d.region_beg; g.region_end = d.region_end; g.min_dist = params->min_distance; g.max_dist = params->max_distance;
-        g.n_reads = d.n_reads; g.min_qual = params->min_qual; g.tile_flag = ctx->p_tflag.as<uint32_t>();
+        g.n_reads = d.n_reads; g.min_qual = params->min_qual; g.tile_flag = ctx->p_tflag.as<uint32_t>(); g.tile_shift = tile_shift;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)d.n_reads + 255) / 256 + 1, 8192);
         MTH_HIP(ctx, hipMemsetAsync(ps, 0, sizeof(unsigned long long), s));
         {
@@ -443,13 +490,8 @@ int mth_lpmd_pairs_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t
     if (!ctx) return MTH_ERR_INVALID;
     int rc = sync_and_check(ctx);
     if (rc) return rc;
-    const uint64_t n = ctx->p_rows;
-    if (n_rows) *n_rows = n;
-    if (n == 0 || (!tid && !pos1 && !pos2 && !lpmd && !n_concordant && !n_discordant)) return MTH_OK;
-    std::vector<unsigned long long> key(n);
-    std::vector<uint32_t> cnt(2 * n);
-    MTH_HIP(ctx, hipMemcpy(key.data(), ctx->p_out_key.p, n * 8, hipMemcpyDeviceToHost));
-    MTH_HIP(ctx, hipMemcpy(cnt.data(), ctx->p_out_cnt.p, n * 8, hipMemcpyDeviceToHost));
+    // Rows live in [0, p_rows) with gaps (the unused tails of the tile kernel's chunks); the per-tile ranges say where.
+    const uint64_t extent = ctx->p_rows;
     const uint64_t n_tiles = ctx->p_meta.empty() ? 0 : ctx->p_meta.back().tile_end;
     std::vector<unsigned long long> trow0(n_tiles);
     std::vector<uint32_t> trows(n_tiles);
@@ -460,26 +502,42 @@ int mth_lpmd_pairs_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t
     // lpmd.rs:94 (pairs.sort()): the tiles in position order give sorted rows; only a run of batches of one contig that
     // holds rows of the global path is sorted here (batches arrive tid-ordered)
     std::vector<uint64_t> order;
-    order.reserve(n);
-    uint64_t batch_end = 0;
-    const size_t nb = ctx->p_meta.size();
-    for (size_t b = 0; b < nb;) {
-        size_t e = b;
-        const size_t run0 = order.size();
-        bool unsorted = false;
-        while (e < nb && ctx->p_meta[e].tid == ctx->p_meta[b].tid) {
-            const auto &mb = ctx->p_meta[e];
-            batch_end += mb.rows;
-            for (uint64_t t = e ? ctx->p_meta[e - 1].tile_end : 0; t < mb.tile_end; ++t)
-                for (uint32_t j = 0; j < trows[t]; ++j) order.push_back(trow0[t] + j);
-            for (uint64_t i = mb.heavy0; i < batch_end; ++i) { order.push_back(i); unsorted = true; }
-            ++e;
+    std::vector<std::pair<size_t, size_t>> unsorted_runs;
+    std::vector<std::pair<size_t, int32_t>> run_tid;       // (first output row of the run, tid)
+    {
+        uint64_t batch_end = 0;
+        const size_t nb = ctx->p_meta.size();
+        for (size_t b = 0; b < nb;) {
+            size_t e = b;
+            const size_t run0 = order.size();
+            bool unsorted = false;
+            while (e < nb && ctx->p_meta[e].tid == ctx->p_meta[b].tid) {
+                const auto &mb = ctx->p_meta[e];
+                batch_end += mb.rows;
+                for (uint64_t t = e ? ctx->p_meta[e - 1].tile_end : 0; t < mb.tile_end; ++t)
+                    for (uint32_t j = 0; j < trows[t]; ++j) order.push_back(trow0[t] + j);
+                for (uint64_t i = mb.heavy0; i < batch_end; ++i) { order.push_back(i); unsorted = true; }
+                ++e;
+            }
+            if (unsorted) unsorted_runs.emplace_back(run0, order.size());
+            run_tid.emplace_back(run0, ctx->p_meta[b].tid);
+            b = e;
         }
-        if (unsorted) std::sort(order.begin() + run0, order.end(), [&](uint64_t x, uint64_t y) { return key[x] < key[y]; });
-        if (tid) for (size_t r = run0; r < order.size(); ++r) tid[r] = ctx->p_meta[b].tid;
-        b = e;
     }
-    if (order.size() != n) return fail(ctx, MTH_ERR_STATE, "pairs: tile ranges do not add up to the row count");
+    const uint64_t n = order.size();
+    if (n_rows) *n_rows = n;
+    if (n == 0 || (!tid && !pos1 && !pos2 && !lpmd && !n_concordant && !n_discordant)) return MTH_OK;
+    std::vector<unsigned long long> key(extent);
+    std::vector<uint32_t> cnt(2 * extent);
+    MTH_HIP(ctx, hipMemcpy(key.data(), ctx->p_out_key.p, extent * 8, hipMemcpyDeviceToHost));
+    MTH_HIP(ctx, hipMemcpy(cnt.data(), ctx->p_out_cnt.p, extent * 8, hipMemcpyDeviceToHost));
+    for (const auto &r : unsorted_runs)
+        std::sort(order.begin() + r.first, order.begin() + r.second, [&](uint64_t x, uint64_t y) { return key[x] < key[y]; });
+    if (tid)
+        for (size_t k = 0; k < run_tid.size(); ++k) {
+            const size_t r1 = k + 1 < run_tid.size() ? run_tid[k + 1].first : n;
+            for (size_t r = run_tid[k].first; r < r1; ++r) tid[r] = run_tid[k].second;
+        }
     for (uint64_t r = 0; r < n; ++r) {
         const uint64_t x = order[r];
         const uint32_t c = cnt[2 * x], dd = cnt[2 * x + 1];

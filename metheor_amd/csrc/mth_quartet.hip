@@ -7,7 +7,7 @@
 // bins visited 0..15 in order; min_depth is applied when rows are written (me.rs:82).
 //
 // Device design.  A quartet is owned by the position of its first CpG, so -- as for the per-site counters of PDR -- the
-// 8192-bp tile that contains p1 sees ALL updates of its quartets: k_quartet_tile keeps a 512-slot hash table in LDS
+// tile (8192 / 16384 / 32768 bp, by the batch's call density) that contains p1 sees ALL updates of its quartets: k_quartet_tile keeps a 512-slot hash table in LDS
 // (64-bit key, sixteen 16-bit bins packed in 8 words), fed by the tile's candidate reads (linear read index), and emits
 // its rows straight from LDS (one global atomic per tile to claim the output range).  The first version sent every
 // update to a global table: 6 M CAS + 6 M adds through L2 per 10 M reads were what it spent its time on.  Tiles that do
@@ -29,9 +29,8 @@ namespace mth {
 constexpr unsigned long long QKEY_EMPTY = ~0ull;
 // tile kernel: reference positions per tile, LDS table slots, threads.  Measured on S-chr19-10M (profiles/r01_quartet_tile.md):
 // wider tiles re-read fewer halo reads and clear LDS less often, a smaller table lets more tiles share a CU (25 KB each).
-constexpr int QT_W = 8192, QT_S = 512, QT_B = 256;
+constexpr int QT_S = 512, QT_B = 256, QT_U = 4, QT_CHUNK = 512, QT_GRID = 8192;   // (the tile width is a template parameter: 8192 / 16384 / 32768, chosen per batch)
 constexpr int Q_STATE_WORDS = 8;
-constexpr uint32_t QT_RANK_MAX = 192;          // up to this many quartets in a tile: rank sort; above: bitonic network
 
 __device__ __forceinline__ unsigned long long qhash(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -70,7 +69,8 @@ __global__ __launch_bounds__(256) void k_quartet_insert(const uint32_t *__restri
                                                         unsigned long long *__restrict__ keys,
                                                         uint32_t *__restrict__ hist, unsigned long long mask,
                                                         unsigned long long *__restrict__ overflow, DevState *__restrict__ st,
-                                                        const uint32_t *__restrict__ tile_flag /* nullptr: every quartet */) {
+                                                        const uint32_t *__restrict__ tile_flag /* nullptr: every quartet */,
+                                                        int tile_shift /* log2 of the tile width the flags were made with */) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_reads) return;
     const uint32_t o0 = cpg_off[i], o1 = cpg_off[i + 1];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_quartet_insert(const uint32_t *__restri
     for (uint32_t k = o0 + 3; k < o1; ++k) {                // readutil.rs:105-129
         const uint32_t d = cpg_pos[k];
         const int32_t p1 = (int32_t)(a & 0x7fffffffu);
-        if (p1 >= region_beg && p1 < region_end && (!tile_flag || tile_flag[(uint32_t)(p1 - region_beg) / QT_W])) {
+        if (p1 >= region_beg && p1 < region_end && (!tile_flag || tile_flag[(uint32_t)(p1 - region_beg) >> tile_shift])) {
             const uint32_t d2 = (b & 0x7fffffffu) - (a & 0x7fffffffu), d3 = (c & 0x7fffffffu) - (b & 0x7fffffffu),
                            d4 = (d & 0x7fffffffu) - (c & 0x7fffffffu);
             const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 33) | ((unsigned long long)d2 << 22) |
@@ -206,9 +206,9 @@ struct QTileArgs {
     const uint8_t  *read_mapq;
     const uint32_t *cpg_off, *cpg_pos, *idx;
     int32_t region_beg, region_end, idx_base, max_span;
-    uint32_t n_reads;
+    uint32_t n_reads, ntiles;
     uint8_t min_qual, force_heavy;            // force_heavy: tests send every tile down the global path
-    unsigned long long *row_total;            // rows emitted so far (all batches): the tile claims its range with one atomic
+    unsigned long long *row_total;            // rows claimed so far (all batches, gaps included)
     unsigned long long row_cap;               // rows the output holds; a range beyond it is claimed but not written ...
     unsigned long long *unfit;                // ... and reported here (the host redoes the batch with the exact size)
     unsigned long long *n_heavy;              // tiles left to the global path
@@ -218,15 +218,22 @@ struct QTileArgs {
     int32_t *out_pos; uint32_t *out_cnt; float *out_me, *out_pm; uint32_t *out_depth;
     DevState *st;
 };
+template <int QT_W>
 __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
-    __shared__ unsigned long long keys[QT_S];  // the hash table ...
-    __shared__ unsigned long long skey[QT_S];  // ... and its keys once more, compacted and sorted
-    __shared__ uint16_t sslot[QT_S];           // slot of compacted key r
+    __shared__ unsigned long long keys[QT_S];  // the hash table; later its keys in bucket order
+    __shared__ uint16_t sslot[QT_S];           // ... and the slot each of them came from
+    __shared__ uint32_t bcnt[QT_B], bbase[QT_B];   // bucket sort on p1: keys per bucket, first rank of the bucket
     __shared__ uint32_t bins[QT_S * 8];        // bin 2w in the low half of word w, bin 2w+1 in the high half
     __shared__ uint32_t s_heavy, ws[QT_B / 64 + 1];
     __shared__ unsigned long long s_row0;
+    __shared__ unsigned long long s_chunk_pos, s_chunk_end;   // rows claimed from the global counter, handed out tile by tile
     const int tid = threadIdx.x;
-    const uint32_t t = blockIdx.x;
+    if (tid == 0) { s_chunk_pos = 0; s_chunk_end = 0; }
+    // Persistent workgroups: each takes tiles t, t + grid, ... and claims output rows for several tiles at once.  (One claim
+    // per tile was the kernel's floor on sparse WGBS: same-address returning atomics serialise at ~12 ns each, and a
+    // human genome is 378 k tiles.)  The unused tail of a chunk stays a gap; the fetch walks per-tile ranges.
+    for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    __syncthreads();                                    // the previous tile's rows have left LDS
     const int32_t T0 = a.region_beg + (int32_t)(t * QT_W);
     const int32_t T1 = (int32_t)min((int64_t)T0 + QT_W, (int64_t)a.region_end);
     // candidate reads: a read with a CpG at p1 >= T0 starts after T0 - max_span and not after T1 - 1
@@ -234,48 +241,69 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
     const uint32_t hi = min(a.idx[(((uint32_t)T0 + (uint32_t)QT_W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
     if (lo >= hi) {                                             // nothing starts here: no LDS work at all
         if (tid == 0) { a.tile_flag[t] = 0u; a.tile_rows[t] = 0u; a.tile_row0[t] = 0ull; }
-        return;
+        continue;
     }
     for (int i = tid; i < QT_S; i += QT_B) keys[i] = QKEY_EMPTY;
+    bcnt[tid] = 0;
     for (int i = tid; i < QT_S * 8; i += QT_B) bins[i] = 0;
     if (tid == 0) s_heavy = (hi - lo > 65535u || a.force_heavy) ? 1u : 0u;      // a bin counts at most one update per candidate read
     __syncthreads();
     if (!s_heavy) {
         uint32_t bad = 0;
-        for (uint32_t i = lo + tid; i < hi; i += QT_B) {
-            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
-            if (o1 - o0 < 4 || a.read_mapq[i] < a.min_qual) continue;      // readutil.rs:101, me.rs:115
-            uint32_t x = a.cpg_pos[o0], y = a.cpg_pos[o0 + 1], z = a.cpg_pos[o0 + 2];
-            // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (a reverse read's first call may
-            // sit one base before its start, readutil.rs:338; rule of the PDR tile kernel).  Unsigned: a call further left is
-            // caught too; the windows' deltas are checked to be 1..2047 below, so the calls in between are ordered.
-            const uint32_t sm1 = (uint32_t)a.read_start[i] - 1u;
-            bad |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
-            bad |= ((a.cpg_pos[o1 - 1] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
-            for (uint32_t k = o0 + 3; k < o1; ++k) {                        // readutil.rs:105-129
-                const uint32_t w = a.cpg_pos[k];
-                const int32_t p1 = (int32_t)(x & 0x7fffffffu);
-                if (p1 >= T0 && p1 < T1) {
-                    const uint32_t d2 = (y & 0x7fffffffu) - (x & 0x7fffffffu), d3 = (z & 0x7fffffffu) - (y & 0x7fffffffu),
-                                   d4 = (w & 0x7fffffffu) - (z & 0x7fffffffu);
-                    const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 33) | ((unsigned long long)d2 << 22) |
-                                                   ((unsigned long long)d3 << 11) | (unsigned long long)d4;
-                    if (d2 - 1u >= 2047u || d3 - 1u >= 2047u || d4 - 1u >= 2047u || key == QKEY_EMPTY) {
-                        atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);
-                    } else {
-                        const uint32_t pat = ((x >> 31) << 3) | ((y >> 31) << 2) | ((z >> 31) << 1) | (w >> 31);
-                        uint32_t h = qslot(key), probes = 0;
-                        bool placed = false;
-                        while (probes++ < (uint32_t)QT_S) {
-                            const unsigned long long cur = atomicCAS(&keys[h], QKEY_EMPTY, key);
-                            if (cur == QKEY_EMPTY || cur == key) { placed = true; break; }
-                            h = (h + 1) & (QT_S - 1);
+        // QT_U reads per thread and round, their fields and first calls requested before any of them is used: the chain
+        // idx -> offsets -> calls is paid once per round, not once per read (sparse WGBS: a tile's time is this latency)
+        for (uint32_t b0 = lo; b0 < hi; b0 += QT_B * QT_U) {
+            uint32_t o0s[QT_U], o1s[QT_U], xs[QT_U], ys[QT_U], zs[QT_U], ls[QT_U];
+            int32_t st[QT_U];
+            bool ok[QT_U];
+#pragma unroll
+            for (int u = 0; u < QT_U; ++u) {
+                const uint32_t i = b0 + (uint32_t)u * QT_B + tid, ii = min(i, hi - 1);
+                o0s[u] = a.cpg_off[ii]; o1s[u] = a.cpg_off[ii + 1];
+                ok[u] = i < hi && a.read_mapq[ii] >= a.min_qual;
+                st[u] = a.read_start[ii];
+            }
+#pragma unroll
+            for (int u = 0; u < QT_U; ++u) {
+                ok[u] = ok[u] && o1s[u] - o0s[u] >= 4;                      // readutil.rs:101, me.rs:115
+                if (ok[u]) { xs[u] = a.cpg_pos[o0s[u]]; ys[u] = a.cpg_pos[o0s[u] + 1]; zs[u] = a.cpg_pos[o0s[u] + 2]; ls[u] = a.cpg_pos[o1s[u] - 1]; }
+            }
+#pragma unroll
+            for (int u = 0; u < QT_U; ++u) {
+                if (!ok[u]) continue;
+                const uint32_t o0 = o0s[u], o1 = o1s[u];
+                uint32_t x = xs[u], y = ys[u], z = zs[u];
+                // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (a reverse read's first call
+                // may sit one base before its start, readutil.rs:338; rule of the PDR tile kernel).  Unsigned: a call further
+                // left is caught too; the windows' deltas are checked to be 1..2047 below, so the calls in between are ordered.
+                const uint32_t sm1 = (uint32_t)st[u] - 1u;
+                bad |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+                bad |= ((ls[u] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+                for (uint32_t k = o0 + 3; k < o1; ++k) {                        // readutil.rs:105-129
+                    const uint32_t w = a.cpg_pos[k];
+                    const int32_t p1 = (int32_t)(x & 0x7fffffffu);
+                    if (p1 >= T0 && p1 < T1) {
+                        const uint32_t d2 = (y & 0x7fffffffu) - (x & 0x7fffffffu), d3 = (z & 0x7fffffffu) - (y & 0x7fffffffu),
+                                       d4 = (w & 0x7fffffffu) - (z & 0x7fffffffu);
+                        const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 33) | ((unsigned long long)d2 << 22) |
+                                                       ((unsigned long long)d3 << 11) | (unsigned long long)d4;
+                        if (d2 - 1u >= 2047u || d3 - 1u >= 2047u || d4 - 1u >= 2047u || key == QKEY_EMPTY) {
+                            atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);
+                        } else {
+                            const uint32_t pat = ((x >> 31) << 3) | ((y >> 31) << 2) | ((z >> 31) << 1) | (w >> 31);
+                            uint32_t h = qslot(key), probes = 0;
+                            bool placed = false;
+                            while (probes++ < (uint32_t)QT_S) {
+                                const unsigned long long cur = atomicCAS(&keys[h], QKEY_EMPTY, key);
+                                if (cur == QKEY_EMPTY || cur == key) { placed = true; break; }
+                                h = (h + 1) & (QT_S - 1);
+                            }
+                            if (placed) atomicAdd(&bins[h * 8 + (pat >> 1)], (pat & 1u) ? 0x10000u : 1u);      // me.rs:121-125
+                            else s_heavy = 1u;                                   // more distinct quartets than slots
                         }
-                        if (placed) atomicAdd(&bins[h * 8 + (pat >> 1)], (pat & 1u) ? 0x10000u : 1u);      // me.rs:121-125
-                        else s_heavy = 1u;                                   // more distinct quartets than slots
                     }
+                    x = y; y = z; z = w;
                 }
-                x = y; y = z; z = w;
             }
         }
         if (bad) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
@@ -283,16 +311,26 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
     __syncthreads();
     if (s_heavy) {                                      // block-uniform: the whole tile goes to the global path
         if (tid == 0) { a.tile_flag[t] = 1u; a.tile_rows[t] = 0u; a.tile_row0[t] = 0ull; atomicAdd(a.n_heavy, 1ull); }
-        return;
+        continue;
     }
-    // compact the occupied slots (each thread owns 4) ...
-    static_assert(QT_S % QT_B == 0, "each thread owns QT_S / QT_B slots");
+    // Rows go out sorted by key = (p1, d2, d3, d4) = (p1, p2, p3, p4).  Bucket sort on p1: QT_B buckets of QT_W / QT_B
+    // positions, a few keys each.  Every thread holds its slots in registers, so the table is rebuilt in place in bucket
+    // order; a key's final rank = start of its bucket + the keys of that bucket below it.  (Before: an all-pairs rank
+    // sort / bitonic network over the tile's keys -- most of the kernel's time on sparse WGBS.)
+    static_assert(QT_S % QT_B == 0 && QT_B == 256, "each thread owns QT_S / QT_B slots and one bucket");
     constexpr int PER = QT_S / QT_B;
+    constexpr int BSHIFT = __builtin_ctz((unsigned)QT_W) - 8;
     unsigned long long kk[PER];
-    uint32_t m = 0;
+    uint32_t pib[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { kk[k] = keys[tid * PER + k]; m += kk[k] != QKEY_EMPTY ? 1u : 0u; }
+    for (int k = 0; k < PER; ++k) {
+        kk[k] = keys[tid * PER + k];
+        pib[k] = 0;
+        if (kk[k] != QKEY_EMPTY) pib[k] = atomicAdd(&bcnt[((uint32_t)(kk[k] >> 33) - (uint32_t)T0) >> BSHIFT], 1u);
+    }
+    __syncthreads();                                    // every slot is in registers now: the table can be overwritten
     const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t m = bcnt[tid];
     uint32_t incl = m;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -306,19 +344,38 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
         for (int w = 1; w <= QT_B / 64; ++w) ws[w] += ws[w - 1];
         const uint32_t n_all = ws[QT_B / 64];
         a.tile_flag[t] = 0u; a.tile_rows[t] = n_all;
-        s_row0 = n_all ? atomicAdd(a.row_total, (unsigned long long)n_all) : 0ull;
+        if (n_all && s_chunk_pos + n_all > s_chunk_end) {       // next chunk (what is left of the old one stays unused)
+            // enough for this workgroup's remaining tiles if they are like this one, at most QT_CHUNK rows: the gaps stay
+            // small next to the rows (a single-tile workgroup claims exactly its rows)
+            const unsigned long long left = (unsigned long long)((a.ntiles - 1u - t) / gridDim.x + 1u);
+            const unsigned long long claim = max((unsigned long long)n_all, min((unsigned long long)n_all * left, (unsigned long long)QT_CHUNK));
+            s_chunk_pos = atomicAdd(a.row_total, claim);
+            s_chunk_end = s_chunk_pos + claim;
+            if (s_chunk_end > a.row_cap) atomicAdd(a.unfit, 1ull);
+        }
+        s_row0 = s_chunk_pos;
+        s_chunk_pos += n_all;
         a.tile_row0[t] = s_row0;
-        if (n_all && s_row0 + n_all > a.row_cap) atomicAdd(a.unfit, 1ull);
     }
     __syncthreads();
     const uint32_t n = ws[QT_B / 64];
-    if (n == 0 || s_row0 + n > a.row_cap) return;      // block-uniform
-    {
-        uint32_t o = ws[wave] + incl - m;
+    if (n == 0 || s_row0 + n > a.row_cap) continue;      // block-uniform
+    bbase[tid] = ws[wave] + incl - m;
+    __syncthreads();
 #pragma unroll
-        for (int k = 0; k < PER; ++k) if (kk[k] != QKEY_EMPTY) { skey[o] = kk[k]; sslot[o] = (uint16_t)(tid * PER + k); ++o; }
+    for (int k = 0; k < PER; ++k) {
+        if (kk[k] == QKEY_EMPTY) continue;
+        const uint32_t dst = bbase[((uint32_t)(kk[k] >> 33) - (uint32_t)T0) >> BSHIFT] + pib[k];
+        keys[dst] = kk[k];
+        sslot[dst] = (uint16_t)(tid * PER + k);
     }
-    auto emit_row = [&](unsigned long long key, uint32_t h, uint32_t r) {
+    __syncthreads();
+    for (uint32_t j = tid; j < n; j += QT_B) {
+        const unsigned long long key = keys[j];
+        const uint32_t bk = ((uint32_t)(key >> 33) - (uint32_t)T0) >> BSHIFT, b0 = bbase[bk], b1 = b0 + bcnt[bk];
+        uint32_t r = b0;
+        for (uint32_t i = b0; i < b1; ++i) r += keys[i] < key ? 1u : 0u;
+        const uint32_t h = sslot[j];
         const unsigned long long o = s_row0 + r;
         const int32_t p1 = (int32_t)(key >> 33);
         const int32_t p2 = p1 + (int32_t)((key >> 22) & 2047u), p3 = p2 + (int32_t)((key >> 11) & 2047u),
@@ -337,41 +394,7 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
         uint32_t total;
         quartet_values(c, me, pm, total);
         a.out_me[o] = me; a.out_pm[o] = pm; a.out_depth[o] = total;
-    };
-    // rows go out sorted by key = (p1, d2, d3, d4) = (p1, p2, p3, p4) order
-    if (n <= QT_RANK_MAX) {
-        // few keys (the usual case): thread j counts the keys below compacted key j -- no barriers, LDS broadcast reads
-        __syncthreads();
-        for (uint32_t j = tid; j < n; j += QT_B) {
-            const unsigned long long key = skey[j];
-            uint32_t r = 0;
-            for (uint32_t i = 0; i < n; ++i) r += skey[i] < key ? 1u : 0u;
-            emit_row(key, sslot[j], r);
-        }
-        return;
     }
-    uint32_t P = 2;
-    while (P < n) P <<= 1;
-    for (uint32_t i = n + tid; i < P; i += QT_B) skey[i] = QKEY_EMPTY;      // pads sort to the end
-    __syncthreads();
-    for (uint32_t k = 2; k <= P; k <<= 1) {                                  // bitonic network over P = pow2 >= n keys
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < P; i += QT_B) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const unsigned long long u = skey[i], v = skey[l];
-                    const bool up = (i & k) == 0;
-                    if ((u > v) == up) { skey[i] = v; skey[l] = u; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t r = tid; r < n; r += QT_B) {
-        const unsigned long long key = skey[r];
-        uint32_t h = qslot(key);
-        while (keys[h] != key) h = (h + 1) & (QT_S - 1);
-        emit_row(key, h, r);
     }
 }
 
@@ -398,6 +421,19 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
     // [3] its overflow flag [5] tiles left to the global path [6] tiles whose rows did not fit the output
     unsigned long long *qs = ctx->q_state.as<unsigned long long>();
     const int64_t region_len = (int64_t)d.region_end - d.region_beg;
+    // Tile width: wide tiles pay the per-tile costs (index look-up, LDS clear, barriers, halo reads) less often, but the
+    // table holds QT_S quartets and a 16-bit bin 65535 candidate reads.  About one quartet starts per CpG site; sites per
+    // bp ~ calls per read / read length (max_span stands in for the length).  Tiles that overflow anyway take the global path.
+    int tile_shift = 13;
+    if (d.n_reads && region_len > 0) {
+        const double sites_per_bp = (double)d.n_cpgs / (double)d.n_reads / (double)std::max(d.max_span, 1);
+        const double reads_per_bp = (double)d.n_reads / (double)region_len;
+        while (tile_shift < 15 && sites_per_bp * (double)(2 << tile_shift) <= 0.35 * QT_S &&
+               reads_per_bp * (double)((2 << tile_shift) + d.max_span + 2 * IDX_Q) <= 30000.0)
+            ++tile_shift;
+    }
+    if (const char *e = getenv("MTH_QUARTET_TILE_SHIFT")) tile_shift = std::min(15, std::max(13, atoi(e)));   // tests / tuning
+    const int QT_W = 1 << tile_shift;
     const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + QT_W - 1) / QT_W) : 0u;
     const uint64_t tiles_before = ctx->q_meta.empty() ? 0 : ctx->q_meta.back().tile_end;
     const uint64_t rows_before = ctx->q_rows;
@@ -424,7 +460,7 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
     // there is no counting pre-pass
     uint64_t want = rows_before + (uint64_t)((double)d.n_cpgs * ctx->q_rows_per_cpg * 1.25) + 4096;
     if (const char *e = getenv("MTH_QUARTET_ROWS_MIN")) want = rows_before + strtoull(e, nullptr, 10);   // tests: force the redo
-    unsigned long long st[Q_STATE_WORDS];
+    unsigned long long *st = ctx->h_words;     // pinned: the read-back does not go through a staging copy
     for (int attempt = 0;; ++attempt) {
         if (want > ctx->q_cap) MTH_HIP(ctx, grow_rows(want, rows_before));
         hipLaunchKernelGGL(k_quartet_rewind, dim3(1), dim3(1), 0, s, qs, (unsigned long long)rows_before);
@@ -432,7 +468,7 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
         a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
         a.idx = ctx->idx.as<uint32_t>();
         a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
-        a.n_reads = d.n_reads; a.min_qual = params->min_qual;
+        a.n_reads = d.n_reads; a.ntiles = ntiles; a.min_qual = params->min_qual;
         a.force_heavy = getenv("MTH_QUARTET_FORCE_GLOBAL") ? 1 : 0;
         a.row_total = qs + 1; a.row_cap = ctx->q_cap; a.unfit = qs + 6; a.n_heavy = qs + 5;
         a.tile_flag = ctx->q_tflag.as<uint32_t>();
@@ -442,9 +478,11 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
         a.out_pm = ctx->q_pm.as<float>(); a.out_depth = ctx->q_depth.as<uint32_t>(); a.st = ctx->d_state;
         {
             LaunchTimer lt(ctx, K_QTILE);
-            hipLaunchKernelGGL(k_quartet_tile, dim3(ntiles), dim3(QT_B), 0, s, a);
+            if (tile_shift == 13) hipLaunchKernelGGL(k_quartet_tile<8192>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
+            else if (tile_shift == 14) hipLaunchKernelGGL(k_quartet_tile<16384>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
+            else hipLaunchKernelGGL(k_quartet_tile<32768>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
         }
-        MTH_HIP(ctx, hipMemcpyAsync(st, qs, sizeof st, hipMemcpyDeviceToHost, s));
+        MTH_HIP(ctx, hipMemcpyAsync(st, qs, Q_STATE_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         MTH_HIP(ctx, hipStreamSynchronize(s));            // one sync per batch: rows, flagged tiles, fit
         if (!st[6]) break;
         if (attempt) return fail(ctx, MTH_ERR_STATE, "quartets: rows did not fit an exactly sized output");
@@ -479,7 +517,7 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
                 hipLaunchKernelGGL(k_quartet_insert, dim3((d.n_reads + 255) / 256), dim3(256), 0, s, d.cpg_off, d.cpg_pos,
                                    d.read_mapq, d.n_reads, params->min_qual, d.region_beg, d.region_end,
                                    ctx->q_keys.as<unsigned long long>(), ctx->q_hist.as<uint32_t>(), n_slots - 1, qs + 3,
-                                   ctx->d_state, (const uint32_t *)ctx->q_tflag.as<uint32_t>());
+                                   ctx->d_state, (const uint32_t *)ctx->q_tflag.as<uint32_t>(), tile_shift);
             }
             unsigned long long ovf = 0;
             MTH_HIP(ctx, hipMemcpyAsync(&ovf, qs + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
@@ -522,11 +560,33 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
     if (!ctx) return MTH_ERR_INVALID;
     int rc = sync_and_check(ctx);
     if (rc) return rc;
+    // Rows live in [0, q_rows) with gaps (the unused tails of the tile kernel's chunks).  Row order: per batch, the tiles in
+    // position order (each tile's rows are sorted by (p1..p4)), then the rows of the tiles that took the global path
+    // (table order).  The reference's order is HashMap-random.
     const uint64_t total = ctx->q_rows;
     std::vector<uint32_t> depth(total);
     if (total) MTH_HIP(ctx, hipMemcpy(depth.data(), ctx->q_depth.p, total * 4, hipMemcpyDeviceToHost));
-    uint64_t n = 0;
-    for (uint64_t i = 0; i < total; ++i) n += depth[i] >= min_depth ? 1 : 0;
+    const uint64_t n_tiles = ctx->q_meta.empty() ? 0 : ctx->q_meta.back().tile_end;
+    std::vector<unsigned long long> trow0(n_tiles);
+    std::vector<uint32_t> trows(n_tiles);
+    if (n_tiles) {
+        MTH_HIP(ctx, hipMemcpy(trow0.data(), ctx->q_tile_row0.p, n_tiles * 8, hipMemcpyDeviceToHost));
+        MTH_HIP(ctx, hipMemcpy(trows.data(), ctx->q_tile_rows.p, n_tiles * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<uint64_t> order;            // device row of every output row that passes the depth filter
+    std::vector<int32_t> order_tid;
+    {
+        uint64_t batch_end = 0;
+        for (size_t b = 0; b < ctx->q_meta.size(); ++b) {
+            const auto &mb = ctx->q_meta[b];
+            batch_end += mb.rows;
+            auto put = [&](uint64_t i) { if (depth[i] >= min_depth) { order.push_back(i); order_tid.push_back(mb.tid); } };
+            for (uint64_t t = b ? ctx->q_meta[b - 1].tile_end : 0; t < mb.tile_end; ++t)
+                for (uint32_t j = 0; j < trows[t]; ++j) put(trow0[t] + j);
+            for (uint64_t i = mb.heavy0; i < batch_end; ++i) put(i);
+        }
+    }
+    const uint64_t n = order.size();
     if (n_rows) *n_rows = n;
     if (!tid && !pos4 && !counts16 && !me && !pm) return MTH_OK;
     std::vector<int32_t> hp(pos4 ? total * 4 : 0);
@@ -538,31 +598,13 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
         if (me) MTH_HIP(ctx, hipMemcpy(hme.data(), ctx->q_me.p, total * 4, hipMemcpyDeviceToHost));
         if (pm) MTH_HIP(ctx, hipMemcpy(hpm.data(), ctx->q_pm.p, total * 4, hipMemcpyDeviceToHost));
     }
-    // Row order: per batch, the tiles in position order (each tile's rows are sorted by (p1..p4)), then the rows of the
-    // tiles that took the global path (table order).  The reference's order is HashMap-random.
-    const uint64_t n_tiles = ctx->q_meta.empty() ? 0 : ctx->q_meta.back().tile_end;
-    std::vector<unsigned long long> trow0(n_tiles);
-    std::vector<uint32_t> trows(n_tiles);
-    if (n_tiles) {
-        MTH_HIP(ctx, hipMemcpy(trow0.data(), ctx->q_tile_row0.p, n_tiles * 8, hipMemcpyDeviceToHost));
-        MTH_HIP(ctx, hipMemcpy(trows.data(), ctx->q_tile_rows.p, n_tiles * 4, hipMemcpyDeviceToHost));
-    }
-    uint64_t o = 0, batch_end = 0;
-    auto put = [&](int32_t t_id, uint64_t i) {
-        if (depth[i] < min_depth) return;
-        if (tid) tid[o] = t_id;
+    for (uint64_t o = 0; o < n; ++o) {
+        const uint64_t i = order[o];
+        if (tid) tid[o] = order_tid[o];
         if (pos4) memcpy(pos4 + o * 4, hp.data() + i * 4, 16);
         if (counts16) memcpy(counts16 + o * 16, hc.data() + i * 16, 64);
         if (me) me[o] = hme[i];
         if (pm) pm[o] = hpm[i];
-        ++o;
-    };
-    for (size_t b = 0; b < ctx->q_meta.size(); ++b) {
-        const auto &mb = ctx->q_meta[b];
-        batch_end += mb.rows;
-        for (uint64_t t = b ? ctx->q_meta[b - 1].tile_end : 0; t < mb.tile_end; ++t)
-            for (uint32_t j = 0; j < trows[t]; ++j) put(mb.tid, trow0[t] + j);
-        for (uint64_t i = mb.heavy0; i < batch_end; ++i) put(mb.tid, i);
     }
     return MTH_OK;
 }

@@ -153,3 +153,17 @@ def test_deep_tile_exceeds_16bit_counters(eng):
     d = run_device(eng, [c], kw)
     check(d, reads, kw)
     assert int((d["n_concordant"] + d["n_discordant"]).max()) == 70_000
+
+
+@pytest.mark.parametrize("shift", [13, 14, 15])
+def test_every_tile_width(eng, monkeypatch, shift):
+    """the tile width is chosen per batch from its call density; each of the three widths gives the same rows"""
+    from metheor_amd import shard, synth
+    rng = np.random.default_rng(60 + shift)
+    cs = [synth.make_contig(0, 400_000, 60_000, 0.012, rng), synth.make_contig(1, 150_000, 20_000, 0.05, rng)]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    kw = dict(min_distance=2, max_distance=30, min_qual=10)
+    monkeypatch.setenv("MTH_PAIRS_TILE_SHIFT", str(shift))
+    d = run_device(eng, cs, kw, regions=[shard.plan_regions(cs[0], 2), [(0, cs[1]["length"])]])
+    monkeypatch.delenv("MTH_PAIRS_TILE_SHIFT")
+    assert check(d, reads, kw) > 8000

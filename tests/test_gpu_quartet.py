@@ -257,3 +257,17 @@ def test_output_redo_when_rows_do_not_fit(eng, monkeypatch):
     monkeypatch.delenv("MTH_QUARTET_ROWS_MIN")
     check(d, reads, 10, 0)
     assert len(d["tid"]) > 10000
+
+
+@pytest.mark.parametrize("shift", [13, 14, 15])
+def test_every_tile_width(eng, monkeypatch, shift):
+    """the tile width is chosen per batch from its call density; each of the three widths gives the same rows"""
+    from metheor_amd import shard, synth
+    rng = np.random.default_rng(40 + shift)
+    cs = [synth.make_contig(0, 400_000, 60_000, 0.012, rng), synth.make_contig(1, 150_000, 20_000, 0.05, rng)]
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    monkeypatch.setenv("MTH_QUARTET_TILE_SHIFT", str(shift))
+    d = run_device(eng, cs, 10, 0, regions=[shard.plan_regions(cs[0], 2), [(0, cs[1]["length"])]])
+    monkeypatch.delenv("MTH_QUARTET_TILE_SHIFT")
+    check(d, reads, 10, 0)
+    assert len(d["tid"]) > 7000
