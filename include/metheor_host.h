@@ -71,6 +71,23 @@ typedef struct {
     uint64_t        header_bytes;
 } mth_host_bgzf_t;
 int  mth_host_bgzf_blocks(mth_host_t *h, mth_host_bgzf_t *out);
+/* Byte-range sharding of a coordinate-sorted BAM whose records do not straddle BGZF blocks ("lets 8 GPUs'
+ * host threads read disjoint BAM ranges instead of one streaming router" -- done here WITHOUT a .bai: BGZF blocks are
+ * self-contained, so a shard can start at any block; the reference never uses the .bai files its fixtures ship).
+ * The data blocks are cut into `world` runs of about equal compressed size.  Shard `rank` owns the genomic interval from
+ * the first record of its run to the first record of the next run, in (tid, pos) order (sites / quartets / pairs are owned
+ * by position, reads by their start: what mth_batch_t's region_beg / region_end mean).  To complete its sites it also
+ * loads the blocks before its run that can hold reads starting within halo_bp of its interval (same contig) and the
+ * blocks after it that hold reads starting exactly at the interval's end (a reverse read reports start - 1).
+ * tid_beg = -1: from the start of the file; tid_end = INT32_MAX: to its end.  block_beg == block_end: nothing to load.
+ * MTH_HOST_ERR_FORMAT if a run does not start at a record boundary (records straddle blocks). */
+typedef struct {
+    uint64_t block_beg, block_end;   /* BGZF blocks to inflate and decode, halo blocks included */
+    uint64_t first_byte;             /* inflated bytes of block_beg before the first record (the BAM header, shard 0) */
+    int32_t  tid_beg, pos_beg;       /* owned interval [(tid_beg, pos_beg), (tid_end, pos_end)) */
+    int32_t  tid_end, pos_end;
+} mth_host_shard_t;
+int  mth_host_plan_shard(mth_host_t *h, int rank, int world, int64_t halo_bp, mth_host_shard_t *out);
 int64_t mth_host_n_reads(const mth_host_t *h);
 int64_t mth_host_n_cpgs(const mth_host_t *h);
 const int32_t  *mth_host_read_tid(const mth_host_t *h);

@@ -202,8 +202,26 @@ Args parse_args(const Cmd &c, int argc, char **argv, int first) {
 // A contig's reads are a contiguous slice of the decoded SoA (the file is coordinate-sorted), so the
 // batch points straight into the decoder's arrays; only the CSR offsets are rebased (4 B/read).  A
 // contig that contains a read without any aligned base (start = -1) is copied without those reads.
+// METHEOR_SHARD=r/N: this process is shard r of N of ONE run (one process per GPU): it loads its own run of BGZF blocks
+// (mth_host_plan_shard: no index, no router), owns a (tid, pos) interval and writes <output>.shard-r-of-N; the parts
+// concatenated in shard order are the unsharded file (tools/run_sharded.py launches the shards and merges them, summing the
+// four LPMD counters).  METHEOR_SHARD_HALO: bp of reads loaded before the interval (default 65536; must cover the
+// longest alignment + FDRP's 201-bp window, checked).
+struct Shard { int rank = 0, world = 1; int64_t halo = 65536; mth_host_shard_t plan; };
+Shard g_shard;
+
+void parse_shard_env() {
+    if (const char *e = getenv("METHEOR_SHARD")) {
+        int r = -1, n = 0;
+        if (sscanf(e, "%d/%d", &r, &n) != 2 || n < 1 || r < 0 || r >= n) die(std::string("bad METHEOR_SHARD (want r/N): ") + e);
+        g_shard.rank = r; g_shard.world = n;
+    }
+    if (const char *e = getenv("METHEOR_SHARD_HALO")) { const long long k = atoll(e); if (k >= 0) g_shard.halo = k; }
+}
+
 struct Contig {
     int32_t tid;
+    int32_t region_beg = 0, region_end = -1;   // owned positions (-1: to the contig's end); a shard may own part of a contig
     const int32_t *start, *end;
     const uint8_t *mapq;
     const uint32_t *pos;
@@ -295,13 +313,20 @@ int window_to_device(void *user, const uint8_t *buf, const uint64_t *rec_off, ui
 bool load_bgzf_on_device(Input &in) {
     mth_host_bgzf_t bz;
     if (mth_host_bgzf_blocks(in.h, &bz) != 0) die(mth_host_last_error(in.h));
+    uint64_t blk_beg = 0;
+    if (g_shard.world > 1) {      // this shard's run of blocks (+ halo blocks) instead of the whole file
+        if (mth_host_plan_shard(in.h, g_shard.rank, g_shard.world, g_shard.halo, &g_shard.plan) != 0) die(mth_host_last_error(in.h));
+        blk_beg = g_shard.plan.block_beg;
+        bz.n_blocks = g_shard.plan.block_end;
+        bz.header_bytes = g_shard.plan.first_byte;
+    }
     Phase ph("  device inflate + walk + decode");
     // chunks of whole blocks, <= ~1 GiB of file bytes each (bounds the staging buffers, not the decoded SoA)
     size_t chunk = (size_t)1 << 30;
     if (const char *e = getenv("METHEOR_DEVICE_CHUNK_MB")) { const long k = atol(e); if (k >= 1 && k <= 65536) chunk = (size_t)k << 20; }
     bool first = true;
     uint64_t hdr_left = bz.header_bytes;      // header bytes still ahead of the next chunk's inflated stream
-    for (uint64_t b0 = 0; b0 < bz.n_blocks || first;) {
+    for (uint64_t b0 = blk_beg; b0 < bz.n_blocks || first;) {
         uint64_t b1 = b0;
         uint64_t ubytes = 0;
         while (b1 < bz.n_blocks && (b1 == b0 || bz.coff[b1] + bz.csize[b1] - bz.coff[b0] <= chunk)) { ubytes += bz.isize[b1]; ++b1; }
@@ -339,6 +364,7 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
     in.ctx = cf.get();
     if (cpg_set) check(in.ctx, mth_decode_set_cpg_filter(in.ctx, keys, n_keys, 1));
     const bool on_device = !getenv("METHEOR_HOST_INFLATE") && load_bgzf_on_device(in);
+    if (!on_device && g_shard.world > 1) die("METHEOR_SHARD needs the device load path (a coordinate-sorted BAM whose records do not straddle BGZF blocks)");
     if (!on_device) {
         StreamState st;
         st.ctx = in.ctx;
@@ -366,9 +392,17 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
     if (flags || n_runs > cap) return false;                       // unaligned / contig-less records, or contigs not grouped
     for (uint32_t k = 0; k < n_runs; ++k) {
         for (const Contig &c : in.contigs) if (c.tid == tids[k]) return false;   // the host path reports it
+        int32_t reg_beg = 0, reg_end = -1;
+        if (g_shard.world > 1) {      // the part of this contig inside the shard's interval [(tid_beg, pos_beg), (tid_end, pos_end))
+            const mth_host_shard_t &pl = g_shard.plan;
+            if (tids[k] < pl.tid_beg || tids[k] > pl.tid_end) continue;               // halo reads of a neighbour's contig
+            if (tids[k] == pl.tid_beg) reg_beg = pl.pos_beg;
+            if (tids[k] == pl.tid_end) { reg_end = pl.pos_end; if (reg_end <= reg_beg) continue; }
+        }
         in.contigs.emplace_back();
         Contig &c = in.contigs.back();
         c.tid = tids[k]; c.r0 = rb[k]; c.r1 = re[k]; c.n_reads = (size_t)(re[k] - rb[k]); c.n_cpgs = 0;
+        c.region_beg = reg_beg; c.region_end = reg_end;
     }
     in.device = true;
     return true;
@@ -437,7 +471,10 @@ mth_batch_t make_batch(const Input &in, const Contig &c) {
     memset(&b, 0, sizeof b);
     if (in.device) {
         const int64_t len = mth_host_ref_len(in.h, c.tid);
-        check(in.ctx, mth_decoded_batch(in.ctx, c.r0, c.r1, c.tid, 0, (int32_t)std::min<int64_t>(len, INT32_MAX), &b));
+        const int32_t end = c.region_end >= 0 ? c.region_end : (int32_t)std::min<int64_t>(len, INT32_MAX);
+        check(in.ctx, mth_decoded_batch(in.ctx, c.r0, c.r1, c.tid, c.region_beg, end, &b));
+        if (g_shard.world > 1 && (int64_t)b.max_span + 202 > g_shard.halo)
+            die("an alignment spans " + std::to_string(b.max_span) + " bp: set METHEOR_SHARD_HALO to at least " + std::to_string(b.max_span + 202));
         return b;
     }
     b.tid = c.tid;
@@ -501,7 +538,8 @@ void write_rows(FILE *f, uint64_t n, Row &&row) {
     for (auto &w : parts) { w.f = f; w.flush(); }
 }
 
-FILE *open_output(const std::string &path) {
+FILE *open_output(const std::string &path0) {
+    const std::string path = g_shard.world > 1 ? path0 + ".shard-" + std::to_string(g_shard.rank) + "-of-" + std::to_string(g_shard.world) : path0;
     FILE *f = fopen(path.c_str(), "wb");   // create + truncate (pdr.rs:95-101)
     if (!f) die("called `Result::unwrap()` on an `Err` value: cannot open output file " + path + ": " + strerror(errno));
     static char buf[1 << 20];
@@ -560,7 +598,10 @@ int run_lpmd(const Args &a) {
     FILE *f = open_output(a.s.at("output"));
     char fb[64];
     mth_host_format_f32(lp, fb);
-    fprintf(f, "name\tlpmd\n%s\t%s\n", input.c_str(), fb);   // lpmd.rs:145-147
+    if (g_shard.world > 1)        // a part: the four counters of the reads this shard owns (the merge sums them and applies lpmd.rs:145-147)
+        fprintf(f, "#lpmd_counts\t%s\t%lld\t%lld\t%lld\t%lld\n", input.c_str(), (long long)g[0], (long long)g[1], (long long)g[2], (long long)g[3]);
+    else
+        fprintf(f, "name\tlpmd\n%s\t%s\n", input.c_str(), fb);   // lpmd.rs:145-147
     if (fclose(f) != 0) die("Error writing to output file.");
     if (a.has("pairs")) {                                       // lpmd.rs:149-151, 89-122
         mth_lpmd_pairs_params_t pp;
@@ -576,7 +617,7 @@ int run_lpmd(const Args &a) {
         std::vector<uint32_t> nc(n), nd(n);
         check(ctx, mth_lpmd_pairs_fetch(ctx, &n, tid.data(), p1.data(), p2.data(), v.data(), nc.data(), nd.data()));
         FILE *g = open_output(a.s.at("pairs"));
-        fprintf(g, "chrom\tcpg1\tcpg2\tlpmd\tn_concordant\tn_discordant\n");
+        if (g_shard.rank == 0) fprintf(g, "chrom\tcpg1\tcpg2\tlpmd\tn_concordant\tn_discordant\n");
         fflush(g);
         write_rows(g, n, [&](LineWriter &w, uint64_t i) {
             w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(p1[i]); w.ch('\t'); w.i32(p2[i]); w.ch('\t');
@@ -692,6 +733,7 @@ int main(int argc, char **argv) {
         usage_error(nullptr, "unrecognized subcommand '" + sub + "'");
     }
     const Args a = parse_args(*cmd, argc, argv, 2);
+    parse_shard_env();
     if (sub == "pdr") return run_pdr(a);
     if (sub == "lpmd") return run_lpmd(a);
     if (sub == "mhl") return run_mhl(a);

@@ -9,7 +9,10 @@
 //   D/N    consume reference only  : nothing yielded by reference_positions_full()
 //   H/P    nothing
 // start_pos / end_pos = first / last aligned reference position, -1 if none (readutil.rs:25-33).
+#include <zlib.h>
+
 #include <algorithm>
+#include <climits>
 #include <charconv>
 #include <cmath>
 #include <cstring>
@@ -150,6 +153,91 @@ int mth_host_bgzf_blocks(mth_host_t *h, mth_host_bgzf_t *out) {
     out->file = h->bgzf->file; out->file_bytes = h->bgzf->file_bytes;
     out->coff = h->bgzf->coff.data(); out->csize = h->bgzf->csize.data(); out->isize = h->bgzf->isize.data();
     out->n_blocks = h->bgzf->coff.size(); out->header_bytes = h->header_bytes;
+    return MTH_HOST_OK;
+}
+
+// first record of BGZF block `b` at inflated offset `off`: (refID, pos); refID -1 (no contig) sorts last
+static bool peek_record(const BgzfMap &m, uint64_t b, uint64_t off, int32_t &tid, int32_t &pos) {
+    const uint32_t isz = m.isize[b];
+    if (off + 12 > isz) return false;
+    std::vector<uint8_t> buf(isz);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t *>(m.file + m.coff[b]); zs.avail_in = m.csize[b];
+    zs.next_out = buf.data(); zs.avail_out = isz;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.avail_out != 0) return false;
+    auto rd = [&](uint64_t o) { int32_t v; memcpy(&v, buf.data() + o, 4); return v; };
+    const int32_t block_size = rd(off);
+    if (block_size < 32) return false;                       // not a record header: the run does not start at a record
+    tid = rd(off + 4); pos = rd(off + 8);
+    if (tid < -1 || pos < -1) return false;
+    if (tid < 0) tid = INT32_MAX;
+    return true;
+}
+
+int mth_host_plan_shard(mth_host_t *h, int rank, int world, int64_t halo_bp, mth_host_shard_t *out) {
+    if (!h || !out || world < 1 || rank < 0 || rank >= world || halo_bp < 0) return MTH_HOST_ERR_INVALID;
+    mth_host_bgzf_t bz;
+    const int rc = mth_host_bgzf_blocks(h, &bz);
+    if (rc != MTH_HOST_OK) return rc;
+    const BgzfMap &m = *h->bgzf;
+    memset(out, 0, sizeof *out);
+    out->tid_beg = -1; out->tid_end = INT32_MAX;
+    // data blocks [D, E): D holds the first record (at inflated offset d_off), E drops trailing empty blocks (the EOF marker)
+    uint64_t D = 0, cum = 0, E = bz.n_blocks;
+    while (D < E && cum + m.isize[D] <= h->header_bytes) cum += m.isize[D++];
+    const uint64_t d_off = h->header_bytes - cum;
+    while (E > D && m.isize[E - 1] == 0) --E;
+    if (D >= E) { out->block_beg = out->block_end = 0; out->first_byte = 0; return MTH_HOST_OK; }   // no record at all
+    auto cut = [&](int k) -> uint64_t {      // first block of run k: runs of about equal compressed size
+        if (k <= 0) return D;
+        if (k >= world) return E;
+        const uint64_t total = m.coff[E - 1] + m.csize[E - 1] - m.coff[D];
+        const uint64_t want = m.coff[D] + (uint64_t)((unsigned __int128)total * (unsigned)k / (unsigned)world);
+        const auto it = std::lower_bound(m.coff.begin() + (ptrdiff_t)D, m.coff.begin() + (ptrdiff_t)E, want);
+        return (uint64_t)(it - m.coff.begin());
+    };
+    auto first_of = [&](uint64_t b, int32_t &t, int32_t &p) { return peek_record(m, b, b == D ? d_off : 0, t, p); };
+    const uint64_t B0 = cut(rank), B1 = cut(rank + 1);
+    auto fail = [&]() { h->last_error = "a shard does not start at a record boundary (records straddle BGZF blocks)"; return MTH_HOST_ERR_FORMAT; };
+    uint64_t L = D, R = E;
+    if (rank > 0) {
+        if (B0 >= E) { out->tid_beg = INT32_MAX; out->pos_beg = 0; L = E; }
+        else {
+            int32_t t, p;
+            if (!first_of(B0, t, p)) return fail();
+            out->tid_beg = t; out->pos_beg = p;
+            // left halo: back to the block that holds the last record starting before p - halo_bp (or of an earlier contig)
+            L = B0;
+            while (L > D) {
+                int32_t tj, pj;
+                if (!first_of(L - 1, tj, pj)) return fail();
+                --L;
+                if (tj != t || (int64_t)pj < (int64_t)p - halo_bp) break;
+            }
+        }
+    }
+    if (rank < world - 1 && B1 < E) {
+        int32_t t, p;
+        if (!first_of(B1, t, p)) return fail();
+        out->tid_end = t; out->pos_end = p;
+        // right halo: the blocks that can hold reads starting exactly at p
+        R = B1 + 1;
+        while (R < E) {
+            int32_t tj, pj;
+            if (!first_of(R, tj, pj)) return fail();
+            if (tj != t || pj != p) break;
+            ++R;
+        }
+    }
+    const bool empty = out->tid_beg == out->tid_end && out->pos_beg == out->pos_end;
+    if (empty || L >= R) { out->block_beg = out->block_end = L; out->first_byte = 0; return MTH_HOST_OK; }
+    if (L <= D) { out->block_beg = 0; out->first_byte = h->header_bytes; }    // from the top of the file: the header comes along
+    else { out->block_beg = L; out->first_byte = 0; }
+    out->block_end = R;
     return MTH_HOST_OK;
 }
 

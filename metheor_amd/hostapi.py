@@ -9,10 +9,20 @@ _LIB = None
 
 SYMBOLS = [
     "mth_host_open", "mth_host_close", "mth_host_last_error", "mth_host_n_refs", "mth_host_ref_name",
-    "mth_host_ref_len", "mth_host_ref_tid", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
+    "mth_host_ref_len", "mth_host_ref_tid", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
     "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
     "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32", "mth_host_write_synthetic_bam",
 ]
+
+
+class _Bgzf(C.Structure):      # mth_host_bgzf_t
+    _fields_ = [("file", C.c_void_p), ("file_bytes", C.c_uint64), ("coff", C.c_void_p), ("csize", C.c_void_p),
+                ("isize", C.c_void_p), ("n_blocks", C.c_uint64), ("header_bytes", C.c_uint64)]
+
+
+class _Shard(C.Structure):     # mth_host_shard_t
+    _fields_ = [("block_beg", C.c_uint64), ("block_end", C.c_uint64), ("first_byte", C.c_uint64),
+                ("tid_beg", C.c_int32), ("pos_beg", C.c_int32), ("tid_end", C.c_int32), ("pos_end", C.c_int32)]
 
 
 class HostError(RuntimeError):
@@ -45,6 +55,8 @@ def lib():
             getattr(L, "mth_host_" + f).argtypes = [vp]; getattr(L, "mth_host_" + f).restype = C.c_int64
         for f in ("read_tid", "read_start", "read_end", "read_mapq", "read_fwd", "cpg_off", "cpg_pos", "cpg_rel"):
             getattr(L, "mth_host_" + f).argtypes = [vp]; getattr(L, "mth_host_" + f).restype = vp
+        L.mth_host_bgzf_blocks.argtypes = [vp, vp]
+        L.mth_host_plan_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int64, vp]
         L.mth_host_format_f32.argtypes = [C.c_float, C.c_char_p]
         L.mth_host_write_synthetic_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int32] + [vp] * 6 + [C.c_uint64, C.c_int]
         _LIB = L
@@ -92,6 +104,28 @@ class BamFile:
             self.close()
         except Exception:
             pass
+
+    def bgzf_blocks(self):
+        """the file's BGZF block table: dict(coff, csize, isize (numpy), header_bytes)"""
+        bz = _Bgzf()
+        rc = self.L.mth_host_bgzf_blocks(self.h, C.byref(bz))
+        if rc != 0:
+            raise HostError(rc, self.L.mth_host_last_error(self.h).decode())
+        n = int(bz.n_blocks)
+
+        def arr(p, dt):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy() if n else np.zeros(0, dt)
+        return dict(coff=arr(bz.coff, np.uint64), csize=arr(bz.csize, np.uint32), isize=arr(bz.isize, np.uint32),
+                    header_bytes=int(bz.header_bytes), file_bytes=int(bz.file_bytes))
+
+    def plan_shard(self, rank, world, halo_bp=65536):
+        """mth_host_plan_shard: the BGZF blocks shard `rank` of `world` loads and the (tid, pos) interval it owns"""
+        sh = _Shard()
+        rc = self.L.mth_host_plan_shard(self.h, int(rank), int(world), int(halo_bp), C.byref(sh))
+        if rc != 0:
+            raise HostError(rc, self.L.mth_host_last_error(self.h).decode())
+        return dict(block_beg=int(sh.block_beg), block_end=int(sh.block_end), first_byte=int(sh.first_byte),
+                    beg=(int(sh.tid_beg), int(sh.pos_beg)), end=(int(sh.tid_end), int(sh.pos_end)))
 
     def decode(self, cpg_set=None):
         """-> SoA dict with the same keys as oracle.pyoracle.Reads.soa()"""

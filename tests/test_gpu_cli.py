@@ -266,31 +266,7 @@ def test_device_decode_reports_missing_xm(golden_dir, tmp_path):
         assert r.returncode == 101 and "Error reading XM tag in BAM record" in r.stderr, r.stderr
 
 
-def reblock_aligned(src, dst):
-    """rewrite a BAM so that every BGZF block holds whole records (what htslib writes): the header in blocks of its own,
-    then records packed greedily into <= 0xff00-byte blocks"""
-    import gzip
-    import struct
-    raw = gzip.decompress(open(src, "rb").read())
-    l_text, = struct.unpack_from("<i", raw, 4)
-    o = 8 + l_text
-    n_ref, = struct.unpack_from("<i", raw, o); o += 4
-    for _ in range(n_ref):
-        l_name, = struct.unpack_from("<i", raw, o); o += 8 + l_name
-    with open(dst, "wb") as fh:
-        for k in range(0, o, 0xff00):
-            fh.write(bamio._bgzf_block(raw[k:min(k + 0xff00, o)]))
-        blk = bytearray()
-        while o < len(raw):
-            bs, = struct.unpack_from("<i", raw, o)
-            r = raw[o:o + 4 + bs]
-            if blk and len(blk) + len(r) > 0xff00:
-                fh.write(bamio._bgzf_block(bytes(blk))); blk = bytearray()
-            blk += r
-            o += 4 + bs
-        if blk:
-            fh.write(bamio._bgzf_block(bytes(blk)))
-        fh.write(bamio._bgzf_block(b""))
+reblock_aligned = util.reblock_aligned
 
 
 def test_device_inflate_path_large_header_many_contigs(tmp_path):
@@ -323,3 +299,44 @@ def test_device_inflate_path_large_header_many_contigs(tmp_path):
         rh = run_env({"METHEOR_HOST_DECODE": "1"}, sub, "-i", bam, "-o", str(oh), *extra)
         assert rd.returncode == 0 and rh.returncode == 0, (rd.stderr, rh.stderr)
         assert sorted(od.read_text().splitlines()) == sorted(oh.read_text().splitlines()) and (sub == "lpmd" or len(od.read_text()) > 100)
+
+
+@pytest.mark.parametrize("n_shards", [2, 5])
+def test_sharded_run_equals_single_run(tmp_path, n_shards):
+    """METHEOR_SHARD=r/N: every shard loads its own run of BGZF blocks (no index, no router), owns a (tid, pos) interval;
+    the parts concatenated in shard order (LPMD: counters summed) are byte-identical to the single-process TSV -- all
+    measures, cuts inside contigs and at contig changes, empty contigs in between"""
+    from metheor_amd import sharded, synth
+    rng = np.random.default_rng(77)
+    refs = [("sA", 120_000), ("sEmpty", 5_000), ("sB", 200_000), ("sC", 60_000)]
+    tid, pos, flag, mapq, cig, xms = [], [], [], [], [], []
+    for t, n in ((0, 5000), (2, 9000), (3, 2500)):
+        c = synth.make_contig(t, refs[t][1], n, 0.04, rng)
+        r = util.contig_to_records(c, refs[t][0])
+        tid += [t] * len(r); pos += r.pos.tolist(); flag += r.flag.tolist(); mapq += r.mapq.tolist(); cig += r.cigars; xms += r.xms
+    rec = bamio.Records(refs, tid, pos, flag, mapq, cig, xms)
+    raw_bam, bam = str(tmp_path / "u.bam"), str(tmp_path / "a.bam")
+    bamio.write_bam(raw_bam, rec)
+    reblock_aligned(raw_bam, bam)
+    cases = (("pdr", ["-d", "3", "-p", "1"]), ("lpmd", []), ("mhl", ["-d", "3", "-p", "1"]), ("me", ["-d", "2"]), ("pm", ["-d", "2"]),
+             ("fdrp", ["-d", "3"]), ("qfdrp", ["-d", "3"]))
+    for sub, extra in cases:
+        o1, oN = tmp_path / ("one_%s.tsv" % sub), tmp_path / ("sh_%s.tsv" % sub)
+        a1 = [sub, "-i", bam, "-o", str(o1)] + extra
+        aN = [sub, "-i", bam, "-o", str(oN)] + extra
+        if sub == "lpmd":
+            a1 += ["--pairs", str(tmp_path / "one_pairs.tsv")]
+            aN += ["--pairs", str(tmp_path / "sh_pairs.tsv")]
+        r = run(*a1)
+        assert r.returncode == 0, r.stderr
+        assert sharded.run(n_shards, aN, gpus=1, env=dict(os.environ, METHEOR_SEED="7", METHEOR_SHARD_HALO="4000")) == 0
+        assert not list(tmp_path.glob("*.shard-*"))
+        assert oN.read_bytes() == o1.read_bytes(), sub
+        assert len(o1.read_bytes()) > (20 if sub == "lpmd" else 1000)
+        if sub == "lpmd":
+            assert (tmp_path / "sh_pairs.tsv").read_bytes() == (tmp_path / "one_pairs.tsv").read_bytes()
+    # a halo smaller than an alignment is refused, not silently wrong
+    e = dict(os.environ, METHEOR_SHARD="1/2", METHEOR_SHARD_HALO="100")
+    import subprocess
+    r = subprocess.run([EXE, "pdr", "-i", bam, "-o", str(tmp_path / "x.tsv")], env=e, capture_output=True, text=True)
+    assert r.returncode != 0 and "METHEOR_SHARD_HALO" in r.stderr

@@ -90,3 +90,35 @@ def subset_reads(c, mask):
     out["cpg_pos"] = c["cpg_pos"][keep_call]
     out["cpg_rel"] = c["cpg_rel"][keep_call]
     return out
+
+
+def reblock_aligned(src, dst):
+    """rewrite a BAM so that every BGZF block holds whole records (what htslib writes): the header in blocks of its own,
+    then records packed greedily into <= 0xff00-byte blocks"""
+    import gzip
+    import struct
+    raw = gzip.decompress(open(src, "rb").read())
+    l_text, = struct.unpack_from("<i", raw, 4)
+    o = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, o); o += 4
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, o); o += 8 + l_name
+    with open(dst, "wb") as fh:
+        for k in range(0, o, 0xff00):
+            fh.write(_bamio()._bgzf_block(raw[k:min(k + 0xff00, o)]))
+        blk = bytearray()
+        while o < len(raw):
+            bs, = struct.unpack_from("<i", raw, o)
+            r = raw[o:o + 4 + bs]
+            if blk and len(blk) + len(r) > 0xff00:
+                fh.write(_bamio()._bgzf_block(bytes(blk))); blk = bytearray()
+            blk += r
+            o += 4 + bs
+        if blk:
+            fh.write(_bamio()._bgzf_block(bytes(blk)))
+        fh.write(_bamio()._bgzf_block(b""))
+
+
+def _bamio():
+    from oracle import bamio
+    return bamio
