@@ -5,6 +5,8 @@
 // usage errors exit 2 with clap-style text on stderr; run-time failures (the reference panics) exit
 // 101 with the panic message on stderr.  There is no CPU fallback: a measure whose device kernel is
 // not built yet fails loudly.
+#include <unistd.h>
+
 #include <algorithm>
 #include <cerrno>
 #include <chrono>
@@ -255,6 +257,20 @@ struct Phase {
         fprintf(stderr, "[metheor timing] %-28s %.3f s\n", name, s);
     }
 };
+
+// End of a run, output files closed.  Releasing gigabytes of device buffers, unmapping the input and unloading the HIP
+// runtime cost tens of milliseconds that nobody reads the result of: the process leaves through _exit and the driver
+// reclaims everything (METHEOR_TEARDOWN=1 keeps the orderly release, e.g. under a leak checker).
+int finish(mth_ctx_t *ctx, mth_host_t *h) {
+    if (getenv("METHEOR_TEARDOWN")) {
+        Phase ph("teardown");
+        mth_ctx_destroy(ctx);
+        mth_host_close(h);
+        return 0;
+    }
+    fflush(nullptr);
+    _exit(0);
+}
 
 void check(mth_ctx_t *ctx, int rc) {
     if (rc == MTH_OK) return;
@@ -562,20 +578,21 @@ int run_pdr(const Args &a) {
         submit(ctx, in, p);
         check(ctx, mth_pdr_count(ctx, &n));
     }
-    Phase ph3("fetch + TSV write");
-    std::vector<int32_t> tid(n), pos(n);
-    std::vector<float> pdr(n);
-    std::vector<uint32_t> nc(n), nd(n);
-    check(ctx, mth_pdr_fetch(ctx, tid.data(), pos.data(), pdr.data(), nc.data(), nd.data()));
-    FILE *f = open_output(a.s.at("output"));
-    write_rows(f, n, [&](LineWriter &w, uint64_t i) {   // pdr.rs:102-116
-        w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(pos[i]); w.ch('\t'); w.i32(pos[i] + 2); w.ch('\t');
-        w.f32(pdr[i]); w.ch('\t'); w.u32(nc[i]); w.ch('\t'); w.u32(nd[i]); w.eol();
-    });
-    if (fclose(f) != 0) die("Error writing to output file.");
-    mth_ctx_destroy(ctx);
-    mth_host_close(in.h);
-    return 0;
+    {
+        Phase ph3("fetch + TSV write");
+        std::vector<int32_t> tid(n), pos(n);
+        std::vector<float> pdr(n);
+        std::vector<uint32_t> nc(n), nd(n);
+        { Phase pf("  fetch"); check(ctx, mth_pdr_fetch(ctx, tid.data(), pos.data(), pdr.data(), nc.data(), nd.data())); }
+        Phase pw("  format + write");
+        FILE *f = open_output(a.s.at("output"));
+        write_rows(f, n, [&](LineWriter &w, uint64_t i) {   // pdr.rs:102-116
+            w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(pos[i]); w.ch('\t'); w.i32(pos[i] + 2); w.ch('\t');
+            w.f32(pdr[i]); w.ch('\t'); w.u32(nc[i]); w.ch('\t'); w.u32(nd[i]); w.eol();
+        });
+        if (fclose(f) != 0) die("Error writing to output file.");
+    }
+    return finish(ctx, in.h);
 }
 
 int run_lpmd(const Args &a) {
@@ -625,9 +642,7 @@ int run_lpmd(const Args &a) {
         });
         if (fclose(g) != 0) die("Error writing to output file.");
     }
-    mth_ctx_destroy(ctx);
-    mth_host_close(in.h);
-    return 0;
+    return finish(ctx, in.h);
 }
 
 // me.rs:68-88 / pm.rs:63-83: one line per quartet with depth >= min_depth,
@@ -637,27 +652,31 @@ int run_quartet(const Args &a, bool want_me) {
     mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_quartet_params_t p;
     p.min_qual = (uint8_t)a.n.at("min-qual");
-    for (const Contig &c : in.contigs) {
-        const mth_batch_t b = make_batch(in, c);
-        check(ctx, mth_quartet_accumulate(ctx, &b, &p));
+    {
+        Phase ph("H2D + kernels (sync)");
+        for (const Contig &c : in.contigs) {
+            const mth_batch_t b = make_batch(in, c);
+            check(ctx, mth_quartet_accumulate(ctx, &b, &p));
+        }
     }
-    const uint32_t min_depth = (uint32_t)a.n.at("min-depth");
-    uint64_t n = 0;
-    check(ctx, mth_quartet_fetch(ctx, min_depth, &n, nullptr, nullptr, nullptr, nullptr, nullptr));
-    std::vector<int32_t> tid(n), pos(n * 4);
-    std::vector<float> val(n);
-    check(ctx, mth_quartet_fetch(ctx, min_depth, &n, tid.data(), pos.data(), nullptr, want_me ? val.data() : nullptr,
-                                 want_me ? nullptr : val.data()));
-    FILE *f = open_output(a.s.at("output"));
-    write_rows(f, n, [&](LineWriter &w, uint64_t i) {
-        w.str(mth_host_ref_name(in.h, tid[i]));
-        for (int k = 0; k < 4; ++k) { w.ch('\t'); w.i32(pos[4 * i + k]); }
-        w.ch('\t'); w.f32(val[i]); w.eol();
-    });
-    if (fclose(f) != 0) die("Error writing to output file.");
-    mth_ctx_destroy(ctx);
-    mth_host_close(in.h);
-    return 0;
+    {
+        Phase ph("fetch + TSV write");
+        const uint32_t min_depth = (uint32_t)a.n.at("min-depth");
+        uint64_t n = 0;
+        check(ctx, mth_quartet_fetch(ctx, min_depth, &n, nullptr, nullptr, nullptr, nullptr, nullptr));
+        std::vector<int32_t> tid(n), pos(n * 4);
+        std::vector<float> val(n);
+        check(ctx, mth_quartet_fetch(ctx, min_depth, &n, tid.data(), pos.data(), nullptr, want_me ? val.data() : nullptr,
+                                     want_me ? nullptr : val.data()));
+        FILE *f = open_output(a.s.at("output"));
+        write_rows(f, n, [&](LineWriter &w, uint64_t i) {
+            w.str(mth_host_ref_name(in.h, tid[i]));
+            for (int k = 0; k < 4; ++k) { w.ch('\t'); w.i32(pos[4 * i + k]); }
+            w.ch('\t'); w.f32(val[i]); w.eol();
+        });
+        if (fclose(f) != 0) die("Error writing to output file.");
+    }
+    return finish(ctx, in.h);
 }
 
 // mhl.rs:101-133: chrom, pos, pos+2, mhl -- sorted by (tid,pos)
@@ -682,9 +701,7 @@ int run_mhl(const Args &a) {
         w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(pos[i]); w.ch('\t'); w.i32(pos[i] + 2); w.ch('\t'); w.f32(val[i]); w.eol();
     });
     if (fclose(f) != 0) die("Error writing to output file.");
-    mth_ctx_destroy(ctx);
-    mth_host_close(in.h);
-    return 0;
+    return finish(ctx, in.h);
 }
 
 // fdrp.rs:148-174 / qfdrp.rs:160-186: chrom, pos, pos+2, value -- sorted by (tid,pos)
@@ -714,9 +731,7 @@ int run_fdrp(const Args &a, bool quantitative) {
         w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(pos[i]); w.ch('\t'); w.i32(pos[i] + 2); w.ch('\t'); w.f32(val[i]); w.eol();
     });
     if (fclose(f) != 0) die("Error writing to output file.");
-    mth_ctx_destroy(ctx);
-    mth_host_close(in.h);
-    return 0;
+    return finish(ctx, in.h);
 }
 
 }  // namespace
