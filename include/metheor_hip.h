@@ -161,9 +161,7 @@ int  mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_
  * pm.rs:77; pass 0 for compute_helper's full map).  *n_rows is always set; the arrays may be NULL
  * (count only) or hold >= *n_rows entries: pos4[n*4] = pos1..pos4, counts16[n*16] = pattern
  * histogram (pattern = 8*m1+4*m2+2*m3+m4), me = compute_me() (me.rs:42-55), pm = compute_pm()
- * (pm.rs:42-51).  Rows come sorted by (batch, pos1..pos4); only the rows of 8192-bp tiles that held more than 512
- * distinct quartets or more than 65535 candidate reads follow their batch's sorted rows in table order (the reference's
- * order is HashMap-random).  Like the other measures, batches must be coordinate-sorted (MTH_ERR_UNSORTED) and no CpG call
+ * (pm.rs:42-51).  Rows come sorted by (batch, pos1..pos4) -- deterministic; the reference's order is HashMap-random.  Like the other measures, batches must be coordinate-sorted (MTH_ERR_UNSORTED) and no CpG call
  * of a read may lie outside [start - 1, start - 1 + max_span] (MTH_ERR_SPAN). */
 int  mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int32_t *tid, int32_t *pos4,
                        uint32_t *counts16, float *me, float *pm);

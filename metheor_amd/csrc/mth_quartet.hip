@@ -560,9 +560,9 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
     if (!ctx) return MTH_ERR_INVALID;
     int rc = sync_and_check(ctx);
     if (rc) return rc;
-    // Rows live in [0, q_rows) with gaps (the unused tails of the tile kernel's chunks).  Row order: per batch, the tiles in
-    // position order (each tile's rows are sorted by (p1..p4)), then the rows of the tiles that took the global path
-    // (table order).  The reference's order is HashMap-random.
+    // Rows live in [0, q_rows) with gaps (the unused tails of the tile kernel's chunks).  Row order: per batch, sorted by
+    // (p1..p4): the tiles in position order give that for free (each tile's rows are sorted in LDS); a batch with rows from
+    // the global path is sorted here.  The reference's order is HashMap-random.
     const uint64_t total = ctx->q_rows;
     std::vector<uint32_t> depth(total);
     if (total) MTH_HIP(ctx, hipMemcpy(depth.data(), ctx->q_depth.p, total * 4, hipMemcpyDeviceToHost));
@@ -575,25 +575,40 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
     }
     std::vector<uint64_t> order;            // device row of every output row that passes the depth filter
     std::vector<int32_t> order_tid;
+    std::vector<int32_t> hp;                // pos1..pos4 of every device row (needed below only if some tile took the global path)
+    bool any_heavy = false;
+    {
+        uint64_t batch_end = 0;
+        for (const auto &mb : ctx->q_meta) { batch_end += mb.rows; any_heavy |= mb.heavy0 < batch_end; }
+    }
+    if (total && (pos4 || any_heavy)) {
+        hp.resize(total * 4);
+        MTH_HIP(ctx, hipMemcpy(hp.data(), ctx->q_pos.p, total * 16, hipMemcpyDeviceToHost));
+    }
     {
         uint64_t batch_end = 0;
         for (size_t b = 0; b < ctx->q_meta.size(); ++b) {
             const auto &mb = ctx->q_meta[b];
             batch_end += mb.rows;
+            const size_t first = order.size();
             auto put = [&](uint64_t i) { if (depth[i] >= min_depth) { order.push_back(i); order_tid.push_back(mb.tid); } };
             for (uint64_t t = b ? ctx->q_meta[b - 1].tile_end : 0; t < mb.tile_end; ++t)
                 for (uint32_t j = 0; j < trows[t]; ++j) put(trow0[t] + j);
+            const size_t sorted_end = order.size();
             for (uint64_t i = mb.heavy0; i < batch_end; ++i) put(i);
+            if (order.size() > sorted_end)      // rows of the global path came in table order: put the batch in (pos1..pos4) order
+                std::sort(order.begin() + (ptrdiff_t)first, order.end(), [&](uint64_t x, uint64_t y) {
+                    return std::lexicographical_compare(hp.begin() + (ptrdiff_t)(x * 4), hp.begin() + (ptrdiff_t)(x * 4 + 4),
+                                                        hp.begin() + (ptrdiff_t)(y * 4), hp.begin() + (ptrdiff_t)(y * 4 + 4));
+                });
         }
     }
     const uint64_t n = order.size();
     if (n_rows) *n_rows = n;
     if (!tid && !pos4 && !counts16 && !me && !pm) return MTH_OK;
-    std::vector<int32_t> hp(pos4 ? total * 4 : 0);
     std::vector<uint32_t> hc(counts16 ? total * 16 : 0);
     std::vector<float> hme(me ? total : 0), hpm(pm ? total : 0);
     if (total) {
-        if (pos4) MTH_HIP(ctx, hipMemcpy(hp.data(), ctx->q_pos.p, total * 16, hipMemcpyDeviceToHost));
         if (counts16) MTH_HIP(ctx, hipMemcpy(hc.data(), ctx->q_cnt.p, total * 64, hipMemcpyDeviceToHost));
         if (me) MTH_HIP(ctx, hipMemcpy(hme.data(), ctx->q_me.p, total * 4, hipMemcpyDeviceToHost));
         if (pm) MTH_HIP(ctx, hipMemcpy(hpm.data(), ctx->q_pm.p, total * 4, hipMemcpyDeviceToHost));

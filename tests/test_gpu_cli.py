@@ -335,6 +335,19 @@ def test_sharded_run_equals_single_run(tmp_path, n_shards):
         assert len(o1.read_bytes()) > (20 if sub == "lpmd" else 1000)
         if sub == "lpmd":
             assert (tmp_path / "sh_pairs.tsv").read_bytes() == (tmp_path / "one_pairs.tsv").read_bytes()
+    # --cpg-set is applied by each shard's device decode
+    bed = tmp_path / "sites.bed"
+    names = [n for n, _ in refs]
+    soa = pyoracle.Reads.decode(rec).soa()
+    key = (np.repeat(soa["tid"].astype(np.int64), np.diff(soa["cpg_off"].astype(np.int64))) << 32) | (soa["cpg_pos"] & 0x7fffffff).astype(np.int64)
+    keep = np.unique(key)[::3]
+    bed.write_text("".join("%s\t%d\t%d\n" % (names[int(k >> 32)], int(k & 0xffffffff), int(k & 0xffffffff) + 2) for k in keep))
+    o1, oN = tmp_path / "one_set.tsv", tmp_path / "sh_set.tsv"
+    r = run("pdr", "-i", bam, "-o", str(o1), "-d", "2", "-p", "1", "-c", str(bed))
+    assert r.returncode == 0, r.stderr
+    assert sharded.run(n_shards, ["pdr", "-i", bam, "-o", str(oN), "-d", "2", "-p", "1", "-c", str(bed)], gpus=1,
+                       env=dict(os.environ, METHEOR_SHARD_HALO="4000")) == 0
+    assert oN.read_bytes() == o1.read_bytes() and len(o1.read_bytes()) > 1000
     # a halo smaller than an alignment is refused, not silently wrong
     e = dict(os.environ, METHEOR_SHARD="1/2", METHEOR_SHARD_HALO="100")
     import subprocess
