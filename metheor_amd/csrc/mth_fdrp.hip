@@ -34,6 +34,8 @@
 namespace mth {
 
 constexpr int FD_WIN = 201;   // MAX_READ_LEN, fdrp.rs:10
+constexpr int FD_SLOTS = 64;  // stored reads of a site: one lane each.  max_depth > 64 is accepted as long as no site ever holds
+                              // more than 64 reads at once (MTH_ERR_CAPACITY otherwise: loud, never a sampled or truncated result)
 // FD_NB (template parameter of the walk): calls of a stored read held in the slot's registers (8 or 16)
 
 struct FdrpArgs {
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
         const uint32_t hi = sgpr(min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads));
         // wave-uniform segment state
         int32_t total = 0, sampled = 0;
-        bool entry = false, have = false;
+        bool entry = false, have = false, deep = false;
         float res_f = 0.0f, res_q = 0.0f;
         uint32_t res_n = 0;
         const bool win_check = a.max_span > 200;   // a stored read calls c and spans <= 200 bp: all its calls are inside +-201
@@ -317,12 +319,13 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 if (m_hit) {
                     entry = true;                                             // fdrp.rs:226-228, 81-85
                     const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_hit, 0u));
-                    if (pass && hit) put_row(total + pre);
+                    if (pass && hit && total + pre < FD_SLOTS) put_row(total + pre);
                     total += n_hit; sampled += n_hit;
+                    deep = deep || total > FD_SLOTS;                          // only reachable with max_depth > 64
                 }
                 if (m_flush) {                                                // fdrp.rs:212-223
                     if (entry) {
-                        if ((uint32_t)sampled >= a.min_depth) finalize();
+                        if ((uint32_t)sampled >= a.min_depth && !deep) finalize();
                         entry = false; total = 0; sampled = 0;
                     }
                     break;   // reads are sorted by start: none from here on can call c, and further flushes find no entry
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 ev &= ev - 1;
                 if ((m_flush >> l) & 1ull) {                                  // fdrp.rs:212-223
                     if (entry) {
-                        if ((uint32_t)sampled >= a.min_depth) finalize();
+                        if ((uint32_t)sampled >= a.min_depth && !deep) finalize();
                         entry = false; total = 0; sampled = 0;
                     }
                     continue;
@@ -353,10 +356,12 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                     if (jr > (int32_t)a.max_depth) continue;
                     slot = jr - 1;
                 }
+                if (slot >= FD_SLOTS) { deep = true; continue; }               // only reachable with max_depth > 64
                 if (lane == l) put_row(slot);
             }
         }
-        if (entry && (uint32_t)sampled >= a.min_depth) finalize();           // fdrp.rs:239-243
+        if (entry && (uint32_t)sampled >= a.min_depth && !deep) finalize();  // fdrp.rs:239-243
+        if (deep && lane == 0) atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);   // a site held more than 64 reads at once
         if (lane == 0) {
             a.fdrp[j] = res_f; a.qfdrp[j] = res_q; a.nreads[j] = res_n;
             a.flags[j] = have ? 1u : 0u;
@@ -404,7 +409,6 @@ extern "C" {
 
 int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp_params_t *params) {
     if (!ctx || !batch || !params) return MTH_ERR_INVALID;
-    if (params->max_depth > 64) return fail(ctx, MTH_ERR_CAPACITY, "fdrp/qfdrp: max_depth > 64 is not supported by the device path (one lane per stored read)");
     mth_batch_t d;
     int rc = stage_batch(ctx, *batch, d);
     if (rc) return rc;

@@ -106,6 +106,14 @@ def test_reference_cli_success_cases(tmp_path):
     assert r.returncode == 0 and o.read_text().count("\n") == 4
     r = run("pdr", "--input", bam, "--output", "/nonexistent_directory/readonly_output.tsv")
     assert r.returncode != 0
+    # output_validation.rs:304-353, 356-405: fdrp / qfdrp with --max-depth 100 succeed (test1.bam is 16 reads deep)
+    for sub in ("fdrp", "qfdrp"):
+        r = run(sub, "--input", bam, "--output", str(o), "--min-depth", "1", "--max-depth", "100", "--min-overlap", "1", "--min-qual", "10")
+        assert r.returncode == 0, r.stderr
+        rows = o.read_text().splitlines()
+        assert len(rows) == 4 and all(0.0 <= float(x.split("\t")[3]) <= 1.0 for x in rows)
+        r40 = run(sub, "--input", bam, "--output", str(tmp_path / "o40.tsv"), "--min-depth", "1", "--max-depth", "40", "--min-overlap", "1")
+        assert r40.returncode == 0 and (tmp_path / "o40.tsv").read_text() == o.read_text()
 
 
 def _quartet_lines(tbl, names, fmt_tol=None):

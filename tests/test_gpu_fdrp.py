@@ -228,7 +228,23 @@ def test_capacity_and_empty(eng):
     eng.reset()
     eng.fdrp_accumulate(b)
     assert len(eng.fdrp_fetch()["pos"]) == 0
+    eng.fdrp_accumulate(b, max_depth=65)           # accepted: the limit is 64 reads STORED for a site (test_max_depth_above_64)
+    assert len(eng.fdrp_fetch()["pos"]) == 0
+    eng.reset()
+
+
+def test_max_depth_above_64(eng):
+    """the device stores at most 64 reads per site (one lane each): max_depth = 100 is exact while no site holds more than 64
+    (output_validation.rs runs --max-depth 100 on the 16-read fixture), and refused loudly -- never truncated -- when one does"""
+    from metheor_amd import MthError, synth
+    c = synth.make_contig(0, 300_000, 50_000, 0.03, np.random.default_rng(91))           # ~25x: every site below 64 reads
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    kw = dict(min_qual=10, min_depth=5, max_depth=100, min_overlap=20)
+    check(run_device(eng, [c], kw), reads, kw)
+    deep = synth.make_contig(0, 20_000, 12_000, 0.03, np.random.default_rng(92))         # ~90x: sites with more than 64 reads
     with pytest.raises(MthError) as e:
-        eng.fdrp_accumulate(b, max_depth=65)
+        run_device(eng, [deep], kw)
     assert e.value.status == -8
     eng.reset()
+    kw64 = dict(min_qual=10, min_depth=5, max_depth=64, min_overlap=20, seed=5)           # the same data with -D 64 samples instead
+    check(run_device(eng, [deep], kw64), pyoracle.Reads.from_soa(*synth.to_oracle_soa(deep)), kw64)
