@@ -361,3 +361,32 @@ def test_sharded_run_equals_single_run(tmp_path, n_shards):
     import subprocess
     r = subprocess.run([EXE, "pdr", "-i", bam, "-o", str(tmp_path / "x.tsv")], env=e, capture_output=True, text=True)
     assert r.returncode != 0 and "METHEOR_SHARD_HALO" in r.stderr
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6])
+def test_output_validation_cases(golden_dir, tmp_path, k):
+    """the command lines of the reference's tests/output_validation.rs (one per measure, :61-405; :409-450 runs them on
+    several fixtures), each against the oracle's text: values in [0, 1], one row per site / quartet"""
+    bam = os.path.join(golden_dir, "test%d.bam" % k)
+    reads = pyoracle.Reads.decode(bamio.read_bam(bam))
+    o = tmp_path / "o.tsv"
+    site = lambda t: "".join("chr1\t%d\t%d\t%s\n" % (p, p + 2, pyoracle.format_f32(v)) for p, v in zip(t.pos[:, 0], t.val))
+    r = run("pdr", "--input", bam, "--output", str(o), "--min-depth", "1", "--min-cpgs", "1", "--min-qual", "10")
+    assert r.returncode == 0 and o.read_text() == util.oracle_tsv_pdr(reads, ["chr1"], min_depth=1, min_cpgs=1, min_qual=10)
+    r = run("lpmd", "--input", bam, "--output", str(o), "--min-distance", "1", "--max-distance", "1000", "--min-qual", "10")
+    assert r.returncode == 0 and o.read_text() == util.oracle_tsv_lpmd(reads, bam, min_distance=1, max_distance=1000, min_qual=10)
+    r = run("mhl", "--input", bam, "--output", str(o), "--min-depth", "1", "--min-cpgs", "1", "--min-qual", "10")
+    assert r.returncode == 0 and o.read_text() == site(reads.mhl(min_depth=1, min_cpgs=1, min_qual=10))
+    r = run("pm", "--input", bam, "--output", str(o), "--min-depth", "1", "--min-qual", "10")
+    assert r.returncode == 0 and sorted(o.read_text().splitlines()) == _quartet_lines(reads.pm(min_depth=1, min_qual=10), ["chr1"])
+    r = run("me", "--input", bam, "--output", str(o), "--min-depth", "1", "--min-qual", "10")
+    got, want = sorted(o.read_text().splitlines()), _quartet_lines(reads.me(min_depth=1, min_qual=10), ["chr1"])
+    assert r.returncode == 0 and len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.split("\t")[:5] == w.split("\t")[:5] and abs(float(g.split("\t")[5]) - float(w.split("\t")[5])) <= 1e-6
+    kw = dict(min_qual=10, min_depth=1, max_depth=100, min_overlap=1)
+    for sub, t in (("fdrp", reads.fdrp(**kw)), ("qfdrp", reads.qfdrp(**kw))):
+        r = run(sub, "--input", bam, "--output", str(o), "--min-depth", "1", "--max-depth", "100", "--min-overlap", "1", "--min-qual", "10")
+        assert r.returncode == 0, r.stderr
+        assert o.read_text() == site(t)
+        assert all(0.0 <= float(x.split("\t")[3]) <= 1.0 for x in o.read_text().splitlines())
