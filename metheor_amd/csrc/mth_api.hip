@@ -71,7 +71,7 @@ int sync_and_check(mth_ctx *ctx) {
     if (e & ERRB_UNSORTED) return fail(ctx, MTH_ERR_UNSORTED, "reads of a batch are not sorted by start position");
     if (e & ERRB_SPAN) return fail(ctx, MTH_ERR_SPAN, "a read spans more reference bases than batch.max_span");
     if (e & ERRB_RANGE) return fail(ctx, MTH_ERR_RANGE, "CpG position outside the declared range");
-    if (e & ERRB_CAPACITY) return fail(ctx, MTH_ERR_CAPACITY, "on-chip capacity exceeded (CpGs of a read >= 2048 bp apart in a quartet, or more than 64 reads stored for one FDRP site with max_depth > 64)");
+    if (e & ERRB_CAPACITY) return fail(ctx, MTH_ERR_CAPACITY, "on-chip capacity exceeded (CpGs of a read >= 2048 bp apart in a quartet, or more than 256 reads stored for one FDRP site)");
     if (e & ERRB_CRC) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block (CRC32 mismatch)");
     if (e & ERRB_FORMAT) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block or malformed BAM record (DEFLATE / ISIZE / block_size / field lengths inconsistent)");
     if (e & ERRB_NOXM) return fail(ctx, MTH_ERR_FORMAT, "a record has no XM:Z tag (the reference panics: Error reading XM tag)");
@@ -133,7 +133,7 @@ const char *mth_strerror(int s) {
         case MTH_ERR_SPAN: return "read span exceeds batch.max_span";
         case MTH_ERR_REOPEN: return "input needs flush re-open semantics not implemented on this path";
         case MTH_ERR_RANGE: return "CpG position out of declared range";
-        case MTH_ERR_CAPACITY: return "on-chip capacity exceeded (CpGs of a read >= 2048 bp apart in a quartet, or more than 64 reads stored for one FDRP site with max_depth > 64)";
+        case MTH_ERR_CAPACITY: return "on-chip capacity exceeded (CpGs of a read >= 2048 bp apart in a quartet, or more than 256 reads stored for one FDRP site)";
         case MTH_ERR_STATE: return "call order violated";
         case MTH_ERR_FORMAT: return "malformed BAM record or record without XM:Z";
         case MTH_ERR_UNALIGNED: return "BAM records straddle BGZF blocks";

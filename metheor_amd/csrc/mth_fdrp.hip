@@ -34,8 +34,11 @@
 namespace mth {
 
 constexpr int FD_WIN = 201;   // MAX_READ_LEN, fdrp.rs:10
-constexpr int FD_SLOTS = 64;  // stored reads of a site: one lane each.  max_depth > 64 is accepted as long as no site ever holds
-                              // more than 64 reads at once (MTH_ERR_CAPACITY otherwise: loud, never a sampled or truncated result)
+// Stored reads of a site (template parameter SLOTS of the walk): 64 -- one lane each -- in the main pass.  With max_depth > 64 a
+// site that holds more than 64 reads at once is flagged (flags = 2) and redone by a second pass with 256 slots, whose
+// finalize works pair-parallel from the LDS rows (a sorted merge of the two reads' calls per pair) instead of lane = slot.
+// More than 256 stored reads: MTH_ERR_CAPACITY (loud, never a sampled or truncated result).
+constexpr int FD_SLOTS_DEEP = 256;
 // FD_NB (template parameter of the walk): calls of a stored read held in the slot's registers (8 or 16)
 
 struct FdrpArgs {
@@ -75,8 +78,9 @@ constexpr uint32_t FD_NOPOS = 0xffffffffu;   // "no call" in a slot's call regis
 __device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ int32_t sgpr(int32_t x) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)x); }
 
-template <int FD_NB>
+template <int FD_NB, int SLOTS>
 __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
+    constexpr int FD_SLOTS = SLOTS;
     const int lane = threadIdx.x & 63;
     const uint32_t wave_id = sgpr((uint32_t)((blockIdx.x * 256 + threadIdx.x) >> 6)), n_waves = (gridDim.x * 256) >> 6;
     const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
     uint8_t *const bit_of = s_bit[threadIdx.x >> 6];
     // per wave: the stored reads of the open segment, one row per slot: {cpg_off, n_calls, start, end, FD_NB packed calls}
     constexpr int ROW = 4 + FD_NB;
-    __shared__ __attribute__((aligned(16))) uint32_t s_rows[4][64 * ROW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[4][SLOTS * ROW];
     uint32_t *const rows = s_rows[threadIdx.x >> 6];
     for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
         const int32_t c = sgpr(a.site_pos[j]);
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
         float res_f = 0.0f, res_q = 0.0f;
         uint32_t res_n = 0;
         const bool win_check = a.max_span > 200;   // a stored read calls c and spans <= 200 bp: all its calls are inside +-201
+        if (SLOTS > 64 && a.flags[j] != 2u) continue;   // second pass: only the sites the 64-slot pass could not hold
 
         auto finalize = [&]() {   // compute_fdrp / compute_qfdrp over slots 0..sampled-1
             const int nS = sampled;
@@ -279,6 +284,74 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             __builtin_amdgcn_wave_barrier();                                  // LDS reads done before the next segment's / site's writes
         };
 
+        // SLOTS > 64: lane = pair.  Rows stay {cpg_off, n_calls, start, end, FD_NB calls}; the k-th pair of the reference's
+        // lexicographic (i, j) order goes to lane k of a round, walks the two sorted call lists once (calls beyond the row's
+        // registers come from memory), and the round's 64 terms are chained in that order by DPP adds as in the compact path.
+        auto finalize_deep = [&]() {
+            const int nS = sampled;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t disc = 0;
+            float q = 0.0f;
+            const int P = (nS * (nS - 1)) >> 1;
+            const int twoN = 2 * nS;
+            const float bq = (float)(twoN - 1);
+            auto call_of = [&](const uint32_t *r, uint32_t t) { return t < (uint32_t)FD_NB ? r[4 + t] : a.cpg_pos[r[0] + t]; };
+#define MTH_FD_DPP x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)) + term;
+            for (int k0 = 0; k0 < P; k0 += 64) {
+                const int k = min(k0 + lane, P - 1);
+                int pi = (int)((bq - __builtin_sqrtf(bq * bq - 8.0f * (float)k)) * 0.5f);
+                pi = max(0, min(pi, nS - 2));
+                int off = (pi * (twoN - pi - 1)) >> 1;
+                if (k < off) { pi -= 1; off = (pi * (twoN - pi - 1)) >> 1; }
+                const int off1 = ((pi + 1) * (twoN - pi - 2)) >> 1;
+                if (k >= off1) { pi += 1; off = off1; }
+                const int pj = k - off + pi + 1;
+                const uint32_t *ri = rows + pi * ROW, *rj = rows + pj * ROW;
+                const int32_t si = (int32_t)ri[2], ei = (int32_t)ri[3], sj = (int32_t)rj[2], ej = (int32_t)rj[3];
+                const int32_t mx = max(si, sj);
+                const int32_t ov = min(ei, ej) - mx + 1;                     // get_num_overlap_bases, fdrp.rs:97-107
+                const bool pair_ok = (k0 + lane < P) & (max(ov, 0) >= a.min_overlap);   // fdrp.rs:134
+                uint32_t ham = 0, ncpg = 0;
+                const uint32_t ni = ri[1], nj = rj[1];
+                uint32_t ti = 0, tj = 0;
+                while (ti < ni && tj < nj) {
+                    const uint32_t wi = call_of(ri, ti), wj = call_of(rj, tj);
+                    const uint32_t pa = wi & 0x7fffffffu, pb = wj & 0x7fffffffu;
+                    if (pa == pb) {
+                        // (positions outside the reference's 403-slot array around c are not compared, as in the 64-slot path)
+                        if (!(win_check && (uint32_t)((int32_t)pa - (c - FD_WIN)) > 2u * FD_WIN)) {
+                            ncpg += 1;                                        // get_num_overlap_cpgs, qfdrp.rs:109-119
+                            ham += ((int32_t)pa >= mx && ((wi ^ wj) >> 31)) ? 1u : 0u;   // fdrp.rs:114-115
+                        }
+                        ++ti; ++tj;
+                    } else if (pa < pb) ++ti; else ++tj;
+                }
+                disc += (pair_ok && ham != 0u) ? 1u : 0u;                    // fdrp.rs:138-140
+                const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;   // qfdrp.rs:152; +0.0 for skipped pairs
+                float x = (lane == 0) ? q + term : term;
+                const int steps = min(64, P - k0) - 1;
+                for (int st = 0; st < steps; ++st) { MTH_FD_DPP }
+                q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), steps));
+            }
+#undef MTH_FD_DPP
+            uint32_t n_disc = disc;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) n_disc += __shfl_xor(n_disc, o, 64);
+            n_disc = sgpr(n_disc);
+            const unsigned long long prod = (unsigned long long)(long long)nS * (unsigned long long)((long long)nS - 1);
+            const float den = (float)prod / 2.0f;                            // fdrp.rs:143
+            res_f = (float)n_disc / den;
+            res_q = q / den;
+            res_n = (uint32_t)nS;
+            have = true;
+            __builtin_amdgcn_wave_barrier();
+        };
+// (not a wrapper lambda: one more call level and the compiler stops inlining finalize -- its by-reference captures then live in
+// scratch memory and the walk runs 3.5x slower)
+#define MTH_FD_FINISH() do { if constexpr (SLOTS > 64) finalize_deep(); else finalize(); } while (0)
+
         // Candidates are inspected 64 at a time, one per lane (their field and call loads are issued together:
         // the one-candidate-per-iteration scalar walk was latency-bound, ~3 dependent loads x ~35 candidates
         // per site); the ordered part below runs over ballots and touches no memory.
@@ -325,7 +398,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 }
                 if (m_flush) {                                                // fdrp.rs:212-223
                     if (entry) {
-                        if ((uint32_t)sampled >= a.min_depth && !deep) finalize();
+                        if ((uint32_t)sampled >= a.min_depth && !deep) MTH_FD_FINISH();
                         entry = false; total = 0; sampled = 0;
                     }
                     break;   // reads are sorted by start: none from here on can call c, and further flushes find no entry
@@ -338,7 +411,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 ev &= ev - 1;
                 if ((m_flush >> l) & 1ull) {                                  // fdrp.rs:212-223
                     if (entry) {
-                        if ((uint32_t)sampled >= a.min_depth && !deep) finalize();
+                        if ((uint32_t)sampled >= a.min_depth && !deep) MTH_FD_FINISH();
                         entry = false; total = 0; sampled = 0;
                     }
                     continue;
@@ -360,14 +433,16 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 if (lane == l) put_row(slot);
             }
         }
-        if (entry && (uint32_t)sampled >= a.min_depth && !deep) finalize();  // fdrp.rs:239-243
-        if (deep && lane == 0) atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);   // a site held more than 64 reads at once
+        if (entry && (uint32_t)sampled >= a.min_depth && !deep) MTH_FD_FINISH();  // fdrp.rs:239-243
+        if (deep && SLOTS > 64 && lane == 0) atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);   // more than FD_SLOTS_DEEP reads stored at once
         if (lane == 0) {
             a.fdrp[j] = res_f; a.qfdrp[j] = res_q; a.nreads[j] = res_n;
-            a.flags[j] = have ? 1u : 0u;
+            a.flags[j] = deep ? 2u : (have ? 1u : 0u);                      // 2: for the 256-slot pass (main pass only)
         }
     }
 }
+
+#undef MTH_FD_FINISH
 
 __global__ __launch_bounds__(256) void k_fdrp_emit(const uint32_t *__restrict__ flags, const int32_t *__restrict__ site_pos,
                                                    const float *__restrict__ f, const float *__restrict__ q,
@@ -455,8 +530,10 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         // dense CpGs (hotspots, RRBS): 16 call registers per stored read keep the per-call match out of
         // the memory loop; sparse WGBS keeps 8 (half the compares per call)
         const bool dense = d.n_reads && ((double)d.n_cpgs / (double)d.n_reads) > 6.0;
-        if (dense) hipLaunchKernelGGL((k_fdrp_walk<16>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_fdrp_walk<8>), dim3(grid), dim3(256), 0, s, a);
+        if (dense) hipLaunchKernelGGL((k_fdrp_walk<16, 64>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_fdrp_walk<8, 64>), dim3(grid), dim3(256), 0, s, a);
+        // max_depth > 64: the sites that held more than 64 reads at once were flagged, not computed: 256-slot pass over them
+        if (params->max_depth > 64) hipLaunchKernelGGL((k_fdrp_walk<8, FD_SLOTS_DEEP>), dim3(grid), dim3(256), 0, s, a);
     }
     unsigned long long *fs = ctx->f_state.as<unsigned long long>();
     const uint32_t nblk = (uint32_t)((bound + 256 * SCAN_PER - 1) / (256 * SCAN_PER));

@@ -234,17 +234,30 @@ def test_capacity_and_empty(eng):
 
 
 def test_max_depth_above_64(eng):
-    """the device stores at most 64 reads per site (one lane each): max_depth = 100 is exact while no site holds more than 64
-    (output_validation.rs runs --max-depth 100 on the 16-read fixture), and refused loudly -- never truncated -- when one does"""
+    """the main pass stores at most 64 reads per site (one lane each); with max_depth > 64 deeper sites are redone by a
+    256-slot pass (pair-parallel merge of the call lists) -- exact, including the reservoir branch beyond max_depth;
+    more than 256 reads stored at once is refused loudly (output_validation.rs runs --max-depth 100)"""
     from metheor_amd import MthError, synth
     c = synth.make_contig(0, 300_000, 50_000, 0.03, np.random.default_rng(91))           # ~25x: every site below 64 reads
     reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
     kw = dict(min_qual=10, min_depth=5, max_depth=100, min_overlap=20)
     check(run_device(eng, [c], kw), reads, kw)
-    deep = synth.make_contig(0, 20_000, 12_000, 0.03, np.random.default_rng(92))         # ~90x: sites with more than 64 reads
+    deep = synth.make_contig(0, 20_000, 12_000, 0.03, np.random.default_rng(92))         # ~90x: sites with 64..130 reads
+    dreads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(deep))
+    for kw in (dict(min_qual=10, min_depth=5, max_depth=100, min_overlap=20, seed=3),     # stored in full up to 100, sampled beyond
+               dict(min_qual=0, min_depth=5, max_depth=200, min_overlap=1),               # never sampled
+               dict(min_qual=10, min_depth=5, max_depth=64, min_overlap=20, seed=5)):     # the 64-slot pass alone, sampling
+        n, nf, nq = check(run_device(eng, [deep], kw), dreads, kw)
+        assert n > 400
+    assert int(dreads.fdrp(min_qual=0, min_depth=5, max_depth=200, min_overlap=1).cnt[:, 0].max()) > 64
+    # region split + device-resident batches through the deep pass
+    from metheor_amd import shard
+    kw = dict(min_qual=10, min_depth=5, max_depth=150, min_overlap=20)
+    check(run_device(eng, [deep], kw, device="cuda:0", regions=[shard.plan_regions(deep, 3)]), dreads, kw)
+    very = synth.make_contig(0, 6_000, 14_000, 0.03, np.random.default_rng(93))          # ~350x: more than 256 reads on a site
     with pytest.raises(MthError) as e:
-        run_device(eng, [deep], kw)
+        run_device(eng, [very], dict(min_qual=10, min_depth=5, max_depth=300, min_overlap=20))
     assert e.value.status == -8
     eng.reset()
-    kw64 = dict(min_qual=10, min_depth=5, max_depth=64, min_overlap=20, seed=5)           # the same data with -D 64 samples instead
-    check(run_device(eng, [deep], kw64), pyoracle.Reads.from_soa(*synth.to_oracle_soa(deep)), kw64)
+    kw = dict(min_qual=10, min_depth=5, max_depth=256, min_overlap=20, seed=9)            # 256 slots hold it, sampling beyond
+    check(run_device(eng, [very], kw), pyoracle.Reads.from_soa(*synth.to_oracle_soa(very)), kw)
