@@ -429,6 +429,7 @@ Input load(const std::string &path, const char *cpg_set) {
     Input in;
     char err[1024];
     const bool try_device = !getenv("METHEOR_HOST_DECODE");
+    if (!try_device && g_shard.world > 1) die("METHEOR_SHARD needs the device load path (METHEOR_HOST_DECODE is set)");
     CtxFuture cf;
     if (try_device) cf.start();
     if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) { cf.wait(); die(err); }    // bamutil.rs:7-9
