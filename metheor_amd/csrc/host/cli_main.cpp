@@ -435,6 +435,7 @@ Input load(const std::string &path, const char *cpg_set) {
     if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) { cf.wait(); die(err); }    // bamutil.rs:7-9
     if (try_device) {
         if (load_on_device(in, cpg_set, cf)) return in;
+        if (g_shard.world > 1) die("METHEOR_SHARD needs the device load path (coordinate-sorted input, contigs grouped, records inside BGZF blocks)");
         in.contigs.clear();
     }
     {
