@@ -215,6 +215,7 @@ int mth_reset(mth_ctx_t *ctx) {
     if (ctx->q_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->q_state.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     ctx->q_meta.clear();
     ctx->q_rows = 0;
+    ctx->q_epoch += 1;
     if (ctx->m_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->m_state.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
     ctx->m_batches.clear();
     ctx->m_rows_bound = 0;

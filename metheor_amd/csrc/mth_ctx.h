@@ -66,6 +66,12 @@ struct mth_ctx {
     double q_rows_per_cpg = 0.15;          // output sizing of the next batch
     mth::DevBuf q_pos, q_cnt, q_me, q_pm, q_depth;
     uint64_t q_cap = 0, q_rows = 0;        // row capacity, rows in use (known exactly: one sync per batch)
+    // the row order worked out by a count-only mth_quartet_fetch, kept for the fetch that follows it (same min_depth,
+    // nothing accumulated in between: q_epoch)
+    uint64_t q_epoch = 0, q_order_epoch = ~0ull;
+    uint32_t q_order_min_depth = 0;
+    std::vector<uint64_t> q_order;
+    std::vector<int32_t> q_order_tid;
 
     // site-walk measures (mth_sites.hip): discovery sink, per-candidate work arrays, MHL result rows
     mth::DevState *d_state2 = nullptr;

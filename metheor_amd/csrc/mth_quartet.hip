@@ -409,6 +409,7 @@ extern "C" {
 
 int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_quartet_params_t *params) {
     if (!ctx || !batch || !params) return MTH_ERR_INVALID;
+    ctx->q_epoch += 1;
     mth_batch_t d;
     int rc = stage_batch(ctx, *batch, d);
     if (rc) return rc;
@@ -564,44 +565,49 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
     // (p1..p4): the tiles in position order give that for free (each tile's rows are sorted in LDS); a batch with rows from
     // the global path is sorted here.  The reference's order is HashMap-random.
     const uint64_t total = ctx->q_rows;
-    std::vector<uint32_t> depth(total);
-    if (total) MTH_HIP(ctx, hipMemcpy(depth.data(), ctx->q_depth.p, total * 4, hipMemcpyDeviceToHost));
-    const uint64_t n_tiles = ctx->q_meta.empty() ? 0 : ctx->q_meta.back().tile_end;
-    std::vector<unsigned long long> trow0(n_tiles);
-    std::vector<uint32_t> trows(n_tiles);
-    if (n_tiles) {
-        MTH_HIP(ctx, hipMemcpy(trow0.data(), ctx->q_tile_row0.p, n_tiles * 8, hipMemcpyDeviceToHost));
-        MTH_HIP(ctx, hipMemcpy(trows.data(), ctx->q_tile_rows.p, n_tiles * 4, hipMemcpyDeviceToHost));
-    }
-    std::vector<uint64_t> order;            // device row of every output row that passes the depth filter
-    std::vector<int32_t> order_tid;
-    std::vector<int32_t> hp;                // pos1..pos4 of every device row (needed below only if some tile took the global path)
-    bool any_heavy = false;
-    {
-        uint64_t batch_end = 0;
-        for (const auto &mb : ctx->q_meta) { batch_end += mb.rows; any_heavy |= mb.heavy0 < batch_end; }
-    }
-    if (total && (pos4 || any_heavy)) {
-        hp.resize(total * 4);
-        MTH_HIP(ctx, hipMemcpy(hp.data(), ctx->q_pos.p, total * 16, hipMemcpyDeviceToHost));
-    }
-    {
-        uint64_t batch_end = 0;
-        for (size_t b = 0; b < ctx->q_meta.size(); ++b) {
-            const auto &mb = ctx->q_meta[b];
-            batch_end += mb.rows;
-            const size_t first = order.size();
-            auto put = [&](uint64_t i) { if (depth[i] >= min_depth) { order.push_back(i); order_tid.push_back(mb.tid); } };
-            for (uint64_t t = b ? ctx->q_meta[b - 1].tile_end : 0; t < mb.tile_end; ++t)
-                for (uint32_t j = 0; j < trows[t]; ++j) put(trow0[t] + j);
-            const size_t sorted_end = order.size();
-            for (uint64_t i = mb.heavy0; i < batch_end; ++i) put(i);
-            if (order.size() > sorted_end)      // rows of the global path came in table order: put the batch in (pos1..pos4) order
-                std::sort(order.begin() + (ptrdiff_t)first, order.end(), [&](uint64_t x, uint64_t y) {
-                    return std::lexicographical_compare(hp.begin() + (ptrdiff_t)(x * 4), hp.begin() + (ptrdiff_t)(x * 4 + 4),
-                                                        hp.begin() + (ptrdiff_t)(y * 4), hp.begin() + (ptrdiff_t)(y * 4 + 4));
-                });
+    std::vector<int32_t> hp;                // pos1..pos4 of every device row
+    std::vector<uint64_t> &order = ctx->q_order;            // device row of every output row that passes the depth filter
+    std::vector<int32_t> &order_tid = ctx->q_order_tid;
+    const bool cached = ctx->q_order_epoch == ctx->q_epoch && ctx->q_order_min_depth == min_depth;
+    if (!cached) {
+        std::vector<uint32_t> depth(total);
+        if (total) MTH_HIP(ctx, hipMemcpy(depth.data(), ctx->q_depth.p, total * 4, hipMemcpyDeviceToHost));
+        const uint64_t n_tiles = ctx->q_meta.empty() ? 0 : ctx->q_meta.back().tile_end;
+        std::vector<unsigned long long> trow0(n_tiles);
+        std::vector<uint32_t> trows(n_tiles);
+        if (n_tiles) {
+            MTH_HIP(ctx, hipMemcpy(trow0.data(), ctx->q_tile_row0.p, n_tiles * 8, hipMemcpyDeviceToHost));
+            MTH_HIP(ctx, hipMemcpy(trows.data(), ctx->q_tile_rows.p, n_tiles * 4, hipMemcpyDeviceToHost));
         }
+        order.clear(); order_tid.clear();
+        bool any_heavy = false;
+        {
+            uint64_t batch_end = 0;
+            for (const auto &mb : ctx->q_meta) { batch_end += mb.rows; any_heavy |= mb.heavy0 < batch_end; }
+        }
+        if (total && (pos4 || any_heavy)) {
+            hp.resize(total * 4);
+            MTH_HIP(ctx, hipMemcpy(hp.data(), ctx->q_pos.p, total * 16, hipMemcpyDeviceToHost));
+        }
+        {
+            uint64_t batch_end = 0;
+            for (size_t b = 0; b < ctx->q_meta.size(); ++b) {
+                const auto &mb = ctx->q_meta[b];
+                batch_end += mb.rows;
+                const size_t first = order.size();
+                auto put = [&](uint64_t i) { if (depth[i] >= min_depth) { order.push_back(i); order_tid.push_back(mb.tid); } };
+                for (uint64_t t = b ? ctx->q_meta[b - 1].tile_end : 0; t < mb.tile_end; ++t)
+                    for (uint32_t j = 0; j < trows[t]; ++j) put(trow0[t] + j);
+                const size_t sorted_end = order.size();
+                for (uint64_t i = mb.heavy0; i < batch_end; ++i) put(i);
+                if (order.size() > sorted_end)      // rows of the global path came in table order: put the batch in (pos1..pos4) order
+                    std::sort(order.begin() + (ptrdiff_t)first, order.end(), [&](uint64_t x, uint64_t y) {
+                        return std::lexicographical_compare(hp.begin() + (ptrdiff_t)(x * 4), hp.begin() + (ptrdiff_t)(x * 4 + 4),
+                                                            hp.begin() + (ptrdiff_t)(y * 4), hp.begin() + (ptrdiff_t)(y * 4 + 4));
+                    });
+            }
+        }
+        ctx->q_order_epoch = ctx->q_epoch; ctx->q_order_min_depth = min_depth;
     }
     const uint64_t n = order.size();
     if (n_rows) *n_rows = n;
@@ -609,6 +615,7 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
     std::vector<uint32_t> hc(counts16 ? total * 16 : 0);
     std::vector<float> hme(me ? total : 0), hpm(pm ? total : 0);
     if (total) {
+        if (pos4 && hp.empty()) { hp.resize(total * 4); MTH_HIP(ctx, hipMemcpy(hp.data(), ctx->q_pos.p, total * 16, hipMemcpyDeviceToHost)); }
         if (counts16) MTH_HIP(ctx, hipMemcpy(hc.data(), ctx->q_cnt.p, total * 64, hipMemcpyDeviceToHost));
         if (me) MTH_HIP(ctx, hipMemcpy(hme.data(), ctx->q_me.p, total * 4, hipMemcpyDeviceToHost));
         if (pm) MTH_HIP(ctx, hipMemcpy(hpm.data(), ctx->q_pm.p, total * 4, hipMemcpyDeviceToHost));
