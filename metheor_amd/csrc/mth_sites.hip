@@ -179,11 +179,48 @@ __device__ __forceinline__ void mhl_walk_site(const WalkArgs &a, const Src &src,
             if (S32[l - 1] > 0) { const float t = ((float)l * (float)S32[l - 1]) / (float)D32[l - 1]; mhl = mhl + t; }
         return mhl / l_sum;
     };
+    // Only the LAST segment that reaches min_depth is reported, and the lanes of a wave close their segments at different
+    // reads: evaluating compute_mhl at every close made the whole wave run its ~300 instructions a dozen times per 64
+    // sites.  A close now only keeps the segment's packed counters (16 registers); the f32 evaluation happens once, after
+    // the walk, with all lanes together.  (A segment deep enough to have spilled its 16-bit counters is evaluated on the spot.)
+    uint32_t qS[LCAP / 2], qD[LCAP / 2], q_maxn = 0;
+    bool pending = false;
+#pragma unroll
+    for (int w = 0; w < LCAP / 2; ++w) { qS[w] = 0; qD[w] = 0; }
+    auto close_segment = [&]() {
+        res_cov = seg_cov; have = true;
+        if (seg_cov < (uint32_t)MHL_SPILL) {
+#pragma unroll
+            for (int w = 0; w < LCAP / 2; ++w) { qS[w] = Sp[w]; qD[w] = Dp[w]; }
+            q_maxn = maxn; pending = true;
+        } else { res = finalize(); pending = false; }
+    };
+    auto finalize_packed = [&]() {   // compute_mhl (mhl.rs:43-73) on the kept counters: same operations, same order as finalize()
+        float l_sum = 0.0f;
+        for (uint32_t l = 1; l < q_maxn + 1; ++l) l_sum = l_sum + (float)l;
+        float mhl = 0.0f;
+#pragma unroll
+        for (int l = 1; l <= LCAP; ++l) {
+            const uint32_t S = (l & 1) ? (qS[(l - 1) >> 1] & 0xffffu) : (qS[(l - 1) >> 1] >> 16);
+            const uint32_t D = (l & 1) ? (qD[(l - 1) >> 1] & 0xffffu) : (qD[(l - 1) >> 1] >> 16);
+            if (S > 0) { const float t = ((float)l * (float)S) / (float)D; mhl = mhl + t; }
+        }
+        return mhl / l_sum;
+    };
     for (uint32_t i = lo; i < hi; ++i) {
         const uint32_t o0 = src.off(i), n = src.off(i + 1) - o0;
         if (n == 0) continue;                                          // no first CpG: neither flushes nor contributes
-        if (c < src.pos(o0) && seg_cov > 0) {                          // mhl.rs:163-171 (strict '<', before the filters)
-            if (seg_cov >= a.min_depth) { res = finalize(); res_cov = seg_cov; have = true; }
+        // The read's first four calls are requested together (82 % of WGBS reads have no more): the flush test, the hit test
+        // and the run lengths then work from registers instead of one dependent LDS round trip per call.
+        int32_t p4[4];
+        uint32_t m4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t kk = o0 + min((uint32_t)t, n - 1);
+            p4[t] = src.pos(kk); m4[t] = src.meth(kk);
+        }
+        if (c < p4[0] && seg_cov > 0) {                                // mhl.rs:163-171 (strict '<', before the filters)
+            if (seg_cov >= a.min_depth) close_segment();
             seg_cov = 0; maxn = 0;
 #pragma unroll
             for (int w = 0; w < LCAP / 2; ++w) { Sp[w] = 0; Dp[w] = 0; }
@@ -192,12 +229,19 @@ __device__ __forceinline__ void mhl_walk_site(const WalkArgs &a, const Src &src,
         }
         if (src.mq(i) < a.min_qual) continue;                          // mhl.rs:176
         if (n < a.min_cpgs) continue;                                  // mhl.rs:181
-        bool hit = false;                                              // does the read call c ?
-        for (uint32_t k = o0; k < o0 + n; ++k) {
-            const int32_t p = src.pos(k);
-            if (p == c) { hit = true; break; }
-            if (p > c) break;
+        bool hit = false, decided = false;                             // does the read call c ?
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool live = !decided && (uint32_t)t < n;
+            hit = hit || (live && p4[t] == c);
+            decided = decided || (live && p4[t] >= c);
         }
+        if (!decided)
+            for (uint32_t k = o0 + 4; k < o0 + n; ++k) {
+                const int32_t p = src.pos(k);
+                if (p == c) { hit = true; break; }
+                if (p > c) break;
+            }
         if (!hit) continue;
         if (n > (uint32_t)LCAP) { overflow = true; continue; }         // deferred to the sequential variant / refused
         seg_cov += 1;                                                   // add_num_cpgs, mhl.rs:75-80
@@ -205,14 +249,22 @@ __device__ __forceinline__ void mhl_walk_site(const WalkArgs &a, const Src &src,
         maxn = max(maxn, n);
         add_vec(Dp, n);
         uint32_t cur = 0;                                               // get_stretch_info, readutil.rs:147-164
-        for (uint32_t k = o0; k < o0 + n; ++k) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if ((uint32_t)t < n) {
+                if (m4[t]) { cur += 1; }
+                else if (cur) { add_vec(Sp, cur); cur = 0; }
+            }
+        }
+        for (uint32_t k = o0 + 4; k < o0 + n; ++k) {
             if (src.meth(k)) { cur += 1; }
             else if (cur) { add_vec(Sp, cur); cur = 0; }
         }
         if (cur) add_vec(Sp, cur);
         if ((seg_cov & (MHL_SPILL - 1)) == 0) spill();
     }
-    if (seg_cov > 0 && seg_cov >= a.min_depth) { res = finalize(); res_cov = seg_cov; have = true; }   // mhl.rs:201-205
+    if (seg_cov > 0 && seg_cov >= a.min_depth) close_segment();       // mhl.rs:201-205
+    if (pending) res = finalize_packed();
     if (overflow) { a.flags[j] = 2u; return; }
     a.val[j] = res;
     a.cov[j] = res_cov;
