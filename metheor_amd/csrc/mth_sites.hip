@@ -37,17 +37,311 @@ struct WalkArgs {
     uint8_t min_qual;
 };
 
-// Sequential variant for the sites the fast kernel below defers (flags == 2): a covering read with more than
-// 16 CpGs, or a segment deep enough for the f32 denominators to leave the exact-integer range.  One thread per
-// site, global-memory walk over the index's candidate range, dynamically indexed arrays (scratch) -- rare sites only.
+// The fast variant again, with the gathers taken out.  One thread per site is efficient in VALU terms (every
+// lane busy) but each candidate costs ~5 dependent gathers from three arrays, while neighbouring sites share
+// almost all their candidates.  A block takes 256 consecutive sites and stages ALL its candidate reads in LDS with
+// coalesced loads -- 16-bit call offsets, mapq, and the calls as 16-bit words (15-bit position relative to the
+// block, state in bit 15) -- then every thread walks its own range [lo, hi) out of LDS.  A block whose candidates
+// do not fit (too many reads or calls, or positions spread over >= 2^15 bp) runs the same walk on global memory.
+constexpr int MW_RC = 3072;    // reads staged per block
+constexpr int MW_CC = 10240;   // call words staged per block
+constexpr int MW_MAX_PARTS = 2; // a group is staged whole or as two runs of waves; deeper data walks global memory (measured:
+                                // four runs of 64 sites are slower than the global walk at 100x depth)
+
+struct MhlGlobalSrc {
+    const uint32_t *cpg_off, *cpg_pos;
+    const uint8_t *mapq;
+    uint32_t k_end;     // one past the last call that may be read
+    __device__ __forceinline__ uint32_t off(uint32_t i) const { return cpg_off[i]; }
+    __device__ __forceinline__ uint32_t mq(uint32_t i) const { return mapq[i]; }
+    __device__ __forceinline__ int32_t pos(uint32_t k) const { return (int32_t)(cpg_pos[k] & 0x7fffffffu); }
+    __device__ __forceinline__ uint32_t meth(uint32_t k) const { return cpg_pos[k] >> 31; }
+};
+struct MhlLdsSrc {
+    const uint16_t *ofs, *call;
+    const uint8_t *mapq;
+    uint32_t r0;
+    int32_t base;
+    uint32_t k_end;     // one past the last staged call
+    __device__ __forceinline__ uint32_t off(uint32_t i) const { return ofs[i - r0]; }
+    __device__ __forceinline__ uint32_t mq(uint32_t i) const { return mapq[i - r0]; }
+    __device__ __forceinline__ int32_t pos(uint32_t k) const { return base + (int32_t)(call[k] & 0x7fffu); }
+    __device__ __forceinline__ uint32_t meth(uint32_t k) const { return call[k] >> 15; }
+};
+
+// The per-site walk (file order over the site's candidate reads [lo, hi)), read lengths up to LCAP = 16 CpGs.
+// Both accumulations are "add the vector v_m[l] = max(0, m-l+1), l = 1..16": S (mhl.rs:36-41) once per maximal
+// methylated run of length m (the run contributes m-l+1 windows of length l), D (mhl.rs:53-58) once per covering
+// read with m = n_r.  Unrolled over 16 register slots that is 32-80 VALU per event, and under SIMT the whole wave
+// pays for every event of any lane.  Here v_m comes from a 17-row LDS table packed as 16-bit pairs: two 16-byte
+// LDS reads + 8 packed adds per event.  The packed sums spill into 32-bit accumulators every 2048 covering reads
+// (a field grows by at most 16 per read), so the counts are exact at any depth; D is the reference's f32 running
+// sum of integers, exact (and order-free) below 2^24 -- deeper sites go to the sequential variant.
+constexpr int MHL_SPILL = 2048;
+// SPILL: keep 32-bit accumulators behind the packed 16-bit ones (exact at any depth; 32 more registers).  Without them a
+// segment that reaches MHL_SPILL - 1 covering reads is handed to the sequential variant (flags = 2).
+template <typename Src, bool SPILL>
+__device__ __forceinline__ void mhl_walk_site(const WalkArgs &a, const Src &src, const uint4 *__restrict__ vtab,
+                                              const uint32_t j, const int32_t c, const uint32_t lo, const uint32_t hi) {
+    constexpr int LCAP = 16;
+    uint32_t Sp[LCAP / 2], Dp[LCAP / 2];     // packed pairs: low half l = 2w+1, high half l = 2w+2
+    uint32_t S32[LCAP], D32[LCAP];
+#pragma unroll
+    for (int w = 0; w < LCAP / 2; ++w) { Sp[w] = 0; Dp[w] = 0; }
+#pragma unroll
+    for (int l = 0; l < LCAP; ++l) { S32[l] = 0; D32[l] = 0; }
+    uint32_t seg_cov = 0, maxn = 0, res_cov = 0;
+    float res = 0.0f;
+    bool have = false, overflow = false;
+    auto add_vec = [&](uint32_t (&acc)[LCAP / 2], const uint32_t m) {
+        const uint4 x = vtab[2 * m], y = vtab[2 * m + 1];
+        acc[0] += x.x; acc[1] += x.y; acc[2] += x.z; acc[3] += x.w;
+        acc[4] += y.x; acc[5] += y.y; acc[6] += y.z; acc[7] += y.w;
+    };
+    auto spill = [&]() {
+#pragma unroll
+        for (int w = 0; w < LCAP / 2; ++w) {
+            S32[2 * w] += Sp[w] & 0xffffu; S32[2 * w + 1] += Sp[w] >> 16; Sp[w] = 0;
+            D32[2 * w] += Dp[w] & 0xffffu; D32[2 * w + 1] += Dp[w] >> 16; Dp[w] = 0;
+        }
+    };
+    auto finalize = [&]() {   // compute_mhl, mhl.rs:43-73
+        spill();
+        float l_sum = 0.0f;
+        for (uint32_t l = 1; l < maxn + 1; ++l) l_sum = l_sum + (float)l;
+        float mhl = 0.0f;
+#pragma unroll
+        for (int l = 1; l <= LCAP; ++l)
+            if (S32[l - 1] > 0) { const float t = ((float)l * (float)S32[l - 1]) / (float)D32[l - 1]; mhl = mhl + t; }
+        return mhl / l_sum;
+    };
+    // Only the LAST segment that reaches min_depth is reported, and the lanes of a wave close their segments at different
+    // reads: evaluating compute_mhl at every close made the whole wave run its ~300 instructions a dozen times per 64
+    // sites.  A close now only keeps the segment's packed counters (16 registers); the f32 evaluation happens once, after
+    // the walk, with all lanes together.  (A segment deep enough to have spilled its 16-bit counters is evaluated on the spot.)
+    uint32_t qS[LCAP / 2], qD[LCAP / 2], q_maxn = 0;
+    bool pending = false;
+#pragma unroll
+    for (int w = 0; w < LCAP / 2; ++w) { qS[w] = 0; qD[w] = 0; }
+    auto close_segment = [&]() {
+        res_cov = seg_cov; have = true;
+        if (!SPILL || seg_cov < (uint32_t)MHL_SPILL) {
+#pragma unroll
+            for (int w = 0; w < LCAP / 2; ++w) { qS[w] = Sp[w]; qD[w] = Dp[w]; }
+            q_maxn = maxn; pending = true;
+        } else { res = finalize(); pending = false; }
+    };
+    auto finalize_packed = [&]() {   // compute_mhl (mhl.rs:43-73) on the kept counters: same operations, same order as finalize()
+        float l_sum = 0.0f;
+        for (uint32_t l = 1; l < q_maxn + 1; ++l) l_sum = l_sum + (float)l;
+        float mhl = 0.0f;
+#pragma unroll
+        for (int l = 1; l <= LCAP; ++l) {
+            const uint32_t S = (l & 1) ? (qS[(l - 1) >> 1] & 0xffffu) : (qS[(l - 1) >> 1] >> 16);
+            const uint32_t D = (l & 1) ? (qD[(l - 1) >> 1] & 0xffffu) : (qD[(l - 1) >> 1] >> 16);
+            if (S > 0) { const float t = ((float)l * (float)S) / (float)D; mhl = mhl + t; }
+        }
+        return mhl / l_sum;
+    };
+    // Software pipeline: a read's call offsets, mapq and FIRST FOUR CALLS (82 % of WGBS reads have no more) are requested
+    // one iteration ahead, so the flush test, the hit test and the run lengths of the common read work from registers --
+    // the walk is a chain of dependent look-ups otherwise (4 waves per SIMD, 62 % of their cycles waiting; PMC).  The four
+    // slots are read past the read's last call when it has fewer (clamped to the staged / batch range): every use checks t < n.
+    const uint32_t k_last = src.k_end - 1u;
+    uint32_t o_cur = 0, o_nxt = 0, mq_nxt = 0;
+    int32_t p4n[4] = {0, 0, 0, 0};
+    uint32_t m4n[4] = {0, 0, 0, 0};
+    if (lo < hi) {
+        o_cur = src.off(lo); o_nxt = src.off(lo + 1); mq_nxt = src.mq(lo);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const uint32_t kk = min(o_cur + (uint32_t)t, k_last); p4n[t] = src.pos(kk); m4n[t] = src.meth(kk); }
+    }
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t o0 = o_cur, n = o_nxt - o_cur, mq_i = mq_nxt;
+        int32_t p4[4];
+        uint32_t m4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { p4[t] = p4n[t]; m4[t] = m4n[t]; }
+        o_cur = o_nxt;
+        if (i + 1 < hi) {
+            o_nxt = src.off(i + 2); mq_nxt = src.mq(i + 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const uint32_t kk = min(o_cur + (uint32_t)t, k_last); p4n[t] = src.pos(kk); m4n[t] = src.meth(kk); }
+        }
+        if (n == 0) continue;                                          // no first CpG: neither flushes nor contributes
+        if (c < p4[0] && seg_cov > 0) {                                // mhl.rs:163-171 (strict '<', before the filters)
+            if (seg_cov >= a.min_depth) close_segment();
+            seg_cov = 0; maxn = 0;
+#pragma unroll
+            for (int w = 0; w < LCAP / 2; ++w) { Sp[w] = 0; Dp[w] = 0; }
+            if constexpr (SPILL) {
+#pragma unroll
+                for (int l = 0; l < LCAP; ++l) { S32[l] = 0; D32[l] = 0; }
+            }
+        }
+        if (mq_i < a.min_qual) continue;                               // mhl.rs:176
+        if (n < a.min_cpgs) continue;                                  // mhl.rs:181
+        bool hit = false, decided = false;                             // does the read call c ?
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool live = !decided && (uint32_t)t < n;
+            hit = hit || (live && p4[t] == c);
+            decided = decided || (live && p4[t] >= c);
+        }
+        if (!decided)
+            for (uint32_t k = o0 + 4; k < o0 + n; ++k) {
+                const int32_t p = src.pos(k);
+                if (p == c) { hit = true; break; }
+                if (p > c) break;
+            }
+        if (!hit) continue;
+        if (n > (uint32_t)LCAP) { overflow = true; continue; }         // deferred to the sequential variant / refused
+        seg_cov += 1;                                                   // add_num_cpgs, mhl.rs:75-80
+        if (seg_cov >= (1u << 20)) overflow = true;                     // D would leave the exact f32 range
+        maxn = max(maxn, n);
+        add_vec(Dp, n);
+        uint32_t cur = 0;                                               // get_stretch_info, readutil.rs:147-164
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if ((uint32_t)t < n) {
+                if (m4[t]) { cur += 1; }
+                else if (cur) { add_vec(Sp, cur); cur = 0; }
+            }
+        }
+        for (uint32_t k = o0 + 4; k < o0 + n; ++k) {
+            if (src.meth(k)) { cur += 1; }
+            else if (cur) { add_vec(Sp, cur); cur = 0; }
+        }
+        if (cur) add_vec(Sp, cur);
+        if constexpr (SPILL) { if ((seg_cov & (MHL_SPILL - 1)) == 0) spill(); }
+        else if (seg_cov >= (uint32_t)MHL_SPILL - 1u) overflow = true;   // the 16-bit counters are full: sequential variant
+    }
+    if (seg_cov > 0 && seg_cov >= a.min_depth) close_segment();       // mhl.rs:201-205
+    if (pending) res = finalize_packed();
+    if (overflow) { a.flags[j] = 2u; return; }
+    a.val[j] = res;
+    a.cov[j] = res_cov;
+    a.flags[j] = have ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
+    __shared__ uint16_t s_call[MW_CC];
+    __shared__ uint16_t s_ofs[MW_RC + 2];     // call offset of a staged read relative to the block's first call
+    __shared__ uint8_t s_mq[MW_RC];
+    __shared__ uint16_t s_st[MW_RC];          // read start relative to the block's base
+    __shared__ uint32_t s_wv[4][8];           // per wave: lo, hi, first / last site position, has sites, call offsets at lo / hi
+    __shared__ __attribute__((aligned(16))) uint32_t s_vtab[17 * 8];   // row m: max(0, m-l+1) for l = 1..16 as 16-bit pairs
+    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    const int tid = threadIdx.x;
+    if (tid < 17 * 8) {
+        const int m = tid >> 3, w = tid & 7;
+        s_vtab[tid] = (uint32_t)max(0, m - 2 * w) | ((uint32_t)max(0, m - 2 * w - 1) << 16);
+    }
+    for (uint32_t g0 = blockIdx.x * 256u; g0 < n_sites; g0 += gridDim.x * 256u) {
+        const uint32_t j = g0 + (uint32_t)tid;
+        const bool valid = j < n_sites;
+        int32_t c = 0;
+        uint32_t lo = 0, hi = 0;
+        if (valid) {
+            c = a.site_pos[j];
+            lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
+            hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        }
+        // Sites ascend, so do lo and hi: the candidates of a run of sites are [lo of its first site, hi of its last site).
+        // The group's 256 sites are staged together when their reads fit; denser or deeper stretches are staged as 2 or 4
+        // runs of whole waves, one after the other (a group that misses the staging walks global memory in
+        // k_mhl_walk_big -- a few such groups per batch used to be a third of this kernel's time).
+        const int wv = tid >> 6;
+        if ((tid & 63) == 0) {
+            s_wv[wv][0] = valid ? lo : 0u; s_wv[wv][2] = (uint32_t)c; s_wv[wv][4] = valid ? 1u : 0u;
+            s_wv[wv][5] = valid ? a.cpg_off[lo] : 0u;
+        }
+        if (valid && (j + 1 == n_sites || (tid & 63) == 63)) { s_wv[wv][1] = hi; s_wv[wv][3] = (uint32_t)c; s_wv[wv][6] = a.cpg_off[hi]; }
+        __syncthreads();
+        int nw = 0;                                     // waves of the group that hold sites (a prefix)
+        while (nw < 4 && s_wv[nw][4]) ++nw;
+        nw = __builtin_amdgcn_readfirstlane(nw);
+        int parts = 0;                                  // 1, 2 or 4 runs; 0: does not fit
+        for (int pz = 1; pz <= MW_MAX_PARTS && !parts; pz <<= 1) {
+            const int per = 4 / pz;
+            bool fits = true;
+            for (int q = 0; q * per < nw; ++q) {
+                const int w0 = q * per, w1 = min(w0 + per, nw) - 1;
+                const uint32_t rlo = s_wv[w0][0], rhi = s_wv[w1][1];
+                const long long sp = (long long)(int32_t)s_wv[w1][3] - (long long)(int32_t)s_wv[w0][2] + 2LL * a.max_span + 2LL * (IDX_Q + 1) + 1;
+                fits = fits && rhi - rlo <= (uint32_t)MW_RC && s_wv[w1][6] - s_wv[w0][5] <= (uint32_t)MW_CC && sp < 32768;
+            }
+            if (fits) parts = pz;
+        }
+        parts = __builtin_amdgcn_readfirstlane(parts);
+        if (!parts) {
+            if (valid) a.flags[j] = 4u;                 // deep data: k_mhl_walk_big walks these sites from global memory
+        } else {
+            const int per = 4 / parts;
+            for (int q = 0; q * per < nw; ++q) {
+                const int w0 = q * per, w1 = min(w0 + per, nw) - 1;
+                const uint32_t blo = __builtin_amdgcn_readfirstlane(s_wv[w0][0]), bhi = __builtin_amdgcn_readfirstlane(s_wv[w1][1]);
+                const int32_t c_first = (int32_t)__builtin_amdgcn_readfirstlane(s_wv[w0][2]);
+                // the index hands out whole 256-bp quanta: a staged read starts in [c_first - max_span - 255, c_last + 257]
+                // and calls positions in [start-1, start+max_span-1] (the tile pipeline that discovered the sites has
+                // checked that on every call)
+                const int32_t base = c_first - a.max_span - (IDX_Q + 1);
+                const uint32_t c0 = __builtin_amdgcn_readfirstlane(s_wv[w0][5]);
+                const uint32_t ncall = __builtin_amdgcn_readfirstlane(s_wv[w1][6]) - c0;
+                if (q) __syncthreads();                 // the previous run's walks are done with the buffers
+                for (uint32_t k = tid; k <= bhi - blo; k += 256) s_ofs[k] = (uint16_t)(a.cpg_off[blo + k] - c0);
+                for (uint32_t k = tid; k < bhi - blo; k += 256) {
+                    s_mq[k] = a.read_mapq[blo + k];
+                    s_st[k] = (uint16_t)((uint32_t)(a.read_start[blo + k] - base) & 0x7fffu);
+                }
+                for (uint32_t w = tid; w < ncall; w += 256) {
+                    const uint32_t x = a.cpg_pos[c0 + w];
+                    s_call[w] = (uint16_t)((((x & 0x7fffffffu) - (uint32_t)base) & 0x7fffu) | ((x >> 31) << 15));
+                }
+                __syncthreads();
+                if (valid && wv >= w0 && wv <= w1) {
+                    // The index hands out whole 256-bp quanta (~110 candidates); only reads starting in
+                    // [c - max_span + 1, c + 1] matter (~35): an earlier read cannot call c and comes before every
+                    // contributor (its flush finds nothing open), and the first later read can only flush what the
+                    // end-of-range flush below finalises identically.  Two binary searches over the staged starts.
+                    const uint32_t s_lo = (uint32_t)(c - a.max_span + 1 - base), s_hi = (uint32_t)(c + 1 - base);
+                    uint32_t x0 = lo - blo, x1 = hi - blo;
+                    while (x0 < x1) { const uint32_t m = (x0 + x1) >> 1; if (s_st[m] < s_lo) x0 = m + 1; else x1 = m; }
+                    const uint32_t e_lo = x0;
+                    x1 = hi - blo;
+                    while (x0 < x1) { const uint32_t m = (x0 + x1) >> 1; if (s_st[m] <= s_hi) x0 = m + 1; else x1 = m; }
+                    mhl_walk_site<MhlLdsSrc, false>(a, MhlLdsSrc{s_ofs, s_call, s_mq, blo, base, max(ncall, 1u)},
+                                                    reinterpret_cast<const uint4 *>(s_vtab), j, c, blo + e_lo, blo + x0);
+                }
+            }
+        }
+        __syncthreads();   // the LDS buffers and s_wv are rewritten by the next group
+    }
+}
+
+// What k_mhl_walk_lds left: (flags == 4) the sites of groups whose candidate reads did not fit the LDS staging -- deep data --
+// take the same per-site walk straight from global memory, with the 32-bit spill accumulators (exact at any depth); (flags == 2)
+// a covering read with more than 16 CpGs, or a segment too deep for the 16-bit counters / for the f32 denominators to stay
+// exact integers: the sequential variant, one thread per site, dynamically indexed arrays (scratch) -- rare sites only.
 template <int LCAP>
 __global__ __launch_bounds__(256) void k_mhl_walk_big(const WalkArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_vtab[17 * 8];   // as in k_mhl_walk_lds
+    if (threadIdx.x < 17 * 8) {
+        const int m = threadIdx.x >> 3, w = threadIdx.x & 7;
+        s_vtab[threadIdx.x] = (uint32_t)max(0, m - 2 * w) | ((uint32_t)max(0, m - 2 * w - 1) << 16);
+    }
+    __syncthreads();
     const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
     for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n_sites; j += gridDim.x * 256) {
-        if (!(a.flags[j] & 2u)) continue;                  // only what the fast kernel deferred
+        if (!(a.flags[j] & 6u)) continue;                  // only what the fast kernel deferred
         const int32_t c = a.site_pos[j];
         const uint32_t lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
         const uint32_t hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        if (a.flags[j] & 4u) {
+            mhl_walk_site<MhlGlobalSrc, true>(a, MhlGlobalSrc{a.cpg_off, a.cpg_pos, a.read_mapq, max(a.cpg_off[hi], 1u)},
+                                              reinterpret_cast<const uint4 *>(s_vtab), j, c, lo, hi);
+            if (!(a.flags[j] & 2u)) continue;              // done unless that walk deferred the site in turn
+        }
         uint32_t S[LCAP];      // S[l-1] = sum over covering reads of count_l   (mhl.rs:36-41)
         float D[LCAP];         // D[l-1] = sum over covering reads with n_r >= l of (n_r-l+1) as f32   (mhl.rs:53-58)
         for (int l = 0; l < LCAP; ++l) { S[l] = 0; D[l] = 0.0f; }
@@ -104,240 +398,6 @@ __global__ __launch_bounds__(256) void k_mhl_walk_big(const WalkArgs a) {
         a.val[j] = res;
         a.cov[j] = res_cov;
         a.flags[j] = have ? 1u : 0u;
-    }
-}
-
-// The fast variant again, with the gathers taken out.  One thread per site is efficient in VALU terms (every
-// lane busy) but each candidate costs ~5 dependent gathers from three arrays, while neighbouring sites share
-// almost all their candidates.  A block takes 256 consecutive sites and stages ALL its candidate reads in LDS with
-// coalesced loads -- 16-bit call offsets, mapq, and the calls as 16-bit words (15-bit position relative to the
-// block, state in bit 15) -- then every thread walks its own range [lo, hi) out of LDS.  A block whose candidates
-// do not fit (too many reads or calls, or positions spread over >= 2^15 bp) runs the same walk on global memory.
-constexpr int MW_RC = 3072;    // reads staged per block
-constexpr int MW_CC = 10240;   // call words staged per block
-
-struct MhlGlobalSrc {
-    const uint32_t *cpg_off, *cpg_pos;
-    const uint8_t *mapq;
-    __device__ __forceinline__ uint32_t off(uint32_t i) const { return cpg_off[i]; }
-    __device__ __forceinline__ uint32_t mq(uint32_t i) const { return mapq[i]; }
-    __device__ __forceinline__ int32_t pos(uint32_t k) const { return (int32_t)(cpg_pos[k] & 0x7fffffffu); }
-    __device__ __forceinline__ uint32_t meth(uint32_t k) const { return cpg_pos[k] >> 31; }
-};
-struct MhlLdsSrc {
-    const uint16_t *ofs, *call;
-    const uint8_t *mapq;
-    uint32_t r0;
-    int32_t base;
-    __device__ __forceinline__ uint32_t off(uint32_t i) const { return ofs[i - r0]; }
-    __device__ __forceinline__ uint32_t mq(uint32_t i) const { return mapq[i - r0]; }
-    __device__ __forceinline__ int32_t pos(uint32_t k) const { return base + (int32_t)(call[k] & 0x7fffu); }
-    __device__ __forceinline__ uint32_t meth(uint32_t k) const { return call[k] >> 15; }
-};
-
-// The per-site walk (file order over the site's candidate reads [lo, hi)), read lengths up to LCAP = 16 CpGs.
-// Both accumulations are "add the vector v_m[l] = max(0, m-l+1), l = 1..16": S (mhl.rs:36-41) once per maximal
-// methylated run of length m (the run contributes m-l+1 windows of length l), D (mhl.rs:53-58) once per covering
-// read with m = n_r.  Unrolled over 16 register slots that is 32-80 VALU per event, and under SIMT the whole wave
-// pays for every event of any lane.  Here v_m comes from a 17-row LDS table packed as 16-bit pairs: two 16-byte
-// LDS reads + 8 packed adds per event.  The packed sums spill into 32-bit accumulators every 2048 covering reads
-// (a field grows by at most 16 per read), so the counts are exact at any depth; D is the reference's f32 running
-// sum of integers, exact (and order-free) below 2^24 -- deeper sites go to the sequential variant.
-constexpr int MHL_SPILL = 2048;
-template <typename Src>
-__device__ __forceinline__ void mhl_walk_site(const WalkArgs &a, const Src &src, const uint4 *__restrict__ vtab,
-                                              const uint32_t j, const int32_t c, const uint32_t lo, const uint32_t hi) {
-    constexpr int LCAP = 16;
-    uint32_t Sp[LCAP / 2], Dp[LCAP / 2];     // packed pairs: low half l = 2w+1, high half l = 2w+2
-    uint32_t S32[LCAP], D32[LCAP];
-#pragma unroll
-    for (int w = 0; w < LCAP / 2; ++w) { Sp[w] = 0; Dp[w] = 0; }
-#pragma unroll
-    for (int l = 0; l < LCAP; ++l) { S32[l] = 0; D32[l] = 0; }
-    uint32_t seg_cov = 0, maxn = 0, res_cov = 0;
-    float res = 0.0f;
-    bool have = false, overflow = false;
-    auto add_vec = [&](uint32_t (&acc)[LCAP / 2], const uint32_t m) {
-        const uint4 x = vtab[2 * m], y = vtab[2 * m + 1];
-        acc[0] += x.x; acc[1] += x.y; acc[2] += x.z; acc[3] += x.w;
-        acc[4] += y.x; acc[5] += y.y; acc[6] += y.z; acc[7] += y.w;
-    };
-    auto spill = [&]() {
-#pragma unroll
-        for (int w = 0; w < LCAP / 2; ++w) {
-            S32[2 * w] += Sp[w] & 0xffffu; S32[2 * w + 1] += Sp[w] >> 16; Sp[w] = 0;
-            D32[2 * w] += Dp[w] & 0xffffu; D32[2 * w + 1] += Dp[w] >> 16; Dp[w] = 0;
-        }
-    };
-    auto finalize = [&]() {   // compute_mhl, mhl.rs:43-73
-        spill();
-        float l_sum = 0.0f;
-        for (uint32_t l = 1; l < maxn + 1; ++l) l_sum = l_sum + (float)l;
-        float mhl = 0.0f;
-#pragma unroll
-        for (int l = 1; l <= LCAP; ++l)
-            if (S32[l - 1] > 0) { const float t = ((float)l * (float)S32[l - 1]) / (float)D32[l - 1]; mhl = mhl + t; }
-        return mhl / l_sum;
-    };
-    // Only the LAST segment that reaches min_depth is reported, and the lanes of a wave close their segments at different
-    // reads: evaluating compute_mhl at every close made the whole wave run its ~300 instructions a dozen times per 64
-    // sites.  A close now only keeps the segment's packed counters (16 registers); the f32 evaluation happens once, after
-    // the walk, with all lanes together.  (A segment deep enough to have spilled its 16-bit counters is evaluated on the spot.)
-    uint32_t qS[LCAP / 2], qD[LCAP / 2], q_maxn = 0;
-    bool pending = false;
-#pragma unroll
-    for (int w = 0; w < LCAP / 2; ++w) { qS[w] = 0; qD[w] = 0; }
-    auto close_segment = [&]() {
-        res_cov = seg_cov; have = true;
-        if (seg_cov < (uint32_t)MHL_SPILL) {
-#pragma unroll
-            for (int w = 0; w < LCAP / 2; ++w) { qS[w] = Sp[w]; qD[w] = Dp[w]; }
-            q_maxn = maxn; pending = true;
-        } else { res = finalize(); pending = false; }
-    };
-    auto finalize_packed = [&]() {   // compute_mhl (mhl.rs:43-73) on the kept counters: same operations, same order as finalize()
-        float l_sum = 0.0f;
-        for (uint32_t l = 1; l < q_maxn + 1; ++l) l_sum = l_sum + (float)l;
-        float mhl = 0.0f;
-#pragma unroll
-        for (int l = 1; l <= LCAP; ++l) {
-            const uint32_t S = (l & 1) ? (qS[(l - 1) >> 1] & 0xffffu) : (qS[(l - 1) >> 1] >> 16);
-            const uint32_t D = (l & 1) ? (qD[(l - 1) >> 1] & 0xffffu) : (qD[(l - 1) >> 1] >> 16);
-            if (S > 0) { const float t = ((float)l * (float)S) / (float)D; mhl = mhl + t; }
-        }
-        return mhl / l_sum;
-    };
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t o0 = src.off(i), n = src.off(i + 1) - o0;
-        if (n == 0) continue;                                          // no first CpG: neither flushes nor contributes
-        // The read's first four calls are requested together (82 % of WGBS reads have no more): the flush test, the hit test
-        // and the run lengths then work from registers instead of one dependent LDS round trip per call.
-        int32_t p4[4];
-        uint32_t m4[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t kk = o0 + min((uint32_t)t, n - 1);
-            p4[t] = src.pos(kk); m4[t] = src.meth(kk);
-        }
-        if (c < p4[0] && seg_cov > 0) {                                // mhl.rs:163-171 (strict '<', before the filters)
-            if (seg_cov >= a.min_depth) close_segment();
-            seg_cov = 0; maxn = 0;
-#pragma unroll
-            for (int w = 0; w < LCAP / 2; ++w) { Sp[w] = 0; Dp[w] = 0; }
-#pragma unroll
-            for (int l = 0; l < LCAP; ++l) { S32[l] = 0; D32[l] = 0; }
-        }
-        if (src.mq(i) < a.min_qual) continue;                          // mhl.rs:176
-        if (n < a.min_cpgs) continue;                                  // mhl.rs:181
-        bool hit = false, decided = false;                             // does the read call c ?
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bool live = !decided && (uint32_t)t < n;
-            hit = hit || (live && p4[t] == c);
-            decided = decided || (live && p4[t] >= c);
-        }
-        if (!decided)
-            for (uint32_t k = o0 + 4; k < o0 + n; ++k) {
-                const int32_t p = src.pos(k);
-                if (p == c) { hit = true; break; }
-                if (p > c) break;
-            }
-        if (!hit) continue;
-        if (n > (uint32_t)LCAP) { overflow = true; continue; }         // deferred to the sequential variant / refused
-        seg_cov += 1;                                                   // add_num_cpgs, mhl.rs:75-80
-        if (seg_cov >= (1u << 20)) overflow = true;                     // D would leave the exact f32 range
-        maxn = max(maxn, n);
-        add_vec(Dp, n);
-        uint32_t cur = 0;                                               // get_stretch_info, readutil.rs:147-164
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if ((uint32_t)t < n) {
-                if (m4[t]) { cur += 1; }
-                else if (cur) { add_vec(Sp, cur); cur = 0; }
-            }
-        }
-        for (uint32_t k = o0 + 4; k < o0 + n; ++k) {
-            if (src.meth(k)) { cur += 1; }
-            else if (cur) { add_vec(Sp, cur); cur = 0; }
-        }
-        if (cur) add_vec(Sp, cur);
-        if ((seg_cov & (MHL_SPILL - 1)) == 0) spill();
-    }
-    if (seg_cov > 0 && seg_cov >= a.min_depth) close_segment();       // mhl.rs:201-205
-    if (pending) res = finalize_packed();
-    if (overflow) { a.flags[j] = 2u; return; }
-    a.val[j] = res;
-    a.cov[j] = res_cov;
-    a.flags[j] = have ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
-    __shared__ uint16_t s_call[MW_CC];
-    __shared__ uint16_t s_ofs[MW_RC + 2];     // call offset of a staged read relative to the block's first call
-    __shared__ uint8_t s_mq[MW_RC];
-    __shared__ uint16_t s_st[MW_RC];          // read start relative to the block's base
-    __shared__ uint32_t s_rng[4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_vtab[17 * 8];   // row m: max(0, m-l+1) for l = 1..16 as 16-bit pairs
-    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
-    const int tid = threadIdx.x;
-    if (tid < 17 * 8) {
-        const int m = tid >> 3, w = tid & 7;
-        s_vtab[tid] = (uint32_t)max(0, m - 2 * w) | ((uint32_t)max(0, m - 2 * w - 1) << 16);
-    }
-    for (uint32_t g0 = blockIdx.x * 256u; g0 < n_sites; g0 += gridDim.x * 256u) {
-        const uint32_t j = g0 + (uint32_t)tid;
-        const bool valid = j < n_sites;
-        int32_t c = 0;
-        uint32_t lo = 0, hi = 0;
-        if (valid) {
-            c = a.site_pos[j];
-            lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
-            hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
-        }
-        // sites ascend, so do lo and hi: the block's candidates are [lo of its first site, hi of its last site)
-        if (tid == 0) { s_rng[0] = lo; s_rng[2] = (uint32_t)c; }
-        if (valid && (j + 1 == n_sites || tid == 255)) { s_rng[1] = hi; s_rng[3] = (uint32_t)c; }
-        __syncthreads();
-        const uint32_t blo = __builtin_amdgcn_readfirstlane(s_rng[0]), bhi = __builtin_amdgcn_readfirstlane(s_rng[1]);
-        const int32_t c_first = (int32_t)__builtin_amdgcn_readfirstlane(s_rng[2]);
-        const int32_t c_last = (int32_t)__builtin_amdgcn_readfirstlane(s_rng[3]);
-        // the index hands out whole 256-bp quanta: a staged read starts in [c_first - max_span - 255, c_last + 257]
-        // and calls positions in [start-1, start+max_span-1] (the tile pipeline that discovered the sites has
-        // checked that on every call)
-        const int32_t base = c_first - a.max_span - (IDX_Q + 1);
-        const long long span = (long long)c_last + a.max_span + (IDX_Q + 1) - base + 1;
-        const uint32_t c0 = blo < bhi ? __builtin_amdgcn_readfirstlane(a.cpg_off[blo]) : 0u;
-        const uint32_t ncall = blo < bhi ? __builtin_amdgcn_readfirstlane(a.cpg_off[bhi]) - c0 : 0u;
-        const bool staged = bhi - blo <= (uint32_t)MW_RC && ncall <= (uint32_t)MW_CC && span < 32768;
-        if (staged) {
-            for (uint32_t k = tid; k <= bhi - blo; k += 256) s_ofs[k] = (uint16_t)(a.cpg_off[blo + k] - c0);
-            for (uint32_t k = tid; k < bhi - blo; k += 256) {
-                s_mq[k] = a.read_mapq[blo + k];
-                s_st[k] = (uint16_t)((uint32_t)(a.read_start[blo + k] - base) & 0x7fffu);
-            }
-            for (uint32_t w = tid; w < ncall; w += 256) {
-                const uint32_t x = a.cpg_pos[c0 + w];
-                s_call[w] = (uint16_t)((((x & 0x7fffffffu) - (uint32_t)base) & 0x7fffu) | ((x >> 31) << 15));
-            }
-            __syncthreads();
-            if (valid) {
-                // The index hands out whole 256-bp quanta (~110 candidates); only reads starting in
-                // [c - max_span + 1, c + 1] matter (~35): an earlier read cannot call c and comes before every
-                // contributor (its flush finds nothing open), and the first later read can only flush what the
-                // end-of-range flush below finalises identically.  Two binary searches over the staged starts.
-                const uint32_t s_lo = (uint32_t)(c - a.max_span + 1 - base), s_hi = (uint32_t)(c + 1 - base);
-                uint32_t x0 = lo - blo, x1 = hi - blo;
-                while (x0 < x1) { const uint32_t m = (x0 + x1) >> 1; if (s_st[m] < s_lo) x0 = m + 1; else x1 = m; }
-                const uint32_t e_lo = x0;
-                x1 = hi - blo;
-                while (x0 < x1) { const uint32_t m = (x0 + x1) >> 1; if (s_st[m] <= s_hi) x0 = m + 1; else x1 = m; }
-                mhl_walk_site(a, MhlLdsSrc{s_ofs, s_call, s_mq, blo, base}, reinterpret_cast<const uint4 *>(s_vtab), j, c,
-                              blo + e_lo, blo + x0);
-            }
-        } else if (valid) {
-            mhl_walk_site(a, MhlGlobalSrc{a.cpg_off, a.cpg_pos, a.read_mapq}, reinterpret_cast<const uint4 *>(s_vtab), j, c, lo, hi);
-        }
-        __syncthreads();   // the LDS buffers and s_rng are rewritten by the next group
     }
 }
 
