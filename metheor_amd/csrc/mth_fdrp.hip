@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
     // per wave: window position (p - (c - FD_WIN)) -> index of that CpG in the wave's 64-site window
     __shared__ uint8_t s_bit[4][2 * FD_WIN + 1 + 13];
     uint8_t *const bit_of = s_bit[threadIdx.x >> 6];
+    __shared__ float s_terms[4][64];           // per wave: a round's non-zero qFDRP terms, packed
+    float *const s_term = s_terms[threadIdx.x >> 6];
     // per wave: the stored reads of the open segment, one row per slot: {cpg_off, n_calls, start, end, FD_NB packed calls}
     constexpr int ROW = 4 + FD_NB;
     __shared__ __attribute__((aligned(16))) uint32_t s_rows[4][SLOTS * ROW];
@@ -192,15 +194,27 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                     const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) +
                                          __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));                      // fdrp.rs:114-115
                     disc += (pair_ok && ham != 0u) ? 1u : 0u;                // fdrp.rs:138-140
-                    const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;   // qfdrp.rs:152; +0.0 for skipped pairs
+                    const float term0 = pair_ok ? (float)ham / (float)ncpg : 0.0f;  // qfdrp.rs:152; +0.0 for skipped pairs
+                    // x + 0.0 == x, so only the non-zero terms (NaN included: 0 / 0 when two reads share no CpG) have to be
+                    // chained, in their order: they are packed into the low lanes through LDS first.  (The chain is one dependent
+                    // VALU per term and was ~30 % of a VALU-bound kernel; most pairs of a site agree and contribute +0.0.)
+                    const unsigned long long nz = __ballot(term0 != 0.0f);
+                    const int m_nz = __popcll(nz);
+                    if (m_nz == 0) continue;                                 // wave-uniform
+                    if (term0 != 0.0f) s_term[__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u))] = term0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const float term = lane < m_nz ? s_term[lane] : 0.0f;
                     float x = (lane == 0) ? q + term : term;
-                    const int steps = min(64, P - k0) - 1;
-                    const int up8 = (steps + 7) & ~7;                        // lanes past the last pair hold +0.0: sliding is exact
+                    const int steps = m_nz - 1;
+                    const int up8 = (steps + 7) & ~7;                        // lanes past the last term hold +0.0: sliding is exact
                     const bool slide = up8 <= 56;
                     const int blocks = slide ? up8 >> 3 : 7;
                     for (int b8 = 0; b8 < blocks; ++b8) { MTH_FD_DPP8 }
                     if (!slide) { MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP MTH_FD_DPP }
                     q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), slide ? up8 : 63));
+                    __builtin_amdgcn_wave_barrier();                         // s_term is rewritten by the next round
                 }
             }
             for (int i = 0; !compact && i + 1 < nS; ++i) {
