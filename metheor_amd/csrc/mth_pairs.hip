@@ -54,6 +54,7 @@ struct PairArgs {
 constexpr int PT_S = 2048, PT_B = 256, PT_U = 4, PT_CHUNK = 1024, PT_GRID = 8192;   // tile kernel: LDS slots, threads, reads per thread and round (the tile
                                                    // width is a template parameter: 8192 / 16384 / 32768, chosen per batch)
 constexpr int P_STATE_WORDS = 8;
+constexpr int PT_NC = 8;                                 // calls of a read parked in LDS for the pair loops
 
 // COUNT: only count the updates (table sizing); otherwise insert them
 template <typename RelT, bool COUNT>
@@ -174,6 +175,8 @@ __global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
     __shared__ unsigned long long tab64[PT_S];
     __shared__ uint32_t s_heavy, ws[PT_B / 64 + 1];
     __shared__ uint32_t bcnt[PT_B], bbase[PT_B];        // bucket sort: words per bucket, first rank of the bucket
+    __shared__ uint32_t s_cw[PT_NC][PT_B];              // per thread (column): the first calls of the read it is working on
+    __shared__ uint16_t s_cr[PT_NC][PT_B];
     __shared__ unsigned long long s_row0;
     uint32_t *tab = reinterpret_cast<uint32_t *>(tab64);
     const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
@@ -224,14 +227,26 @@ __global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
             const uint32_t sm1 = (uint32_t)st[u] - 1u;
             bad |= ((fs[u] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
             bad |= ((ls[u] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+            // The pair loops below are a chain of dependent look-ups (PMC: 77 % of the wave cycles waiting, VALU 25 % busy).
+            // The read's first PT_NC calls -- all of them for most reads -- are fetched together and parked in the thread's own
+            // LDS column (call word and relative position), so the loops wait on LDS instead of on global memory.
+            const uint32_t n_calls = o1 - o0;
+#pragma unroll
+            for (int t = 0; t < PT_NC; ++t) {
+                const uint32_t kk = o0 + min((uint32_t)t, n_calls - 1);
+                s_cw[t][tid] = a.cpg_pos[kk];
+                s_cr[t][tid] = (uint16_t)rel[kk];
+            }
+            auto call_w = [&](uint32_t k) { return k - o0 < (uint32_t)PT_NC ? s_cw[k - o0][tid] : a.cpg_pos[k]; };
+            auto call_r = [&](uint32_t k) { return (int32_t)(k - o0 < (uint32_t)PT_NC ? (uint32_t)s_cr[k - o0][tid] : (uint32_t)rel[k]); };
             for (uint32_t k = o0 + 1; k < o1; ++k) {
-                const int32_t rk = (int32_t)rel[k];
-                const uint32_t wk = a.cpg_pos[k];
+                const int32_t rk = call_r(k);
+                const uint32_t wk = call_w(k);
                 for (uint32_t j = k; j-- > o0;) {
-                    const int32_t dist = rk - (int32_t)rel[j];
+                    const int32_t dist = rk - call_r(j);
                     if (dist > a.max_dist) break;                              // readutil.rs:184
                     if (dist < a.min_dist) continue;                           // readutil.rs:196
-                    const uint32_t wj = a.cpg_pos[j];
+                    const uint32_t wj = call_w(j);
                     const int32_t p1 = (int32_t)(wj & 0x7fffffffu);
                     if (p1 < T0 || p1 >= T1) continue;                         // owned by the tile of pos1
                     const uint32_t delta = (wk & 0x7fffffffu) - (uint32_t)p1;
