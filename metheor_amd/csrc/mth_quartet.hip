@@ -253,7 +253,7 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
         // QT_U reads per thread and round, their fields and first calls requested before any of them is used: the chain
         // idx -> offsets -> calls is paid once per round, not once per read (sparse WGBS: a tile's time is this latency)
         for (uint32_t b0 = lo; b0 < hi; b0 += QT_B * QT_U) {
-            uint32_t o0s[QT_U], o1s[QT_U], xs[QT_U], ys[QT_U], zs[QT_U], ls[QT_U];
+            uint32_t o0s[QT_U], o1s[QT_U], xs[QT_U], ys[QT_U], zs[QT_U], ws4[QT_U], ls[QT_U];
             int32_t st[QT_U];
             bool ok[QT_U];
 #pragma unroll
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
 #pragma unroll
             for (int u = 0; u < QT_U; ++u) {
                 ok[u] = ok[u] && o1s[u] - o0s[u] >= 4;                      // readutil.rs:101, me.rs:115
-                if (ok[u]) { xs[u] = a.cpg_pos[o0s[u]]; ys[u] = a.cpg_pos[o0s[u] + 1]; zs[u] = a.cpg_pos[o0s[u] + 2]; ls[u] = a.cpg_pos[o1s[u] - 1]; }
+                if (ok[u]) { xs[u] = a.cpg_pos[o0s[u]]; ys[u] = a.cpg_pos[o0s[u] + 1]; zs[u] = a.cpg_pos[o0s[u] + 2]; ws4[u] = a.cpg_pos[o0s[u] + 3]; ls[u] = a.cpg_pos[o1s[u] - 1]; }
             }
 #pragma unroll
             for (int u = 0; u < QT_U; ++u) {
@@ -279,8 +279,10 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
                 const uint32_t sm1 = (uint32_t)st[u] - 1u;
                 bad |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
                 bad |= ((ls[u] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+                uint32_t w_next = ws4[u];                                       // the window's last call is requested one window ahead
                 for (uint32_t k = o0 + 3; k < o1; ++k) {                        // readutil.rs:105-129
-                    const uint32_t w = a.cpg_pos[k];
+                    const uint32_t w = w_next;
+                    w_next = a.cpg_pos[min(k + 1, o1 - 1)];
                     const int32_t p1 = (int32_t)(x & 0x7fffffffu);
                     if (p1 >= T0 && p1 < T1) {
                         const uint32_t d2 = (y & 0x7fffffffu) - (x & 0x7fffffffu), d3 = (z & 0x7fffffffu) - (y & 0x7fffffffu),
