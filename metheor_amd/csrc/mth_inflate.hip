@@ -29,10 +29,6 @@ struct InflArgs {
     uint32_t *err;
 };
 
-__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // one Huffman code: lens[0..n) -> direct table (entry = sym << 4 | len, 0 = not a short code) + canonical arrays
@@ -210,11 +206,18 @@ __global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
             if (sym == 256) break;
             if (sym > 285) { bad = true; break; }
             const int li = sym - 257;
-            const uint32_t len = c_len_base[li] + b.take(c_len_extra[li]);
+            // base and extra bits of a length / distance symbol by arithmetic (RFC 1951 3.2.5: from the 9th symbol on, four -- two
+            // for distances -- symbols per extra-bit count): the tables lived in constant memory and cost two dependent global
+            // loads per match each
+            const uint32_t lx = (li < 8 || li == 28) ? 0u : (uint32_t)(li >> 2) - 1u;
+            const uint32_t lbase = li < 8 ? (uint32_t)li + 3u : (li == 28 ? 258u : ((4u + ((uint32_t)li & 3u)) << lx) + 3u);
+            const uint32_t len = lbase + b.take((int)lx);
             b.refill();
             const int ds = huff_decode(HD, b);
             if (ds < 0 || ds > 29) { bad = true; break; }
-            const uint32_t dist = c_dist_base[ds] + b.take(c_dist_extra[ds]);
+            const uint32_t dx = ds < 4 ? 0u : (uint32_t)(ds >> 1) - 1u;
+            const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u;
+            const uint32_t dist = dbase + b.take((int)dx);
             if (dist > pos || pos + len > isize) { bad = true; break; }
             // the bytes written so far must be visible to the loads below (same wave, but loads and stores return
             // out of order with respect to each other)
