@@ -51,7 +51,8 @@ enum {
     MTH_ERR_CAPACITY = -8,  /* an on-chip capacity was exceeded */
     MTH_ERR_STATE = -9,     /* call order violated */
     MTH_ERR_FORMAT = -10,   /* device decode: corrupt BGZF block, malformed BAM record, or a record without XM:Z */
-    MTH_ERR_UNALIGNED = -11 /* mth_bgzf_decode: a record straddles two BGZF blocks (decode via the host walk instead) */
+    MTH_ERR_UNALIGNED = -11,/* mth_bgzf_decode: a record straddles two BGZF blocks (decode via the host walk instead) */
+    MTH_ERR_RCCL = -12      /* librccl could not be loaded, or an RCCL call failed (mth_last_error has the text) */
 };
 
 enum { MTH_MEM_HOST = 0, MTH_MEM_DEVICE = 1 };
@@ -136,6 +137,25 @@ int  mth_lpmd_export_device(mth_ctx_t *ctx, int64_t *dst_device4);
 /* compute_lpmd() (lpmd.rs:51-55, wrapping-i32 semantics) from summed integer counters, e.g. the
  * all-reduced ones */
 float mth_lpmd_from_counts(int64_t n_concordant, int64_t n_discordant);
+
+/* ---- multi-GPU: the path's one exchange step ------------------------------------------------
+ * A sharded run gives every GPU a genomic region; per-site / per-quartet / per-pair rows are owned by region and
+ * never exchanged.  Only LPMDResult's four counters (lpmd.rs:11-12: n_concordant, n_discordant, n_read,
+ * n_valid_read, accumulated per read at lpmd.rs:176-200 and divided at lpmd.rs:51-55) are genome-wide: they are
+ * summed with ONE RCCL all-reduce (ncclInt64 x 4, ncclSum) over xGMI, enqueued on each context's stream and done in
+ * place, so that afterwards mth_lpmd_global() of EVERY context returns the node-wide LPMDResult.  Call it once,
+ * after the last mth_pdr_lpmd_accumulate (a second call without new batches is MTH_ERR_STATE: it would add the
+ * totals again).  librccl.so.1 is loaded on first use; a single-GPU run never touches it. */
+int  mth_device_count(int *n_devices);
+/* one process, one context per GPU: collective over ctxs[0..n) called from ONE host thread.  Contexts that share a
+ * device are summed on that device and RCCL runs between the distinct devices. */
+int  mth_allreduce_lpmd(mth_ctx_t **ctxs, int n);
+/* one process per GPU: rank 0 makes the id, the host ships its 128 bytes to every rank (MPI_Bcast,
+ * torch.distributed.broadcast, a file), every rank joins, every rank calls the reduce. */
+#define MTH_RCCL_ID_BYTES 128
+int  mth_rccl_unique_id(void *id128);
+int  mth_rccl_init_rank(mth_ctx_t *ctx, const void *id128, int rank, int world);
+int  mth_allreduce_lpmd_rank(mth_ctx_t *ctx);
 
 /* ---- LPMD per-pair table (`lpmd --pairs`; lpmd.rs:70-122) -------------------------------------
  * Separate pass over the same batches (the global counters above do not need it). */

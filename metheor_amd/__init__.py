@@ -5,6 +5,6 @@ host around it.  This Python package is only the thin ctypes binding that tests 
 through; it never computes anything itself and has NO CPU fallback: if the HIP library is missing
 or no gfx950 device is present, it raises.
 """
-from .capi import (Batch, Engine, MthError, PdrLpmdParams, lib, library_path)  # noqa: F401
+from .capi import (Batch, Engine, MthError, PdrLpmdParams, allreduce_lpmd, device_count, lib, library_path)  # noqa: F401
 
-__all__ = ["Batch", "Engine", "MthError", "PdrLpmdParams", "lib", "library_path"]
+__all__ = ["Batch", "Engine", "MthError", "PdrLpmdParams", "allreduce_lpmd", "device_count", "lib", "library_path"]

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmetheor_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip", "mth_quartet.hip", "mth_scan.hip", "mth_sites.hip", "mth_fdrp.hip", "mth_pairs.hip", "mth_decode.hip", "mth_inflate.hip"]
+HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip", "mth_quartet.hip", "mth_scan.hip", "mth_sites.hip", "mth_fdrp.hip", "mth_pairs.hip", "mth_decode.hip", "mth_inflate.hip", "mth_rccl.hip"]
 HOST_LIB = os.path.join(HERE, "libmetheor_host.so")
 HOST_SOURCES = [os.path.join("host", "bam_reader.cpp"), os.path.join("host", "host_api.cpp"),
                 os.path.join("host", "parallel_decode.cpp"), os.path.join("host", "synth_bam.cpp")]
@@ -90,7 +90,7 @@ def _build_libs(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

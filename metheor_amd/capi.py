@@ -14,7 +14,8 @@ SYMBOLS = [
     "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
-    "mth_lpmd_export_device", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
+    "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
+    "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
     "mth_decode_records", "mth_decode_set_cpg_filter", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
@@ -104,6 +105,11 @@ def lib():
         L.mth_lpmd_from_counts.restype = C.c_float
         L.mth_lpmd_from_counts.argtypes = [C.c_int64, C.c_int64]
         L.mth_lpmd_export_device.argtypes = [vp, vp]
+        L.mth_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.mth_allreduce_lpmd.argtypes = [C.POINTER(vp), C.c_int]
+        L.mth_rccl_unique_id.argtypes = [vp]
+        L.mth_rccl_init_rank.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.mth_allreduce_lpmd_rank.argtypes = [vp]
         L.mth_quartet_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_quartet_params_t)]
         L.mth_quartet_fetch.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)] + [vp] * 5
         L.mth_mhl_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_mhl_params_t)]
@@ -262,6 +268,26 @@ class Engine:
         """dst_ptr: device address of 4 x int64 (e.g. torch_tensor.data_ptr())"""
         self._check(self.L.mth_lpmd_export_device(self.h, C.c_void_p(dst_ptr)))
 
+    # ---- the exchange step (mth_rccl.hip): one RCCL all-reduce of the four LPMD counters ----
+    @staticmethod
+    def rccl_unique_id():
+        """128 bytes made by rank 0; ship them to every rank (torch.distributed.broadcast, MPI, a file)"""
+        buf = (C.c_uint8 * 128)()
+        rc = lib().mth_rccl_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise MthError(rc, lib().mth_strerror(rc).decode())
+        return bytes(buf)
+
+    def rccl_init_rank(self, unique_id, rank, world):
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.L.mth_rccl_init_rank(self.h, C.cast(buf, C.c_void_p), int(rank), int(world)))
+
+    def allreduce_lpmd_rank(self):
+        """collective over the ranks of rccl_init_rank, enqueued on this context's stream; afterwards lpmd_global()
+        returns the node-wide counters"""
+        self._check(self.L.mth_allreduce_lpmd_rank(self.h))
+
     def lpmd_from_counts(self, n_conc, n_disc):
         return np.float32(self.L.mth_lpmd_from_counts(int(n_conc), int(n_disc)))
 
@@ -407,3 +433,18 @@ class Engine:
             self._check(self.L.mth_timing_get(self.h, name, C.byref(ms), C.byref(n)))
             out[name.decode()] = (ms.value, n.value)
         return out
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().mth_device_count(C.byref(n))
+    return n.value
+
+
+def allreduce_lpmd(engines):
+    """one process, one Engine per GPU (or several per GPU): one RCCL all-reduce of the four LPMD counters between the
+    distinct devices; afterwards every engine's lpmd_global() returns the totals"""
+    arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    rc = lib().mth_allreduce_lpmd(arr, len(engines))
+    if rc != 0:
+        engines[0]._check(rc)

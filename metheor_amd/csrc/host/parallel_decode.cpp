@@ -94,8 +94,12 @@ class Pool {
     std::vector<std::thread> th_;
 };
 
-bool find_xm(const uint8_t *aux, uint32_t len, const char *&xm, uint32_t &xm_len) {
-    uint32_t o = 0;
+// 0 = found, 1 = malformed aux block, 2 = no XM:Z.  Offsets are 64-bit: a crafted B-array count must not wrap the
+// cursor back into the block (htslib's skip_aux rejects such a record; so do we).  Either failure is the SAME
+// failure in the reference: Record::aux(b"XM") returns Err for a bad block as for a missing tag, and
+// readutil.rs:46-48 panics with the XM text -- decode_record reports both as "no XM".
+int find_xm(const uint8_t *aux, uint32_t len, const char *&xm, uint32_t &xm_len) {
+    uint64_t o = 0;
     while (o + 3 <= len) {
         const uint8_t t0 = aux[o], t1 = aux[o + 1], ty = aux[o + 2];
         o += 3;
@@ -104,25 +108,33 @@ bool find_xm(const uint8_t *aux, uint32_t len, const char *&xm, uint32_t &xm_len
             case 's': case 'S': o += 2; break;
             case 'i': case 'I': case 'f': o += 4; break;
             case 'Z': case 'H': {
-                const uint32_t b = o;
+                const uint64_t b = o;
                 while (o < len && aux[o] != 0) ++o;
-                if (o >= len) return false;
-                if (ty == 'Z' && t0 == 'X' && t1 == 'M') { xm = reinterpret_cast<const char *>(aux + b); xm_len = o - b; return true; }
+                if (o >= len) return 1;
+                if (ty == 'Z' && t0 == 'X' && t1 == 'M') { xm = reinterpret_cast<const char *>(aux + b); xm_len = (uint32_t)(o - b); return 0; }
                 o += 1;
                 break;
             }
             case 'B': {
-                if (o + 5 > len) return false;
+                if (o + 5 > len) return 1;
                 const uint8_t sub = aux[o];
-                const uint32_t cnt = read_u32(aux + o + 1);
-                const uint32_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                const uint64_t cnt = read_u32(aux + o + 1);
+                uint64_t w;
+                switch (sub) {
+                    case 'c': case 'C': w = 1; break;
+                    case 's': case 'S': w = 2; break;
+                    case 'i': case 'I': case 'f': w = 4; break;
+                    default: return 1;
+                }
                 o += 5 + cnt * w;
+                if (o > len) return 1;
                 break;
             }
-            default: return false;
+            default: return 1;
         }
+        if (o > len) return 1;
     }
-    return false;
+    return 2;   // fewer than 3 bytes left: htslib's bam_aux_get ends its search the same way (ENOENT)
 }
 
 // one record (p points at the 32-byte fixed part, len = block_size) -> appended to the piece
@@ -137,7 +149,7 @@ int decode_record(const uint8_t *p, uint32_t len, const std::unordered_set<uint6
     if (o_aux > len) return 1;
     const char *xm = nullptr;
     uint32_t xm_len = 0;
-    if (!find_xm(p + o_aux, (uint32_t)(len - o_aux), xm, xm_len)) return 2;
+    if (find_xm(p + o_aux, (uint32_t)(len - o_aux), xm, xm_len) != 0) return 2;
     const bool forward = flag == 0 || flag == 99 || flag == 147;   // readutil.rs:332
     int32_t first = -1, last = -1;
     int64_t r = pos;

@@ -137,6 +137,7 @@ const char *mth_strerror(int s) {
         case MTH_ERR_STATE: return "call order violated";
         case MTH_ERR_FORMAT: return "malformed BAM record or record without XM:Z";
         case MTH_ERR_UNALIGNED: return "BAM records straddle BGZF blocks";
+        case MTH_ERR_RCCL: return "RCCL unavailable or an RCCL call failed";
         default: return "unknown status";
     }
 }
@@ -173,6 +174,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    rccl_release(ctx);
     for (DevBuf *b : {&ctx->st_start, &ctx->st_end, &ctx->st_mapq, &ctx->st_fwd, &ctx->st_off, &ctx->st_pos,
                       &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_bucket, &ctx->scratch, &ctx->dec_raw, &ctx->dec_recoff, &ctx->dec_tid, &ctx->dec_start, &ctx->dec_end,
                       &ctx->dec_mapq, &ctx->dec_fwd, &ctx->dec_n, &ctx->dec_off, &ctx->dec_pos, &ctx->dec_rel, &ctx->dec_blk, &ctx->dec_off32, &ctx->dec_runs, &ctx->dec_xm, &ctx->dec_filter,
@@ -212,6 +214,7 @@ int mth_reset(mth_ctx_t *ctx) {
     MTH_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream));
     ctx->batches.clear();
     ctx->out_bound = 0;
+    ctx->lpmd_reduced = false;
     if (ctx->q_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->q_state.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     ctx->q_meta.clear();
     ctx->q_rows = 0;
@@ -236,6 +239,7 @@ int mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_
     // never re-open a flushed site, and the stream result equals plain per-site counting (the fused
     // tile kernel).  Longer spans take the exact site walk (mth_sites.hip) for the PDR half.
     const bool pdr_exact = params->want_pdr && b.max_span > PDR_FLUSH_MARGIN;
+    if (params->want_lpmd) ctx->lpmd_reduced = false;
     mth_batch_t d;
     {
         const int rcs = stage_batch(ctx, b, d);

@@ -92,6 +92,12 @@ struct mth_ctx {
     double p_rows_per_cpg = 0.1;           // output sizing of the next batch
     std::vector<TileBatch> p_meta;
 
+    // multi-GPU exchange step (mth_rccl.hip): communicator of the one-process-per-GPU form; lpmd_reduced = DevState.lpmd
+    // already holds the all-reduced totals (cleared by the next batch that adds to them)
+    void *rccl_comm = nullptr;
+    int rccl_rank = 0, rccl_world = 1;
+    bool lpmd_reduced = false;
+
     bool timing = false;
     std::vector<mth::TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
@@ -115,6 +121,7 @@ struct LaunchTimer {
     ~LaunchTimer();
 };
 
+void rccl_release(mth_ctx *ctx);    // mth_rccl.hip: destroy the context's communicator, if any
 int sync_and_check(mth_ctx *ctx);   // stream sync + read DevState + map error bits
 // validate a caller batch and make it device-resident (MTH_MEM_HOST arrays go through the staging buffers)
 int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &dev);

@@ -67,9 +67,18 @@ __device__ __forceinline__ bool dev_find_xm(const uint8_t *aux, uint32_t len, co
             case 'B': {
                 if (o + 5 > len) return false;
                 const uint8_t sub = aux[o];
-                const uint32_t cnt = ld_u32(aux + o + 1);
-                const uint32_t w = (sub == 'c' || sub == 'C') ? 1u : (sub == 's' || sub == 'S') ? 2u : 4u;
-                o += 5 + cnt * w;
+                const uint64_t cnt = ld_u32(aux + o + 1);
+                uint64_t w;
+                switch (sub) {
+                    case 'c': case 'C': w = 1; break;
+                    case 's': case 'S': w = 2; break;
+                    case 'i': case 'I': case 'f': w = 4; break;
+                    default: return false;
+                }
+                // 64-bit: a crafted count must not wrap the cursor back into the block (the thread would never leave)
+                const uint64_t nx = (uint64_t)o + 5u + cnt * w;
+                if (nx > len) return false;
+                o = (uint32_t)nx;
                 break;
             }
             default: return false;

@@ -173,3 +173,25 @@ def test_random_aux_fields(eng, tmp_path, seed):
     refs, body, offs = record_stream(p)
     eng.decode_records(body, offs)
     same_soa(eng.decoded_fetch(), pyoracle.Reads.decode(rec).soa())
+
+
+@pytest.mark.timeout(120)
+def test_crafted_aux_is_rejected_not_looped(eng, golden_dir, tmp_path):
+    """a B-array count that wraps a 32-bit cursor back onto its own tag must end the record's scan (MTH_ERR_FORMAT), not spin
+    the decode kernel; same for counts running past the record and an unknown sub-type (htslib rejects them: the reference
+    panics with the XM text, readutil.rs:46-48)"""
+    from metheor_amd import MthError
+    from tests.test_host_decode import crafted_aux_cases
+    for case, blob in sorted(crafted_aux_cases().items()):
+        rec = bamio.read_bam(os.path.join(golden_dir, "test1.bam"))
+        rec.aux_extra = [(b"NMC\x00", b"XRZCT\0")] * len(rec)
+        rec.aux_extra[2] = (blob, b"")
+        p = str(tmp_path / ("crafted_%s.bam" % case))
+        bamio.write_bam(p, rec)
+        refs, body, offs = record_stream(p)
+        with pytest.raises(MthError) as e:
+            eng.decode_records(body, offs)
+        assert e.value.status == -10, case
+        eng.reset()
+    refs, body, offs = record_stream(os.path.join(golden_dir, "test1.bam"))
+    assert eng.decode_records(body, offs)[0] == len(offs) - 1      # the context is usable again

@@ -254,3 +254,31 @@ def test_random_aux_fields(tmp_path, seed):
     want = pyoracle.Reads.decode(rec).soa()
     same_soa(hostapi.BamFile(p).decode(), want)
     same_soa(pyoracle.Reads.decode(bamio.read_bam(p)).soa(), want)      # (the oracle's own loader steps over them too)
+
+
+def crafted_aux_cases():
+    """aux blocks a hostile file can carry in front of XM:Z: a B-array count whose byte length wraps a 32-bit
+    cursor back onto the same tag (5 + 0x3FFFFFFE*4 == -3 mod 2^32: a scanner doing the sum in 32 bits never leaves the
+    record), counts that merely run past the record, and an unknown B sub-type.  htslib's skip_aux rejects all of them, so
+    Record::aux(b"XM") is Err and the reference panics with the XM text (readutil.rs:46-48)."""
+    import struct
+    return {
+        "wrap_to_same_tag": b"XXBi" + struct.pack("<I", 0x3FFFFFFE),
+        "wrap_short": b"XXBs" + struct.pack("<I", 0x7FFFFFFE) + b"\0" * 6,
+        "past_the_end": b"YYBC" + struct.pack("<I", 5000),
+        "huge_float_array": b"YYBf" + struct.pack("<I", 0xFFFFFFFF),
+        "unknown_subtype": b"YYBq" + struct.pack("<I", 1) + b"\0\0\0\0",
+    }
+
+
+@pytest.mark.timeout(60)
+@pytest.mark.parametrize("case", sorted(crafted_aux_cases()))
+def test_crafted_aux_is_rejected_not_looped(golden_dir, tmp_path, case):
+    rec = bamio.read_bam(os.path.join(golden_dir, "test1.bam"))
+    rec.aux_extra = [(b"NMC\x00", b"XRZCT\0")] * len(rec)
+    rec.aux_extra[2] = (crafted_aux_cases()[case], b"")
+    p = str(tmp_path / "crafted.bam")
+    bamio.write_bam(p, rec)
+    with pytest.raises(hostapi.HostError) as e:
+        hostapi.BamFile(p).decode()
+    assert "Error reading XM tag in BAM record" in str(e.value)
