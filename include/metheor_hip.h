@@ -142,8 +142,8 @@ float mth_lpmd_from_counts(int64_t n_concordant, int64_t n_discordant);
  * A sharded run gives every GPU a genomic region; per-site / per-quartet / per-pair rows are owned by region and
  * never exchanged.  Only LPMDResult's four counters (lpmd.rs:11-12: n_concordant, n_discordant, n_read,
  * n_valid_read, accumulated per read at lpmd.rs:176-200 and divided at lpmd.rs:51-55) are genome-wide: they are
- * summed with ONE RCCL all-reduce (ncclInt64 x 4, ncclSum) over xGMI, enqueued on each context's stream and done in
- * place, so that afterwards mth_lpmd_global() of EVERY context returns the node-wide LPMDResult.  Call it once,
+ * summed with ONE RCCL all-reduce (ncclInt64 x 4, ncclSum) over xGMI, ordered after the work already enqueued on each
+ * context's stream; afterwards mth_lpmd_global() of EVERY context returns the node-wide LPMDResult.  Call it once,
  * after the last mth_pdr_lpmd_accumulate (a second call without new batches is MTH_ERR_STATE: it would add the
  * totals again).  librccl.so.1 is loaded on first use; a single-GPU run never touches it. */
 int  mth_device_count(int *n_devices);
@@ -155,6 +155,8 @@ int  mth_allreduce_lpmd(mth_ctx_t **ctxs, int n);
 #define MTH_RCCL_ID_BYTES 128
 int  mth_rccl_unique_id(void *id128);
 int  mth_rccl_init_rank(mth_ctx_t *ctx, const void *id128, int rank, int world);
+/* asynchronous: the counters are snapshotted on the context's stream and reduced on a side stream (the context's
+ * stream does not wait for the collective; mth_lpmd_global does) */
 int  mth_allreduce_lpmd_rank(mth_ctx_t *ctx);
 
 /* ---- LPMD per-pair table (`lpmd --pairs`; lpmd.rs:70-122) -------------------------------------

@@ -106,6 +106,11 @@ int  mth_host_write_synthetic_bam(const char *path, const char *contig, int64_t 
                                   int32_t read_len, const int32_t *start, const uint8_t *fwd, const uint8_t *mapq,
                                   const uint64_t *cpg_off, const uint16_t *cpg_rel, const uint32_t *cpg_pos,
                                   uint64_t seed, int nthreads);
+/* the same over several contigs: tid[i] = contig of read i (reads grouped by contig, coordinate-sorted inside) */
+int  mth_host_write_synthetic_bam_multi(const char *path, int32_t n_contigs, const char *const *contigs, const int64_t *contig_lens,
+                                        int64_t n_reads, int32_t read_len, const int32_t *tid, const int32_t *start,
+                                        const uint8_t *fwd, const uint8_t *mapq, const uint64_t *cpg_off,
+                                        const uint16_t *cpg_rel, const uint32_t *cpg_pos, uint64_t seed, int nthreads);
 
 /* Rust `{}` of an f32 (shortest round-trip digits, positional, "NaN"/"inf"); buf >= 64 bytes */
 int  mth_host_format_f32(float v, char *buf);

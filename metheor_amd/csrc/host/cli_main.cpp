@@ -8,7 +8,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -41,6 +44,8 @@ struct Cmd {
 
 const Opt O_IN = {"input", 'i', "INPUT", "Input BAM file", nullptr, true, 's'};
 const Opt O_CPG = {"cpg-set", 'c', "CPG_SET", "(Optional) Specify a predefined set of CpGs (in BED file) to be analyzed", nullptr, false, 's'};
+// not in the reference (outer row): one run split over the GPUs of the node by genomic region
+const Opt O_GPUS = {"gpus", 'G', "GPUS", "(MI355X extension) Number of GPUs to split the run over, by genomic region", "1", false, 'U'};
 
 // lib.rs:24-231
 const std::vector<Cmd> &commands() {
@@ -49,41 +54,41 @@ const std::vector<Cmd> &commands() {
          {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of PDR calculation", nullptr, true, 's'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG stretches to consider", "10", false, 'U'},
           {"min-cpgs", 'p', "MIN_CPGS", "Minimum number of consecutive CpGs in a CpG stretch to consider", "4", false, 'Z'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
         {"pm", "Compute epipolymorphism",
          {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of PM calculation", nullptr, true, 's'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG quartets to consider", "10", false, 'U'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
         {"me", "Compute methylation entropy",
          {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of PDR calculation", nullptr, true, 's'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG quartets to consider", "10", false, 'U'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
         {"fdrp", "Compute fraction of discordant read pairs (FDRP)",
          {{"input", 'i', "INPUT", "Path to input BAM file", nullptr, true, 's'},
           {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of FDRP calculation", nullptr, true, 's'},
           {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum number of reads mapped to a CpG in order to be considered", "10", false, 'Z'},
           {"max-depth", 'D', "MAX_DEPTH", "Maximum number of reads to consider", "40", false, 'Z'},
-          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG}},
+          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG, O_GPUS}},
         {"qfdrp", "Compute quantitative fraction of discordant read pairs (qFDRP)",
          {{"input", 'i', "INPUT", "Path to input BAM file", nullptr, true, 's'},
           {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of FDRP calculation", nullptr, true, 's'},
           {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum number of reads mapped to a CpG in order to be considered", "10", false, 'Z'},
           {"max-depth", 'D', "MAX_DEPTH", "Maximum number of reads to consider", "40", false, 'Z'},
-          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG}},
+          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG, O_GPUS}},
         {"mhl", "Compute methylation haplotype load (MHL)",
          {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of MHL calculation", nullptr, true, 's'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG stretches to consider", "10", false, 'U'},
           {"min-cpgs", 'p', "MIN_CPGS", "Minimum number of consecutive CpGs in a CpG stretch to consider", "4", false, 'Z'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
         {"lpmd", "Compute local pairwise methylation discordance (LPMD)",
          {{"input", 'i', "INPUT", "Path to input BAM file", nullptr, true, 's'},
           {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of LPMD calculation", nullptr, true, 's'},
           {"pairs", 'p', "PAIRS", "(Optional) Concordance information for all CpG pairs", nullptr, false, 's'},
           {"min-distance", 'm', "MIN_DISTANCE", "Minimum distance between CpG pairs to consider", "2", false, 'I'},
           {"max-distance", 'M', "MAX_DISTANCE", "Maximum distance between CpG pairs to consider", "16", false, 'I'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
         {"tag", "Add bismark XM tag to BAM file",
          {{"input", 'i', "INPUT", "", nullptr, true, 's'}, {"output", 'o', "OUTPUT", "", nullptr, true, 's'},
           {"genome", 'g', "GENOME", "", nullptr, true, 's'}}},
@@ -120,8 +125,11 @@ void print_cmd_help(FILE *f, const Cmd &c) {
 }
 
 // the reference panics on run-time failures: message on stderr, exit status 101
+// (with --gpus N the failing shard's thread ends the process: _exit, the other shards' threads are mid-run)
+std::atomic<bool> g_threads{false};
 [[noreturn]] void die(const std::string &msg) {
     fprintf(stderr, "%s\n", msg.c_str());
+    if (g_threads.load()) { fflush(nullptr); _exit(101); }
     exit(101);
 }
 
@@ -204,22 +212,27 @@ Args parse_args(const Cmd &c, int argc, char **argv, int first) {
 // A contig's reads are a contiguous slice of the decoded SoA (the file is coordinate-sorted), so the
 // batch points straight into the decoder's arrays; only the CSR offsets are rebased (4 B/read).  A
 // contig that contains a read without any aligned base (start = -1) is copied without those reads.
-// METHEOR_SHARD=r/N: this process is shard r of N of ONE run (one process per GPU): it loads its own run of BGZF blocks
-// (mth_host_plan_shard: no index, no router), owns a (tid, pos) interval and writes <output>.shard-r-of-N; the parts
-// concatenated in shard order are the unsharded file (tools/run_sharded.py launches the shards and merges them, summing the
-// four LPMD counters).  METHEOR_SHARD_HALO: bp of reads loaded before the interval (default 65536; must cover the
-// longest alignment + FDRP's 201-bp window, checked).
-struct Shard { int rank = 0, world = 1; int64_t halo = 65536; mth_host_shard_t plan; };
-Shard g_shard;
+// --gpus N: the run is N shards, one host thread and one device context each (shard r on device r mod the devices
+// present, or mod METHEOR_DEVICES).  Every shard loads its own run of BGZF blocks (mth_host_plan_shard: no index, no
+// router), owns a (tid, pos) interval and formats its rows into memory; the parts concatenated in shard order are the
+// unsharded file.  The only exchange is the RCCL all-reduce of the four LPMD counters (mth_allreduce_lpmd).
+// METHEOR_SHARD_HALO: bp of reads loaded before the interval (default 65536; must cover the longest alignment + FDRP's
+// 201-bp window, checked).
+struct Shard { int rank = 0, world = 1, device = 0; int64_t halo = 65536; mth_host_shard_t plan; };
+thread_local Shard g_shard;
 
-void parse_shard_env() {
-    if (const char *e = getenv("METHEOR_SHARD")) {
-        int r = -1, n = 0;
-        if (sscanf(e, "%d/%d", &r, &n) != 2 || n < 1 || r < 0 || r >= n) die(std::string("bad METHEOR_SHARD (want r/N): ") + e);
-        g_shard.rank = r; g_shard.world = n;
-    }
-    if (const char *e = getenv("METHEOR_SHARD_HALO")) { const long long k = atoll(e); if (k >= 0) g_shard.halo = k; }
-}
+// what one shard contributes to the output files (filled through open_memstream when world > 1)
+struct Part { char *out = nullptr; size_t out_len = 0; char *pairs = nullptr; size_t pairs_len = 0; };
+thread_local Part *g_part = nullptr;
+
+// the shards' threads meet here once: the last to arrive runs the collective for all of them
+struct Gang {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<mth_ctx_t *> ctxs;
+    int arrived = 0, rc = MTH_OK;
+    bool done = false;
+} g_gang;
 
 struct Contig {
     int32_t tid;
@@ -262,6 +275,7 @@ struct Phase {
 // runtime cost tens of milliseconds that nobody reads the result of: the process leaves through _exit and the driver
 // reclaims everything (METHEOR_TEARDOWN=1 keeps the orderly release, e.g. under a leak checker).
 int finish(mth_ctx_t *ctx, mth_host_t *h) {
+    if (g_shard.world > 1) return 0;      // a shard's thread: main() writes the files and leaves
     if (getenv("METHEOR_TEARDOWN")) {
         Phase ph("teardown");
         mth_ctx_destroy(ctx);
@@ -286,10 +300,10 @@ struct CtxFuture {
     mth_ctx_t *ctx = nullptr;
     int rc = MTH_OK;
     void start() {
-        th = std::thread([this] {
+        const int device = g_shard.device;
+        th = std::thread([this, device] {
             Phase ph("device context (overlapped)");
-            const char *dev = getenv("METHEOR_DEVICE");
-            rc = mth_ctx_create(dev ? atoi(dev) : 0, &ctx);
+            rc = mth_ctx_create(device, &ctx);
         });
     }
     void wait() { if (th.joinable()) th.join(); }
@@ -303,8 +317,7 @@ struct CtxFuture {
 mth_ctx_t *make_ctx() {
     Phase ph("device context");
     mth_ctx_t *ctx = nullptr;
-    const char *dev = getenv("METHEOR_DEVICE");
-    const int rc = mth_ctx_create(dev ? atoi(dev) : 0, &ctx);
+    const int rc = mth_ctx_create(g_shard.device, &ctx);
     if (rc != MTH_OK) die(std::string("metheor (MI355X path): ") + mth_strerror(rc));
     return ctx;
 }
@@ -380,7 +393,7 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
     in.ctx = cf.get();
     if (cpg_set) check(in.ctx, mth_decode_set_cpg_filter(in.ctx, keys, n_keys, 1));
     const bool on_device = !getenv("METHEOR_HOST_INFLATE") && load_bgzf_on_device(in);
-    if (!on_device && g_shard.world > 1) die("METHEOR_SHARD needs the device load path (a coordinate-sorted BAM whose records do not straddle BGZF blocks)");
+    if (!on_device && g_shard.world > 1) die("--gpus N needs the device load path (a coordinate-sorted BAM whose records do not straddle BGZF blocks)");
     if (!on_device) {
         StreamState st;
         st.ctx = in.ctx;
@@ -429,13 +442,13 @@ Input load(const std::string &path, const char *cpg_set) {
     Input in;
     char err[1024];
     const bool try_device = !getenv("METHEOR_HOST_DECODE");
-    if (!try_device && g_shard.world > 1) die("METHEOR_SHARD needs the device load path (METHEOR_HOST_DECODE is set)");
+    if (!try_device && g_shard.world > 1) die("--gpus N needs the device load path (METHEOR_HOST_DECODE is set)");
     CtxFuture cf;
     if (try_device) cf.start();
     if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) { cf.wait(); die(err); }    // bamutil.rs:7-9
     if (try_device) {
         if (load_on_device(in, cpg_set, cf)) return in;
-        if (g_shard.world > 1) die("METHEOR_SHARD needs the device load path (coordinate-sorted input, contigs grouped, records inside BGZF blocks)");
+        if (g_shard.world > 1) die("--gpus N needs the device load path (coordinate-sorted input, contigs grouped, records inside BGZF blocks)");
         in.contigs.clear();
     }
     {
@@ -540,7 +553,7 @@ template <class Row>
 void write_rows(FILE *f, uint64_t n, Row &&row) {
     int nt = (int)std::thread::hardware_concurrency();
     if (const char *e = getenv("METHEOR_THREADS")) { const int k = atoi(e); if (k >= 1 && k <= 1024) nt = k; }
-    nt = std::max(1, std::min(nt, 32));
+    nt = std::max(1, std::min(nt / g_shard.world, 32));      // the shards of a --gpus N run format side by side
     if (n < 50000) nt = 1;
     std::vector<LineWriter> parts;
     parts.reserve((size_t)nt);
@@ -556,13 +569,39 @@ void write_rows(FILE *f, uint64_t n, Row &&row) {
     for (auto &w : parts) { w.f = f; w.flush(); }
 }
 
-FILE *open_output(const std::string &path0) {
-    const std::string path = g_shard.world > 1 ? path0 + ".shard-" + std::to_string(g_shard.rank) + "-of-" + std::to_string(g_shard.world) : path0;
+FILE *open_file(const std::string &path) {
     FILE *f = fopen(path.c_str(), "wb");   // create + truncate (pdr.rs:95-101)
     if (!f) die("called `Result::unwrap()` on an `Err` value: cannot open output file " + path + ": " + strerror(errno));
+    return f;
+}
+
+// one shard of several: its rows are collected in memory (main() concatenates the parts in shard order)
+FILE *open_output(const std::string &path, bool pairs = false) {
+    if (g_shard.world > 1) {
+        FILE *f = pairs ? open_memstream(&g_part->pairs, &g_part->pairs_len) : open_memstream(&g_part->out, &g_part->out_len);
+        if (!f) die("cannot allocate an output part");
+        return f;
+    }
+    FILE *f = open_file(path);
     static char buf[1 << 20];
     setvbuf(f, buf, _IOFBF, sizeof buf);
     return f;
+}
+
+// LPMDResult's counters are genome-wide: the shards meet, the last one to arrive runs the RCCL all-reduce for all
+// of them (mth_allreduce_lpmd; lpmd.rs:11-12, 51-55), and every context then holds the totals
+void gang_allreduce_lpmd(mth_ctx_t *ctx) {
+    std::unique_lock<std::mutex> lk(g_gang.mu);
+    g_gang.ctxs.resize((size_t)g_shard.world);
+    g_gang.ctxs[(size_t)g_shard.rank] = ctx;
+    if (++g_gang.arrived == g_shard.world) {
+        g_gang.rc = mth_allreduce_lpmd(g_gang.ctxs.data(), g_shard.world);
+        g_gang.done = true;
+        g_gang.cv.notify_all();
+    } else {
+        g_gang.cv.wait(lk, [] { return g_gang.done; });
+    }
+    if (g_gang.rc != MTH_OK) check(g_gang.ctxs[0], g_gang.rc);
 }
 
 int run_pdr(const Args &a) {
@@ -610,6 +649,7 @@ int run_lpmd(const Args &a) {
     p.lpmd_min_distance = mind; p.lpmd_max_distance = maxd;
     p.want_lpmd = 1;
     submit(ctx, in, p);
+    if (g_shard.world > 1) gang_allreduce_lpmd(ctx);             // every shard now holds the genome-wide counters
     int64_t g[4] = {0, 0, 0, 0};
     float lp = 0.f;
     check(ctx, mth_lpmd_global(ctx, g, &lp));
@@ -617,10 +657,7 @@ int run_lpmd(const Args &a) {
     FILE *f = open_output(a.s.at("output"));
     char fb[64];
     mth_host_format_f32(lp, fb);
-    if (g_shard.world > 1)        // a part: the four counters of the reads this shard owns (the merge sums them and applies lpmd.rs:145-147)
-        fprintf(f, "#lpmd_counts\t%s\t%lld\t%lld\t%lld\t%lld\n", input.c_str(), (long long)g[0], (long long)g[1], (long long)g[2], (long long)g[3]);
-    else
-        fprintf(f, "name\tlpmd\n%s\t%s\n", input.c_str(), fb);   // lpmd.rs:145-147
+    if (g_shard.rank == 0) fprintf(f, "name\tlpmd\n%s\t%s\n", input.c_str(), fb);   // lpmd.rs:145-147
     if (fclose(f) != 0) die("Error writing to output file.");
     if (a.has("pairs")) {                                       // lpmd.rs:149-151, 89-122
         mth_lpmd_pairs_params_t pp;
@@ -635,7 +672,7 @@ int run_lpmd(const Args &a) {
         std::vector<float> v(n);
         std::vector<uint32_t> nc(n), nd(n);
         check(ctx, mth_lpmd_pairs_fetch(ctx, &n, tid.data(), p1.data(), p2.data(), v.data(), nc.data(), nd.data()));
-        FILE *g = open_output(a.s.at("pairs"));
+        FILE *g = open_output(a.s.at("pairs"), true);
         if (g_shard.rank == 0) fprintf(g, "chrom\tcpg1\tcpg2\tlpmd\tn_concordant\tn_discordant\n");
         fflush(g);
         write_rows(g, n, [&](LineWriter &w, uint64_t i) {
@@ -750,20 +787,60 @@ int main(int argc, char **argv) {
         usage_error(nullptr, "unrecognized subcommand '" + sub + "'");
     }
     const Args a = parse_args(*cmd, argc, argv, 2);
-    parse_shard_env();
-    if (sub == "pdr") return run_pdr(a);
-    if (sub == "lpmd") return run_lpmd(a);
-    if (sub == "mhl") return run_mhl(a);
-    if (sub == "fdrp") return run_fdrp(a, false);
-    if (sub == "qfdrp") return run_fdrp(a, true);
-    if (sub == "me") return run_quartet(a, true);
-    if (sub == "pm") return run_quartet(a, false);
-    // the reference opens the BAM first; keep its open errors visible before refusing
-    if (sub != "tag") {
+    auto run = [&]() -> int {
+        if (sub == "pdr") return run_pdr(a);
+        if (sub == "lpmd") return run_lpmd(a);
+        if (sub == "mhl") return run_mhl(a);
+        if (sub == "fdrp") return run_fdrp(a, false);
+        if (sub == "qfdrp") return run_fdrp(a, true);
+        if (sub == "me") return run_quartet(a, true);
+        if (sub == "pm") return run_quartet(a, false);
+        return -1;
+    };
+    if (sub == "tag") {
+        die("metheor (MI355X path): subcommand '" + sub + "' has no device kernel yet; there is no CPU fallback");
+    }
+    int64_t halo = 65536;
+    if (const char *e = getenv("METHEOR_SHARD_HALO")) { const long long k = atoll(e); if (k >= 0) halo = k; }
+    const int world = (int)std::min<int64_t>(a.n.at("gpus"), 4096);
+    if (world < 1) usage_error(cmd, "invalid value '0' for '--gpus <GPUS>': at least one GPU");
+    if (world == 1) {
+        if (const char *dev = getenv("METHEOR_DEVICE")) g_shard.device = atoi(dev);
+        g_shard.halo = halo;
+        return run();
+    }
+    // --gpus N: shard r runs on its own thread with its own context on device r mod the devices in use
+    int ndev = 0;
+    mth_device_count(&ndev);
+    if (const char *e = getenv("METHEOR_DEVICES")) { const int k = atoi(e); if (k >= 1 && k < ndev) ndev = k; }
+    if (ndev < 1) die(std::string("metheor (MI355X path): ") + mth_strerror(MTH_ERR_NO_DEVICE));
+    {   // the reference opens the BAM before anything else: report an unreadable input once, not once per shard
         mth_host_t *h = nullptr;
         char err[1024];
         if (mth_host_open(a.s.at("input").c_str(), &h, err, sizeof err) != 0) die(err);
         mth_host_close(h);
     }
-    die("metheor (MI355X path): subcommand '" + sub + "' has no device kernel yet; there is no CPU fallback");
+    std::vector<Part> parts((size_t)world);
+    std::vector<std::thread> th;
+    g_threads.store(true);
+    for (int r = 0; r < world; ++r)
+        th.emplace_back([&, r] {
+            g_shard.rank = r; g_shard.world = world; g_shard.device = r % ndev; g_shard.halo = halo;
+            g_part = &parts[(size_t)r];
+            run();
+        });
+    for (auto &t : th) t.join();
+    auto write_parts = [&](const std::string &path, bool pairs) {
+        FILE *f = open_file(path);
+        for (const Part &p : parts) {
+            const char *b = pairs ? p.pairs : p.out;
+            const size_t n = pairs ? p.pairs_len : p.out_len;
+            if (n && fwrite(b, 1, n, f) != n) die("Error writing to output file.");
+        }
+        if (fclose(f) != 0) die("Error writing to output file.");
+    };
+    write_parts(a.s.at("output"), false);
+    if (sub == "lpmd" && a.has("pairs")) write_parts(a.s.at("pairs"), true);
+    fflush(nullptr);
+    _exit(0);
 }

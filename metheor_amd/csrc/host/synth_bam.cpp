@@ -1,5 +1,5 @@
 // synth_bam.cpp -- fast writer of a synthetic Bismark-style BAM from the decoded SoA (bench / test
-// tooling: the SURVEY's "seeded synthetic Bismark BAM generator").  One contig, `read_len`M reads,
+// tooling: the SURVEY's "seeded synthetic Bismark BAM generator").  `read_len`M reads on one or several contigs,
 // XM:Z strings with z/Z at the call offsets, random sequence and quality bytes so that the file
 // compresses like a real BAM.  Records are built and deflated (BGZF, zlib level 6) in parallel.
 // Block layout as htslib writes it (bgzf_flush_try before every record): a block holds whole records, at most
@@ -47,21 +47,24 @@ inline uint64_t rng_next(uint64_t &s) { s += 0x9e3779b97f4a7c15ULL; uint64_t z =
 
 }  // namespace
 
-extern "C" int mth_host_write_synthetic_bam(const char *path, const char *contig, int64_t contig_len, int64_t n_reads,
-                                            int32_t read_len, const int32_t *start, const uint8_t *fwd, const uint8_t *mapq,
-                                            const uint64_t *cpg_off, const uint16_t *cpg_rel, const uint32_t *cpg_pos,
-                                            uint64_t seed, int nthreads) {
-    if (!path || !contig || n_reads < 0 || read_len <= 0) return MTH_HOST_ERR_INVALID;
+extern "C" int mth_host_write_synthetic_bam_multi(const char *path, int32_t n_contigs, const char *const *contigs, const int64_t *contig_lens,
+                                                  int64_t n_reads, int32_t read_len, const int32_t *tid, const int32_t *start,
+                                                  const uint8_t *fwd, const uint8_t *mapq, const uint64_t *cpg_off,
+                                                  const uint16_t *cpg_rel, const uint32_t *cpg_pos, uint64_t seed, int nthreads) {
+    if (!path || !contigs || !contig_lens || n_contigs < 1 || n_reads < 0 || read_len <= 0) return MTH_HOST_ERR_INVALID;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
     if (nthreads <= 0) nthreads = 1;
     if (nthreads > 128) nthreads = 128;
     std::vector<uint8_t> head;
-    const std::string text = std::string("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:") + contig + "\tLN:" + std::to_string(contig_len) + "\n";
+    std::string text = "@HD\tVN:1.0\tSO:coordinate\n";
+    for (int32_t c = 0; c < n_contigs; ++c) text += std::string("@SQ\tSN:") + contigs[c] + "\tLN:" + std::to_string(contig_lens[c]) + "\n";
     head.insert(head.end(), {'B', 'A', 'M', 1});
     put32(head, (uint32_t)text.size()); head.insert(head.end(), text.begin(), text.end());
-    put32(head, 1);
-    put32(head, (uint32_t)strlen(contig) + 1); head.insert(head.end(), contig, contig + strlen(contig) + 1);
-    put32(head, (uint32_t)contig_len);
+    put32(head, (uint32_t)n_contigs);
+    for (int32_t c = 0; c < n_contigs; ++c) {
+        put32(head, (uint32_t)strlen(contigs[c]) + 1); head.insert(head.end(), contigs[c], contigs[c] + strlen(contigs[c]) + 1);
+        put32(head, (uint32_t)contig_lens[c]);
+    }
     std::vector<std::vector<uint8_t>> parts((size_t)nthreads);
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t] {
@@ -77,7 +80,7 @@ extern "C" int mth_host_write_synthetic_bam(const char *path, const char *contig
             const uint32_t aux_len = 4 + 3 + (uint32_t)read_len + 1 + 6;
             const uint32_t bs = 32 + (uint32_t)ln + 4 + seqb + (uint32_t)read_len + aux_len;
             if (!raw.empty() && raw.size() + 4 + bs > BGZF_BLOCK) { bgzf_append(out, raw.data(), raw.size()); raw.clear(); }   // bgzf_flush_try
-            put32(raw, bs); put32(raw, 0); put32(raw, (uint32_t)start[i]);
+            put32(raw, bs); put32(raw, tid ? (uint32_t)tid[i] : 0u); put32(raw, (uint32_t)start[i]);
             raw.push_back((uint8_t)ln); raw.push_back(mapq[i]); put16(raw, 4680); put16(raw, 1);
             put16(raw, fwd[i] ? 0 : 16); put32(raw, (uint32_t)read_len); put32(raw, 0xffffffffu); put32(raw, 0xffffffffu); put32(raw, 0);
             raw.insert(raw.end(), name, name + ln);
@@ -105,4 +108,13 @@ extern "C" int mth_host_write_synthetic_bam(const char *path, const char *contig
     ok = ok && fwrite(eof_blk, 1, 28, f) == 28;
     ok = (fclose(f) == 0) && ok;
     return ok ? MTH_HOST_OK : MTH_HOST_ERR_OPEN;
+}
+
+extern "C" int mth_host_write_synthetic_bam(const char *path, const char *contig, int64_t contig_len, int64_t n_reads,
+                                            int32_t read_len, const int32_t *start, const uint8_t *fwd, const uint8_t *mapq,
+                                            const uint64_t *cpg_off, const uint16_t *cpg_rel, const uint32_t *cpg_pos,
+                                            uint64_t seed, int nthreads) {
+    if (!contig) return MTH_HOST_ERR_INVALID;
+    return mth_host_write_synthetic_bam_multi(path, 1, &contig, &contig_len, n_reads, read_len, nullptr, start, fwd, mapq, cpg_off, cpg_rel,
+                                              cpg_pos, seed, nthreads);
 }

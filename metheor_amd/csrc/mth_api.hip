@@ -65,6 +65,7 @@ LaunchTimer::~LaunchTimer() {
 }
 
 int sync_and_check(mth_ctx *ctx) {
+    MTH_HIP(ctx, hipSetDevice(ctx->device));   // every entry point passes through here or stage_batch: the calling thread may be new
     MTH_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
     MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t e = ctx->h_state->err;
@@ -198,6 +199,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
 
 int mth_ctx_set_stream(mth_ctx_t *ctx, void *hip_stream) {
     if (!ctx) return MTH_ERR_INVALID;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
     MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return MTH_OK;
@@ -338,13 +340,20 @@ int mth_lpmd_global(mth_ctx_t *ctx, int64_t out[4], float *lpmd) {
     if (!ctx) return MTH_ERR_INVALID;
     int rc = sync_and_check(ctx);
     if (rc) return rc;
-    if (out) for (int k = 0; k < 4; ++k) out[k] = ctx->h_state->lpmd[k];
-    if (lpmd) *lpmd = mth_lpmd_from_counts(ctx->h_state->lpmd[0], ctx->h_state->lpmd[1]);
+    long long v[4];
+    for (int k = 0; k < 4; ++k) v[k] = ctx->h_state->lpmd[k];
+    if (ctx->lpmd_reduced && ctx->red_slot >= 0) {      // all-reduced on the side stream (mth_allreduce_lpmd_rank): totals are in the ring slot
+        MTH_HIP(ctx, hipStreamSynchronize(ctx->red_stream));
+        MTH_HIP(ctx, hipMemcpy(v, ctx->red_buf + 4 * ctx->red_slot, sizeof v, hipMemcpyDeviceToHost));
+    }
+    if (out) for (int k = 0; k < 4; ++k) out[k] = v[k];
+    if (lpmd) *lpmd = mth_lpmd_from_counts(v[0], v[1]);
     return MTH_OK;
 }
 
 int mth_lpmd_export_device(mth_ctx_t *ctx, int64_t *dst) {
     if (!ctx || !dst) return MTH_ERR_INVALID;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
     MTH_HIP(ctx, hipMemcpyAsync(dst, ctx->d_state->lpmd, 4 * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
     return MTH_OK;
 }

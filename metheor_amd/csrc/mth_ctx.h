@@ -97,6 +97,14 @@ struct mth_ctx {
     void *rccl_comm = nullptr;
     int rccl_rank = 0, rccl_world = 1;
     bool lpmd_reduced = false;
+    // the rank form reduces out of place on a side stream: ring of 4-counter slots, red_slot = slot of the latest reduce
+    // (-1: the totals are in DevState.lpmd itself)
+    static constexpr int RED_RING = 4;
+    hipStream_t red_stream = nullptr;
+    long long *red_buf = nullptr;
+    hipEvent_t red_ready[RED_RING] = {}, red_done[RED_RING] = {};
+    uint64_t red_head = 0;
+    int red_slot = -1;
 
     bool timing = false;
     std::vector<mth::TimedLaunch> timed;

@@ -5,8 +5,8 @@
 //   * one process, one context per GPU (the `metheor --gpus N` executable): mth_allreduce_lpmd(ctxs, n);
 //   * one process per GPU (torch.distributed / MPI style launchers): mth_rccl_unique_id on rank 0, the host ships
 //     the 128 bytes to the other ranks, mth_rccl_init_rank everywhere, mth_allreduce_lpmd_rank everywhere.
-// The collective is enqueued on each context's own stream, in place on DevState.lpmd: afterwards mth_lpmd_global
-// of every context returns the node-wide counters.
+// Afterwards mth_lpmd_global of every context returns the node-wide counters (the single-process form reduces in
+// place on DevState.lpmd; the rank form on a side stream into a ring slot, so the context's stream never waits).
 //
 // librccl is loaded on first use (dlopen): a single-GPU run never pays for it (it is a large library, the CLI's
 // whole run is ~0.3 s), and a process that already carries an RCCL (PyTorch) keeps using that copy.
@@ -107,16 +107,35 @@ int mth_rccl_init_rank(mth_ctx_t *ctx, const void *id128, int rank, int world) {
     return MTH_OK;
 }
 
+// The ctx stream never waits for the collective: the counters are copied into a ring slot on the ctx stream, the
+// all-reduce runs on a side stream ordered after that copy, and mth_lpmd_global reads the slot after draining the side
+// stream.  A slot is reused RED_RING calls later (ordered by its done-event), so a host that issues one reduce per batch
+// loop iteration overlaps it with the next iterations' kernels (32 bytes: pure latency, ~10-30 us over xGMI).
 int mth_allreduce_lpmd_rank(mth_ctx_t *ctx) {
     if (!ctx) return MTH_ERR_INVALID;
     if (!ctx->rccl_comm) return fail(ctx, MTH_ERR_STATE, "mth_rccl_init_rank first");
     if (ctx->lpmd_reduced) return fail(ctx, MTH_ERR_STATE, "the LPMD counters of this context are already all-reduced");
     Rccl *r = rccl();
     MTH_HIP(ctx, hipSetDevice(ctx->device));
-    long long *buf = reinterpret_cast<long long *>(ctx->d_state->lpmd);
-    const ncclResult_t e = r->AllReduce(buf, buf, 4, ncclInt64, ncclSum, (ncclComm_t)ctx->rccl_comm, ctx->stream);
+    if (!ctx->red_stream) {
+        MTH_HIP(ctx, hipStreamCreateWithFlags(&ctx->red_stream, hipStreamNonBlocking));
+        MTH_HIP(ctx, hipMalloc((void **)&ctx->red_buf, mth_ctx::RED_RING * 4 * sizeof(long long)));
+        for (int k = 0; k < mth_ctx::RED_RING; ++k) {
+            MTH_HIP(ctx, hipEventCreateWithFlags(&ctx->red_ready[k], hipEventDisableTiming));
+            MTH_HIP(ctx, hipEventCreateWithFlags(&ctx->red_done[k], hipEventDisableTiming));
+        }
+    }
+    const int k = (int)(ctx->red_head++ % mth_ctx::RED_RING);
+    long long *buf = ctx->red_buf + 4 * k;
+    if (ctx->red_head > (uint64_t)mth_ctx::RED_RING) MTH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->red_done[k], 0));   // the slot's previous collective
+    MTH_HIP(ctx, hipMemcpyAsync(buf, ctx->d_state->lpmd, 4 * sizeof(long long), hipMemcpyDeviceToDevice, ctx->stream));
+    MTH_HIP(ctx, hipEventRecord(ctx->red_ready[k], ctx->stream));
+    MTH_HIP(ctx, hipStreamWaitEvent(ctx->red_stream, ctx->red_ready[k], 0));
+    const ncclResult_t e = r->AllReduce(buf, buf, 4, ncclInt64, ncclSum, (ncclComm_t)ctx->rccl_comm, ctx->red_stream);
     if (e != ncclSuccess) return rccl_fail(ctx, "ncclAllReduce", e);
+    MTH_HIP(ctx, hipEventRecord(ctx->red_done[k], ctx->red_stream));
     ctx->lpmd_reduced = true;
+    ctx->red_slot = k;
     return MTH_OK;
 }
 
@@ -127,7 +146,7 @@ int mth_allreduce_lpmd(mth_ctx_t **ctxs, int n) {
         for (int j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return fail(ctxs[i], MTH_ERR_INVALID, "a context appears twice");
         if (ctxs[i]->lpmd_reduced) return fail(ctxs[i], MTH_ERR_STATE, "the LPMD counters of this context are already all-reduced");
     }
-    if (n == 1) { ctxs[0]->lpmd_reduced = true; return MTH_OK; }
+    if (n == 1) { ctxs[0]->lpmd_reduced = true; ctxs[0]->red_slot = -1; return MTH_OK; }
     // contexts that share a GPU (several shards per device) are summed on that GPU into the first of them; RCCL
     // then runs between one context per distinct GPU (it refuses two ranks on one device); the result is copied back
     std::vector<int> leader((size_t)n);
@@ -193,6 +212,7 @@ int mth_allreduce_lpmd(mth_ctx_t **ctxs, int n) {
     for (int i = 0; i < n; ++i) {
         if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) { cleanup(); return fail(ctxs[i], MTH_ERR_HIP, "sync"); }
         ctxs[i]->lpmd_reduced = true;
+        ctxs[i]->red_slot = -1;       // in place: DevState.lpmd holds the totals
     }
     cleanup();
     return MTH_OK;
@@ -202,6 +222,13 @@ int mth_allreduce_lpmd(mth_ctx_t **ctxs, int n) {
 
 namespace mth {
 void rccl_release(mth_ctx *ctx) {
+    if (ctx->red_stream) {
+        (void)hipStreamSynchronize(ctx->red_stream);
+        for (int k = 0; k < mth_ctx::RED_RING; ++k) { (void)hipEventDestroy(ctx->red_ready[k]); (void)hipEventDestroy(ctx->red_done[k]); }
+        (void)hipFree(ctx->red_buf);
+        (void)hipStreamDestroy(ctx->red_stream);
+        ctx->red_stream = nullptr; ctx->red_buf = nullptr;
+    }
     if (!ctx->rccl_comm) return;
     if (Rccl *r = rccl()) (void)r->CommDestroy((ncclComm_t)ctx->rccl_comm);
     ctx->rccl_comm = nullptr;

@@ -12,6 +12,7 @@ SYMBOLS = [
     "mth_host_ref_len", "mth_host_ref_tid", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
     "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
     "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32", "mth_host_write_synthetic_bam",
+    "mth_host_write_synthetic_bam_multi",
 ]
 
 
@@ -59,6 +60,7 @@ def lib():
         L.mth_host_plan_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int64, vp]
         L.mth_host_format_f32.argtypes = [C.c_float, C.c_char_p]
         L.mth_host_write_synthetic_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int32] + [vp] * 6 + [C.c_uint64, C.c_int]
+        L.mth_host_write_synthetic_bam_multi.argtypes = [C.c_char_p, C.c_int32, vp, vp, C.c_int64, C.c_int32] + [vp] * 7 + [C.c_uint64, C.c_int]
         _LIB = L
     return _LIB
 
@@ -78,6 +80,24 @@ def write_synthetic_bam(path, c, contig="chr19", seed=0, threads=0):
             np.ascontiguousarray(c["cpg_rel"], np.uint16), np.ascontiguousarray(c["cpg_pos"], np.uint32)]
     rc = lib().mth_host_write_synthetic_bam(os.fsencode(path), contig.encode(), int(c["length"]), n, rl,
                                             *[a.ctypes.data_as(C.c_void_p) for a in arrs], seed, threads)
+    if rc != 0:
+        raise HostError(rc, "cannot write " + path)
+
+
+def write_synthetic_bam_multi(path, contigs, names, seed=0, threads=0):
+    """contigs: metheor_amd.synth contig dicts in tid order (c["tid"] indexes names / the header) -> one BAM file"""
+    from . import synth
+    tid, start, end, mapq, fwd, off, pos, rel = synth.concat_oracle_soa(contigs)
+    n = len(start)
+    rl = int(end[0] - start[0] + 1) if n else 150
+    lens = {c["tid"]: int(c["length"]) for c in contigs}
+    nm = (C.c_char_p * len(names))(*[x.encode() for x in names])
+    ln = (C.c_int64 * len(names))(*[lens.get(t, 1000) for t in range(len(names))])
+    arrs = [np.ascontiguousarray(tid, np.int32), np.ascontiguousarray(start, np.int32), np.ascontiguousarray(fwd, np.uint8),
+            np.ascontiguousarray(mapq, np.uint8), np.ascontiguousarray(off, np.uint64), np.ascontiguousarray(rel, np.uint16),
+            np.ascontiguousarray(pos, np.uint32)]
+    rc = lib().mth_host_write_synthetic_bam_multi(os.fsencode(path), len(names), nm, ln, n, rl,
+                                                  *[a.ctypes.data_as(C.c_void_p) for a in arrs], seed, threads)
     if rc != 0:
         raise HostError(rc, "cannot write " + path)
 

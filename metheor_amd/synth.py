@@ -73,6 +73,29 @@ def wgbs(n_reads=200_000_000, seed=2000, density=0.0091, contigs=None):
         yield make_contig(tid, ln, int(round(n_reads * ln / tot)), density, rng)
 
 
+def wgbs_small(n_reads=2_000_000, seed=2000, density=0.0091, dense_frac=0.85, dense_span_frac=0.002, contigs=None):
+    """config 3 / 5 at a size a parity test can check against the oracle: the same 24 hg38-sized contigs (same lengths,
+    so the same coordinates, tile counts and contig changes as wgbs()), reads spread by contig length; inside a contig
+    dense_frac of the reads fall into a few windows that together cover dense_span_frac of it (WGBS-like depth there)
+    and the rest uniformly (almost every tile empty or with one read: the sparse-tile paths)."""
+    lens = HG38_LENGTHS if contigs is None else contigs
+    tot = float(sum(lens))
+    rng = np.random.default_rng(seed)
+    out = []
+    for tid, ln in enumerate(lens):
+        n = int(round(n_reads * ln / tot))
+        nd = int(n * dense_frac)
+        hi = max(ln - 150, 1)
+        nwin = 4
+        wlen = max(int(ln * dense_span_frac / nwin), 1000)
+        w0 = np.sort(rng.integers(0, max(hi - wlen, 1), size=nwin))
+        w0[-1] = max(hi - wlen, 0)                       # one window ends at the contig's last base
+        dense = (w0[rng.integers(0, nwin, size=nd)] + rng.integers(0, wlen, size=nd)).astype(np.int64)
+        starts = np.sort(np.concatenate([dense, rng.integers(0, hi, size=n - nd)])).astype(np.int32)
+        out.append(make_contig(tid, ln, n, density, rng, starts=starts))
+    return out
+
+
 def hotspots(n_windows=20000, window=1000, depth=50, density=0.08, seed=50, read_len=150):
     """BASELINE config 4: 1-kbp windows at an exact depth (stresses the O(d^2) read-pair tile)"""
     rng = np.random.default_rng(seed)

@@ -311,10 +311,11 @@ def test_device_inflate_path_large_header_many_contigs(tmp_path):
 
 @pytest.mark.parametrize("n_shards", [2, 5])
 def test_sharded_run_equals_single_run(tmp_path, n_shards):
-    """METHEOR_SHARD=r/N: every shard loads its own run of BGZF blocks (no index, no router), owns a (tid, pos) interval;
-    the parts concatenated in shard order (LPMD: counters summed) are byte-identical to the single-process TSV -- all
-    measures, cuts inside contigs and at contig changes, empty contigs in between"""
-    from metheor_amd import sharded, synth
+    """`metheor <sub> --gpus N`: every shard (one host thread + one device context each, here all on device 0) loads its own
+    run of BGZF blocks (no index, no router) and owns a (tid, pos) interval; the parts concatenated in shard order (LPMD:
+    counters summed by mth_allreduce_lpmd) are byte-identical to the single run AND equal to the oracle's text -- all
+    measures, cuts inside contigs and at contig changes, an empty contig in between"""
+    from metheor_amd import synth
     rng = np.random.default_rng(77)
     refs = [("sA", 120_000), ("sEmpty", 5_000), ("sB", 200_000), ("sC", 60_000)]
     tid, pos, flag, mapq, cig, xms = [], [], [], [], [], []
@@ -326,6 +327,9 @@ def test_sharded_run_equals_single_run(tmp_path, n_shards):
     raw_bam, bam = str(tmp_path / "u.bam"), str(tmp_path / "a.bam")
     bamio.write_bam(raw_bam, rec)
     reblock_aligned(raw_bam, bam)
+    reads = pyoracle.Reads.decode(rec)
+    names = [n for n, _ in refs]
+    env = {"METHEOR_SEED": "7", "METHEOR_SHARD_HALO": "4000"}
     cases = (("pdr", ["-d", "3", "-p", "1"]), ("lpmd", []), ("mhl", ["-d", "3", "-p", "1"]), ("me", ["-d", "2"]), ("pm", ["-d", "2"]),
              ("fdrp", ["-d", "3"]), ("qfdrp", ["-d", "3"]))
     for sub, extra in cases:
@@ -334,32 +338,38 @@ def test_sharded_run_equals_single_run(tmp_path, n_shards):
         aN = [sub, "-i", bam, "-o", str(oN)] + extra
         if sub == "lpmd":
             a1 += ["--pairs", str(tmp_path / "one_pairs.tsv")]
-            aN += ["--pairs", str(tmp_path / "sh_pairs.tsv")]
-        r = run(*a1)
+            aN += ["-p", str(tmp_path / "sh_pairs.tsv")]                # the short flag too
+        r = run_env(env, *a1)
         assert r.returncode == 0, r.stderr
-        assert sharded.run(n_shards, aN, gpus=1, env=dict(os.environ, METHEOR_SEED="7", METHEOR_SHARD_HALO="4000")) == 0
+        r = run_env(env, *aN, "--gpus", str(n_shards))
+        assert r.returncode == 0, r.stderr
         assert not list(tmp_path.glob("*.shard-*"))
         assert oN.read_bytes() == o1.read_bytes(), sub
         assert len(o1.read_bytes()) > (20 if sub == "lpmd" else 1000)
+        want, want_pairs = util.oracle_text(reads, names, sub, input_name=bam, seed=7, **util.oracle_kwargs(sub, extra))
+        util.assert_tsv_equals_oracle(sub, oN.read_text(), want)
         if sub == "lpmd":
             assert (tmp_path / "sh_pairs.tsv").read_bytes() == (tmp_path / "one_pairs.tsv").read_bytes()
+            assert (tmp_path / "sh_pairs.tsv").read_text() == want_pairs and want_pairs.count("\n") > 100
+    # the old launcher is now a wrapper around --gpus
+    from metheor_amd import sharded
+    oW = tmp_path / "wrap.tsv"
+    assert sharded.run(n_shards, ["pdr", "-i", bam, "-o", str(oW), "-d", "3", "-p", "1"], gpus=1, env=dict(os.environ, **env)) == 0
+    assert oW.read_bytes() == (tmp_path / "one_pdr.tsv").read_bytes()
     # --cpg-set is applied by each shard's device decode
     bed = tmp_path / "sites.bed"
-    names = [n for n, _ in refs]
-    soa = pyoracle.Reads.decode(rec).soa()
+    soa = reads.soa()
     key = (np.repeat(soa["tid"].astype(np.int64), np.diff(soa["cpg_off"].astype(np.int64))) << 32) | (soa["cpg_pos"] & 0x7fffffff).astype(np.int64)
     keep = np.unique(key)[::3]
     bed.write_text("".join("%s\t%d\t%d\n" % (names[int(k >> 32)], int(k & 0xffffffff), int(k & 0xffffffff) + 2) for k in keep))
     o1, oN = tmp_path / "one_set.tsv", tmp_path / "sh_set.tsv"
     r = run("pdr", "-i", bam, "-o", str(o1), "-d", "2", "-p", "1", "-c", str(bed))
     assert r.returncode == 0, r.stderr
-    assert sharded.run(n_shards, ["pdr", "-i", bam, "-o", str(oN), "-d", "2", "-p", "1", "-c", str(bed)], gpus=1,
-                       env=dict(os.environ, METHEOR_SHARD_HALO="4000")) == 0
+    r = run_env(env, "pdr", "-i", bam, "-o", str(oN), "-d", "2", "-p", "1", "-c", str(bed), "--gpus", str(n_shards))
+    assert r.returncode == 0, r.stderr
     assert oN.read_bytes() == o1.read_bytes() and len(o1.read_bytes()) > 1000
     # a halo smaller than an alignment is refused, not silently wrong
-    e = dict(os.environ, METHEOR_SHARD="1/2", METHEOR_SHARD_HALO="100")
-    import subprocess
-    r = subprocess.run([EXE, "pdr", "-i", bam, "-o", str(tmp_path / "x.tsv")], env=e, capture_output=True, text=True)
+    r = run_env({"METHEOR_SHARD_HALO": "100"}, "pdr", "-i", bam, "-o", str(tmp_path / "x.tsv"), "--gpus", "2")
     assert r.returncode != 0 and "METHEOR_SHARD_HALO" in r.stderr
 
 

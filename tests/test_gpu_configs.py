@@ -1,0 +1,154 @@
+"""GPU parity for the BASELINE.json configurations that had no driver-run test:
+
+config 3  "Synthetic 200M-read WGBS (150bp, 30x human), all 7 measures, 1xMI355X" -- the 24 hg38-sized contigs at a size
+          the oracle finishes in seconds (every measure + the pairs table, bit-exact / 1e-6), and one chr1-sized contig at
+          the configuration's FULL density and depth through size-independent properties (closed forms on the SoA,
+          idempotence, an oracle-checked prefix);
+config 5  "Whole-genome 1B-read WGBS sharded by contig across 8xMI355X with RCCL final reduce" -- the same generator written
+          as ONE 24-contig BAM, `metheor <measure> --gpus 8` (eight shards, eight device contexts, the RCCL/all-reduce entry
+          point for LPMD; all on the one GPU a test box has), every measure against the ORACLE's text.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tests import test_gpu_fdrp as T_fdrp
+from tests import test_gpu_mhl as T_mhl
+from tests import test_gpu_pairs as T_pairs
+from tests import test_gpu_pdr_lpmd as T_pdr
+from tests import test_gpu_quartet as T_quartet
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "metheor_amd", "metheor")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import metheor_amd
+    e = metheor_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def wgbs24():
+    """S-WGBS scaled to 1.5 M reads: 24 contigs, hg38 lengths, dense windows (~60x) inside an almost empty genome"""
+    from metheor_amd import synth
+    cs = synth.wgbs_small(1_500_000)
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    return cs, reads
+
+
+def test_config3_wgbs_all_measures_vs_oracle(eng, wgbs24):
+    from metheor_amd import PdrLpmdParams, synth
+    cs, reads = wgbs24
+    assert len(cs) == 24 and cs[0]["length"] == synth.HG38_LENGTHS[0] and sum(len(c["read_start"]) for c in cs) > 1_400_000
+    # reference CLI defaults (lib.rs:36-46, 206-214) and a permissive set that also emits the sparse part's rows
+    for pk, lk in ((dict(min_depth=10, min_cpgs=4, min_qual=10), dict(min_distance=2, max_distance=16, min_qual=10)),
+                   (dict(min_depth=1, min_cpgs=1, min_qual=0), dict(min_distance=1, max_distance=40, min_qual=0))):
+        p = PdrLpmdParams(min_distance=lk["min_distance"], max_distance=lk["max_distance"], lpmd_min_qual=lk["min_qual"], **pk)
+        d, l = T_pdr.run_device(eng, cs, p, device="cuda:0")
+        T_pdr.check_against_oracle(d, l, reads, pk, lk)
+        assert len(d["pos"]) > 1000 and len(set(d["tid"].tolist())) == 24
+    lk = dict(min_distance=2, max_distance=16, min_qual=10)
+    T_pairs.check(T_pairs.run_device(eng, cs, lk), reads, lk)
+    for mq, qd in ((10, 10), (0, 1)):
+        T_quartet.check(T_quartet.run_device(eng, cs, mq, qd), reads, mq, qd)
+    for mk in (dict(min_depth=10, min_cpgs=4, min_qual=10), dict(min_depth=1, min_cpgs=1, min_qual=10)):
+        T_mhl.check(T_mhl.run_device(eng, cs, mk), reads, mk)
+    # -D 64 with ~60x windows: some sites sample (device and oracle share the counter-based draw), most do not
+    for fk in (dict(min_qual=10, min_depth=10, max_depth=64, min_overlap=35, seed=3), dict(min_qual=10, min_depth=2, max_depth=40, min_overlap=35, seed=5)):
+        T_fdrp.check(T_fdrp.run_device(eng, cs, fk), reads, fk)
+
+
+def test_config3_full_density_chr1_properties(eng):
+    """one chr1-sized contig at S-WGBS-200M's own density (0.0091) and depth (200 M x 248.96 / 3088 Mbp = 16.1 M reads, 9.7x):
+    the tile count (60 781), per-tile occupancy and call density of the real configuration, checked through properties"""
+    from metheor_amd import PdrLpmdParams, shard, synth
+    ln = synth.HG38_LENGTHS[0]
+    n = int(round(200_000_000 * ln / float(sum(synth.HG38_LENGTHS))))
+    c = synth.make_contig(0, ln, n, 0.0091, np.random.default_rng(2000))
+    bt = util.device_batch(c, device="cuda:0")
+    kw = dict(min_depth=0, min_cpgs=0, min_qual=10)
+    eng.reset()
+    eng.pdr_lpmd_accumulate(bt, PdrLpmdParams(**kw))
+    p, l = eng.pdr_fetch(), eng.lpmd_global()
+    off = c["cpg_off"].astype(np.int64)
+    ncpg = np.diff(off)
+    assert 1.2 < ncpg.mean() < 1.5
+    ok = (c["read_mapq"] >= 10) & (ncpg > 0)
+    meth = (c["cpg_pos"] >> 31).astype(np.int64)
+    msum = np.add.reduceat(np.concatenate([meth, [0]]), off[:-1])
+    msum[ncpg == 0] = 0
+    disc = (msum > 0) & (msum < ncpg)
+    assert int(p["n_concordant"].sum()) == int(ncpg[ok & ~disc].sum())
+    assert int(p["n_discordant"].sum()) == int(ncpg[ok & disc].sum())
+    called = np.unique((c["cpg_pos"] & 0x7fffffff)[np.repeat(ok, ncpg)])
+    assert len(p["pos"]) == len(called) and (p["pos"] == called).all()
+    assert l["n_read"] == n and l["n_valid_read"] == int((c["read_mapq"] >= 10).sum())
+    # LPMD pair counts in closed form for the default window: pairs (j < k) of a read with 2 <= rel_k - rel_j <= 16
+    rel = c["cpg_rel"].astype(np.int64)
+    lp_ok = np.repeat(c["read_mapq"] >= 10, ncpg)
+    read_of = np.repeat(np.arange(n), ncpg)
+    tot_c = tot_d = 0
+    for g in range(1, 9):                              # CpGs are >= 2 bp apart: at most 8 gaps inside 16 bp
+        same = (read_of[g:] == read_of[:-g]) & lp_ok[g:]
+        dist = rel[g:] - rel[:-g]
+        inw = same & (dist >= 2) & (dist <= 16)
+        dd = inw & (meth[g:] != meth[:-g])
+        tot_d += int(dd.sum()); tot_c += int(inw.sum()) - int(dd.sum())
+    assert l["n_concordant"] == tot_c and l["n_discordant"] == tot_d
+    # the same resident batch through the other tile measures: mass conservation
+    eng.quartet_accumulate(bt, 10)
+    q = eng.quartet_fetch(0)
+    assert int(q["cnt"].sum()) == int(np.maximum(ncpg[c["read_mapq"] >= 10] - 3, 0).sum())
+    eng.lpmd_pairs_accumulate(bt, 2, 16, 10)
+    pr = eng.lpmd_pairs_fetch()
+    assert int(pr["n_concordant"].sum()) == tot_c and int(pr["n_discordant"].sum()) == tot_d
+    # idempotence
+    eng.reset()
+    eng.pdr_lpmd_accumulate(bt, PdrLpmdParams(**kw))
+    p2 = eng.pdr_fetch()
+    assert all((p[k] == p2[k]).all() for k in p)
+    # exact against the oracle on a 400 k-read prefix and on a 400 k-read slice at the contig's far end
+    for lo_i, hi_i in ((0, 400_000), (n - 400_000, n)):
+        beg = 0 if lo_i == 0 else int(c["read_start"][lo_i]) + 200
+        end = int(c["read_start"][hi_i]) if hi_i < n else ln
+        sub = shard.slice_region(c, max(beg - 400, 0), end)
+        reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(sub))
+        o = reads.pdr(**kw)
+        keep = (o.pos[:, 0] >= beg) & (o.pos[:, 0] < end)
+        m = (p["pos"] >= beg) & (p["pos"] < end)
+        assert m.sum() > 100_000 and (p["pos"][m] == o.pos[keep, 0]).all()
+        assert (p["n_concordant"][m] == o.cnt[keep, 0]).all() and (p["n_discordant"][m] == o.cnt[keep, 1]).all()
+        assert (p["pdr"][m].view(np.uint32) == o.val[keep].view(np.uint32)).all()
+
+
+def test_config5_sharded_8_vs_oracle_text(wgbs24, tmp_path):
+    """one 24-contig BAM, `metheor <sub> --gpus 8`: eight shards cut by compressed size (inside contigs and at contig
+    changes), eight device contexts, LPMD counters through mth_allreduce_lpmd -- every output file against the ORACLE's
+    text (not against another run of the same engine)"""
+    from metheor_amd import hostapi, synth
+    cs, reads = wgbs24
+    bam = str(tmp_path / "wgbs24.bam")
+    hostapi.write_synthetic_bam_multi(bam, cs, synth.HG38_NAMES, seed=11)
+    env = dict(os.environ, METHEOR_SEED="9")
+    cases = (("pdr", []), ("pdr", ["-d", "1", "-p", "1"]), ("lpmd", []), ("mhl", ["-d", "5", "-p", "2"]), ("me", ["-d", "5"]), ("pm", ["-d", "5"]),
+             ("fdrp", ["-d", "5", "-D", "64"]), ("qfdrp", ["-d", "5", "-D", "64"]))
+    for sub, extra in cases:
+        o, pf = tmp_path / ("%s.tsv" % sub), tmp_path / "pairs.tsv"
+        args = [EXE, sub, "-i", bam, "-o", str(o)] + extra + ["--gpus", "8"]
+        if sub == "lpmd":
+            args += ["-p", str(pf)]
+        r = subprocess.run(args, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+        assert r.returncode == 0, (sub, r.stderr)
+        want, want_pairs = util.oracle_text(reads, synth.HG38_NAMES, sub, input_name=bam, seed=9, **util.oracle_kwargs(sub, extra))
+        util.assert_tsv_equals_oracle(sub, o.read_text(), want)
+        assert len(want) > (20 if sub == "lpmd" else 10_000), sub
+        if sub == "lpmd":
+            assert pf.read_text() == want_pairs and want_pairs.count("\n") > 10_000

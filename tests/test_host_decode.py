@@ -282,3 +282,18 @@ def test_crafted_aux_is_rejected_not_looped(golden_dir, tmp_path, case):
     with pytest.raises(hostapi.HostError) as e:
         hostapi.BamFile(p).decode()
     assert "Error reading XM tag in BAM record" in str(e.value)
+
+
+def test_multi_contig_synthetic_writer_round_trip(tmp_path):
+    """the multi-contig form of the C++ synthetic-BAM writer (config 3 / 5 test input): decodes back to the generator's SoA"""
+    from metheor_amd import synth
+    rng = np.random.default_rng(12)
+    names = ["cA", "cEmpty", "cB"]
+    cs = [synth.make_contig(0, 400_000, 9_000, 0.02, rng), synth.make_contig(2, 150_000, 4_000, 0.03, rng)]
+    p = str(tmp_path / "multi.bam")
+    hostapi.write_synthetic_bam_multi(p, cs, names, seed=5, threads=3)
+    want = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs)).soa()
+    f = hostapi.BamFile(p)
+    assert f.refs == [("cA", 400_000), ("cEmpty", 1000), ("cB", 150_000)]
+    same_soa(f.decode(), want)
+    same_soa(pyoracle.Reads.decode(bamio.read_bam(p)).soa(), want)

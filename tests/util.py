@@ -122,3 +122,57 @@ def reblock_aligned(src, dst):
 def _bamio():
     from oracle import bamio
     return bamio
+
+
+# ---- oracle text of a whole `metheor <sub>` run (the TSV bytes the reference writes; SURVEY Q2) ---------------------
+CLI_PARAMS = {   # command-line flags -> oracle keyword arguments
+    "pdr": {"-d": "min_depth", "-p": "min_cpgs", "-q": "min_qual"},
+    "mhl": {"-d": "min_depth", "-p": "min_cpgs", "-q": "min_qual"},
+    "me": {"-d": "min_depth", "-q": "min_qual"}, "pm": {"-d": "min_depth", "-q": "min_qual"},
+    "fdrp": {"-q": "min_qual", "-d": "min_depth", "-D": "max_depth", "-l": "min_overlap"},
+    "qfdrp": {"-q": "min_qual", "-d": "min_depth", "-D": "max_depth", "-l": "min_overlap"},
+    "lpmd": {"-m": "min_distance", "-M": "max_distance", "-q": "min_qual"},
+}
+
+
+def oracle_kwargs(sub, flags):
+    """["-d", "3", "-p", "1"] -> {"min_depth": 3, "min_cpgs": 1}"""
+    m = CLI_PARAMS[sub]
+    return {m[flags[i]]: int(flags[i + 1]) for i in range(0, len(flags), 2)}
+
+
+def oracle_text(reads, names, sub, input_name="", seed=0, **kw):
+    """-> (output text, pairs-table text or None) of `metheor <sub>` as the oracle computes it"""
+    from oracle import pyoracle
+    f = pyoracle.format_f32
+    if sub == "pdr":
+        return oracle_tsv_pdr(reads, names, **kw), None
+    if sub == "lpmd":
+        res = reads.lpmd(pairs=True, **kw)
+        t = res["pairs"]
+        pairs = "chrom\tcpg1\tcpg2\tlpmd\tn_concordant\tn_discordant\n" + "".join(
+            "%s\t%d\t%d\t%s\t%d\t%d\n" % (names[ti], p[0], p[1], f(v), c[0], c[1]) for ti, p, v, c in zip(t.tid, t.pos, t.val, t.cnt))
+        return "name\tlpmd\n%s\t%s\n" % (input_name, f(res["lpmd"])), pairs
+    if sub in ("mhl", "fdrp", "qfdrp"):
+        t = reads.mhl(**kw) if sub == "mhl" else getattr(reads, sub)(seed=seed, **kw)
+        return "".join("%s\t%d\t%d\t%s\n" % (names[ti], p[0], p[0] + 2, f(v)) for ti, p, v in zip(t.tid, t.pos, t.val)), None
+    if sub in ("me", "pm"):
+        t = getattr(reads, sub)(**kw)
+        return "".join("%s\t%d\t%d\t%d\t%d\t%s\n" % (names[ti], p[0], p[1], p[2], p[3], f(v)) for ti, p, v in zip(t.tid, t.pos, t.val)), None
+    raise ValueError(sub)
+
+
+def assert_tsv_equals_oracle(sub, got, want):
+    """byte equality for the sorted outputs; ME / PM are written in HashMap order by the reference (compare as sets of
+    lines), and ME's value within 1e-6 (log2f last-ulp differences; the bar of BASELINE.json's north_star)"""
+    if sub in ("me", "pm"):
+        g, w = sorted(got.splitlines()), sorted(want.splitlines())
+        assert len(g) == len(w), (sub, len(g), len(w))
+        if sub == "pm":
+            assert g == w, sub
+        else:
+            for a, b in zip(g, w):
+                fa, fb = a.split("\t"), b.split("\t")
+                assert fa[:5] == fb[:5] and abs(float(fa[5]) - float(fb[5])) <= 1e-6, (a, b)
+    else:
+        assert got == want, sub
