@@ -124,7 +124,7 @@ def test_config3_full_density_chr1_properties(eng):
         o = reads.pdr(**kw)
         keep = (o.pos[:, 0] >= beg) & (o.pos[:, 0] < end)
         m = (p["pos"] >= beg) & (p["pos"] < end)
-        assert m.sum() > 100_000 and (p["pos"][m] == o.pos[keep, 0]).all()
+        assert m.sum() > 30_000 and (p["pos"][m] == o.pos[keep, 0]).all()
         assert (p["n_concordant"][m] == o.cnt[keep, 0]).all() and (p["n_discordant"][m] == o.cnt[keep, 1]).all()
         assert (p["pdr"][m].view(np.uint32) == o.val[keep].view(np.uint32)).all()
 
