@@ -445,262 +445,6 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
     }
 }
 
-// =============================================================================================
-// Tile kernel, second form (round 2): lane = CpG CALL.
-//
-// Why: with lane = read a wave carries 8 call slots per read and 63 % of them are dead at 2.94 calls per read; the
-// kernel is VALU-issue bound on that padding (profiles/r02_ubench_valu.md).  Here the calls themselves are the lanes:
-// coalesced 4-byte + 1-byte loads, ~1.7x fewer wave-instructions per call.  What a call needs from its READ (start,
-// verdicts, first-call state) and from its neighbours (pair distances) travels through LDS:
-//
-//   A tile's candidate reads [lo, hi) are consumed in CHUNKS of whole reads (<= KR*B reads, <= C = 4*B calls; calls of
-//   a chunk are the contiguous range [cb, cb + nc) of the batch's call arrays).  Per chunk, four phases:
-//   P1 lane = read   9 B/read record (prefetched one chunk ahead) -> verdicts (pdr.rs:147-157, lpmd.rs:176-179), LPMD read
-//                    totals, and a 16-bit HEAD WORD {start - sbase : 13, discordant : 1 (set later), lp_ok : 1, pdr_ok : 1}
-//                    stored at the read's first call position hd[x0]; reads that straddle a 64-call block also leave
-//                    their word in carry[block] for the scan below.
-//   P2 lane = call   loads pos|state and relpos; an inclusive wave max-scan (6 DPP ops) of (j+1) << 16 | hd[j] hands
-//                    every call the head word AND head position of its read; span check (call within
-//                    [start - 1, start - 1 + max_span]); key = state << 31 | head position << 17 | relpos -> keys[j];
-//                    scatter word (position in tile | head position << 16) -> sc[j].
-//   P3 lane = call   neighbour keys from LDS: a read is discordant iff two ADJACENT calls of it differ
-//                    (readutil.rs:134-145 restated) -> LDS OR into the head word; the windowed pair counts
-//                    (readutil.rs:166-224) walk the diagonals g = 1, 2, .. with ONE subtraction per pair:
-//                    key_j - key_{j-g} = state-differs << 31 | relpos distance when both calls belong to one read,
-//                    >= 2^17 - 65535 otherwise; lanes whose distance passed max_distance drop out (exec mask), the
-//                    wave leaves the loop when none is left.
-//   P4 lane = call,  PERMUTED: lane l of a wave takes call l*S + m (S odd ~ nc/64), so the 64 lanes of one ds_add are
-//                    spread over the whole chunk instead of sitting on 22 neighbouring reads that cover the same
-//                    sites (same-address LDS atomics serialise at ~4 cycles per extra lane, measured); the head word
-//                    now carries the read's discordance -> +1 into the packed 16|16 counters of the old kernel.
-//   Chunks are double-buffered in hd / carry so that P4 of a chunk and P1 of the next need no barrier between them
-//   (4 barriers per chunk).  Compaction, LPMD partials, wide-counter passes and the gather kernel are shared with
-//   the lane = read form, which stays for batches whose reads span more than CALLS_MAX_SPAN bp.
-// =============================================================================================
-constexpr int CALLS_MAX_SPAN = 2046;   // <= C/2 - 1 calls... a read of span S has at most S/2 + 1 calls: fits one chunk; start - sbase fits 13 bits
-constexpr int CALLS_KRMAX = 4;
-constexpr uint32_t KEY_SENTINEL = 0x3ffe0000u;   // a head position no chunk has, relpos 0: never "same read", never inside a window
-
-__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {
-    v = max(v, MTH_DPP(v, 0x111 /*row_shr:1*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x112 /*row_shr:2*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x114 /*row_shr:4*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x118 /*row_shr:8*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x142 /*row_bcast:15*/, 0xa, false));
-    v = max(v, MTH_DPP(v, 0x143 /*row_bcast:31*/, 0xc, false));
-    return v;
-}
-
-template <int W, int B>
-struct CallsLds {
-    static constexpr int C = 4 * B;
-    uint32_t cnt[W];                                  // site counters (packed 16|16, or 32-bit halves when WIDE)
-    uint32_t keys_pad[4];                             // keys[-1] = KEY_SENTINEL
-    uint32_t keys[C];
-    uint32_t sc[C];
-    uint16_t hd[2][C];
-    uint32_t carry[2][C / 64];
-    uint32_t sh_nc[2], sh_nr[2];
-    uint32_t red[4][B / 64];
-    uint32_t wave_off[B / 64 + 1];
-};
-
-// one pass of a tile over its candidate reads [lo, hi) (see the block comment above).  Returns the rows appended.
-template <int W, int B, typename RelT, bool WIDE>
-__device__ __forceinline__ uint32_t calls_pass(const TileArgs &a, CallsLds<W, B> &L, const uint32_t t, const int32_t T0, const int32_t T1,
-                                               const int32_t P0, const uint32_t Wp, const uint32_t lo, const uint32_t hi,
-                                               const uint32_t cb0, const uint32_t KR, const bool do_lp, const uint32_t out_base) {
-    constexpr int C = 4 * B, NW = B / 64;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
-    for (int i = tid; i < W / 4; i += B) reinterpret_cast<uint4 *>(L.cnt)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < C; i += B) reinterpret_cast<uint32_t *>(&L.hd[0][0])[i] = 0u;        // both buffers (2 * C u16)
-    if (tid < 2 * (C / 64)) (&L.carry[0][0])[tid] = 0u;
-    if (tid < 2) { L.sh_nc[tid] = 0u; L.sh_nr[tid] = 0xffffffffu; }
-    if (tid == 0) L.keys_pad[3] = KEY_SENTINEL;
-    __syncthreads();
-
-    // start - sbase >= 1 for every candidate (the index hands out whole 256-bp quanta below T0 - max_span + 1)
-    const uint32_t sbase = (uint32_t)T0 - (uint32_t)a.max_span - 2u - (uint32_t)IDX_Q;
-    const int32_t maxd = min(a.max_dist, 65535);
-    const bool do_pairs = do_lp && a.max_dist >= 0 && maxd >= a.min_dist;
-    uint32_t lp_c = 0, lp_d = 0, n_read = 0, n_valid = 0, bad = 0;
-
-    // P1 record of up to KR reads per thread, prefetched one chunk ahead
-    uint32_t f_o0[CALLS_KRMAX], f_o1[CALLS_KRMAX], f_mq[CALLS_KRMAX];
-    int32_t f_s[CALLS_KRMAX];
-    auto fetch = [&](const uint32_t rb) {
-#pragma unroll
-        for (int q = 0; q < CALLS_KRMAX; ++q) {
-            const uint32_t i = rb + (uint32_t)q * B + tid;
-            if ((uint32_t)q < KR && i < hi) {
-                f_o0[q] = a.cpg_off[i]; f_o1[q] = a.cpg_off[i + 1]; f_s[q] = a.read_start[i]; f_mq[q] = a.read_mapq[i];
-            } else {
-                f_o0[q] = 0; f_o1[q] = 0; f_s[q] = 0; f_mq[q] = 0;
-            }
-        }
-    };
-    uint32_t rb = lo, cb = cb0, c = 0;
-    fetch(rb);
-    while (rb < hi) {
-        const uint32_t buf = c & 1u;
-        const uint32_t rend = min(rb + KR * (uint32_t)B, hi);
-        // ---- P1: lane = read -----------------------------------------------------------------------
-#pragma unroll
-        for (int q = 0; q < CALLS_KRMAX; ++q) {
-            if ((uint32_t)q >= KR) break;
-            const uint32_t li = (uint32_t)q * B + tid, i = rb + li;
-            const bool valid = i < rend;
-            const uint32_t n = f_o1[q] - f_o0[q], x0 = f_o0[q] - cb, x1 = f_o1[q] - cb;
-            const bool fit = valid && x1 <= (uint32_t)C;
-            const unsigned long long bf = __ballot(fit), bn = __ballot(valid && !fit);
-            if (bf && lane == 63u - (uint32_t)__builtin_clzll(bf)) atomicMax(&L.sh_nc[buf], x1);           // calls of the chunk so far
-            if (bn && lane == (uint32_t)__builtin_ctzll(bn)) atomicMin(&L.sh_nr[buf], li);                 // first read that does not fit
-            const int32_t s = f_s[q];
-            const uint32_t mq = f_mq[q];
-            const bool owned = (s >= T0) && (s < T1);
-            const bool lp_ok = do_lp && owned && (mq >= a.lpmd_min_qual);                                  // lpmd.rs:176-179
-            if (fit && do_lp && owned) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
-            const bool pdr_ok = a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual);                 // pdr.rs:147-157
-            if (fit && n > 0) {
-                const uint32_t srel = (uint32_t)s - sbase;
-                bad |= (srel > 0x1fffu) ? 1u : 0u;
-                const uint32_t word = ((srel & 0x1fffu) << 3) | (lp_ok ? 2u : 0u) | (pdr_ok ? 1u : 0u);
-                L.hd[buf][x0] = (uint16_t)word;
-                for (uint32_t blk = (x0 >> 6) + 1; blk <= ((x1 - 1) >> 6); ++blk) L.carry[buf][blk] = ((x0 + 1) << 16) | word;
-            }
-        }
-        __syncthreads();                                                                                  // B1
-        const uint32_t nc = L.sh_nc[buf];
-        const uint32_t nr = min(L.sh_nr[buf], rend - rb);
-        if (nr == 0) { bad = 1; break; }                     // a read with more than C calls: the batch lied about max_span
-        const uint32_t rb_next = rb + nr, cb_next = cb + nc;
-        // ---- P2: lane = call -----------------------------------------------------------------------
-        const uint32_t K = (nc + B - 1) / B;
-        uint32_t cw[4], cr[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t j = (uint32_t)k * B + tid;
-            if ((uint32_t)k < K && j < nc) { cw[k] = a.cpg_pos[cb + j]; cr[k] = (uint32_t)rel[cb + j]; } else { cw[k] = 0; cr[k] = 0; }
-        }
-        fetch(rb_next);                                       // next chunk's read records: in flight during P2..P4
-        for (int i = tid; i < C / 2; i += B) reinterpret_cast<uint32_t *>(&L.hd[buf ^ 1u][0])[i] = 0u;
-        if (tid < C / 64) L.carry[buf ^ 1u][tid] = 0u;
-        uint32_t kq[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            kq[k] = 0;
-            if ((uint32_t)k >= K) break;
-            const uint32_t j = (uint32_t)k * B + tid;
-            const uint32_t h = L.hd[buf][j];
-            uint32_t sw = h ? (((j + 1) << 16) | h) : 0u;
-            const uint32_t cin = L.carry[buf][j >> 6];
-            if (lane == 0) sw = max(sw, cin);
-            sw = wave_scan_max(sw);
-            const uint32_t hpos = (sw >> 16) - 1u, srel = (sw >> 3) & 0x1fffu;
-            const uint32_t w = cw[k], pos = w & 0x7fffffffu;
-            const bool live = j < nc;
-            // every call within [start - 1, start - 1 + max_span]: what makes the halo complete (checked on the calls)
-            bad |= (live && (pos - sbase - srel + 1u > (uint32_t)a.max_span)) ? 1u : 0u;
-            const uint32_t key = (w & 0x80000000u) | (hpos << 17) | cr[k];
-            kq[k] = key | ((sw & 2u) ? 0u : 0x40000000u);    // bit 30: this call's read takes no part in LPMD
-            if (live) {
-                L.keys[j] = key;
-                L.sc[j] = min(pos - (uint32_t)P0, 0xffffu) | (hpos << 16);
-            }
-        }
-        __syncthreads();                                                                                  // B2
-        if (tid == 0) { L.sh_nc[buf] = 0u; L.sh_nr[buf] = 0xffffffffu; }
-        // ---- P3: lane = call, neighbours from LDS --------------------------------------------------
-        uint32_t *hd32 = reinterpret_cast<uint32_t *>(&L.hd[buf][0]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if ((uint32_t)k >= K) break;
-            const uint32_t j = (uint32_t)k * B + tid;
-            if (j < nc) {
-                const uint32_t me = kq[k];
-                uint32_t p = (&L.keys[0])[(int32_t)j - 1];    // j = 0 reads the sentinel in front of the array
-                const uint32_t x = me ^ p;
-                if (a.want_pdr && ((x & 0x3ffe0000u) == 0u) && (x >> 31)) {
-                    const uint32_t hpos = (me >> 17) & 0x1fffu;
-                    atomicOr(hd32 + (hpos >> 1), 4u << ((hpos & 1u) * 16u));
-                }
-                if (do_pairs) {
-                    uint32_t acc = 0;
-                    bool alive = true;
-                    for (uint32_t g = 1;; ++g) {
-                        if (alive) {
-                            const uint32_t d = me - p, td = d & 0x7fffffffu;
-                            alive = td <= (uint32_t)maxd;
-                            if (alive && (int32_t)td >= a.min_dist) acc += 1u + ((d >> 31) << 16);
-                        }
-                        if (!__any(alive)) break;
-                        if (alive) p = (&L.keys[0])[(int32_t)j - (int32_t)g - 1];
-                    }
-                    lp_c += (acc & 0xffffu) - (acc >> 16);
-                    lp_d += acc >> 16;
-                }
-            }
-        }
-        __syncthreads();                                                                                  // B3
-        // ---- P4: lane = call, permuted: lane l takes call l*S + m ----------------------------------
-        if (a.want_pdr) {
-            const uint32_t S = ((nc + 63u) >> 6) | 1u;
-            for (uint32_t m = wv; m < S; m += NW) {
-                const uint32_t jp = lane * S + m;
-                if (jp < nc) {
-                    const uint32_t v = L.sc[jp], pk = v & 0xffffu;
-                    const uint32_t h = L.hd[buf][v >> 16];
-                    if ((h & 1u) && pk < Wp) {
-                        if (!WIDE) atomicAdd(L.cnt + pk, (h & 4u) ? 0x10000u : 1u);
-                        else atomicAdd(L.cnt + pk + ((h & 4u) ? (uint32_t)(W / 2) : 0u), 1u);
-                    }
-                }
-            }
-        }
-        rb = rb_next; cb = cb_next; ++c;
-    }
-    if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
-    __syncthreads();
-    if (do_lp) tile_lpmd_partials<B>(a, t, L.red, lp_c, lp_d, n_read, n_valid);
-    __syncthreads();
-    if (!a.want_pdr) return 0u;
-    return tile_compact<W, B, WIDE>(a, t, P0, Wp, L.cnt, L.wave_off, out_base);
-}
-
-template <int W, int B, typename RelT>
-__global__ __launch_bounds__(B) void k_pdr_lpmd_calls(const TileArgs a, const uint32_t ntiles) {
-    __shared__ __attribute__((aligned(16))) CallsLds<W, B> L;
-    const uint32_t per_xcd = (ntiles + 7) / 8;
-    const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (t >= ntiles) return;
-    const int32_t T0 = a.region_beg + (int32_t)(t * W);
-    const int32_t T1 = (int32_t)min((int64_t)T0 + W, (int64_t)a.region_end);
-    const uint32_t lo = min(a.idx[((uint32_t)T0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
-    const uint32_t hi = min(a.idx[(((uint32_t)T0 + (uint32_t)W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
-    const uint32_t cb0 = a.cpg_off[lo], ce = a.cpg_off[hi];
-    // reads per thread and chunk: as many as keep a chunk's calls within ~90 % of C on this tile's call density
-    uint32_t KR = 1;
-    {
-        const uint32_t calls = ce - cb0, reads = max(hi - lo, 1u);
-        const uint64_t fit = ((uint64_t)(4 * B) * 9u / 10u) * reads / max(calls, 1u);     // reads that fill 90 % of a chunk
-        KR = (uint32_t)min<uint64_t>(max<uint64_t>(fit / B, 1u), (uint64_t)CALLS_KRMAX);
-    }
-    uint32_t rows;
-    if (hi - lo <= 65535u) {
-        rows = calls_pass<W, B, RelT, false>(a, L, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, cb0, KR, a.want_lpmd != 0, 0u);
-    } else {
-        const int32_t Tm = (int32_t)min((int64_t)T0 + W / 2, (int64_t)T1);
-        rows = calls_pass<W, B, RelT, true>(a, L, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, cb0, KR, a.want_lpmd != 0, 0u);
-        __syncthreads();
-        rows += calls_pass<W, B, RelT, true>(a, L, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, cb0, KR, false, rows);
-    }
-    if (threadIdx.x == 0) {
-        a.tile_cnt[t] = rows;
-        if (rows) atomicAdd(a.bucket + (t >> TILE_BUCKET_SHIFT), (unsigned long long)rows);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // One wave per tile.  base = cur_base + rows of the buckets before the tile's bucket + rows of the bucket's
 // earlier tiles (a few coalesced loads per lane, two wave reductions); then scratch -> final sorted SoA with
@@ -761,18 +505,6 @@ template <int W, int B, typename RelT>
 static void launch_tile(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
     const uint32_t grid = ((ntiles + 7) / 8) * 8;   // whole rows of 8 XCDs (remap in the kernel)
     hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT>), dim3(grid), dim3(B), 0, s, a, ntiles);
-}
-template <int W, int B, typename RelT>
-static void launch_calls(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
-    const uint32_t grid = ((ntiles + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_pdr_lpmd_calls<W, B, RelT>), dim3(grid), dim3(B), 0, s, a, ntiles);
-}
-// which form of the tile kernel a batch takes: lane = call whenever its reads are short enough for one chunk
-// (METHEOR_TILE_KERNEL=reads|calls overrides, for A/B timing and for running the test suite over both)
-static bool use_calls_kernel(const mth_batch_t &b) {
-    static const int forced = [] { const char *e = getenv("METHEOR_TILE_KERNEL"); return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'c' ? 2 : 0)); }();
-    if (b.max_span > CALLS_MAX_SPAN) return false;
-    return forced != 1;
 }
 
 // the linear read index alone (for kernels that find a tile's candidate reads without running the PDR/LPMD pass):
@@ -838,12 +570,9 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     a.min_dist = p.lpmd_min_distance; a.max_dist = p.lpmd_max_distance;
     a.pdr_min_qual = p.pdr_min_qual; a.lpmd_min_qual = p.lpmd_min_qual;
     a.want_pdr = p.want_pdr; a.want_lpmd = p.want_lpmd;
-    const bool r8 = b.cpg_rel != nullptr;
-    if (use_calls_kernel(b)) {
-        LaunchTimer lt(ctx, K_TILECALLS);
-        if (r8) launch_calls<4096, 256, uint8_t>(a, ntiles, s); else launch_calls<4096, 256, uint16_t>(a, ntiles, s);
-    } else {
+    {
         LaunchTimer lt(ctx, K_TILE);
+        const bool r8 = b.cpg_rel != nullptr;
         if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
     }
     {
