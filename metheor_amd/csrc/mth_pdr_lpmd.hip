@@ -284,7 +284,7 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         // checked on the calls themselves instead of trusting read_end): max over the live slots.
         const uint32_t sm1 = (uint32_t)(s - 1);
         const uint32_t dead_w = (((uint32_t)T0 + (1u << 28)) & 0x7fffffffu) | (v[0] & 0x80000000u);   // 2^28 bp past the tile
-        const uint32_t n_lp = (lp_ok && n <= (uint32_t)NB) ? n : 0u;   // pairs evaluated from the registers
+        const uint32_t n_lp = lp_ok ? min(n, (uint32_t)NB) : 0u;       // calls whose pairs are evaluated from the registers
         uint32_t acc = 0, xmax = (v[0] & 0x7fffffffu) - sm1;
 #pragma unroll
         for (int k = 1; k < NB; ++k) {
@@ -332,8 +332,11 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
             lp_c += lp_n - lp_dd;
             lp_d += lp_dd;
         }
-        if (any_long && lp_ok && n > (uint32_t)NB) {   // a read with more than NB calls: memory loop (divergent, rare)
-            for (uint32_t k = 1; k < n; ++k) {
+        // a read with more than NB calls: the pairs among its first NB calls were counted above from the registers; pairs
+        // whose LATER call is the (NB+1)-th or beyond come from memory (divergent, rare).  [This loop used to redo ALL
+        // pairs of such a read from memory: 0.24 % of config 2's reads cost 14 % of the kernel, tools/tile_tail_probe.py]
+        if (any_long && lp_ok && n > (uint32_t)NB) {
+            for (uint32_t k = NB; k < n; ++k) {
                 const int32_t rk = (int32_t)rel[o0 + k];
                 const uint32_t mk = a.cpg_pos[o0 + k] >> 31;
                 for (uint32_t j = k; j-- > 0;) {

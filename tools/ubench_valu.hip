@@ -13,9 +13,11 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { OP_ADD, OP_AND, OP_MIN, OP_BFE, OP_XOR, OP_CNDMASK, OP_LSHL_ADD, OP_ADD3, OP_DPP_ADD, OP_MAX_DPP, OP_MBCNT, OP_FMA, OP_CMP_ADDC,
+enum { OP_OR, OP_SUB, OP_LSHL, OP_LSHR, OP_CND_VCC, OP_CND_SGPR, OP_MAX, OP_CMP, OP_AND_OR, OP_LSHL_OR, OP_BCNT, OP_MOV, OP_MAD24, OP_DPP_NONOP, OP_MOV_DPP, OP_SDWA, OP_ADD, OP_AND, OP_MIN, OP_BFE, OP_XOR, OP_CNDMASK, OP_LSHL_ADD, OP_ADD3, OP_DPP_ADD, OP_MAX_DPP, OP_MBCNT, OP_FMA, OP_CMP_ADDC,
        OP_SUB_U16PK, OP_LDS_ADD_SPREAD, OP_LDS_ADD_SAME4, OP_LDS_ADD_SAME16, OP_LDS_READ, OP_LDS_WRITE, OP_READLANE, OP_N };
-static const char *op_name[OP_N] = {"v_add_u32", "v_and_b32", "v_min_u32", "v_bfe_u32", "v_xor_b32", "v_cndmask_b32", "v_lshl_add_u32", "v_add3_u32",
+static const char *op_name[OP_N] = {"v_or_b32", "v_sub_u32", "v_lshlrev_b32", "v_lshrrev_b32", "v_cndmask_b32 (vcc)", "v_cndmask_b32 e64 (sgpr mask)", "v_max_u32", "v_cmp_lt_u32 (to vcc)",
+                                     "v_and_or_b32", "v_lshl_or_b32", "v_bcnt_u32_b32", "v_mov_b32", "v_mad_u32_u24", "v_add_u32 dpp row_shr:1 (8 chains, no nop)", "v_mov_b32 dpp row_shr:1 (8 chains)", "v_add_u32 sdwa (WORD_1)",
+                                     "v_add_u32", "v_and_b32", "v_min_u32", "v_bfe_u32", "v_xor_b32", "v_cndmask_b32", "v_lshl_add_u32", "v_add3_u32",
                                      "v_add_u32 dpp row_shr:1", "v_max_u32 dpp row_shr:1", "v_mbcnt lo+hi (2 ops)", "v_fma_f32", "v_cmp_lt+v_addc (2 ops)",
                                      "v_pk_sub_u16", "ds_add_u32 64 distinct banks/addresses", "ds_add_u32 4 lanes per address", "ds_add_u32 16 lanes per address",
                                      "ds_read_b32", "ds_write_b32", "v_readlane_b32 (to SGPR)"};
@@ -34,12 +36,30 @@ __global__ __launch_bounds__(256) void k_ubench(uint32_t *out, int iters, uint32
     for (int c = 0; c < 8; ++c) f[c] = (float)(seed + c);
     const uint32_t b = seed | 1u;
     uint32_t sacc = 0;
+    const unsigned long long mask64 = 0x5555aaaa3333ccccull ^ seed;
+    asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(tid), "v"(b) : "vcc");   // a defined VCC for the cndmask rows
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                if constexpr (OP == OP_ADD) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
+                if constexpr (OP == OP_OR) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_SUB) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[c]));
+                else if constexpr (OP == OP_LSHR) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[c]));
+                else if constexpr (OP == OP_CND_VCC) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_CND_SGPR) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[c]) : "v"(b), "s"(mask64));
+                else if constexpr (OP == OP_MAX) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_CMP) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a[c]), "v"(b) : "vcc");
+                else if constexpr (OP == OP_AND_OR) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_BCNT) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_MAD24) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_DPP_NONOP) asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[c]));
+                else if constexpr (OP == OP_MOV_DPP) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[c]));
+                else if constexpr (OP == OP_SDWA) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(a[c]) : "v"(b));
+                else if constexpr (OP == OP_ADD) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
                 else if constexpr (OP == OP_AND) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
                 else if constexpr (OP == OP_MIN) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
                 else if constexpr (OP == OP_BFE) asm volatile("v_bfe_u32 %0, %0, 3, 17" : "+v"(a[c]));
@@ -101,6 +121,9 @@ int main() {
     const double ghz = p.clockRate * 1e-6;
     printf("device %s, %d CUs, clockRate %.3f GHz (cycles below assume that clock; DVFS may run lower)\n", p.gcnArchName, p.multiProcessorCount, ghz);
     uint32_t *d; CK(hipMalloc(&d, 4096));
+    run_all<OP_OR>(d, ghz); run_all<OP_SUB>(d, ghz); run_all<OP_LSHL>(d, ghz); run_all<OP_LSHR>(d, ghz); run_all<OP_CND_VCC>(d, ghz); run_all<OP_CND_SGPR>(d, ghz);
+    run_all<OP_MAX>(d, ghz); run_all<OP_CMP>(d, ghz); run_all<OP_AND_OR>(d, ghz); run_all<OP_LSHL_OR>(d, ghz); run_all<OP_BCNT>(d, ghz); run_all<OP_MOV>(d, ghz);
+    run_all<OP_MAD24>(d, ghz); run_all<OP_DPP_NONOP>(d, ghz); run_all<OP_MOV_DPP>(d, ghz); run_all<OP_SDWA>(d, ghz);
     run_all<OP_ADD>(d, ghz); run_all<OP_AND>(d, ghz); run_all<OP_MIN>(d, ghz); run_all<OP_BFE>(d, ghz); run_all<OP_XOR>(d, ghz);
     run_all<OP_CNDMASK>(d, ghz); run_all<OP_LSHL_ADD>(d, ghz); run_all<OP_ADD3>(d, ghz); run_all<OP_DPP_ADD>(d, ghz); run_all<OP_MAX_DPP>(d, ghz);
     run_all<OP_MBCNT>(d, ghz); run_all<OP_FMA>(d, ghz); run_all<OP_CMP_ADDC>(d, ghz); run_all<OP_SUB_U16PK>(d, ghz);
