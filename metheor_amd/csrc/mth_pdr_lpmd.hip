@@ -219,6 +219,34 @@ __device__ __forceinline__ void load_rel(const RelT *__restrict__ rp, int32_t (&
     }
 }
 
+// ---- per-slot liveness without compare + select (profiles/r02_ubench_valu.md: v_cmp, v_cndmask, v_min/max are half rate) ----
+// The live call slots of a read are a PREFIX (k < n), so everything that depends on "slot k is dead" is a function of n
+// alone and comes from two 9-row LDS tables (n = 0..8; built once per pass, 576 bytes):
+//   mtab[n][k]   0xffffffff if k < n else 0                       -> masks for the span check / dead-word insertion
+//   dtab[n][c]   relpos offsets of the packed fields (below) that push every dead slot 0x400 * (k + 1) past the live
+//                ones, so that any distance involving a dead slot is >= 0x400 - 255 and all distances stay >= 0
+// ---- windowed pair counts, two pairs per instruction (8-bit relpos) ----
+// Slots are packed two per register as 16-bit fields: Q_e = (slot 2e, slot 2e+1), O_e = (slot 2e+1, slot 2e+2), slot 8
+// being a dummy that is always dead.  The pairs at call-index gap g are then  later - earlier  with earlier = Q_m and
+// later = O_{(g-1)/2+m} (g odd) or Q_{g/2+m} (g even): one 32-bit subtraction gives two distances (no borrows: relpos
+// ascends with the slot, dead offsets ascend faster).  With A = D + (0x8000 - min) and B = (0x8000 + max) - D per
+// field, bit 15 of A & B says "min <= distance <= max"; the call states sit in bit 15 of a second set of packed words,
+// so one xor + and gives "in the window and discordant".  Only full-rate VALU ops (add / sub / and / xor / or / shift).
+struct SlotTabs {
+    uint32_t mtab[9][8];
+    uint32_t dtab[9][8];
+};
+__device__ __forceinline__ void slot_tabs_init(SlotTabs &T, const int tid) {
+    if (tid < 72) {
+        const uint32_t nn = (uint32_t)tid >> 3, c = (uint32_t)tid & 7u;
+        T.mtab[nn][c] = c < nn ? 0xffffffffu : 0u;
+        auto dead = [&](uint32_t k) { return k >= 8u ? 0x2400u : (k >= nn ? 0x400u * (k + 1u) : 0u); };
+        const uint32_t lo = c < 4 ? 2u * c : 2u * (c - 4u) + 1u;       // first slot of the packed register Q_c / O_(c-4)
+        T.dtab[nn][c] = dead(lo) | (dead(lo + 1u) << 16);
+    }
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   // v_bfi_b32
+
 // One pass of a tile over its candidate reads [lo, hi): LDS counters for the reference positions
 // [P0, P0 + Wp), then compaction.  do_lp: also the LPMD pair counts and read totals of the reads the tile owns
 // (first pass only).  Returns the number of rows the pass appended at scratch[out_base..].
@@ -226,11 +254,13 @@ template <int W, int B, int NB, typename RelT, bool WIDE, bool CLAMP>
 __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t t, const int32_t T0, const int32_t T1,
                                               const int32_t P0, const uint32_t Wp, const uint32_t lo, const uint32_t hi,
                                               const bool do_lp, const uint32_t out_base, uint32_t *cnt,
-                                              uint32_t (*red)[B / 64], uint32_t *wave_off) {
+                                              uint32_t (*red)[B / 64], uint32_t *wave_off, SlotTabs &tabs) {
     const int tid = threadIdx.x;
     const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
+    constexpr bool PACKED = sizeof(RelT) == 1 && NB == 8;      // the table / packed-field forms below (8-bit relpos)
     for (int i = tid; i < W / 4; i += B)
         reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
+    slot_tabs_init(tabs, tid);
     __syncthreads();
 
     uint32_t lp_c = 0, lp_d = 0, n_read = 0, n_valid = 0, bad = 0;
@@ -254,18 +284,23 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         // so neither instantiation merges two load paths inside the loop).
         uint32_t v[NB];
         int32_t r[NB];
+        uint32_t rraw0 = 0, rraw1 = 0;                         // PACKED, !CLAMP: the 8 relpos bytes as loaded
         const uint32_t *__restrict__ cp = a.cpg_pos + o0;
         const RelT *__restrict__ rp = rel + o0;
         // (distances between live calls are < 2^16, so capping max_distance keeps dead-slot differences outside)
-        const int32_t maxd = min(a.max_dist, 1 << 20);
-        const bool any_lp = maxd >= a.min_dist && __any(lp_ok && n > 1);   // min > max: no pair can qualify (and the range trick below would wrap)
+        const int32_t maxd = PACKED ? min(a.max_dist, 255) : min(a.max_dist, 1 << 20);   // 8-bit relpos: no distance beyond 255
+        const int32_t mind = max(a.min_dist, 0);
+        const bool any_lp = maxd >= a.min_dist && maxd >= 0 && __any(lp_ok && n > 1);   // min > max: no pair can qualify (and the range trick below would wrap)
         if (!CLAMP) {
 #pragma unroll
             for (int k4 = 0; k4 < NB / 4; ++k4) {
                 const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(cp + 4 * k4);
                 v[4 * k4] = x.x; v[4 * k4 + 1] = x.y; v[4 * k4 + 2] = x.z; v[4 * k4 + 3] = x.w;
             }
-            if (any_lp) load_rel<RelT, NB>(rp, r);
+            if (any_lp) {
+                if constexpr (PACKED) { const u32x2_a1 x = *reinterpret_cast<const u32x2_a1 *>(rp); rraw0 = x.x; rraw1 = x.y; }
+                else load_rel<RelT, NB>(rp, r);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < NB; ++k) v[k] = cp[min((uint32_t)k, n - 1)];
@@ -286,17 +321,33 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         const uint32_t dead_w = (((uint32_t)T0 + (1u << 28)) & 0x7fffffffu) | (v[0] & 0x80000000u);   // 2^28 bp past the tile
         const uint32_t n_lp = lp_ok ? min(n, (uint32_t)NB) : 0u;       // calls whose pairs are evaluated from the registers
         uint32_t acc = 0, xmax = (v[0] & 0x7fffffffu) - sm1;
+        if constexpr (PACKED) {
+            // masks of the live slots from the table row of n (rows 8.. are all-live): and / sub / and / bfi / xor per slot
+            const uint32_t nrow = min(n, 8u);
+            const uint4 ma = reinterpret_cast<const uint4 *>(&tabs.mtab[nrow][0])[0], mb = reinterpret_cast<const uint4 *>(&tabs.mtab[nrow][0])[1];
+            const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+            uint32_t xs[8];
+            xs[0] = xmax;
 #pragma unroll
-        for (int k = 1; k < NB; ++k) {
-            const bool live = (uint32_t)k < n;
-            const uint32_t x = (v[k] & 0x7fffffffu) - sm1;
-            xmax = max(xmax, live ? x : 0u);
-            v[k] = live ? v[k] : dead_w;
-            acc |= v[k] ^ v[0];
-        }
-        if (any_lp) {
+            for (int k = 1; k < 8; ++k) {
+                xs[k] = ((v[k] & 0x7fffffffu) - sm1) & mk[k];
+                v[k] = bfi(mk[k], v[k], dead_w);
+                acc |= v[k] ^ v[0];
+            }
+            xmax = max(max(max(xs[0], xs[1]), max(xs[2], xs[3])), max(max(xs[4], xs[5]), max(xs[6], xs[7])));
+        } else {
 #pragma unroll
-            for (int k = 0; k < NB; ++k) r[k] = ((uint32_t)k < n_lp) ? r[k] : (int32_t)((k + 1) << 24);
+            for (int k = 1; k < NB; ++k) {
+                const bool live = (uint32_t)k < n;
+                const uint32_t x = (v[k] & 0x7fffffffu) - sm1;
+                xmax = max(xmax, live ? x : 0u);
+                v[k] = live ? v[k] : dead_w;
+                acc |= v[k] ^ v[0];
+            }
+            if (any_lp) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) r[k] = ((uint32_t)k < n_lp) ? r[k] : (int32_t)((k + 1) << 24);
+            }
         }
         bad |= (xmax > (uint32_t)a.max_span) ? 1u : 0u;
         uint32_t disc = acc >> 31;
@@ -313,7 +364,56 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         // The calls are sorted by relpos, so the distance at call-index gap g+1 is >= the distance at gap g:
         // walk the pair matrix by diagonals g = 1, 2, .. and stop once NO lane of the wave has a pair
         // within max_distance on the current diagonal (wave-uniform break).
-        if (any_lp) {
+        if constexpr (PACKED) {
+            if (any_lp) {
+                // packed call states (bit 15 of each field; the other bits of the top bytes are ignored by the masks below)
+                uint32_t SQ[4], SO[4], Q[4], O[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) SQ[e] = __builtin_amdgcn_perm(v[2 * e + 1], v[2 * e], 0x070c030cu);
+#pragma unroll
+                for (int e = 0; e < 3; ++e) SO[e] = __builtin_amdgcn_perm(v[2 * e + 2], v[2 * e + 1], 0x070c030cu);
+                SO[3] = __builtin_amdgcn_perm(0u, v[7], 0x070c030cu);
+                if (!CLAMP) {
+                    Q[0] = __builtin_amdgcn_perm(0u, rraw0, 0x0c010c00u); Q[1] = __builtin_amdgcn_perm(0u, rraw0, 0x0c030c02u);
+                    Q[2] = __builtin_amdgcn_perm(0u, rraw1, 0x0c010c00u); Q[3] = __builtin_amdgcn_perm(0u, rraw1, 0x0c030c02u);
+                    O[0] = __builtin_amdgcn_perm(0u, rraw0, 0x0c020c01u); O[1] = __builtin_amdgcn_perm(rraw1, rraw0, 0x0c040c03u);
+                    O[2] = __builtin_amdgcn_perm(0u, rraw1, 0x0c020c01u); O[3] = __builtin_amdgcn_perm(0u, rraw1, 0x0c0c0c03u);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Q[e] = (uint32_t)r[2 * e] | ((uint32_t)r[2 * e + 1] << 16);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) O[e] = (uint32_t)r[2 * e + 1] | ((uint32_t)r[2 * e + 2] << 16);
+                    O[3] = (uint32_t)r[7];
+                }
+                {
+                    const uint4 da = reinterpret_cast<const uint4 *>(&tabs.dtab[n_lp][0])[0], db = reinterpret_cast<const uint4 *>(&tabs.dtab[n_lp][0])[1];
+                    Q[0] += da.x; Q[1] += da.y; Q[2] += da.z; Q[3] += da.w; O[0] += db.x; O[1] += db.y; O[2] += db.z; O[3] += db.w;
+                }
+                const uint32_t KA = (0x8000u - (uint32_t)mind) * 0x10001u, KB = (0x8000u + (uint32_t)maxd) * 0x10001u;
+                uint32_t accIN = 0, accDD = 0;
+#pragma unroll
+                for (int g = 1; g < 8; ++g) {
+                    uint32_t orB = 0;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int li = (g & 1) ? (g - 1) / 2 + m : g / 2 + m;      // index of the later operand in O (g odd) / Q (g even)
+                        if (li > 3) break;
+                        const uint32_t later = (g & 1) ? O[li] : Q[li], sl = (g & 1) ? SO[li] : SQ[li];
+                        const uint32_t D = later - Q[m];
+                        const uint32_t Bw = KB - D;
+                        const uint32_t IN = (D + KA) & Bw & 0x80008000u;               // min <= distance <= max (readutil.rs:184, 196)
+                        const uint32_t DD = IN & (sl ^ SQ[m]);
+                        accIN += IN >> 15;
+                        accDD += DD >> 15;
+                        orB |= Bw;
+                    }
+                    if (!__any((orB & 0x80008000u) != 0u)) break;      // no lane has a pair within max_distance on this diagonal
+                }
+                const uint32_t lp_n = (accIN & 0xffffu) + (accIN >> 16), lp_dd = (accDD & 0xffffu) + (accDD >> 16);
+                lp_c += lp_n - lp_dd;
+                lp_d += lp_dd;
+            }
+        } else if (any_lp) {
             const uint32_t span_ok = (uint32_t)(maxd - a.min_dist);
             uint32_t lp_n = 0, lp_dd = 0;
 #pragma unroll
@@ -408,10 +508,11 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
 // (packed).  Heavier tiles (deep amplicons) take two passes over their reads with 32-bit counters, each
 // covering half of the tile's positions -- same LDS footprint, no extra launch, exact.
 template <int W, int B, int NB, typename RelT>
-__global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
+__global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
     __shared__ __attribute__((aligned(16))) uint32_t cnt[W + B];   // counters, then one trash word per thread
     __shared__ uint32_t red[4][B / 64];
     __shared__ uint32_t wave_off[B / 64 + 1];
+    __shared__ __attribute__((aligned(16))) SlotTabs tabs;
 
     // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
     const uint32_t per_xcd = (ntiles + 7) / 8;
@@ -433,14 +534,14 @@ __global__ __launch_bounds__(B) void k_pdr_lpmd_tile(const TileArgs a, const uin
         // only a tile that holds the batch's last reads can have a read whose NB-slot window runs past the arrays
         const bool clamp = a.cpg_off[hi] + (uint32_t)NB > a.n_cpgs;   // cpg_off ascends: covers every read of [lo, hi)
         if (!clamp)
-            rows = tile_pass<W, B, NB, RelT, false, false>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
+            rows = tile_pass<W, B, NB, RelT, false, false>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
         else
-            rows = tile_pass<W, B, NB, RelT, false, true>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
+            rows = tile_pass<W, B, NB, RelT, false, true>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
     } else {
         const int32_t Tm = (int32_t)min((int64_t)T0 + W / 2, (int64_t)T1);
-        rows = tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off);
+        rows = tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
         __syncthreads();
-        rows += tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off);
+        rows += tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off, tabs);
     }
     if (threadIdx.x == 0) {
         a.tile_cnt[t] = rows;
@@ -576,7 +677,9 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     {
         LaunchTimer lt(ctx, K_TILE);
         const bool r8 = b.cpg_rel != nullptr;
-        if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
+        static const int tb = [] { const char *e = getenv("METHEOR_TILE_B"); return e ? atoi(e) : 256; }();
+        if (tb == 512) { if (r8) launch_tile<4096, 512, uint8_t>(a, ntiles, s); else launch_tile<4096, 512, uint16_t>(a, ntiles, s); }
+        else if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
     }
     {
         LaunchTimer lt(ctx, K_GATHER);
