@@ -677,9 +677,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     {
         LaunchTimer lt(ctx, K_TILE);
         const bool r8 = b.cpg_rel != nullptr;
-        static const int tb = [] { const char *e = getenv("METHEOR_TILE_B"); return e ? atoi(e) : 256; }();
-        if (tb == 512) { if (r8) launch_tile<4096, 512, uint8_t>(a, ntiles, s); else launch_tile<4096, 512, uint16_t>(a, ntiles, s); }
-        else if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
+        if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
     }
     {
         LaunchTimer lt(ctx, K_GATHER);
