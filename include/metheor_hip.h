@@ -273,7 +273,9 @@ int  mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *
                          uint32_t *n_runs, uint32_t *flags);
 /* reads [read_beg, read_end) of the decoded stream -- ONE contig's reads (or a region slice of them) -- as a
  * device-resident batch for the accumulate calls: 32-bit offsets rebased on the device, max_span reduced on
- * the device.  Valid until the next mth_decoded_batch / mth_decode_records call. */
+ * the device.  region_end < 0 = up to the last position these reads cover (reduced on the device too): what a
+ * whole-contig batch should pass -- the reference emits every site it sees, also past the header's LN.
+ * Valid until the next mth_decoded_batch / mth_decode_records call. */
 int  mth_decoded_batch(mth_ctx_t *ctx, uint64_t read_beg, uint64_t read_end, int32_t tid, int32_t region_beg,
                        int32_t region_end, mth_batch_t *batch);
 

@@ -243,7 +243,7 @@ struct Contig {
     const uint16_t *rel;
     size_t n_reads, n_cpgs;
     std::vector<uint32_t> off;
-    int32_t max_span = 0;
+    int32_t max_span = 0, max_end = -1;
     uint64_t r0 = 0, r1 = 0;   // device-decoded input: the contig's reads in the decoded stream
     // owned copies (only when filtering was needed)
     std::vector<int32_t> o_start, o_end;
@@ -477,7 +477,8 @@ Input load(const std::string &path, const char *cpg_set) {
             c.n_reads = (size_t)(e - i); c.n_cpgs = (size_t)(off[e] - off[i]);
             c.off.resize(c.n_reads + 1);
             int32_t ms = 0;
-            for (int64_t r = i; r < e; ++r) { c.off[(size_t)(r - i)] = (uint32_t)(off[r] - off[i]); ms = std::max(ms, en[r] - st[r] + 1); }
+            if (off[e] - off[i] >= (1ull << 32) || (uint64_t)(e - i) >= (1ull << 32) - 1) die("metheor (MI355X path): a contig with 2^32 or more reads / CpG calls does not fit one batch on the host-decode path");
+            for (int64_t r = i; r < e; ++r) { c.off[(size_t)(r - i)] = (uint32_t)(off[r] - off[i]); ms = std::max(ms, en[r] - st[r] + 1); c.max_end = std::max(c.max_end, en[r]); }
             c.off[c.n_reads] = (uint32_t)(off[e] - off[i]);
             c.max_span = ms;
         } else {
@@ -486,8 +487,10 @@ Input load(const std::string &path, const char *cpg_set) {
                 if (st[r] < 0) continue;                           // no aligned base: no CpG, no position
                 c.o_start.push_back(st[r]); c.o_end.push_back(en[r]); c.o_mapq.push_back(mq[r]);
                 for (uint64_t k = off[r]; k < off[r + 1]; ++k) { c.o_pos.push_back(pos[k]); c.o_rel.push_back(rel[k]); }
+                if (c.o_pos.size() >= (1ull << 32)) die("metheor (MI355X path): a contig with 2^32 or more CpG calls does not fit one batch on the host-decode path");
                 c.off.push_back((uint32_t)c.o_pos.size());
                 c.max_span = std::max(c.max_span, en[r] - st[r] + 1);
+                c.max_end = std::max(c.max_end, en[r]);
             }
             c.start = c.o_start.data(); c.end = c.o_end.data(); c.mapq = c.o_mapq.data(); c.pos = c.o_pos.data(); c.rel = c.o_rel.data();
             c.n_reads = c.o_start.size(); c.n_cpgs = c.o_pos.size();
@@ -501,17 +504,16 @@ mth_batch_t make_batch(const Input &in, const Contig &c) {
     mth_batch_t b;
     memset(&b, 0, sizeof b);
     if (in.device) {
-        const int64_t len = mth_host_ref_len(in.h, c.tid);
-        const int32_t end = c.region_end >= 0 ? c.region_end : (int32_t)std::min<int64_t>(len, INT32_MAX);
-        check(in.ctx, mth_decoded_batch(in.ctx, c.r0, c.r1, c.tid, c.region_beg, end, &b));
+        // a whole contig (or a shard's last piece of it) ends where its reads end, not at the header's LN:
+        // the reference has no notion of LN in this path and emits sites beyond it
+        check(in.ctx, mth_decoded_batch(in.ctx, c.r0, c.r1, c.tid, c.region_beg, c.region_end >= 0 ? c.region_end : -1, &b));
         if (g_shard.world > 1 && (int64_t)b.max_span + 202 > g_shard.halo)
             die("an alignment spans " + std::to_string(b.max_span) + " bp: set METHEOR_SHARD_HALO to at least " + std::to_string(b.max_span + 202));
         return b;
     }
     b.tid = c.tid;
     b.region_beg = 0;
-    const int64_t len = mth_host_ref_len(in.h, c.tid);
-    b.region_end = (int32_t)std::min<int64_t>(len, INT32_MAX);
+    b.region_end = (int32_t)std::min<int64_t>((int64_t)c.max_end + 2, INT32_MAX);      // to the end of the data, not the header's LN
     b.max_span = c.max_span;
     b.n_reads = (uint32_t)c.n_reads;
     b.n_cpgs = (uint32_t)c.n_cpgs;

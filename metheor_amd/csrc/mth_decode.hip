@@ -259,14 +259,16 @@ __global__ __launch_bounds__(256) void k_dec_rebase(const unsigned long long *__
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const unsigned long long c0 = off[r0];
     if (i <= n_reads) off32[i] = (uint32_t)(off[r0 + i] - c0);
-    uint32_t sp = 0;
+    uint32_t sp = 0, me = 0;
     if (i < n_reads) {
         const int32_t s = start[r0 + i], e = end[r0 + i];
         sp = (s >= 0 && e >= s) ? (uint32_t)(e - s + 1) : 0u;
+        me = e >= 0 ? (uint32_t)e + 1u : 0u;                 // max_span[1]: last covered position + 1 over the reads
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sp = max(sp, (uint32_t)__shfl_down(sp, o, 64));
+    for (int o = 32; o > 0; o >>= 1) { sp = max(sp, (uint32_t)__shfl_down(sp, o, 64)); me = max(me, (uint32_t)__shfl_down(me, o, 64)); }
     if ((threadIdx.x & 63) == 0 && sp) atomicMax(max_span, sp);
+    if ((threadIdx.x & 63) == 0 && me) atomicMax(max_span + 1, me);
 }
 
 // contig runs of the decoded stream: every i where tid changes opens a run (appended through an atomic counter, sorted by
@@ -472,18 +474,22 @@ int mth_decoded_batch(mth_ctx_t *ctx, uint64_t read_beg, uint64_t read_end, int3
     hipStream_t s = ctx->stream;
     MTH_HIP(ctx, ctx->dec_off32.reserve((size_t)(n + 1) * 4 + 16, s));
     uint32_t *d_span = ctx->dec_off32.as<uint32_t>() + n + 1;
-    MTH_HIP(ctx, hipMemsetAsync(d_span, 0, 4, s));
+    MTH_HIP(ctx, hipMemsetAsync(d_span, 0, 8, s));
     hipLaunchKernelGGL(k_dec_rebase, dim3((uint32_t)((n + 1 + 255) / 256)), dim3(256), 0, s, ctx->dec_off.as<unsigned long long>(),
                        read_beg, (uint32_t)n, ctx->dec_start.as<int32_t>(), ctx->dec_end.as<int32_t>(),
                        ctx->dec_off32.as<uint32_t>(), d_span);
-    uint32_t span = 0;
+    uint32_t span_end[2] = {0, 0};
     unsigned long long c01[2] = {0, 0};
-    MTH_HIP(ctx, hipMemcpyAsync(&span, d_span, 4, hipMemcpyDeviceToHost, s));
+    MTH_HIP(ctx, hipMemcpyAsync(span_end, d_span, 8, hipMemcpyDeviceToHost, s));
     MTH_HIP(ctx, hipMemcpyAsync(&c01[0], ctx->dec_off.as<unsigned long long>() + read_beg, 8, hipMemcpyDeviceToHost, s));
     MTH_HIP(ctx, hipMemcpyAsync(&c01[1], ctx->dec_off.as<unsigned long long>() + read_end, 8, hipMemcpyDeviceToHost, s));
     MTH_HIP(ctx, hipStreamSynchronize(s));
     if (c01[1] - c01[0] >= (1ull << 32)) return fail(ctx, MTH_ERR_CAPACITY, "batch of more than 2^32 CpG calls: split the contig into regions");
     mth_batch_t b{};
+    const uint32_t span = span_end[0];
+    // region_end < 0: to the end of the DATA -- one past the last position a call of these reads can have (a reverse
+    // read reports start - 1 <= end), whatever the header's LN says: the reference emits every site it sees
+    if (region_end < 0) region_end = (int32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)span_end[1] + 1u, (uint64_t)std::max(region_beg, 0)), (uint64_t)INT32_MAX);
     b.tid = tid; b.region_beg = region_beg; b.region_end = region_end; b.max_span = (int32_t)span;
     b.n_reads = (uint32_t)n; b.n_cpgs = (uint32_t)(c01[1] - c01[0]); b.mem = MTH_MEM_DEVICE;
     b.read_start = ctx->dec_start.as<int32_t>() + read_beg; b.read_end = ctx->dec_end.as<int32_t>() + read_beg;

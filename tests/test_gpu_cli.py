@@ -400,3 +400,28 @@ def test_output_validation_cases(golden_dir, tmp_path, k):
         assert r.returncode == 0, r.stderr
         assert o.read_text() == site(t)
         assert all(0.0 <= float(x.split("\t")[3]) <= 1.0 for x in o.read_text().splitlines())
+
+
+def test_sites_beyond_header_LN_are_emitted(tmp_path):
+    """a reheadered / short-LN BAM: the reference never looks at LN in this path and emits every site it sees
+    (the batches used to end at LN and drop the rest silently) -- device and host load paths, all measures"""
+    from metheor_amd import synth
+    c = synth.make_contig(0, 60_000, 4000, 0.04, np.random.default_rng(5))
+    rec = util.contig_to_records(c, "shortLN")
+    rec.refs = [("shortLN", 9_000)]                      # most of the reads lie beyond it
+    raw_bam, bam = str(tmp_path / "u.bam"), str(tmp_path / "a.bam")
+    bamio.write_bam(raw_bam, rec)
+    reblock_aligned(raw_bam, bam)
+    reads = pyoracle.Reads.decode(rec)
+    for sub, extra in (("pdr", ["-d", "3", "-p", "1"]), ("lpmd", []), ("mhl", ["-d", "3", "-p", "1"]), ("pm", ["-d", "2"]), ("fdrp", ["-d", "3"])):
+        want, want_pairs = util.oracle_text(reads, ["shortLN"], sub, input_name=bam, **util.oracle_kwargs(sub, extra))
+        for env in ({}, {"METHEOR_HOST_DECODE": "1"}):
+            o, pf = tmp_path / "o.tsv", tmp_path / "p.tsv"
+            args = [sub, "-i", bam, "-o", str(o)] + extra + (["-p", str(pf)] if sub == "lpmd" else [])
+            r = run_env(env, *args)
+            assert r.returncode == 0, r.stderr
+            util.assert_tsv_equals_oracle(sub, o.read_text(), want)
+            if sub == "lpmd":
+                assert pf.read_text() == want_pairs
+        if sub == "pdr":
+            assert max(int(l.split("\t")[1]) for l in want.splitlines()) > 50_000
