@@ -248,6 +248,11 @@ int  mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const
  * enabled != 0 with n_keys == 0 is the empty set (every call dropped, as HashSet::contains on an empty set);
  * enabled == 0 removes the filter.  Applies to the following mth_decode_records / mth_bgzf_decode calls. */
 int  mth_decode_set_cpg_filter(mth_ctx_t *ctx, const uint64_t *keys_sorted, uint64_t n_keys, int enabled);
+/* lpmd applies its mapq filter BEFORE BismarkRead::new (lpmd.rs:176-181): a record without XM:Z that the filter skips never
+ * panics there.  Records without XM:Z whose mapq is below min_mapq are decoded with zero calls instead of raising
+ * MTH_ERR_FORMAT (default 0: every such record is an error, as in the other six measures).  Applies to the following
+ * mth_decode_records / mth_bgzf_decode calls. */
+int  mth_decode_set_xm_min_mapq(mth_ctx_t *ctx, uint32_t min_mapq);
 /* the inflate step alone: inflated bytes of the given blocks, concatenated, copied to dst_host (may be NULL); *n_out = size.
  * The 4 bytes after each payload (the gzip trailer's CRC32) must lie inside the file bytes given: they are verified. */
 int  mth_bgzf_inflate(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,

@@ -47,6 +47,9 @@ int  mth_host_ref_tid(const mth_host_t *h, const char *name);   /* -1 if unknown
 
 /* Decode ALL remaining records of the file into one SoA held by the handle, in file order.
  * cpg_set_path may be NULL.  After success the arrays below are valid until close/decode. */
+/* lpmd.rs:176-181 filters on mapq BEFORE BismarkRead::new: records without XM:Z below min_mapq are decoded with zero calls
+ * instead of failing the decode (default 0: every record without XM:Z is an error, readutil.rs:46) */
+int  mth_host_set_xm_min_mapq(mth_host_t *h, int min_mapq);
 int  mth_host_decode(mth_host_t *h, const char *cpg_set_path);
 /* Streaming alternative to mth_host_decode for a device-side record decode (mth_decode_records in metheor_hip.h):
  * BGZF inflate (host threads) and the sequential walk over the records' block_size fields (bamutil.rs:4-11's

@@ -218,7 +218,7 @@ Args parse_args(const Cmd &c, int argc, char **argv, int first) {
 // unsharded file.  The only exchange is the RCCL all-reduce of the four LPMD counters (mth_allreduce_lpmd).
 // METHEOR_SHARD_HALO: bp of reads loaded before the interval (default 65536; must cover the longest alignment + FDRP's
 // 201-bp window, checked).
-struct Shard { int rank = 0, world = 1, device = 0; int64_t halo = 65536; mth_host_shard_t plan; };
+struct Shard { int rank = 0, world = 1, device = 0; int64_t halo = 65536; mth_host_shard_t plan; int xm_min_mapq = 0; };
 thread_local Shard g_shard;
 
 // what one shard contributes to the output files (filled through open_memstream when world > 1)
@@ -392,6 +392,7 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
     }
     in.ctx = cf.get();
     if (cpg_set) check(in.ctx, mth_decode_set_cpg_filter(in.ctx, keys, n_keys, 1));
+    check(in.ctx, mth_decode_set_xm_min_mapq(in.ctx, (uint32_t)g_shard.xm_min_mapq));
     const bool on_device = !getenv("METHEOR_HOST_INFLATE") && load_bgzf_on_device(in);
     if (!on_device && g_shard.world > 1) die("--gpus N needs the device load path (a coordinate-sorted BAM whose records do not straddle BGZF blocks)");
     if (!on_device) {
@@ -453,6 +454,7 @@ Input load(const std::string &path, const char *cpg_set) {
     }
     {
         Phase ph("  host decode (BGZF+BAM+XM)");
+        mth_host_set_xm_min_mapq(in.h, g_shard.xm_min_mapq);
         if (mth_host_decode(in.h, cpg_set) != 0) die(mth_host_last_error(in.h));
     }
     Phase ph2("  contig batches");
@@ -643,6 +645,7 @@ int run_lpmd(const Args &a) {
     const int32_t mind = (int32_t)a.n.at("min-distance"), maxd = (int32_t)a.n.at("max-distance");
     // lpmd.rs:161-164
     fprintf(stderr, "Computing subset-LPMD with parameters input=%s, min_distance=%d, max_distance=%d\n", input.c_str(), mind, maxd);
+    g_shard.xm_min_mapq = (int)a.n.at("min-qual");      // lpmd.rs:176-181: the mapq filter comes before BismarkRead::new (the XM panic)
     Input in = load(input, a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
     mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_pdr_lpmd_params_t p;

@@ -39,6 +39,7 @@ struct mth_host : DecodedSoA {
     size_t header_bytes = 0;
     std::unique_ptr<BgzfMap> bgzf;
     std::vector<uint64_t> cpg_keys;
+    int xm_min_mapq = 0;             // mth_host_set_xm_min_mapq
 };
 
 namespace {
@@ -103,6 +104,12 @@ int mth_host_ref_tid(const mth_host_t *h, const char *name) {
     return it == h->name2tid.end() ? -1 : it->second;
 }
 
+int mth_host_set_xm_min_mapq(mth_host_t *h, int min_mapq) {
+    if (!h) return MTH_HOST_ERR_INVALID;
+    h->xm_min_mapq = min_mapq;
+    return MTH_HOST_OK;
+}
+
 int mth_host_decode(mth_host_t *h, const char *cpg_set_path) {
     if (!h) return MTH_HOST_ERR_INVALID;
     h->tid.clear(); h->start.clear(); h->end.clear(); h->mapq.clear(); h->fwd.clear();
@@ -123,7 +130,7 @@ int mth_host_decode(mth_host_t *h, const char *cpg_set_path) {
     if (const char *e = getenv("METHEOR_THREADS")) { const int k = atoi(e); if (k >= 1 && k <= 1024) nthreads = k; }
     std::string err;
     int kind = 0;
-    if (!parallel_decode(h->path, h->header_bytes, have_set ? &target : nullptr, nthreads, *h, err, kind)) {
+    if (!parallel_decode(h->path, h->header_bytes, have_set ? &target : nullptr, nthreads, *h, err, kind, nullptr, h->xm_min_mapq)) {
         if (kind == 2) { h->last_error = err; return MTH_HOST_ERR_XM; }
         h->last_error = "Error reading BAM record. " + err;
         return MTH_HOST_ERR_FORMAT;

@@ -139,7 +139,7 @@ int find_xm(const uint8_t *aux, uint32_t len, const char *&xm, uint32_t &xm_len)
 
 // one record (p points at the 32-byte fixed part, len = block_size) -> appended to the piece
 // returns 0 ok, 1 corrupt, 2 no XM
-int decode_record(const uint8_t *p, uint32_t len, const std::unordered_set<uint64_t> *target, Piece &out) {
+int decode_record(const uint8_t *p, uint32_t len, const std::unordered_set<uint64_t> *target, int xm_min_mapq, Piece &out) {
     const int32_t tid = read_i32(p), pos = read_i32(p + 4);
     const uint32_t l_read_name = p[8], n_cigar = read_u16(p + 12), l_seq = read_u32(p + 16);
     const uint8_t mapq = p[9];
@@ -149,7 +149,10 @@ int decode_record(const uint8_t *p, uint32_t len, const std::unordered_set<uint6
     if (o_aux > len) return 1;
     const char *xm = nullptr;
     uint32_t xm_len = 0;
-    if (find_xm(p + o_aux, (uint32_t)(len - o_aux), xm, xm_len) != 0) return 2;
+    if (find_xm(p + o_aux, (uint32_t)(len - o_aux), xm, xm_len) != 0) {
+        if ((int)mapq >= xm_min_mapq) return 2;
+        xm = nullptr; xm_len = 0;                  // lpmd.rs:176-181: skipped by the mapq filter before BismarkRead::new -> no calls
+    }
     const bool forward = flag == 0 || flag == 99 || flag == 147;   // readutil.rs:332
     int32_t first = -1, last = -1;
     int64_t r = pos;
@@ -232,7 +235,7 @@ bool bgzf_map(const std::string &path, BgzfMap &out, std::string &err) {
 }
 
 bool parallel_decode(const std::string &path, size_t header_bytes, const std::unordered_set<uint64_t> *target,
-                     int nthreads, DecodedSoA &out, std::string &err, int &err_kind, const WindowSink *sink) {
+                     int nthreads, DecodedSoA &out, std::string &err, int &err_kind, const WindowSink *sink, int xm_min_mapq) {
     err_kind = 0;
     Stopwatch sw;
     const int fd = open(path.c_str(), O_RDONLY);
@@ -379,7 +382,7 @@ bool parallel_decode(const std::string &path, size_t header_bytes, const std::un
             const size_t r0 = nrec * (size_t)t / (size_t)nt, r1 = nrec * (size_t)(t + 1) / (size_t)nt;
             for (size_t r = r0; r < r1; ++r) {
                 const uint8_t *q = buf + rec_off[r];
-                const int rc = decode_record(q + 4, (uint32_t)read_i32(q), target, pc);
+                const int rc = decode_record(q + 4, (uint32_t)read_i32(q), target, xm_min_mapq, pc);
                 if (rc == 1) { corrupt = 1; return; }
                 if (rc == 2) { xm_missing = 1; return; }
             }

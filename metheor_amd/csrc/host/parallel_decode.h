@@ -35,6 +35,7 @@ bool bgzf_map(const std::string &path, BgzfMap &out, std::string &err);
 // header_bytes: uncompressed size of the BAM header (records start right after it).
 // target: --cpg-set keys (tid << 32 | pos) or nullptr.  err_kind: 1 format/IO, 2 record without XM.
 bool parallel_decode(const std::string &path, size_t header_bytes, const std::unordered_set<uint64_t> *target,
-                     int nthreads, DecodedSoA &out, std::string &err, int &err_kind, const WindowSink *sink = nullptr);
+                     int nthreads, DecodedSoA &out, std::string &err, int &err_kind, const WindowSink *sink = nullptr,
+                     int xm_min_mapq = 0 /* records without XM:Z are an error from this mapq up */);
 
 }  // namespace mthh

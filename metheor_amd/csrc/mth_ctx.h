@@ -46,6 +46,7 @@ struct mth_ctx {
     // device-side BAM record decode (mth_decode.hip): staged input, decoded SoA, scan scratch, one batch's 32-bit offsets
     mth::DevBuf dec_raw, dec_recoff, dec_tid, dec_start, dec_end, dec_mapq, dec_fwd, dec_n, dec_off, dec_pos, dec_rel, dec_blk, dec_off32, dec_runs, dec_xm, dec_filter;
     bool dec_filter_on = false;
+    uint32_t dec_xm_min_mapq = 0;       // records without XM:Z are an error from this mapq up (0: always)
     uint64_t dec_filter_n = 0;
     uint64_t dec_reads = 0, dec_cpgs = 0;
     // device-side BGZF inflate + per-block record walk (mth_inflate.hip)

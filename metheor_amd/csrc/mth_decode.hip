@@ -33,6 +33,7 @@ struct DecArgs {
     uint32_t *err;                // DevState.err
     const unsigned long long *filt;   // --cpg-set: sorted keys tid << 32 | pos, or nullptr (no filter)
     uint64_t n_filt;
+    uint32_t xm_min_mapq;         // a record WITHOUT XM:Z is an error only if its mapq >= this (lpmd.rs:176-181 filters on mapq first)
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -127,8 +128,11 @@ __global__ __launch_bounds__(256) void k_decode(const DecArgs a) {
         } else {
             have_xm = dev_find_xm(p + o_aux, (uint32_t)(len - o_aux), xm, xm_len);
             a.xm_loc[i] = have_xm ? make_uint2((uint32_t)(xm - p), xm_len) : make_uint2(0u, 0u);
-            if (!have_xm) atomicOr(a.err, (uint32_t)ERRB_NOXM);   // readutil.rs:46: the reference panics without XM
+            // readutil.rs:46: the reference panics without XM -- in every measure but lpmd for every record, in lpmd only
+            // for records that pass its mapq filter (lpmd.rs:176-181 skips the others before BismarkRead::new)
+            if (!have_xm && (uint32_t)mapq >= a.xm_min_mapq) atomicOr(a.err, (uint32_t)ERRB_NOXM);
         }
+        if (!bad && !have_xm) { xm = p; xm_len = 0; have_xm = true; }   // (tolerated, or reported above) no calls; start / end from the CIGAR
         if (!bad && have_xm) {
             const bool forward = flag == 0u || flag == 99u || flag == 147u;   // readutil.rs:332
             fwd = forward ? 1 : 0;
@@ -338,6 +342,7 @@ int decode_core(mth_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_off, uint6
     a.tid = ctx->dec_tid.as<int32_t>() + R0; a.start = ctx->dec_start.as<int32_t>() + R0; a.end = ctx->dec_end.as<int32_t>() + R0;
     a.mapq = ctx->dec_mapq.as<uint8_t>() + R0; a.fwd = ctx->dec_fwd.as<uint8_t>() + R0; a.ncpg = ctx->dec_n.as<uint32_t>(); a.xm_loc = ctx->dec_xm.as<uint2>();
     a.err = &ctx->d_state->err;
+    a.xm_min_mapq = ctx->dec_xm_min_mapq;
     a.filt = ctx->dec_filter_on ? ctx->dec_filter.as<unsigned long long>() : nullptr; a.n_filt = ctx->dec_filter_n;
     if (ctx->dec_filter_on && ctx->dec_filter_n == 0) a.filt = reinterpret_cast<const unsigned long long *>(ctx->d_state);   // empty set: drops every call
     unsigned long long total = 0;
@@ -408,6 +413,12 @@ int mth_decode_set_cpg_filter(mth_ctx_t *ctx, const uint64_t *keys_sorted, uint6
         MTH_HIP(ctx, hipMemcpyAsync(ctx->dec_filter.p, keys_sorted, (size_t)n_keys * 8, hipMemcpyHostToDevice, ctx->stream));
         MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return MTH_OK;
+}
+
+int mth_decode_set_xm_min_mapq(mth_ctx_t *ctx, uint32_t min_mapq) {
+    if (!ctx) return MTH_ERR_INVALID;
+    ctx->dec_xm_min_mapq = min_mapq;
     return MTH_OK;
 }
 

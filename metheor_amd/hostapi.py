@@ -9,7 +9,7 @@ _LIB = None
 
 SYMBOLS = [
     "mth_host_open", "mth_host_close", "mth_host_last_error", "mth_host_n_refs", "mth_host_ref_name",
-    "mth_host_ref_len", "mth_host_ref_tid", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
+    "mth_host_ref_len", "mth_host_ref_tid", "mth_host_set_xm_min_mapq", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
     "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
     "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32", "mth_host_write_synthetic_bam",
     "mth_host_write_synthetic_bam_multi",

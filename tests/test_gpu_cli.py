@@ -425,3 +425,27 @@ def test_sites_beyond_header_LN_are_emitted(tmp_path):
                 assert pf.read_text() == want_pairs
         if sub == "pdr":
             assert max(int(l.split("\t")[1]) for l in want.splitlines()) > 50_000
+
+
+def test_lpmd_filters_mapq_before_xm(golden_dir, tmp_path):
+    """lpmd.rs:176-181: `if r.mapq() < min_qual { continue; }` comes BEFORE BismarkRead::new, so a low-mapq record without
+    XM:Z is skipped there, while every other measure constructs BismarkRead first and panics (readutil.rs:46).  ADVICE r01."""
+    rec = bamio.read_bam(os.path.join(golden_dir, "test1.bam"))
+    rec.mapq = np.array(rec.mapq).copy()
+    rec.mapq[3] = 3
+    xm3 = rec.xms[3]
+    rec.xms[3] = None
+    raw_bam, bam = str(tmp_path / "u.bam"), str(tmp_path / "noxm.bam")
+    bamio.write_bam(raw_bam, rec)
+    reblock_aligned(raw_bam, bam)
+    rec.xms[3] = xm3                                     # the oracle never looks at a read its mapq filter drops
+    reads = pyoracle.Reads.decode(rec)
+    for env in ({}, {"METHEOR_HOST_DECODE": "1"}):
+        o = tmp_path / "o.tsv"
+        r = run_env(env, "lpmd", "-i", bam, "-o", str(o), "-q", "10")
+        assert r.returncode == 0, r.stderr
+        assert o.read_text() == util.oracle_tsv_lpmd(reads, bam, min_qual=10)
+        r = run_env(env, "lpmd", "-i", bam, "-o", str(o), "-q", "2")          # now the record passes the filter: BismarkRead::new panics
+        assert r.returncode == 101 and "Error reading XM tag in BAM record" in r.stderr
+        r = run_env(env, "pdr", "-i", bam, "-o", str(o), "-q", "10", "-d", "0", "-p", "0")
+        assert r.returncode == 101 and "Error reading XM tag in BAM record" in r.stderr
