@@ -91,6 +91,12 @@ typedef struct {
     int32_t  tid_end, pos_end;
 } mth_host_shard_t;
 int  mth_host_plan_shard(mth_host_t *h, int rank, int world, int64_t halo_bp, mth_host_shard_t *out);
+/* The same kind of plan from the BAM index (.bai, SAM spec 5.2; SURVEY 8(f).2 -- the reference's fixtures ship
+ * tests/test{1..6}.bam.bai, its reader bamutil.rs:4-11 never opens them): the BGZF blocks that can hold records overlapping
+ * [beg - halo_bp, end] of reference `tid`, and the owned interval [(tid, beg), (tid, end)).  bai_path NULL: <bam>.bai, then
+ * <bam without .bam>.bai.  MTH_HOST_ERR_OPEN without an index, MTH_HOST_ERR_FORMAT for one that is not this file's. */
+int  mth_host_plan_region(mth_host_t *h, const char *bai_path, int32_t tid, int32_t beg, int32_t end, int64_t halo_bp,
+                          mth_host_shard_t *out);
 int64_t mth_host_n_reads(const mth_host_t *h);
 int64_t mth_host_n_cpgs(const mth_host_t *h);
 const int32_t  *mth_host_read_tid(const mth_host_t *h);

@@ -46,6 +46,9 @@ const Opt O_IN = {"input", 'i', "INPUT", "Input BAM file", nullptr, true, 's'};
 const Opt O_CPG = {"cpg-set", 'c', "CPG_SET", "(Optional) Specify a predefined set of CpGs (in BED file) to be analyzed", nullptr, false, 's'};
 // not in the reference (outer row): one run split over the GPUs of the node by genomic region
 const Opt O_GPUS = {"gpus", 'G', "GPUS", "(MI355X extension) Number of GPUs to split the run over, by genomic region", "1", false, 'U'};
+// not in the reference either: the .bai files its fixtures ship finally get a reader
+const Opt O_REGION = {"region", 'r', "REGION", "(MI355X extension) Only this region: chr or chr:beg-end (1-based, inclusive); needs the BAM index", nullptr, false, 's'};
+const Opt O_BAI = {"bai", 'b', "BAI", "(MI355X extension) BAM index for --region [default: <input>.bai]", nullptr, false, 's'};
 
 // lib.rs:24-231
 const std::vector<Cmd> &commands() {
@@ -54,41 +57,41 @@ const std::vector<Cmd> &commands() {
          {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of PDR calculation", nullptr, true, 's'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG stretches to consider", "10", false, 'U'},
           {"min-cpgs", 'p', "MIN_CPGS", "Minimum number of consecutive CpGs in a CpG stretch to consider", "4", false, 'Z'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS, O_REGION, O_BAI}},
         {"pm", "Compute epipolymorphism",
          {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of PM calculation", nullptr, true, 's'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG quartets to consider", "10", false, 'U'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS, O_REGION, O_BAI}},
         {"me", "Compute methylation entropy",
          {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of PDR calculation", nullptr, true, 's'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG quartets to consider", "10", false, 'U'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS, O_REGION, O_BAI}},
         {"fdrp", "Compute fraction of discordant read pairs (FDRP)",
          {{"input", 'i', "INPUT", "Path to input BAM file", nullptr, true, 's'},
           {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of FDRP calculation", nullptr, true, 's'},
           {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum number of reads mapped to a CpG in order to be considered", "10", false, 'Z'},
           {"max-depth", 'D', "MAX_DEPTH", "Maximum number of reads to consider", "40", false, 'Z'},
-          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG, O_GPUS}},
+          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG, O_GPUS, O_REGION, O_BAI}},
         {"qfdrp", "Compute quantitative fraction of discordant read pairs (qFDRP)",
          {{"input", 'i', "INPUT", "Path to input BAM file", nullptr, true, 's'},
           {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of FDRP calculation", nullptr, true, 's'},
           {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum number of reads mapped to a CpG in order to be considered", "10", false, 'Z'},
           {"max-depth", 'D', "MAX_DEPTH", "Maximum number of reads to consider", "40", false, 'Z'},
-          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG, O_GPUS}},
+          {"min-overlap", 'l', "MIN_OVERLAP", "Minimum overlap between two reads to consider in bp", "35", false, 'I'}, O_CPG, O_GPUS, O_REGION, O_BAI}},
         {"mhl", "Compute methylation haplotype load (MHL)",
          {O_IN, {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of MHL calculation", nullptr, true, 's'},
           {"min-depth", 'd', "MIN_DEPTH", "Minimum depth of CpG stretches to consider", "10", false, 'U'},
           {"min-cpgs", 'p', "MIN_CPGS", "Minimum number of consecutive CpGs in a CpG stretch to consider", "4", false, 'Z'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS, O_REGION, O_BAI}},
         {"lpmd", "Compute local pairwise methylation discordance (LPMD)",
          {{"input", 'i', "INPUT", "Path to input BAM file", nullptr, true, 's'},
           {"output", 'o', "OUTPUT", "Path to output table file summarizing the result of LPMD calculation", nullptr, true, 's'},
           {"pairs", 'p', "PAIRS", "(Optional) Concordance information for all CpG pairs", nullptr, false, 's'},
           {"min-distance", 'm', "MIN_DISTANCE", "Minimum distance between CpG pairs to consider", "2", false, 'I'},
           {"max-distance", 'M', "MAX_DISTANCE", "Maximum distance between CpG pairs to consider", "16", false, 'I'},
-          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS}},
+          {"min-qual", 'q', "MIN_QUAL", "Minimum quality for a read to be considered", "10", false, 'B'}, O_CPG, O_GPUS, O_REGION, O_BAI}},
         {"tag", "Add bismark XM tag to BAM file",
          {{"input", 'i', "INPUT", "", nullptr, true, 's'}, {"output", 'o', "OUTPUT", "", nullptr, true, 's'},
           {"genome", 'g', "GENOME", "", nullptr, true, 's'}}},
@@ -218,7 +221,17 @@ Args parse_args(const Cmd &c, int argc, char **argv, int first) {
 // unsharded file.  The only exchange is the RCCL all-reduce of the four LPMD counters (mth_allreduce_lpmd).
 // METHEOR_SHARD_HALO: bp of reads loaded before the interval (default 65536; must cover the longest alignment + FDRP's
 // 201-bp window, checked).
-struct Shard { int rank = 0, world = 1, device = 0; int64_t halo = 65536; mth_host_shard_t plan; int xm_min_mapq = 0; };
+struct Shard {
+    int rank = 0, world = 1, device = 0;
+    int64_t halo = 65536;
+    mth_host_shard_t plan;
+    int xm_min_mapq = 0;
+    // --region chr[:beg-end]: the plan comes from the .bai (mth_host_plan_region) instead of a byte-range cut
+    bool region = false;
+    std::string region_name, bai;
+    int32_t r_beg = 0, r_end = INT32_MAX;          // 0-based [r_beg, r_end); INT32_MAX = to the end of the contig's data
+    bool planned() const { return world > 1 || region; }
+};
 thread_local Shard g_shard;
 
 // what one shard contributes to the output files (filled through open_memstream when world > 1)
@@ -343,8 +356,13 @@ bool load_bgzf_on_device(Input &in) {
     mth_host_bgzf_t bz;
     if (mth_host_bgzf_blocks(in.h, &bz) != 0) die(mth_host_last_error(in.h));
     uint64_t blk_beg = 0;
-    if (g_shard.world > 1) {      // this shard's run of blocks (+ halo blocks) instead of the whole file
-        if (mth_host_plan_shard(in.h, g_shard.rank, g_shard.world, g_shard.halo, &g_shard.plan) != 0) die(mth_host_last_error(in.h));
+    if (g_shard.planned()) {      // this shard's run of blocks (+ halo blocks), or the blocks the .bai names for --region, instead of the whole file
+        if (g_shard.region) {
+            const int tid = mth_host_ref_tid(in.h, g_shard.region_name.c_str());
+            if (tid < 0) die("--region: the BAM header has no reference named '" + g_shard.region_name + "'");
+            if (mth_host_plan_region(in.h, g_shard.bai.empty() ? nullptr : g_shard.bai.c_str(), tid, g_shard.r_beg, g_shard.r_end, g_shard.halo, &g_shard.plan) != 0)
+                die(mth_host_last_error(in.h));
+        } else if (mth_host_plan_shard(in.h, g_shard.rank, g_shard.world, g_shard.halo, &g_shard.plan) != 0) die(mth_host_last_error(in.h));
         blk_beg = g_shard.plan.block_beg;
         bz.n_blocks = g_shard.plan.block_end;
         bz.header_bytes = g_shard.plan.first_byte;
@@ -394,7 +412,7 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
     if (cpg_set) check(in.ctx, mth_decode_set_cpg_filter(in.ctx, keys, n_keys, 1));
     check(in.ctx, mth_decode_set_xm_min_mapq(in.ctx, (uint32_t)g_shard.xm_min_mapq));
     const bool on_device = !getenv("METHEOR_HOST_INFLATE") && load_bgzf_on_device(in);
-    if (!on_device && g_shard.world > 1) die("--gpus N needs the device load path (a coordinate-sorted BAM whose records do not straddle BGZF blocks)");
+    if (!on_device && g_shard.planned()) die("--gpus N / --region need the device load path (a coordinate-sorted BAM whose records do not straddle BGZF blocks)");
     if (!on_device) {
         StreamState st;
         st.ctx = in.ctx;
@@ -423,11 +441,11 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
     for (uint32_t k = 0; k < n_runs; ++k) {
         for (const Contig &c : in.contigs) if (c.tid == tids[k]) return false;   // the host path reports it
         int32_t reg_beg = 0, reg_end = -1;
-        if (g_shard.world > 1) {      // the part of this contig inside the shard's interval [(tid_beg, pos_beg), (tid_end, pos_end))
+        if (g_shard.planned()) {      // the part of this contig inside the shard's / region's interval [(tid_beg, pos_beg), (tid_end, pos_end))
             const mth_host_shard_t &pl = g_shard.plan;
             if (tids[k] < pl.tid_beg || tids[k] > pl.tid_end) continue;               // halo reads of a neighbour's contig
             if (tids[k] == pl.tid_beg) reg_beg = pl.pos_beg;
-            if (tids[k] == pl.tid_end) { reg_end = pl.pos_end; if (reg_end <= reg_beg) continue; }
+            if (tids[k] == pl.tid_end && pl.pos_end != INT32_MAX) { reg_end = pl.pos_end; if (reg_end <= reg_beg) continue; }
         }
         in.contigs.emplace_back();
         Contig &c = in.contigs.back();
@@ -443,13 +461,13 @@ Input load(const std::string &path, const char *cpg_set) {
     Input in;
     char err[1024];
     const bool try_device = !getenv("METHEOR_HOST_DECODE");
-    if (!try_device && g_shard.world > 1) die("--gpus N needs the device load path (METHEOR_HOST_DECODE is set)");
+    if (!try_device && g_shard.planned()) die("--gpus N / --region need the device load path (METHEOR_HOST_DECODE is set)");
     CtxFuture cf;
     if (try_device) cf.start();
     if (mth_host_open(path.c_str(), &in.h, err, sizeof err) != 0) { cf.wait(); die(err); }    // bamutil.rs:7-9
     if (try_device) {
         if (load_on_device(in, cpg_set, cf)) return in;
-        if (g_shard.world > 1) die("--gpus N needs the device load path (coordinate-sorted input, contigs grouped, records inside BGZF blocks)");
+        if (g_shard.planned()) die("--gpus N / --region need the device load path (coordinate-sorted input, contigs grouped, records inside BGZF blocks)");
         in.contigs.clear();
     }
     {
@@ -509,7 +527,7 @@ mth_batch_t make_batch(const Input &in, const Contig &c) {
         // a whole contig (or a shard's last piece of it) ends where its reads end, not at the header's LN:
         // the reference has no notion of LN in this path and emits sites beyond it
         check(in.ctx, mth_decoded_batch(in.ctx, c.r0, c.r1, c.tid, c.region_beg, c.region_end >= 0 ? c.region_end : -1, &b));
-        if (g_shard.world > 1 && (int64_t)b.max_span + 202 > g_shard.halo)
+        if (g_shard.planned() && (int64_t)b.max_span + 202 > g_shard.halo)
             die("an alignment spans " + std::to_string(b.max_span) + " bp: set METHEOR_SHARD_HALO to at least " + std::to_string(b.max_span + 202));
         return b;
     }
@@ -807,6 +825,22 @@ int main(int argc, char **argv) {
     }
     int64_t halo = 65536;
     if (const char *e = getenv("METHEOR_SHARD_HALO")) { const long long k = atoll(e); if (k >= 0) halo = k; }
+    if (a.has("region")) {       // chr | chr:beg-end (1-based, inclusive, commas allowed; as samtools view takes it)
+        const std::string reg = a.s.at("region");
+        g_shard.region = true; g_shard.region_name = reg;
+        const size_t c = reg.rfind(':');
+        if (c != std::string::npos && c + 1 < reg.size()) {
+            std::string t;
+            for (char ch : reg.substr(c + 1)) if (ch != ',') t.push_back(ch);
+            long long b = 0, e = 0;
+            char tail = 0;
+            const int k = sscanf(t.c_str(), "%lld-%lld%c", &b, &e, &tail);
+            if (k == 2 && b >= 1 && e >= b && e <= INT32_MAX) { g_shard.region_name = reg.substr(0, c); g_shard.r_beg = (int32_t)(b - 1); g_shard.r_end = (int32_t)e; }
+            else if (k == 2 || reg.find('-', c) != std::string::npos) usage_error(cmd, "invalid value '" + reg + "' for '--region <REGION>': want chr or chr:beg-end with 1 <= beg <= end");
+        }
+        if (a.has("bai")) g_shard.bai = a.s.at("bai");
+        if (a.n.at("gpus") > 1) usage_error(cmd, "the argument '--region <REGION>' cannot be used with '--gpus <GPUS>' above 1");
+    } else if (a.has("bai")) usage_error(cmd, "the argument '--bai <BAI>' needs '--region <REGION>'");
     const int world = (int)std::min<int64_t>(a.n.at("gpus"), 4096);
     if (world < 1) usage_error(cmd, "invalid value '0' for '--gpus <GPUS>': at least one GPU");
     if (world == 1) {

@@ -26,6 +26,7 @@
 
 #include "../../../include/metheor_host.h"
 #include "bam_reader.h"
+#include "bai_internal.h"
 #include "parallel_decode.h"
 
 #include <thread>
@@ -244,6 +245,40 @@ int mth_host_plan_shard(mth_host_t *h, int rank, int world, int64_t halo_bp, mth
     if (empty || L >= R) { out->block_beg = out->block_end = L; out->first_byte = 0; return MTH_HOST_OK; }
     if (L <= D) { out->block_beg = 0; out->first_byte = h->header_bytes; }    // from the top of the file: the header comes along
     else { out->block_beg = L; out->first_byte = 0; }
+    out->block_end = R;
+    return MTH_HOST_OK;
+}
+
+int mth_host_plan_region(mth_host_t *h, const char *bai_path, int32_t tid, int32_t beg, int32_t end, int64_t halo_bp, mth_host_shard_t *out) {
+    if (!h || !out || tid < 0 || tid >= (int32_t)h->reader.refs().size() || beg < 0 || end < beg || halo_bp < 0) return MTH_HOST_ERR_INVALID;
+    mth_host_bgzf_t bz;
+    const int rc = mth_host_bgzf_blocks(h, &bz);
+    if (rc != MTH_HOST_OK) return rc;
+    const BgzfMap &m = *h->bgzf;
+    BaiIndex bai;
+    std::string path = bai_path ? bai_path : h->path + ".bai", err;
+    if (!bai.load(path, err)) {
+        // samtools also writes <name>.bai next to <name>.bam
+        std::string alt = h->path;
+        if (!bai_path && alt.size() > 4 && alt.compare(alt.size() - 4, 4, ".bam") == 0) { alt.replace(alt.size() - 4, 4, ".bai"); std::string e2; if (bai.load(alt, e2)) err.clear(); }
+        if (!err.empty()) { h->last_error = err; return MTH_HOST_ERR_OPEN; }
+    }
+    if (bai.refs.size() != h->reader.refs().size()) { h->last_error = "the BAM index does not belong to this file (different number of references)"; return MTH_HOST_ERR_FORMAT; }
+    memset(out, 0, sizeof *out);
+    out->tid_beg = out->tid_end = tid; out->pos_beg = beg; out->pos_end = end;
+    // records that can touch the region's sites: overlapping [beg - halo, end] (a reverse read starting AT end reports end - 1)
+    uint64_t vlo = 0, vhi = 0;
+    if (end == beg || !bai.query(tid, std::max<int64_t>(0, (int64_t)beg - halo_bp), (int64_t)end + 1, vlo, vhi)) { out->block_beg = out->block_end = 0; return MTH_HOST_OK; }
+    // virtual offset -> block of the table: its payload starts right after the block's header, i.e. it is the first payload
+    // offset above the block's own offset
+    auto block_of = [&](uint64_t v) { return (uint64_t)(std::upper_bound(m.coff.begin(), m.coff.end(), v >> 16) - m.coff.begin()); };
+    uint64_t L = block_of(vlo), R = block_of(vhi) + ((vhi & 0xffffu) ? 1u : 0u);
+    R = std::min<uint64_t>(std::max(R, L + 1), bz.n_blocks);
+    if (L >= bz.n_blocks) { out->block_beg = out->block_end = 0; return MTH_HOST_OK; }
+    // the block that holds the first record also holds the tail of the header: load from the top of the file then
+    uint64_t D = 0, cum = 0;
+    while (D < bz.n_blocks && cum + m.isize[D] <= h->header_bytes) cum += m.isize[D++];
+    if (L <= D) { out->block_beg = 0; out->first_byte = h->header_bytes; } else { out->block_beg = L; out->first_byte = 0; }
     out->block_end = R;
     return MTH_HOST_OK;
 }

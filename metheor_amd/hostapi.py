@@ -9,7 +9,7 @@ _LIB = None
 
 SYMBOLS = [
     "mth_host_open", "mth_host_close", "mth_host_last_error", "mth_host_n_refs", "mth_host_ref_name",
-    "mth_host_ref_len", "mth_host_ref_tid", "mth_host_set_xm_min_mapq", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
+    "mth_host_ref_len", "mth_host_ref_tid", "mth_host_set_xm_min_mapq", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_plan_region", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
     "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
     "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32", "mth_host_write_synthetic_bam",
     "mth_host_write_synthetic_bam_multi",
@@ -58,6 +58,7 @@ def lib():
             getattr(L, "mth_host_" + f).argtypes = [vp]; getattr(L, "mth_host_" + f).restype = vp
         L.mth_host_bgzf_blocks.argtypes = [vp, vp]
         L.mth_host_plan_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int64, vp]
+        L.mth_host_plan_region.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, vp]
         L.mth_host_format_f32.argtypes = [C.c_float, C.c_char_p]
         L.mth_host_write_synthetic_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int32] + [vp] * 6 + [C.c_uint64, C.c_int]
         L.mth_host_write_synthetic_bam_multi.argtypes = [C.c_char_p, C.c_int32, vp, vp, C.c_int64, C.c_int32] + [vp] * 7 + [C.c_uint64, C.c_int]
@@ -137,6 +138,15 @@ class BamFile:
             return np.ctypeslib.as_array(C.cast(p, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy() if n else np.zeros(0, dt)
         return dict(coff=arr(bz.coff, np.uint64), csize=arr(bz.csize, np.uint32), isize=arr(bz.isize, np.uint32),
                     header_bytes=int(bz.header_bytes), file_bytes=int(bz.file_bytes))
+
+    def plan_region(self, tid, beg, end, halo_bp=65536, bai=None):
+        """mth_host_plan_region: the BGZF blocks the .bai index names for [beg - halo, end] of reference tid + the owned interval"""
+        sh = _Shard()
+        rc = self.L.mth_host_plan_region(self.h, os.fsencode(bai) if bai else None, int(tid), int(beg), int(end), int(halo_bp), C.byref(sh))
+        if rc != 0:
+            raise HostError(rc, self.L.mth_host_last_error(self.h).decode())
+        return dict(block_beg=int(sh.block_beg), block_end=int(sh.block_end), first_byte=int(sh.first_byte),
+                    tid_beg=int(sh.tid_beg), pos_beg=int(sh.pos_beg), tid_end=int(sh.tid_end), pos_end=int(sh.pos_end))
 
     def plan_shard(self, rank, world, halo_bp=65536):
         """mth_host_plan_shard: the BGZF blocks shard `rank` of `world` loads and the (tid, pos) interval it owns"""

@@ -6,6 +6,7 @@ BGZF is a series of gzip members, which `gzip.decompress` concatenates.
 """
 import gzip
 import struct
+import zlib
 
 import numpy as np
 
@@ -191,3 +192,148 @@ def write_bam(path, rec, seq_len=None, realistic=False, seed=0):
         for o in range(0, len(data), 60000):
             fh.write(_bgzf_block(data[o:o + 60000]))
         fh.write(_bgzf_block(b""))
+
+
+# ---- BAM index (.bai, SAM spec 5.2): independent Python reader / builder / query (test infrastructure) ------------------
+# Pinned against the reference's own samtools-made fixtures tests/test{1..6}.bam.bai (tests/test_bai.py): build_bai() of
+# testK.bam must reproduce the fixture's bins, chunks and linear index.
+def reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14: return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17: return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20: return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23: return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26: return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def reg2bins(beg, end):
+    end -= 1
+    out = [0]
+    for shift, base in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        out += list(range(base + (beg >> shift), base + (end >> shift) + 1))
+    return out
+
+
+def read_bai(path):
+    """-> list per reference of dict(bins={bin: [(beg, end), ..]}, ioffset=[..]); the metadata pseudo-bin 37450 is dropped"""
+    d = open(path, "rb").read()
+    assert d[:4] == b"BAI\1"
+    n_ref, = struct.unpack_from("<i", d, 4)
+    o, refs = 8, []
+    for _ in range(n_ref):
+        n_bin, = struct.unpack_from("<i", d, o); o += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", d, o); o += 8
+            ch = [struct.unpack_from("<QQ", d, o + 16 * k) for k in range(n_chunk)]
+            o += 16 * n_chunk
+            if b != 37450:
+                bins[b] = ch
+        n_intv, = struct.unpack_from("<i", d, o); o += 4
+        refs.append(dict(bins=bins, ioffset=list(struct.unpack_from("<%dQ" % n_intv, d, o))))
+        o += 8 * n_intv
+    return refs
+
+
+def bam_record_offsets(path):
+    """every record of a BAM file: (tid, pos, end (exclusive), virtual offset of its first byte, virtual offset after its last
+    byte as htslib's bgzf_tell reports it, index of the BGZF block it starts in); plus n_ref"""
+    raw = open(path, "rb").read()
+    blocks, o = [], 0                    # (file offset, inflated bytes)
+    while o < len(raw):
+        xlen, = struct.unpack_from("<H", raw, o + 10)
+        bsize = None
+        e = o + 12
+        while e < o + 12 + xlen:
+            si1, si2, slen = struct.unpack_from("<BBH", raw, e)
+            if si1 == 66 and si2 == 67:
+                bsize, = struct.unpack_from("<H", raw, e + 4)
+            e += 4 + slen
+        data = zlib.decompress(raw[o + 12 + xlen:o + bsize + 1 - 8], -15)
+        blocks.append((o, data))
+        o += bsize + 1
+    stream = b"".join(b for _, b in blocks)
+    starts = np.cumsum([0] + [len(b) for _, b in blocks])       # stream offset of each block
+    def voff(so, end_of_record=False):
+        k = int(np.searchsorted(starts, so, side="right")) - 1
+        if end_of_record and so == starts[k] and k > 0:          # bgzf_tell after a read that ended exactly at a block's end
+            k -= 1
+        return (blocks[k][0] << 16) | (so - int(starts[k])), k
+    l_text, = struct.unpack_from("<i", stream, 4)
+    p = 8 + l_text
+    n_ref, = struct.unpack_from("<i", stream, p); p += 4
+    for _ in range(n_ref):
+        l, = struct.unpack_from("<i", stream, p); p += 8 + l
+    out = []
+    while p < len(stream):
+        bs, = struct.unpack_from("<i", stream, p)
+        t, pos, l_rn, _mq, _bin, n_cig, _fl, _ls = struct.unpack_from("<iiBBHHHi", stream, p + 4)
+        cig = struct.unpack_from("<%dI" % n_cig, stream, p + 36 + l_rn)
+        reflen = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
+        vb, kb = voff(p)
+        ve, _ = voff(p + 4 + bs, end_of_record=True)
+        out.append((t, pos, pos + max(reflen, 1), vb, ve, kb))
+        p += 4 + bs
+    return out, n_ref
+
+
+def build_bai(path):
+    """the index samtools would write for this coordinate-sorted BAM, as read_bai() returns it"""
+    recs, n_ref = bam_record_offsets(path)
+    refs = [dict(bins={}, ioffset=[]) for _ in range(n_ref)]
+    last = (None, None)
+    for t, beg, end, vb, ve, _ in recs:
+        if t < 0:
+            continue
+        r = refs[t]
+        b = reg2bin(beg, end)
+        if last == (t, b):
+            c = r["bins"][b]
+            c[-1] = (c[-1][0], ve)                       # a run of consecutive records of one bin is one chunk
+        else:
+            r["bins"].setdefault(b, []).append((vb, ve))
+            last = (t, b)
+        w0, w1 = beg >> 14, (end - 1) >> 14
+        io = r["ioffset"]
+        if len(io) <= w1:
+            io.extend([0] * (w1 + 1 - len(io)))
+        for w in range(w0, w1 + 1):
+            if io[w] == 0 or vb < io[w]:
+                io[w] = vb
+    for r in refs:                                      # samtools fills the windows nothing starts in with the previous entry
+        for w in range(1, len(r["ioffset"])):
+            if r["ioffset"][w] == 0:
+                r["ioffset"][w] = r["ioffset"][w - 1]
+    return refs
+
+
+def write_bai(bam_path, bai_path=None):
+    refs = build_bai(bam_path)
+    out = bytearray(b"BAI\1") + struct.pack("<i", len(refs))
+    for r in refs:
+        out += struct.pack("<i", len(r["bins"]))
+        for b in sorted(r["bins"]):
+            out += struct.pack("<Ii", b, len(r["bins"][b]))
+            for cb, ce in r["bins"][b]:
+                out += struct.pack("<QQ", cb, ce)
+        out += struct.pack("<i", len(r["ioffset"])) + struct.pack("<%dQ" % len(r["ioffset"]), *r["ioffset"])
+    out += struct.pack("<Q", 0)
+    with open(bai_path or bam_path + ".bai", "wb") as fh:
+        fh.write(bytes(out))
+    return refs
+
+
+def bai_query(refs, tid, beg, end):
+    """virtual offset range [lo, hi) holding every record that overlaps [beg, end), or None"""
+    r = refs[tid]
+    min_off = r["ioffset"][min(beg >> 14, len(r["ioffset"]) - 1)] if r["ioffset"] else 0
+    lo = hi = None
+    for b in reg2bins(beg, end):
+        for cb, ce in r["bins"].get(b, ()):
+            if ce <= min_off:
+                continue
+            cb = max(cb, min_off)
+            lo = cb if lo is None else min(lo, cb)
+            hi = ce if hi is None else max(hi, ce)
+    return None if lo is None else (lo, hi)

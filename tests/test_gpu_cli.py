@@ -449,3 +449,53 @@ def test_lpmd_filters_mapq_before_xm(golden_dir, tmp_path):
         assert r.returncode == 101 and "Error reading XM tag in BAM record" in r.stderr
         r = run_env(env, "pdr", "-i", bam, "-o", str(o), "-q", "10", "-d", "0", "-p", "0")
         assert r.returncode == 101 and "Error reading XM tag in BAM record" in r.stderr
+
+
+def test_region_from_the_bam_index(tmp_path):
+    """`metheor <sub> --region chr:beg-end`: the .bai names the BGZF blocks, only those are loaded, the batch
+    is the region [beg-1, end); rows = the whole-file ORACLE's rows owned by the region (sites by position, quartets and
+    pairs by their first CpG), LPMD = the oracle over the reads that start in the region"""
+    from metheor_amd import hostapi, synth
+    rng = np.random.default_rng(8)
+    names = ["gA", "gEmpty", "gB"]
+    cs = [synth.make_contig(0, 500_000, 20_000, 0.03, rng), synth.make_contig(2, 1_200_000, 50_000, 0.03, rng)]
+    bam = str(tmp_path / "reg.bam")
+    hostapi.write_synthetic_bam_multi(bam, cs, names, seed=2, threads=4)
+    bamio.write_bai(bam)
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    for region, (t, b, e) in (("gB:300,001-700,000", (2, 300_000, 700_000)), ("gA:1-40000", (0, 0, 40_000)), ("gB:1100000-1200000", (2, 1_099_999, 1_200_000))):
+        def owned(text, sub):
+            keep = []
+            for l in text.splitlines(True):
+                f = l.split("\t")
+                if f[0] == names[t] and b <= int(f[1]) < e:
+                    keep.append(l)
+            return "".join(keep)
+        for sub, extra in (("pdr", ["-d", "3", "-p", "1"]), ("mhl", ["-d", "3", "-p", "1"]), ("me", ["-d", "2"]), ("pm", ["-d", "2"]), ("fdrp", ["-d", "3"]), ("qfdrp", ["-d", "3"])):
+            o = tmp_path / "o.tsv"
+            r = run_env({"METHEOR_TIMING": "1"}, sub, "-i", bam, "-o", str(o), *extra, "--region", region)
+            assert r.returncode == 0, r.stderr
+            want, _ = util.oracle_text(reads, names, sub, **util.oracle_kwargs(sub, extra))
+            util.assert_tsv_equals_oracle(sub, o.read_text(), owned(want, sub))
+            assert len(owned(want, sub)) > 1000, (sub, region)
+        # lpmd: the reads that START in the region (what a region batch owns), pairs by cpg1
+        c = cs[0] if t == 0 else cs[1]
+        sel = util.subset_reads(c, (c["read_start"] >= b) & (c["read_start"] < e))
+        sub_reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(sel))
+        o, pf = tmp_path / "l.tsv", tmp_path / "lp.tsv"
+        r = run("lpmd", "-i", bam, "-o", str(o), "-p", str(pf), "-r", region)
+        assert r.returncode == 0, r.stderr
+        want, want_pairs = util.oracle_text(sub_reads, names, "lpmd", input_name=bam)
+        assert o.read_text() == want and pf.read_text() == want_pairs
+    # whole contig by name; unknown contig; no index
+    o = tmp_path / "w.tsv"
+    r = run("pdr", "-i", bam, "-o", str(o), "-d", "3", "-p", "1", "--region", "gA")
+    want, _ = util.oracle_text(reads, names, "pdr", min_depth=3, min_cpgs=1)
+    assert r.returncode == 0 and o.read_text() == "".join(l for l in want.splitlines(True) if l.startswith("gA\t"))
+    r = run("pdr", "-i", bam, "-o", str(o), "--region", "chrNope:1-10")
+    assert r.returncode == 101 and "no reference named" in r.stderr
+    os.remove(bam + ".bai")
+    r = run("pdr", "-i", bam, "-o", str(o), "--region", "gA:1-10")
+    assert r.returncode == 101 and "BAM index" in r.stderr
+    r = run("pdr", "-i", bam, "-o", str(o), "--region", "gA:10-1")
+    assert r.returncode == 2
