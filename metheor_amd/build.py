@@ -1,14 +1,20 @@
 """In-tree build of the gfx950 engine: hipcc -> metheor_amd/libmetheor_hip.so (+ the `metheor` CLI
 when its sources exist).  No JIT cache, no pip install: the built files travel with the tree."""
+import hashlib
+import json
 import os
 import shutil
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmetheor_hip.so")
 ARCH = "gfx950"
+# -ffp-contract=off: every float this engine emits must equal the reference's UNFUSED f32 expressions (Rust never contracts
+# a*b+c); hipcc's default is contract=fast
+HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off", "-Wno-unused-result"]
 
 HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip", "mth_quartet.hip", "mth_scan.hip", "mth_sites.hip", "mth_fdrp.hip", "mth_pairs.hip", "mth_decode.hip", "mth_inflate.hip", "mth_rccl.hip"]
 HOST_LIB = os.path.join(HERE, "libmetheor_host.so")
@@ -25,11 +31,51 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the engine is HIP-only (no CPU fallback)")
 
 
+BUILD_INFO = os.path.join(HERE, "BUILD_INFO.json")
+
+
+def _sha(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def source_files():
+    """every file the three artefacts are built from (relative to the package directory)"""
+    out = [os.path.join("csrc", s) for s in HIP_SOURCES + HEADERS + HOST_SOURCES + HOST_HEADERS] + [os.path.join("csrc", "host", "cli_main.cpp")]
+    return sorted(set(os.path.normpath(p) for p in out))
+
+
+def source_hashes():
+    return {p: _sha(os.path.join(HERE, p)) for p in source_files()}
+
+
+def _write_build_info(rebuilt):
+    """metheor_amd/BUILD_INFO.json: what the in-tree binaries were built from (travels with them; tests/test_build_info.py
+    compares the hashes with the tree, so a stale .so is a test failure, not a silent mismatch)"""
+    try:
+        ver = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:
+        ver = "?"
+    info = {"built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "rebuilt_this_call": bool(rebuilt), "arch": ARCH, "hipcc": ver,
+            "hip_flags": HIP_FLAGS, "artefacts": {os.path.basename(p): _sha(p) for p in (LIB, HOST_LIB, CLI) if os.path.exists(p)},
+            "sources": source_hashes()}
+    old = None
+    if os.path.exists(BUILD_INFO):
+        try:
+            old = json.load(open(BUILD_INFO))
+        except Exception:
+            old = None
+    if old and not rebuilt and old.get("sources") == info["sources"] and old.get("artefacts") == info["artefacts"]:
+        return
+    with open(BUILD_INFO, "w") as f:
+        json.dump(info, f, indent=1, sort_keys=True)
 
 
 def build_host(force=False, verbose=False):
@@ -63,8 +109,18 @@ def build_cli(force=False, verbose=False):
 
 
 def build(force=False, verbose=False):
+    # staleness: mtimes as make would, plus the recorded source hashes (a checkout can rewind mtimes)
+    if not force and os.path.exists(BUILD_INFO):
+        try:
+            if json.load(open(BUILD_INFO)).get("sources") != source_hashes():
+                force = True
+        except Exception:
+            force = True
+    before = {p: (os.path.getmtime(p) if os.path.exists(p) else 0) for p in (LIB, HOST_LIB, CLI)}
     lib = _build_libs(force, verbose)
     build_cli(force, verbose)
+    rebuilt = any((os.path.getmtime(p) if os.path.exists(p) else 0) != before[p] for p in before)
+    _write_build_info(rebuilt)
     return lib
 
 
@@ -81,8 +137,7 @@ def _build_libs(force=False, verbose=False):
         if force or _stale(o, [s] + hdrs):
             # -ffp-contract=off: every float this engine emits must equal the reference's UNFUSED f32
             # expressions (Rust never contracts a*b+c); hipcc's default is contract=fast
-            cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off",
-                   "-Wno-unused-result", "-c", s, "-o", o]
+            cmd = [hipcc, "--offload-arch=" + ARCH] + HIP_FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd)))
