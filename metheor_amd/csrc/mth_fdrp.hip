@@ -95,6 +95,10 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
     uint32_t *const rows = s_rows[threadIdx.x >> 6];
     for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
         const int32_t c = sgpr(a.site_pos[j]);
+        // the 64-site window of the compact finalize depends on j alone: requested here, a full walk before it is used (it
+        // used to be the fifth dependent round trip of a site; on sparse WGBS a site is ~6 us of such round trips)
+        const uint32_t j0w = (j >= 32u) ? min(j - 32u, n_sites > 64u ? n_sites - 64u : 0u) : 0u;
+        const int32_t spw = (j0w + (uint32_t)lane < n_sites) ? a.site_pos[j0w + lane] : 0x7fffffff;
         const uint32_t lo = sgpr(min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads));
         const uint32_t hi = sgpr(min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads));
         // wave-uniform segment state
@@ -131,8 +135,8 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             bool compact = false;
             // (halo reads of a region slice call positions outside the region; those are not in the site list)
             if (!win_check && (int64_t)c - 200 >= a.region_beg && (int64_t)c + 200 < a.region_end) {
-                const uint32_t j0 = (j >= 32u) ? min(j - 32u, n_sites > 64u ? n_sites - 64u : 0u) : 0u;
-                const int32_t sp = (j0 + (uint32_t)lane < n_sites) ? a.site_pos[j0 + lane] : 0x7fffffff;
+                const uint32_t j0 = j0w;
+                const int32_t sp = spw;
                 const int32_t sp_lo = __builtin_amdgcn_readlane(sp, 0), sp_hi = __builtin_amdgcn_readlane(sp, 63);
                 compact = (j0 == 0u || sp_lo < c - 200) && (int64_t)sp_hi > (int64_t)c + 200;       // absent sites read as +inf
                 if (compact) {
@@ -372,10 +376,12 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
         for (uint32_t base = lo; base < hi; base += 64) {
             const uint32_t i = base + (uint32_t)lane;
             const bool valid = i < hi;
-            const uint32_t o0 = valid ? a.cpg_off[i] : 0u, o1 = valid ? a.cpg_off[i + 1] : 0u;
+            const uint32_t ii = valid ? i : lo;                              // (lo < hi here) every lane loads: no dependent round trip
+            const uint32_t o0 = valid ? a.cpg_off[ii] : 0u, o1 = valid ? a.cpg_off[ii + 1] : 0u;
+            const int32_t cs_raw = a.read_start[ii], ce_raw = a.read_end[ii];
             const uint32_t n = o1 - o0;
-            const bool pass = valid && a.read_mapq[i] >= a.min_qual && n > 0;   // fdrp.rs:205, 208
-            const int32_t cs = pass ? a.read_start[i] : 0, ce = pass ? a.read_end[i] : 0;
+            const bool pass = valid && a.read_mapq[ii] >= a.min_qual && n > 0;   // fdrp.rs:205, 208
+            const int32_t cs = pass ? cs_raw : 0, ce = pass ? ce_raw : 0;
             uint32_t cw[FD_NB];
             bool hit = false;                                                // does the candidate call c ?
 #pragma unroll
