@@ -206,9 +206,9 @@ int  mth_mhl_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos,
  * Exact stream semantics (strict '<' flush by reads passing mapq with >= 1 CpG, +-201-bp window
  * drop, fill to max_depth in file order).  Beyond max_depth the reference replaces stored reads at
  * random from an OS-seeded RNG (fdrp.rs:90) -- not reproducible; here the draw is the counter-based
- * hash of (seed, tid, pos, n-th read) shared with the test oracle.  max_depth up to 256 (sites that hold more than 64 reads at once are
- * redone by a second, 256-slot pass); a site that would store more than 256 reads is refused with MTH_ERR_CAPACITY (never a
- * truncated result). */
+ * hash of (seed, tid, pos, n-th read) shared with the test oracle.  max_depth up to 16384: sites that hold more than 64 reads at
+ * once are redone by a second pass with 256 slots in LDS, those beyond 256 by a third with max_depth rows per wave in HBM
+ * scratch; max_depth above 16384 is refused with MTH_ERR_CAPACITY (never a truncated result). */
 typedef struct {
     uint64_t min_depth;    /* -d 10 */
     uint64_t seed;         /* reservoir draws; any value */

@@ -37,8 +37,11 @@ constexpr int FD_WIN = 201;   // MAX_READ_LEN, fdrp.rs:10
 // Stored reads of a site (template parameter SLOTS of the walk): 64 -- one lane each -- in the main pass.  With max_depth > 64 a
 // site that holds more than 64 reads at once is flagged (flags = 2) and redone by a second pass with 256 slots, whose
 // finalize works pair-parallel from the LDS rows (a sorted merge of the two reads' calls per pair) instead of lane = slot.
-// More than 256 stored reads: MTH_ERR_CAPACITY (loud, never a sampled or truncated result).
+// With max_depth > 256 a site that holds more than 256 reads at once is flagged again (flags = 3) and redone by a third pass
+// whose rows live in HBM scratch, max_depth of them per wave (SLOTS = 0: capacity at run time); same pair-parallel finalize.
+// max_depth above FD_DEPTH_MAX is refused (MTH_ERR_CAPACITY, loud): the pair index arithmetic is 32-bit.
 constexpr int FD_SLOTS_DEEP = 256;
+constexpr uint32_t FD_DEPTH_MAX = 16384;
 // FD_NB (template parameter of the walk): calls of a stored read held in the slot's registers (8 or 16)
 
 struct FdrpArgs {
@@ -57,6 +60,8 @@ struct FdrpArgs {
     int32_t region_beg, region_end;   // sites are discovered for [region_beg, region_end) only
     uint32_t n_reads, min_depth, max_depth;
     uint8_t min_qual;
+    uint32_t *rows_scratch;           // SLOTS = 0: slots_cap rows of (4 + FD_NB) words per wave of the launch
+    uint32_t slots_cap;
 };
 
 // the oracle's orc_sample_j: splitmix64 over (seed, tid, pos, total) -> 1..=total
@@ -80,7 +85,7 @@ __device__ __forceinline__ int32_t sgpr(int32_t x) { return (int32_t)__builtin_a
 
 template <int FD_NB, int SLOTS>
 __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
-    constexpr int FD_SLOTS = SLOTS;
+    const int FD_SLOTS = SLOTS ? SLOTS : (int)a.slots_cap;
     const int lane = threadIdx.x & 63;
     const uint32_t wave_id = sgpr((uint32_t)((blockIdx.x * 256 + threadIdx.x) >> 6)), n_waves = (gridDim.x * 256) >> 6;
     const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
@@ -91,8 +96,8 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
     float *const s_term = s_terms[threadIdx.x >> 6];
     // per wave: the stored reads of the open segment, one row per slot: {cpg_off, n_calls, start, end, FD_NB packed calls}
     constexpr int ROW = 4 + FD_NB;
-    __shared__ __attribute__((aligned(16))) uint32_t s_rows[4][SLOTS * ROW];
-    uint32_t *const rows = s_rows[threadIdx.x >> 6];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[4][(SLOTS ? SLOTS : 1) * ROW];
+    uint32_t *const rows = SLOTS ? s_rows[threadIdx.x >> 6] : a.rows_scratch + (size_t)wave_id * a.slots_cap * ROW;
     for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
         const int32_t c = sgpr(a.site_pos[j]);
         // the 64-site window of the compact finalize depends on j alone: requested here, a full walk before it is used (it
@@ -107,7 +112,8 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
         float res_f = 0.0f, res_q = 0.0f;
         uint32_t res_n = 0;
         const bool win_check = a.max_span > 200;   // a stored read calls c and spans <= 200 bp: all its calls are inside +-201
-        if (SLOTS > 64 && a.flags[j] != 2u) continue;   // second pass: only the sites the 64-slot pass could not hold
+        if (SLOTS == FD_SLOTS_DEEP && a.flags[j] != 2u) continue;   // second pass: only the sites the 64-slot pass could not hold
+        if (SLOTS == 0 && a.flags[j] != 3u) continue;               // third pass: only the sites the 256-slot pass could not hold
 
         auto finalize = [&]() {   // compute_fdrp / compute_qfdrp over slots 0..sampled-1
             const int nS = sampled;
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
         };
 // (not a wrapper lambda: one more call level and the compiler stops inlining finalize -- its by-reference captures then live in
 // scratch memory and the walk runs 3.5x slower)
-#define MTH_FD_FINISH() do { if constexpr (SLOTS > 64) finalize_deep(); else finalize(); } while (0)
+#define MTH_FD_FINISH() do { if constexpr (SLOTS != 64) finalize_deep(); else finalize(); } while (0)
 
         // Candidates are inspected 64 at a time, one per lane (their field and call loads are issued together:
         // the one-candidate-per-iteration scalar walk was latency-bound, ~3 dependent loads x ~35 candidates
@@ -454,10 +460,12 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             }
         }
         if (entry && (uint32_t)sampled >= a.min_depth && !deep) MTH_FD_FINISH();  // fdrp.rs:239-243
-        if (deep && SLOTS > 64 && lane == 0) atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);   // more than FD_SLOTS_DEEP reads stored at once
+        // more reads stored at once than this pass has slots: the next pass redoes the site (flags 2 -> 256 slots, 3 -> rows in HBM);
+        // the last pass has max_depth slots, which a site cannot exceed (fdrp.rs:81-85)
+        if (deep && (SLOTS == 0 || (SLOTS == FD_SLOTS_DEEP && a.max_depth <= (uint32_t)FD_SLOTS_DEEP)) && lane == 0) atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);
         if (lane == 0) {
             a.fdrp[j] = res_f; a.qfdrp[j] = res_q; a.nreads[j] = res_n;
-            a.flags[j] = deep ? 2u : (have ? 1u : 0u);                      // 2: for the 256-slot pass (main pass only)
+            a.flags[j] = deep ? (SLOTS == 64 ? 2u : 3u) : (have ? 1u : 0u);
         }
     }
 }
@@ -544,6 +552,8 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     a.min_overlap = params->min_overlap; a.n_reads = d.n_reads; a.region_beg = d.region_beg; a.region_end = d.region_end;
     a.min_depth = (uint32_t)std::min<uint64_t>(params->min_depth, 0xffffffffull); a.max_depth = params->max_depth;
     a.min_qual = params->min_qual;
+    a.rows_scratch = nullptr; a.slots_cap = 0;
+    if (params->max_depth > FD_DEPTH_MAX) return fail(ctx, MTH_ERR_CAPACITY, "FDRP / qFDRP max_depth above 16384 (the pair index of one site is 32-bit arithmetic)");
     const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 3) / 4, 16384);   // 4 waves (sites) per block
     {
         LaunchTimer lt(ctx, K_FDRPWALK);
@@ -554,6 +564,15 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         else hipLaunchKernelGGL((k_fdrp_walk<8, 64>), dim3(grid), dim3(256), 0, s, a);
         // max_depth > 64: the sites that held more than 64 reads at once were flagged, not computed: 256-slot pass over them
         if (params->max_depth > 64) hipLaunchKernelGGL((k_fdrp_walk<8, FD_SLOTS_DEEP>), dim3(grid), dim3(256), 0, s, a);
+        // max_depth > 256: what the 256-slot pass flagged again, with max_depth rows per wave in HBM scratch (as many waves as
+        // ~256 MB of rows allow; these sites are few and their pair count, not the wave count, is what takes the time)
+        if (params->max_depth > (uint32_t)FD_SLOTS_DEEP) {
+            const size_t row_bytes = (size_t)params->max_depth * (4 + 8) * 4;
+            const uint32_t waves3 = (uint32_t)std::max<size_t>(64, std::min<size_t>(((size_t)256 << 20) / row_bytes, (size_t)grid * 4)) & ~3u;
+            MTH_HIP(ctx, ctx->f_rows.reserve((size_t)waves3 * row_bytes, s));
+            a.rows_scratch = ctx->f_rows.as<uint32_t>(); a.slots_cap = params->max_depth;
+            hipLaunchKernelGGL((k_fdrp_walk<8, 0>), dim3(waves3 / 4), dim3(256), 0, s, a);
+        }
     }
     unsigned long long *fs = ctx->f_state.as<unsigned long long>();
     const uint32_t nblk = (uint32_t)((bound + 256 * SCAN_PER - 1) / (256 * SCAN_PER));

@@ -236,7 +236,8 @@ def test_capacity_and_empty(eng):
 def test_max_depth_above_64(eng):
     """the main pass stores at most 64 reads per site (one lane each); with max_depth > 64 deeper sites are redone by a
     256-slot pass (pair-parallel merge of the call lists) -- exact, including the reservoir branch beyond max_depth;
-    more than 256 reads stored at once is refused loudly (output_validation.rs runs --max-depth 100)"""
+    sites beyond 256 stored reads by a third pass with rows in HBM scratch (round 2: the reference has no such limit;
+    output_validation.rs runs --max-depth 100); only max_depth > 16384 is refused"""
     from metheor_amd import MthError, synth
     c = synth.make_contig(0, 300_000, 50_000, 0.03, np.random.default_rng(91))           # ~25x: every site below 64 reads
     reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
@@ -255,9 +256,18 @@ def test_max_depth_above_64(eng):
     kw = dict(min_qual=10, min_depth=5, max_depth=150, min_overlap=20)
     check(run_device(eng, [deep], kw, device="cuda:0", regions=[shard.plan_regions(deep, 3)]), dreads, kw)
     very = synth.make_contig(0, 6_000, 14_000, 0.03, np.random.default_rng(93))          # ~350x: more than 256 reads on a site
+    vreads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(very))
+    kw = dict(min_qual=10, min_depth=5, max_depth=256, min_overlap=20, seed=9)            # 256 slots hold it, sampling beyond
+    check(run_device(eng, [very], kw), vreads, kw)
+    # beyond 256 stored reads: the third pass (rows in HBM scratch) -- sampled at 300, stored in full at 1000 and 16384
+    for kw in (dict(min_qual=10, min_depth=5, max_depth=300, min_overlap=20, seed=4), dict(min_qual=10, min_depth=5, max_depth=1000, min_overlap=20),
+               dict(min_qual=0, min_depth=300, max_depth=16384, min_overlap=1)):
+        n, nf, nq = check(run_device(eng, [very], kw), vreads, kw)
+        assert n > 50
+    assert int(vreads.fdrp(min_qual=10, min_depth=5, max_depth=1000, min_overlap=20).cnt[:, 0].max()) > 256
+    check(run_device(eng, [very], dict(min_qual=10, min_depth=5, max_depth=400, min_overlap=20, seed=2), device="cuda:0",
+                     regions=[shard.plan_regions(very, 2)]), vreads, dict(min_qual=10, min_depth=5, max_depth=400, min_overlap=20, seed=2))
     with pytest.raises(MthError) as e:
-        run_device(eng, [very], dict(min_qual=10, min_depth=5, max_depth=300, min_overlap=20))
+        run_device(eng, [very], dict(min_qual=10, min_depth=5, max_depth=16385, min_overlap=20))
     assert e.value.status == -8
     eng.reset()
-    kw = dict(min_qual=10, min_depth=5, max_depth=256, min_overlap=20, seed=9)            # 256 slots hold it, sampling beyond
-    check(run_device(eng, [very], kw), pyoracle.Reads.from_soa(*synth.to_oracle_soa(very)), kw)
