@@ -2,9 +2,11 @@
 """bench.py -- M reads/s of the fused PDR+LPMD hot path on MI355X (BASELINE.json metric).
 
 A "step" is one complete pass of the hot path over one resident batch: reset -> linear index ->
-tile accumulate (PDR site counters + LPMD pair counts) -> gather (sorted rows + f32 PDR, batch totals)
-[-> the RCCL all-reduce of the 4 LPMD counters when N > 1, issued through the C ABI's
-mth_allreduce_lpmd_rank on a side stream].  Workload at every N: BASELINE config 2, "S-chr19-10M"
+tile accumulate (PDR site counters + LPMD pair counts) -> gather (sorted rows + f32 PDR, batch totals).
+A job is K steps (batches) and, when N > 1, the path's ONE exchange: the RCCL all-reduce of the 4 genome-wide
+LPMD counters (lpmd.rs:51-55 divides them once per run), issued through the C ABI's mth_allreduce_lpmd_rank after
+the last step and INSIDE the timed region (--reduce-every-step issues it after every step instead; the line says which,
+and carries the collective's own latency either way).  Workload at every N: BASELINE config 2, "S-chr19-10M"
 (10 M synthetic 150-bp reads on a 58.6-Mbp contig) PER GPU -- weak scaling, the contig/region sharding of
 SURVEY 8(e): rank r owns contig r; per-site rows are disjoint by construction and only the genome-wide LPMD
 counters are exchanged.
@@ -47,6 +49,8 @@ def parse_args(argv=None):
     ap.add_argument("--share-devices", action="store_true",
                     help="TEST MODE: allow more ranks than GPUs (ranks share devices; RCCL refuses that, so the counters are "
                          "reduced with gloo on the host and the line says \"valid\": false)")
+    ap.add_argument("--reduce-every-step", action="store_true",
+                    help="N > 1: all-reduce the LPMD counters after every step (default: once per job, after the last step, inside the timed region)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="no GPU work: run only the N-rank scaffolding (spawn, rendezvous, barrier, max over ranks, one JSON line)")
     return ap.parse_args(argv)
@@ -218,14 +222,17 @@ def main():
         ids = [metheor_amd.Engine.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         eng.rccl_init_rank(ids[0], rank, world)
-        collective = "RCCL ncclAllReduce(int64 x 4, sum) via mth_allreduce_lpmd_rank, world %d" % world
+        collective = "RCCL ncclAllReduce(int64 x 4, sum) via mth_allreduce_lpmd_rank, world %d, %s" % (
+            world, "after every step" if args.reduce_every_step else "once per job: after the last step, inside the timed region")
     elif use_dist:
         collective = "gloo on host copies (TEST MODE: ranks share devices)"
 
-    def step():
+    rccl = use_dist and not shared and args.only != "pdr"
+
+    def step(last=False):
         eng.reset()
         eng.pdr_lpmd_accumulate(batch, params)
-        if use_dist and not shared and args.only != "pdr":
+        if rccl and (last or args.reduce_every_step):
             eng.allreduce_lpmd_rank()            # asynchronous: side stream, ordered after this step's kernels
 
     def fence():
@@ -235,12 +242,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(last=(k == args.warmup - 1))
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(last=(k == args.steps - 1))
     fence()
     dt_mine = time.perf_counter() - t0
     dt = dt_mine
@@ -321,6 +328,25 @@ def main():
                            "all_kernels_ms": {k: round(v[0], 5) for k, v in tm.items() if v[1] > 0}}
 
     # ---- soak: untimed passes so that an external sampler (rocm-smi every few seconds) can see the GPU working ------
+    # ---- the exchange step on its own: latency of one all-reduce of the 32 bytes (every rank takes part) ---------------
+    if rccl:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.reset()
+            eng.pdr_lpmd_accumulate(batch, params)
+            eng.allreduce_lpmd_rank()
+            eng.lpmd_global()                     # waits for the side stream: step + collective, serialised
+        t_with = (time.perf_counter() - t0) / 20
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.reset()
+            eng.pdr_lpmd_accumulate(batch, params)
+            eng.lpmd_global()
+        t_without = (time.perf_counter() - t0) / 20
+        if rank == 0:
+            out["collective_ms"] = {"serialised_step_with": round(t_with * 1e3, 4), "serialised_step_without": round(t_without * 1e3, 4),
+                                    "all_reduce": round((t_with - t_without) * 1e3, 4)}
     if rank == 0 and world == 1 and args.soak_seconds > 0:
         t0 = time.perf_counter()
         n_soak = 0
