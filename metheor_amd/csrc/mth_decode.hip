@@ -260,19 +260,29 @@ __global__ __launch_bounds__(256) void k_dec_offsets(const uint32_t *__restrict_
 __global__ __launch_bounds__(256) void k_dec_rebase(const unsigned long long *__restrict__ off, uint64_t r0, uint32_t n_reads,
                                                     const int32_t *__restrict__ start, const int32_t *__restrict__ end,
                                                     uint32_t *__restrict__ off32, uint32_t *__restrict__ max_span) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    // grid-stride, one pair of atomics per WORKGROUP: with one per wave the 156 k same-address atomicMax of a 10 M-read
+    // contig serialised into 3.5 ms (profiles/r02_e2e.md)
+    __shared__ uint32_t s_sp[4], s_me[4];
     const unsigned long long c0 = off[r0];
-    if (i <= n_reads) off32[i] = (uint32_t)(off[r0 + i] - c0);
     uint32_t sp = 0, me = 0;
-    if (i < n_reads) {
-        const int32_t s = start[r0 + i], e = end[r0 + i];
-        sp = (s >= 0 && e >= s) ? (uint32_t)(e - s + 1) : 0u;
-        me = e >= 0 ? (uint32_t)e + 1u : 0u;                 // max_span[1]: last covered position + 1 over the reads
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i <= n_reads; i += (uint64_t)gridDim.x * 256) {
+        off32[i] = (uint32_t)(off[r0 + i] - c0);
+        if (i < n_reads) {
+            const int32_t s = start[r0 + i], e = end[r0 + i];
+            sp = max(sp, (s >= 0 && e >= s) ? (uint32_t)(e - s + 1) : 0u);
+            me = max(me, e >= 0 ? (uint32_t)e + 1u : 0u);       // max_span[1]: last covered position + 1 over the reads
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sp = max(sp, (uint32_t)__shfl_down(sp, o, 64)); me = max(me, (uint32_t)__shfl_down(me, o, 64)); }
-    if ((threadIdx.x & 63) == 0 && sp) atomicMax(max_span, sp);
-    if ((threadIdx.x & 63) == 0 && me) atomicMax(max_span + 1, me);
+    if ((threadIdx.x & 63) == 0) { s_sp[threadIdx.x >> 6] = sp; s_me[threadIdx.x >> 6] = me; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sp = max(max(s_sp[0], s_sp[1]), max(s_sp[2], s_sp[3]));
+        me = max(max(s_me[0], s_me[1]), max(s_me[2], s_me[3]));
+        if (sp) atomicMax(max_span, sp);
+        if (me) atomicMax(max_span + 1, me);
+    }
 }
 
 // contig runs of the decoded stream: every i where tid changes opens a run (appended through an atomic counter, sorted by
@@ -486,7 +496,7 @@ int mth_decoded_batch(mth_ctx_t *ctx, uint64_t read_beg, uint64_t read_end, int3
     MTH_HIP(ctx, ctx->dec_off32.reserve((size_t)(n + 1) * 4 + 16, s));
     uint32_t *d_span = ctx->dec_off32.as<uint32_t>() + n + 1;
     MTH_HIP(ctx, hipMemsetAsync(d_span, 0, 8, s));
-    hipLaunchKernelGGL(k_dec_rebase, dim3((uint32_t)((n + 1 + 255) / 256)), dim3(256), 0, s, ctx->dec_off.as<unsigned long long>(),
+    hipLaunchKernelGGL(k_dec_rebase, dim3((uint32_t)std::min<uint64_t>((n + 1 + 255) / 256, 2048)), dim3(256), 0, s, ctx->dec_off.as<unsigned long long>(),
                        read_beg, (uint32_t)n, ctx->dec_start.as<int32_t>(), ctx->dec_end.as<int32_t>(),
                        ctx->dec_off32.as<uint32_t>(), d_span);
     uint32_t span_end[2] = {0, 0};
