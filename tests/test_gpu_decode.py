@@ -195,3 +195,14 @@ def test_crafted_aux_is_rejected_not_looped(eng, golden_dir, tmp_path):
         eng.reset()
     refs, body, offs = record_stream(os.path.join(golden_dir, "test1.bam"))
     assert eng.decode_records(body, offs)[0] == len(offs) - 1      # the context is usable again
+
+
+def test_hand_worked_cigar_and_strand_rules(eng, tmp_path):
+    """the device decoder against expectations worked out by hand from the SAM spec and readutil.rs (tests/test_host_decode.py)"""
+    from tests.test_host_decode import check_hand_worked, hand_worked_records
+    rec, expected = hand_worked_records()
+    p = str(tmp_path / "hand.bam")
+    bamio.write_bam(p, rec)
+    refs, body, offs = record_stream(p)
+    eng.decode_records(body, offs)
+    check_hand_worked(eng.decoded_fetch(), expected)

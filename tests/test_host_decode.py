@@ -297,3 +297,49 @@ def test_multi_contig_synthetic_writer_round_trip(tmp_path):
     assert f.refs == [("cA", 400_000), ("cEmpty", 1000), ("cB", 150_000)]
     same_soa(f.decode(), want)
     same_soa(pyoracle.Reads.decode(bamio.read_bam(p)).soa(), want)
+
+
+def hand_worked_records():
+    """Records whose decode is worked out BY HAND from the SAM spec (CIGAR ops: M/=/X consume query and reference, I/S query
+    only, D/N reference only, H/P nothing) and readutil.rs:24-33, 323-345 (start/end = first/last aligned reference position;
+    a z/Z at query offset q with an aligned reference position p is a call at p for flags in {0, 99, 147}, at p - 1 otherwise;
+    relpos = q; insertions and soft clips have no reference position and are skipped) -- literal expectations, independent of
+    every decoder in this repository.  -> (Records, expected) with expected = per record (start, end, fwd, [(pos, meth, rel)])"""
+    M, I, D, N, S, H, P, EQ, X = range(9)
+    c = lambda *ops: [(l << 4) | op for op, l in ops]
+    recs = [
+        # 2S 3M 2I 2M 3D 2M 1S at 100: query 0-1 clipped, 2-4 -> 100-102, 5-6 inserted, 7-8 -> 103-104, (105-107 deleted), 9-10 -> 108-109, 11 clipped
+        (0, 100, 0, 40, c((S, 2), (M, 3), (I, 2), (M, 2), (D, 3), (M, 2), (S, 1)), b"Z.z.ZZ.xZz.z", (100, 109, 1, [(100, 0, 2), (102, 1, 4), (104, 1, 8), (108, 0, 9)])),
+        # the same alignment on the reverse strand (flag 16): every call one base to the left, start / end unchanged
+        (0, 100, 16, 40, c((S, 2), (M, 3), (I, 2), (M, 2), (D, 3), (M, 2), (S, 1)), b"Z.z.ZZ.xZz.z", (100, 109, 0, [(99, 0, 2), (101, 1, 4), (103, 1, 8), (107, 0, 9)])),
+        # 5H 4M 100N 4M 2H at 200, flag 99 (forward rule): hard clips consume nothing, the ref-skip jumps 204..303
+        (0, 200, 99, 30, c((H, 5), (M, 4), (N, 100), (M, 4), (H, 2)), b"Z..zZ..z", (200, 307, 1, [(200, 1, 0), (203, 0, 3), (304, 1, 4), (307, 0, 7)])),
+        # 3= 1X 2= at 50, flag 163 (not one of 0 / 99 / 147: reverse rule)
+        (0, 50, 163, 20, c((EQ, 3), (X, 1), (EQ, 2)), b".Z.z..", (50, 55, 0, [(50, 1, 1), (52, 0, 3)])),
+        # flag 147 is a forward-rule flag; a leading insertion and a padding op: 2I 3M 1P 2M at 10 -> query 2-4 -> 10-12, 5-6 -> 13-14
+        (0, 10, 147, 5, c((I, 2), (M, 3), (P, 1), (M, 2)), b"zZz..ZZ", (10, 14, 1, [(10, 0, 2), (13, 1, 5), (14, 1, 6)])),
+        # flag 83 (reverse rule) with the first call at the read's first base: position start - 1
+        (0, 1000, 83, 60, c((M, 4),), b"Z..z", (1000, 1003, 0, [(999, 1, 0), (1002, 0, 3)])),
+        # XM shorter than the query (only the first 3 offsets exist), other context letters are not calls
+        (0, 2000, 0, 60, c((M, 8),), b"hZx", (2000, 2007, 1, [(2001, 1, 1)])),
+    ]
+    rec = bamio.Records([("chrH", 10_000)], [r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs],
+                        [r[4] for r in recs], [r[5] for r in recs])
+    return rec, [r[6] for r in recs]
+
+
+def check_hand_worked(soa, expected):
+    off = soa["cpg_off"].astype(np.int64)
+    for i, (st, en, fwd, calls) in enumerate(expected):
+        assert (int(soa["start"][i]), int(soa["end"][i]), int(soa["fwd"][i])) == (st, en, fwd), i
+        got = [(int(p & 0x7fffffff), int(p >> 31), int(r)) for p, r in zip(soa["cpg_pos"][off[i]:off[i + 1]], soa["cpg_rel"][off[i]:off[i + 1]])]
+        assert got == calls, (i, got, calls)
+
+
+def test_hand_worked_cigar_and_strand_rules(tmp_path):
+    rec, expected = hand_worked_records()
+    check_hand_worked(pyoracle.Reads.decode(rec).soa(), expected)              # the oracle's decoder
+    p = str(tmp_path / "hand.bam")
+    bamio.write_bam(p, rec)
+    check_hand_worked(hostapi.BamFile(p).decode(), expected)                    # the product's host decoder
+    check_hand_worked(pyoracle.Reads.decode(bamio.read_bam(p)).soa(), expected) # ... and through the Python BAM loader
