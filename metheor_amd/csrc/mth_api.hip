@@ -247,6 +247,9 @@ int mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_
         const int rcs = stage_batch(ctx, b, d);
         if (rcs) return rcs;
     }
+    // an empty region owns no site and no read: nothing is launched, so nothing may be recorded either (the per-batch
+    // row counts on the device are written by the batch's last kernel; an entry without one stayed uninitialised)
+    if (b.region_end == b.region_beg) return MTH_OK;
 
     // result capacity: at most one row per call and per owned position
     if (params->want_pdr) {
@@ -311,7 +314,8 @@ int mth_pdr_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *pos, float *pdr, uint32
         if (!cnt.empty()) MTH_HIP(ctx, hipMemcpy(cnt.data(), ctx->batch_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
         uint64_t o = 0;
         for (size_t b = 0; b < cnt.size(); ++b)
-            for (uint32_t j = 0; j < cnt[b]; ++j) tid[o++] = ctx->batches[b].tid;
+            for (uint32_t j = 0; j < cnt[b] && o < n; ++j) tid[o++] = ctx->batches[b].tid;
+        if (o != n) return fail(ctx, MTH_ERR_STATE, "per-batch row counts do not add up to the row count");
     }
     return MTH_OK;
 }

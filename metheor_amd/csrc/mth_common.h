@@ -37,7 +37,9 @@ struct DevState {
     uint64_t n_sites;        // PDR rows emitted so far (all batches)
     uint64_t cur_base;       // n_sites before the batch in flight
     int64_t  lpmd[4];        // n_concordant, n_discordant, n_read, n_valid_read
-    uint64_t pad_;           // 64 bytes: the runtime clears a 16-byte multiple with ONE fill kernel (56 bytes took two)
+    uint32_t safe_hi;        // batch in flight: tiles whose candidate reads end at or before this read index can load 8 call slots
+                             // per read without running past the call arrays (k_build_index; spares the tile a dependent load)
+    uint32_t pad_;           // 64 bytes: the runtime clears a 16-byte multiple with ONE fill kernel (56 bytes took two)
 };
 static_assert(sizeof(DevState) == 64, "DevState is cleared with one aligned fill");
 

@@ -56,12 +56,30 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
                                                        uint32_t nq, int aligned16,
                                                        uint32_t *__restrict__ idx,
                                                        DevState *__restrict__ st, DevState *__restrict__ cst,
-                                                       unsigned long long *__restrict__ bucket_sums, uint32_t n_bucket_words) {
+                                                       unsigned long long *__restrict__ bucket_sums, uint32_t n_bucket_words,
+                                                       const uint32_t *__restrict__ cpg_off, uint32_t n_cpgs) {
     // first kernel of a batch: its rows go after everything emitted so far, and the bucket sums start at zero
     // (nothing else runs between the previous batch's last kernel and this one on the stream)
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
     if (gtid == 0) cst->cur_base = cst->n_sites;
     for (uint32_t w = gtid; w < n_bucket_words; w += gridDim.x * BLOCK) bucket_sums[w] = 0ull;
+    // safe_hi: the largest read index r with cpg_off[r] + 8 <= n_cpgs, searched among the batch's last 256 indices by the
+    // first wave (0 if it is not there: every tile then takes the clamped loads).  The tile kernel used to load
+    // cpg_off[hi] for this decision: a dependent round trip before its first useful load.
+    if (cpg_off && gtid < 64) {
+        uint32_t best = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t back = gtid * 4u + k;
+            if (back <= n_reads) {
+                const uint32_t r = n_reads - back;
+                if ((uint64_t)cpg_off[r] + 8u <= (uint64_t)n_cpgs) best = max(best, r);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 64));
+        if (gtid == 0) st->safe_hi = best;
+    }
     const uint32_t i0 = gtid * 4u;
     if (i0 > n_reads) return;
     auto bucket = [&](int32_t s) -> int64_t {  // floor((s-base)/Q), -1 below the base
@@ -258,57 +276,56 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
     const int tid = threadIdx.x;
     const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
     constexpr bool PACKED = sizeof(RelT) == 1 && NB == 8;      // the table / packed-field forms below (8-bit relpos)
-    for (int i = tid; i < W / 4; i += B)
-        reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
-    slot_tabs_init(tabs, tid);
-    __syncthreads();
+    // (the caller has cleared the counters and built the slot tables)
 
     uint32_t lp_c = 0, lp_d = 0, n_read = 0, n_valid = 0, bad = 0;
-    for (uint32_t i = lo + tid; i < hi; i += B) {
-        const int32_t s = a.read_start[i];
-        const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
-        const uint8_t mq = a.read_mapq[i];
-        const uint32_t n = o1 - o0;
+    uint32_t i = lo + tid;
+    int32_t s = 0;
+    uint32_t o0 = 0, n = 0, mq = 0;
+    if (i < hi) { s = a.read_start[i]; o0 = a.cpg_off[i]; n = a.cpg_off[i + 1] - o0; mq = a.read_mapq[i]; }
+    while (i < hi) {
+        const uint32_t inext = i + B;
+        const bool more = inext < hi;
         const bool owned = (s >= T0) && (s < T1);
         // lpmd.rs:176-179
         const bool lp_ok = do_lp && owned && (mq >= a.lpmd_min_qual);
         if (do_lp && owned) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
         // pdr.rs:147-157
         const bool pdr_ok = a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);
-        if (!(lp_ok || pdr_ok) || n == 0) continue;
-
+        const bool work = (lp_ok || pdr_ok) && n != 0;
+        // (distances between live calls are < 2^16, so capping max_distance keeps dead-slot differences outside)
+        const int32_t maxd = PACKED ? min(a.max_dist, 255) : min(a.max_dist, 1 << 20);   // 8-bit relpos: no distance beyond 255
+        const int32_t mind = max(a.min_dist, 0);
+        const bool any_lp = maxd >= a.min_dist && maxd >= 0 && __any(work && lp_ok && n > 1);   // min > max: no pair can qualify (and the range trick below would wrap)
+        uint32_t v[NB];
+        int32_t r[NB];
+        uint32_t rraw0 = 0, rraw1 = 0;                         // PACKED, !CLAMP: the 8 relpos bytes as loaded
         // All calls of the read in flight at once: two 16-byte loads from a per-read base (dword alignment
         // is all global_load_dwordx4 needs) and one 8/16-byte load of the relative positions.  Slots k >= n
         // read the NEXT reads' calls and are neutralised below; only the batch's last few reads could run
         // past the end of the arrays: a tile that holds them runs the CLAMP instantiation (per-tile choice,
         // so neither instantiation merges two load paths inside the loop).
-        uint32_t v[NB];
-        int32_t r[NB];
-        uint32_t rraw0 = 0, rraw1 = 0;                         // PACKED, !CLAMP: the 8 relpos bytes as loaded
-        const uint32_t *__restrict__ cp = a.cpg_pos + o0;
-        const RelT *__restrict__ rp = rel + o0;
-        // (distances between live calls are < 2^16, so capping max_distance keeps dead-slot differences outside)
-        const int32_t maxd = PACKED ? min(a.max_dist, 255) : min(a.max_dist, 1 << 20);   // 8-bit relpos: no distance beyond 255
-        const int32_t mind = max(a.min_dist, 0);
-        const bool any_lp = maxd >= a.min_dist && maxd >= 0 && __any(lp_ok && n > 1);   // min > max: no pair can qualify (and the range trick below would wrap)
-        if (!CLAMP) {
+        if (work) {
+            const uint32_t *__restrict__ cp = a.cpg_pos + o0;
+            const RelT *__restrict__ rp = rel + o0;
+            if (!CLAMP) {
 #pragma unroll
-            for (int k4 = 0; k4 < NB / 4; ++k4) {
-                const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(cp + 4 * k4);
-                v[4 * k4] = x.x; v[4 * k4 + 1] = x.y; v[4 * k4 + 2] = x.z; v[4 * k4 + 3] = x.w;
-            }
-            if (any_lp) {
-                if constexpr (PACKED) { const u32x2_a1 x = *reinterpret_cast<const u32x2_a1 *>(rp); rraw0 = x.x; rraw1 = x.y; }
-                else load_rel<RelT, NB>(rp, r);
-            }
-        } else {
+                for (int k4 = 0; k4 < NB / 4; ++k4) {
+                    const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(cp + 4 * k4);
+                    v[4 * k4] = x.x; v[4 * k4 + 1] = x.y; v[4 * k4 + 2] = x.z; v[4 * k4 + 3] = x.w;
+                }
+                if (any_lp) {
+                    if constexpr (PACKED) { const u32x2_a1 x = *reinterpret_cast<const u32x2_a1 *>(rp); rraw0 = x.x; rraw1 = x.y; }
+                    else load_rel<RelT, NB>(rp, r);
+                }
+            } else {
 #pragma unroll
-            for (int k = 0; k < NB; ++k) v[k] = cp[min((uint32_t)k, n - 1)];
-            if (any_lp) {
+                for (int k = 0; k < NB; ++k) v[k] = cp[min((uint32_t)k, n - 1)];
+                if (any_lp) {
 #pragma unroll
-                for (int k = 0; k < NB; ++k) r[k] = (int32_t)rp[min((uint32_t)k, n - 1)];
+                    for (int k = 0; k < NB; ++k) r[k] = (int32_t)rp[min((uint32_t)k, n - 1)];
+                }
             }
-        }
         // Every instruction type issues from the same few waves here (profiles/r01_tile_variants.md: the
         // kernel is issue-bound), and predicates that are AND-ed / OR-ed per slot become s_and_b64 /
         // s_or_b64 / saveexec chains on the scalar unit.  So the liveness of a slot (k < n) is used ONCE,
@@ -458,7 +475,7 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         if (!WIDE) {
             const uint32_t one = disc ? 0x10000u : 1u;
             const uint32_t base4 = ((uint32_t)P0 << 2) - (pdr_ok ? 0u : (1u << 30));
-            const uint32_t trash4 = (uint32_t)(W + tid) << 2;
+            const uint32_t trash4 = (uint32_t)(W + (tid & 63)) << 2;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const uint32_t a4 = min((v[k] << 2) - base4, trash4);
@@ -473,7 +490,7 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         } else {
             const uint32_t wt = pdr_ok ? Wp : 0u;
             const uint32_t dw = disc ? (uint32_t)(W / 2) : 0u;
-            const uint32_t trash = (uint32_t)(W + tid) - dw;
+            const uint32_t trash = (uint32_t)(W + (tid & 63)) - dw;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const uint32_t pk = (v[k] & 0x7fffffffu) - (uint32_t)P0;
@@ -486,6 +503,11 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
                 }
             }
         }
+        }   // work
+        // the thread's next read.  (Requesting it together with the calls above and parking it in LDS -- one round
+        // trip per iteration instead of two -- was built and measured: no change, profiles/r02_tile_latency.md.)
+        if (more) { s = a.read_start[inext]; o0 = a.cpg_off[inext]; n = a.cpg_off[inext + 1] - o0; mq = a.read_mapq[inext]; }
+        i = inext;
     }
     if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
     if (do_lp) tile_lpmd_partials<B>(a, t, red, lp_c, lp_d, n_read, n_valid);
@@ -509,7 +531,7 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
 // covering half of the tile's positions -- same LDS footprint, no extra launch, exact.
 template <int W, int B, int NB, typename RelT>
 __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[W + B];   // counters, then one trash word per thread
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[W + 64];   // counters, then one trash word per lane
     __shared__ uint32_t red[4][B / 64];
     __shared__ uint32_t wave_off[B / 64 + 1];
     __shared__ __attribute__((aligned(16))) SlotTabs tabs;
@@ -527,19 +549,31 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
     // partial index) then only ever touches in-bounds reads, and its rows are discarded because the
     // getters report the error.  (An explicit load of the error flag here cost every tile a dependent
     // round trip before its first useful load.)
-    const uint32_t lo = min(a.idx[((uint32_t)T0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
-    const uint32_t hi = min(a.idx[(((uint32_t)T0 + (uint32_t)W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+    // The three words the tile needs first are requested together; the counters are cleared while they travel.
+    const uint32_t lo_raw = a.idx[((uint32_t)T0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT];
+    const uint32_t hi_raw = a.idx[(((uint32_t)T0 + (uint32_t)W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1];
+    // only a tile that holds the batch's last reads can have a read whose NB-slot window runs past the call arrays:
+    // k_build_index left the last read index that is safe for every tile ending at or before it
+    const uint32_t safe_hi = a.st->safe_hi;
+    auto clear = [&]() {
+        for (int i = threadIdx.x; i < W / 4; i += B) reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
+    };
+    clear();
+    slot_tabs_init(tabs, threadIdx.x);
+    __syncthreads();
+    const uint32_t lo = min(lo_raw, a.n_reads), hi = min(hi_raw, a.n_reads);
     uint32_t rows;
     if (hi - lo <= 65535u) {
-        // only a tile that holds the batch's last reads can have a read whose NB-slot window runs past the arrays
-        const bool clamp = a.cpg_off[hi] + (uint32_t)NB > a.n_cpgs;   // cpg_off ascends: covers every read of [lo, hi)
-        if (!clamp)
+        static_assert(NB == 8, "safe_hi is computed for 8 call slots");
+        if (hi <= safe_hi)
             rows = tile_pass<W, B, NB, RelT, false, false>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
         else
             rows = tile_pass<W, B, NB, RelT, false, true>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
     } else {
         const int32_t Tm = (int32_t)min((int64_t)T0 + W / 2, (int64_t)T1);
         rows = tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
+        __syncthreads();
+        clear();
         __syncthreads();
         rows += tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off, tabs);
     }
@@ -625,7 +659,7 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &id
     const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK - 1) / BLOCK;
     hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, idx_base, nq,
                        (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0), ctx->idx.as<uint32_t>(), ctx->d_state,
-                       ctx->d_state, (unsigned long long *)nullptr, 0u);   // cur_base is rewritten by the next PDR batch's own index build
+                       ctx->d_state, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr, 0u);   // cur_base is rewritten by the next PDR batch's own index build
     return MTH_OK;
 }
 
@@ -659,7 +693,8 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
         const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK - 1) / BLOCK;
         hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start,
                            b.n_reads, idx_base, nq, (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0),
-                           ctx->idx.as<uint32_t>(), ctx->d_state, cst, ctx->tile_bucket.as<unsigned long long>(), nbk * 5u);
+                           ctx->idx.as<uint32_t>(), ctx->d_state, cst, ctx->tile_bucket.as<unsigned long long>(), nbk * 5u,
+                           b.cpg_off, b.n_cpgs);
     }
     TileArgs a;
     a.read_start = b.read_start; a.read_mapq = b.read_mapq; a.cpg_off = b.cpg_off; a.cpg_pos = b.cpg_pos;
