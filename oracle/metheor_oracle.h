@@ -2,7 +2,7 @@
  * metheor_oracle.h -- C ABI of the CPU ORACLE.
  *
  * TEST INFRASTRUCTURE ONLY.  This is a CPU restatement of the reference
- * algorithm (dohlee/metheor v0.1.9, src/{readutil,pdr,lpmd,mhl,me,pm,fdrp,qfdrp}.rs)
+ * algorithm (dohlee/metheor v0.1.9, src/{readutil,pdr,lpmd,mhl,me,pm,fdrp,qfdrp,tag}.rs)
  * used as the parity checker by tests/, __graft_entry__.smoke() and as the
  * `cpu_baseline` leg of bench.py.  Nothing in the product path
  * (metheor_amd/, include/metheor_hip.h) may include, link or call it.
@@ -103,6 +103,14 @@ const int32_t  *orc_result_pos(const orc_result_t *);  /* n*k */
 const float    *orc_result_val(const orc_result_t *);
 const uint32_t *orc_result_cnt(const orc_result_t *);  /* n*m */
 void            orc_result_free(orc_result_t *);
+
+/* tag.rs:130-384 determine_xm_tag_string for ONE record (oracle/tag_oracle.cpp).  seq = the read's bases as text
+ * (rust-htslib seq().as_bytes()), ref_end = htslib's reference_end, contig = the bases [0, chromsize) of the record's
+ * contig (tag.rs:423-430 fetch_seq).  Returns the XM string's length (written to out, no terminator), or -1 where the
+ * reference panics. */
+int64_t  orc_tag_xm(int32_t pos, int32_t ref_end, uint16_t flag, int is_paired_end, const uint32_t *cigar,
+                    uint32_t n_cigar, const char *seq, int64_t l_seq, const char *contig, int64_t chromsize,
+                    char *out, int64_t out_cap);
 
 /* Rust `{}` of an f32 (shortest round-trip digits, never an exponent, "NaN", "inf").
  * returns strlen; buf must hold >= 64 bytes */

@@ -14,7 +14,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("metheor_oracle.cpp", "metheor_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("metheor_oracle.cpp", "tag_oracle.cpp", "metheor_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -57,6 +57,8 @@ def lib():
             getattr(L, "orc_result_" + f).argtypes = [vp]
         L.orc_result_free.argtypes = [vp]
         L.orc_format_f32.restype = C.c_int; L.orc_format_f32.argtypes = [C.c_float, C.c_char_p]
+        L.orc_tag_xm.restype = i64
+        L.orc_tag_xm.argtypes = [i32, i32, C.c_uint16, C.c_int, vp, u32, C.c_char_p, i64, C.c_char_p, i64, C.c_char_p, i64]
         _LIB = L
     return _LIB
 
@@ -189,3 +191,18 @@ def format_f32(v):
 
 def sample_j(seed, tid, pos, total):
     return lib().orc_sample_j(seed, tid, pos, total)
+
+
+def ref_end(pos, cigar):
+    """htslib bam_endpos: pos + reference bases consumed by M, D, N, =, X (pos + 1 when that is zero)"""
+    rl = sum(int(c) >> 4 for c in cigar if (int(c) & 15) in (0, 2, 3, 7, 8))
+    return pos + (rl if rl else 1)
+
+
+def tag_xm(pos, flag, cigar, seq, contig, is_paired_end=False):
+    """tag.rs:130-384 for one record; cigar = BAM-packed ops, seq / contig = bytes.  None where the reference panics."""
+    cg = np.ascontiguousarray(cigar, dtype=np.uint32)
+    out = C.create_string_buffer(len(seq) + 8)
+    n = lib().orc_tag_xm(int(pos), int(ref_end(pos, cg)), int(flag), int(bool(is_paired_end)), _ptr(cg), len(cg),
+                         bytes(seq), len(seq), bytes(contig), len(contig), out, len(seq) + 8)
+    return None if n < 0 else out.raw[:n]
