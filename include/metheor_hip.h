@@ -284,6 +284,24 @@ int  mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *
 int  mth_decoded_batch(mth_ctx_t *ctx, uint64_t read_beg, uint64_t read_end, int32_t tid, int32_t region_beg,
                        int32_t region_end, mth_batch_t *batch);
 
+/* ---- `metheor tag`: the Bismark XM string of every record from the read's bases and the genome ----------
+ * Replaces src/tag.rs:130-384 determine_xm_tag_string (per record) and the genome side of run(), tag.rs:419-431.
+ * mth_tag_set_genome: n_refs contigs in header (tid) order; ref_len[t] = the header's LN (tag.rs:60-72), seq[t] / seq_len[t] =
+ * the bases the FASTA gave for positions [0, seq_len[t]) (any case; HOST memory; copied).  A contig the FASTA lacks is the
+ * caller's error to raise (tag.rs:427 expect).
+ * mth_tag_records: a window of BAM records as mth_decode_records takes it (raw bytes + n_rec + 1 offsets); is_paired_end =
+ * bamutil.rs:27-37 (flag 0x1 of the file's first record).  On return record i's string is xm[xm_off[i] .. xm_off[i] + xm_len[i])
+ * (host memory owned by the context, valid until the next call).  MTH_ERR_FORMAT where the reference panics. */
+typedef struct {
+    uint64_t        n_records;
+    const uint64_t *xm_off;     /* n_records + 1 slot starts */
+    const uint32_t *xm_len;
+    const char     *xm;
+} mth_tag_out_t;
+int  mth_tag_set_genome(mth_ctx_t *ctx, int32_t n_refs, const int64_t *ref_len, const uint8_t *const *seq, const int64_t *seq_len);
+int  mth_tag_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const uint64_t *rec_off, uint64_t n_rec, int mem,
+                     int is_paired_end, mth_tag_out_t *out);
+
 /* ---- measurement hooks (bench.py's roofline leg) -------------------------------------- */
 /* when enabled, every kernel launch is bracketed by hipEvents on the launch stream */
 int  mth_timing_enable(mth_ctx_t *ctx, int on);

@@ -3,7 +3,7 @@
  * XM-tag decode that produce the SoA batches of metheor_hip.h.
  *
  * Reference interfaces replaced (paths under the reference repo):
- *   src/bamutil.rs:4-11    get_reader(input) -> bam::Reader (rust-htslib / C htslib)   => mth_host_open
+ *   src/bamutil.rs:4-11    get_reader(input) -> bam::Reader (rust-htslib / C htslib; BAM or SAM text) => mth_host_open
  *   src/bamutil.rs:13-25   get_header / tid2chrom / chrom2tid                           => mth_host_n_refs / _ref_name / _ref_len / _ref_tid
  *   src/readutil.rs:24-53  BismarkRead::new(&Record)   (start/end, XM tag required)
  *   src/readutil.rs:323-345 get_cpgs (z/Z only, aligned bases only, strand rule flags in {0,99,147})
@@ -44,6 +44,22 @@ int  mth_host_n_refs(const mth_host_t *h);
 const char *mth_host_ref_name(const mth_host_t *h, int tid);
 int64_t mth_host_ref_len(const mth_host_t *h, int tid);
 int  mth_host_ref_tid(const mth_host_t *h, const char *name);   /* -1 if unknown */
+
+/* the header text as the file holds it (what bam::Header::from_template copies into a writer, tag.rs:403-406) */
+const char *mth_host_header_text(const mth_host_t *h, uint64_t *n_bytes);
+/* One BAM record (the bytes after its block_size field) as a SAM line ending in '\n' -- what bam::Writer with Format::Sam
+ * prints (tag.rs:405-441); xm != NULL appends the field XM:Z:<xm> last, as push_aux does (tag.rs:437).  Returns the line's
+ * length (copied to buf when it fits cap), or a negative status for a malformed record. */
+int64_t mth_host_sam_format(const mth_host_t *h, const uint8_t *rec, uint32_t rec_len, const char *xm, uint32_t xm_len,
+                            char *buf, int64_t cap);
+/* FASTA access for `tag` (faidx::Reader::from_path + fetch_seq, tag.rs:412-431): the .fai next to the file when present,
+ * otherwise one scan of the file.  A missing file reports "file not found: <path>" (tests/tag-cli.rs:42-58).
+ * fetch: the bases [0, end_incl] of `name` clipped to the sequence (faidx_fetch_seq semantics); valid until the next fetch. */
+typedef struct mth_fasta mth_fasta_t;
+int  mth_host_fasta_open(const char *path, mth_fasta_t **out, char *errbuf, int errbuf_len);
+void mth_host_fasta_close(mth_fasta_t *f);
+const char *mth_host_fasta_last_error(const mth_fasta_t *f);
+int  mth_host_fasta_fetch(mth_fasta_t *f, const char *name, int64_t end_incl, const uint8_t **seq, int64_t *len);
 
 /* Decode ALL remaining records of the file into one SoA held by the handle, in file order.
  * cpg_set_path may be NULL.  After success the arrays below are valid until close/decode. */

@@ -16,7 +16,7 @@ SYMBOLS = [
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
     "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
-    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch",
+    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -65,6 +65,10 @@ class mth_fdrp_params_t(C.Structure):
 
 class mth_lpmd_pairs_params_t(C.Structure):
     _fields_ = [("min_distance", C.c_int32), ("max_distance", C.c_int32), ("min_qual", C.c_uint8)]
+
+
+class mth_tag_out_t(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("xm_off", C.c_void_p), ("xm_len", C.c_void_p), ("xm", C.c_void_p)]
 
 
 def library_path():
@@ -123,6 +127,8 @@ def lib():
         L.mth_decode_set_xm_min_mapq.argtypes = [vp, C.c_uint32]
         L.mth_bgzf_inflate.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
         L.mth_bgzf_decode.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(mth_decoded_t)]
+        L.mth_tag_set_genome.argtypes = [vp, C.c_int32, vp, vp, vp]
+        L.mth_tag_records.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(mth_tag_out_t)]
         L.mth_decoded_fetch.argtypes = [vp] * 9
         L.mth_decoded_contigs.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.mth_decoded_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(mth_batch_t)]
@@ -387,6 +393,29 @@ class Engine:
                                            len(coff), int(first_byte), int(bool(append)), C.byref(d)))
         self._decoded = d
         return int(d.n_reads), int(d.n_cpgs)
+
+    def tag_set_genome(self, contigs):
+        """contigs: [(header LN, bases as bytes)] in tid order (mth_tag_set_genome; tag.rs:419-431)"""
+        n = len(contigs)
+        ln = (C.c_int64 * max(n, 1))(*[int(c[0]) for c in contigs])
+        got = (C.c_int64 * max(n, 1))(*[len(c[1]) for c in contigs])
+        bufs = [np.frombuffer(bytes(c[1]), np.uint8) for c in contigs]
+        ptr = (C.c_void_p * max(n, 1))(*[b.ctypes.data if len(b) else None for b in bufs])
+        self._check(self.L.mth_tag_set_genome(self.h, n, ln, ptr, got))
+
+    def tag_records(self, raw, rec_off, is_paired_end=False):
+        """raw: the inflated BAM records (bytes), rec_off: uint64[n_rec + 1]; -> list of XM strings (bytes), tag.rs:130-384"""
+        rb = np.frombuffer(raw, np.uint8)
+        off = np.ascontiguousarray(rec_off, np.uint64)
+        t = mth_tag_out_t()
+        n = len(off) - 1
+        self._check(self.L.mth_tag_records(self.h, rb.ctypes.data if len(rb) else None, len(rb), off.ctypes.data, max(n, 0), 0,
+                                           int(bool(is_paired_end)), C.byref(t)))
+        if n <= 0:
+            return []
+        xo = np.ctypeslib.as_array(C.cast(t.xm_off, C.POINTER(C.c_uint64)), shape=(n + 1,))
+        xl = np.ctypeslib.as_array(C.cast(t.xm_len, C.POINTER(C.c_uint32)), shape=(n,))
+        return [C.string_at(t.xm + int(xo[i]), int(xl[i])) for i in range(n)]
 
     def decoded_fetch(self):
         d = self._decoded

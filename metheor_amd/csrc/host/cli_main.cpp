@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <sys/stat.h>
 #include <thread>
 #include <vector>
 
@@ -798,6 +799,105 @@ int run_fdrp(const Args &a, bool quantitative) {
 
 }  // namespace
 
+// ---- metheor tag (src/tag.rs:386-443 run) ---------------------------------------------------------------------
+// Same order of events as the reference: open the input (BAM or SAM text) and look at its first record's paired flag
+// (bamutil.rs:27-37), refuse an output path whose parent is not a directory (tag.rs:396-403; a bare file name has the
+// parent "" and is refused there too), create the output and write the header as it is (tag.rs:405-410), open the
+// FASTA and fetch every @SQ contig (tag.rs:412-431, printing the two progress lines), then stream the records: the
+// XM string of each is computed on the device (mth_tag_records), appended as the last optional field and the record is
+// written as a SAM line (tag.rs:433-441).
+struct TagState {
+    mth_ctx_t *ctx = nullptr;
+    mth_host_t *h = nullptr;
+    FILE *out = nullptr;
+    int paired = -1;
+    std::string line, fail;
+};
+int tag_window(void *user, const uint8_t *buf, const uint64_t *rec_off, uint64_t n_rec) {
+    TagState *st = static_cast<TagState *>(user);
+    if (n_rec == 0) return 0;
+    if (st->paired < 0) {                          // is_paired_end: the file's first record
+        const uint64_t o = rec_off[0];
+        st->paired = (rec_off[1] - o >= 36) ? ((buf[o + 4 + 14] | (buf[o + 4 + 15] << 8)) & 1) : 0;
+    }
+    mth_tag_out_t t{};
+    const int rc = mth_tag_records(st->ctx, buf, rec_off[n_rec], rec_off, n_rec, MTH_MEM_HOST, st->paired, &t);
+    if (rc != MTH_OK) {
+        st->fail = std::string("metheor (MI355X path): ") + mth_strerror(rc) + (mth_last_error(st->ctx)[0] ? std::string(" -- ") + mth_last_error(st->ctx) : std::string());
+        return 1;
+    }
+    std::vector<char> b;
+    for (uint64_t i = 0; i < n_rec; ++i) {
+        const uint8_t *rec = buf + rec_off[i] + 4;
+        const uint32_t len = (uint32_t)(rec_off[i + 1] - rec_off[i] - 4);
+        const int64_t cap = 4 * (int64_t)len + 256 + t.xm_len[i];
+        if ((int64_t)b.size() < cap) b.resize((size_t)cap);
+        const int64_t n = mth_host_sam_format(st->h, rec, len, t.xm + t.xm_off[i], t.xm_len[i], b.data(), (int64_t)b.size());
+        if (n < 0 || n > (int64_t)b.size()) { st->fail = "Error writing to output file."; return 1; }
+        if (fwrite(b.data(), 1, (size_t)n, st->out) != (size_t)n) { st->fail = "Error writing to output file."; return 1; }
+    }
+    return 0;
+}
+
+int run_tag(const Args &a) {
+    const std::string input = a.s.at("input"), output = a.s.at("output"), genome = a.s.at("genome");
+    CtxFuture cf;
+    cf.start();
+    mth_host_t *h = nullptr;
+    char err[1024];
+    if (mth_host_open(input.c_str(), &h, err, sizeof err) != 0) { cf.wait(); die(err); }   // bamutil.rs:4-11
+    // tag.rs:396-403: PathBuf::from(output).parent() must be a directory
+    {
+        const size_t slash = output.rfind('/');
+        const std::string dir = slash == std::string::npos ? std::string() : (slash == 0 ? std::string("/") : output.substr(0, slash));
+        struct stat sb;
+        if (dir.empty() || stat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode)) { cf.wait(); die("No such directory for output alignment file: " + dir); }
+    }
+    FILE *out = fopen(output.c_str(), "wb");
+    if (!out) { cf.wait(); die("Error opening alignment file to write: " + output + ": " + strerror(errno)); }
+    static char obuf[1 << 20];
+    setvbuf(out, obuf, _IOFBF, sizeof obuf);
+    {   // the header text as it is, newline-terminated (Header::from_template strips and re-adds the final newline)
+        uint64_t n = 0;
+        const char *t = mth_host_header_text(h, &n);
+        std::string text(t, strnlen(t, (size_t)n));
+        while (!text.empty() && text.back() == '\n') text.pop_back();
+        if (!text.empty()) { text += '\n'; fwrite(text.data(), 1, text.size(), out); }
+    }
+    mth_fasta_t *fa = nullptr;
+    if (mth_host_fasta_open(genome.c_str(), &fa, err, sizeof err) != 0) { cf.wait(); fflush(out); die(std::string("Error opening reference genome file: ") + err); }
+    printf("Parsing reference genome...\n");
+    mth_ctx_t *ctx = cf.get();
+    {
+        Phase ph("genome -> device");
+        const int n_refs = mth_host_n_refs(h);
+        std::vector<std::vector<uint8_t>> seqs((size_t)n_refs);
+        std::vector<const uint8_t *> ptr((size_t)n_refs);
+        std::vector<int64_t> ln((size_t)n_refs), got((size_t)n_refs);
+        for (int t = 0; t < n_refs; ++t) {
+            const uint8_t *p = nullptr;
+            int64_t n = 0;
+            ln[(size_t)t] = mth_host_ref_len(h, t);
+            if (mth_host_fasta_fetch(fa, mth_host_ref_name(h, t), ln[(size_t)t], &p, &n) != 0) { fflush(out); die("Error fetching reference genome sequence.: " + std::string(mth_host_fasta_last_error(fa))); }
+            seqs[(size_t)t].assign(p, p + n);
+            ptr[(size_t)t] = seqs[(size_t)t].data(); got[(size_t)t] = n;
+        }
+        check(ctx, mth_tag_set_genome(ctx, n_refs, ln.data(), ptr.data(), got.data()));
+    }
+    printf("Done!\n");
+    fflush(stdout);
+    TagState st;
+    st.ctx = ctx; st.h = h; st.out = out;
+    {
+        Phase ph("records -> XM -> SAM");
+        const int rc = mth_host_decode_stream(h, tag_window, &st);
+        if (rc != 0) { fflush(out); die(!st.fail.empty() ? st.fail : std::string("Error reading BAM record. ") + mth_host_last_error(h)); }
+    }
+    if (fclose(out) != 0) die("Error writing to output file.");
+    mth_host_fasta_close(fa);
+    return finish(ctx, h);
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { print_main_help(stderr); return 2; }   // arg_required_else_help (lib.rs:18)
     const std::string sub = argv[1];
@@ -821,7 +921,8 @@ int main(int argc, char **argv) {
         return -1;
     };
     if (sub == "tag") {
-        die("metheor (MI355X path): subcommand '" + sub + "' has no device kernel yet; there is no CPU fallback");
+        if (const char *dev = getenv("METHEOR_DEVICE")) g_shard.device = atoi(dev);
+        return run_tag(a);
     }
     int64_t halo = 65536;
     if (const char *e = getenv("METHEOR_SHARD_HALO")) { const long long k = atoll(e); if (k >= 0) halo = k; }

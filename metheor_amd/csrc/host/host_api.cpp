@@ -28,6 +28,9 @@
 #include "bam_reader.h"
 #include "bai_internal.h"
 #include "parallel_decode.h"
+#include "sam_text.h"
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <thread>
 
@@ -41,6 +44,14 @@ struct mth_host : DecodedSoA {
     std::unique_ptr<BgzfMap> bgzf;
     std::vector<uint64_t> cpg_keys;
     int xm_min_mapq = 0;             // mth_host_set_xm_min_mapq
+    int memfd = -1;                  // SAM input: the equivalent BAM lives in an anonymous memory file, `path` names it
+    ~mth_host() { if (memfd >= 0) close(memfd); }
+};
+
+struct mth_fasta {
+    Fasta fa;
+    std::vector<uint8_t> seq;
+    std::string last_error;
 };
 
 namespace {
@@ -77,7 +88,30 @@ int mth_host_open(const char *path, mth_host_t **out, char *errbuf, int errbuf_l
     if (!path || !out) return MTH_HOST_ERR_INVALID;
     *out = nullptr;
     auto *h = new mth_host;
-    if (!h->reader.open(path)) {
+    std::string open_path = path;
+    // htslib opens SAM text through the same call (bamutil.rs:4-11; tests/tag-cli.rs feeds `tag` a .sam): the text is
+    // converted once into the bytes of a BGZF-compressed BAM held in an anonymous memory file, and everything behind
+    // this handle -- host inflate, device inflate, the shard planner -- reads that
+    if (looks_like_sam(path)) {
+        std::vector<uint8_t> bam;
+        std::string err;
+        if (!sam_text_to_bam(path, bam, err)) {
+            const std::string msg = "Error opening BAM file. " + err;
+            if (errbuf && errbuf_len > 0) { strncpy(errbuf, msg.c_str(), (size_t)errbuf_len - 1); errbuf[errbuf_len - 1] = 0; }
+            delete h;
+            return MTH_HOST_ERR_OPEN;
+        }
+        h->memfd = memfd_create("metheor_sam_as_bam", 0);
+        bool ok = h->memfd >= 0;
+        for (size_t o = 0; ok && o < bam.size();) { const ssize_t w = write(h->memfd, bam.data() + o, bam.size() - o); if (w <= 0) ok = false; else o += (size_t)w; }
+        if (!ok) {
+            if (errbuf && errbuf_len > 0) { strncpy(errbuf, "Error opening BAM file. cannot stage the SAM input in memory", (size_t)errbuf_len - 1); errbuf[errbuf_len - 1] = 0; }
+            delete h;
+            return MTH_HOST_ERR_OPEN;
+        }
+        open_path = "/proc/self/fd/" + std::to_string(h->memfd);
+    }
+    if (!h->reader.open(open_path)) {
         // bamutil.rs:7-9: panic!("Error opening BAM file. {}", error)
         const std::string msg = "Error opening BAM file. " + h->reader.error();
         if (errbuf && errbuf_len > 0) { strncpy(errbuf, msg.c_str(), (size_t)errbuf_len - 1); errbuf[errbuf_len - 1] = 0; }
@@ -85,7 +119,7 @@ int mth_host_open(const char *path, mth_host_t **out, char *errbuf, int errbuf_l
         return MTH_HOST_ERR_OPEN;
     }
     for (size_t i = 0; i < h->reader.refs().size(); ++i) h->name2tid.emplace(h->reader.refs()[i].name, (int)i);
-    h->path = path;
+    h->path = open_path;
     h->header_bytes = h->reader.consumed();
     *out = h;
     return MTH_HOST_OK;
@@ -103,6 +137,41 @@ int64_t mth_host_ref_len(const mth_host_t *h, int tid) {
 int mth_host_ref_tid(const mth_host_t *h, const char *name) {
     auto it = h->name2tid.find(name);
     return it == h->name2tid.end() ? -1 : it->second;
+}
+
+const char *mth_host_header_text(const mth_host_t *h, uint64_t *n_bytes) {
+    if (n_bytes) *n_bytes = h ? h->reader.header_text().size() : 0;
+    return h ? h->reader.header_text().data() : "";
+}
+
+int64_t mth_host_sam_format(const mth_host_t *h, const uint8_t *rec, uint32_t rec_len, const char *xm, uint32_t xm_len, char *buf, int64_t cap) {
+    if (!h || !rec) return MTH_HOST_ERR_INVALID;
+    std::string line;
+    if (!sam_format_record(h->reader.refs(), rec, rec_len, xm, xm_len, line)) return MTH_HOST_ERR_FORMAT;
+    if (buf && (int64_t)line.size() <= cap) memcpy(buf, line.data(), line.size());
+    return (int64_t)line.size();
+}
+
+int mth_host_fasta_open(const char *path, mth_fasta_t **out, char *errbuf, int errbuf_len) {
+    if (!path || !out) return MTH_HOST_ERR_INVALID;
+    *out = nullptr;
+    auto *f = new mth_fasta;
+    std::string err;
+    if (!f->fa.open(path, err)) {
+        if (errbuf && errbuf_len > 0) { strncpy(errbuf, err.c_str(), (size_t)errbuf_len - 1); errbuf[errbuf_len - 1] = 0; }
+        delete f;
+        return MTH_HOST_ERR_OPEN;
+    }
+    *out = f;
+    return MTH_HOST_OK;
+}
+void mth_host_fasta_close(mth_fasta_t *f) { delete f; }
+const char *mth_host_fasta_last_error(const mth_fasta_t *f) { return f ? f->last_error.c_str() : ""; }
+int mth_host_fasta_fetch(mth_fasta_t *f, const char *name, int64_t end_incl, const uint8_t **seq, int64_t *len) {
+    if (!f || !name || !seq || !len) return MTH_HOST_ERR_INVALID;
+    if (!f->fa.fetch(name, end_incl, f->seq, f->last_error)) return MTH_HOST_ERR_FORMAT;
+    *seq = f->seq.data(); *len = (int64_t)f->seq.size();
+    return MTH_HOST_OK;
 }
 
 int mth_host_set_xm_min_mapq(mth_host_t *h, int min_mapq) {

@@ -75,6 +75,7 @@ int sync_and_check(mth_ctx *ctx) {
     if (e & ERRB_CAPACITY) return fail(ctx, MTH_ERR_CAPACITY, "capacity exceeded (CpGs of a read >= 2048 bp apart in a quartet, a read with more than 512 CpGs in MHL, or FDRP max_depth above 16384)");
     if (e & ERRB_CRC) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block (CRC32 mismatch)");
     if (e & ERRB_FORMAT) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block or malformed BAM record (DEFLATE / ISIZE / block_size / field lengths inconsistent)");
+    if (e & ERRB_TAGPANIC) return fail(ctx, MTH_ERR_FORMAT, "tag: a record the reference cannot tag either (unplaced or outside its contig / the FASTA, a base without a complement, or a C whose context ends in a deletion): determine_xm_tag_string panics there");
     if (e & ERRB_NOXM) return fail(ctx, MTH_ERR_FORMAT, "a record has no XM:Z tag (the reference panics: Error reading XM tag)");
     if (e & ERRB_UNALIGNED) return fail(ctx, MTH_ERR_UNALIGNED, "a BAM record straddles two BGZF blocks: the per-block device walk does not apply (use the host walk)");
     return MTH_OK;
@@ -180,6 +181,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
                       &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_bucket, &ctx->scratch, &ctx->dec_raw, &ctx->dec_recoff, &ctx->dec_tid, &ctx->dec_start, &ctx->dec_end,
                       &ctx->dec_mapq, &ctx->dec_fwd, &ctx->dec_n, &ctx->dec_off, &ctx->dec_pos, &ctx->dec_rel, &ctx->dec_blk, &ctx->dec_off32, &ctx->dec_runs, &ctx->dec_xm, &ctx->dec_filter,
                       &ctx->inf_file, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff, &ctx->crc_mat,
+                      &ctx->tag_genome, &ctx->tag_goff, &ctx->tag_ncol, &ctx->tag_coloff, &ctx->tag_xmlen, &ctx->tag_cols, &ctx->tag_xm,
                       &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
                       &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_tflag, &ctx->q_tile_row0, &ctx->q_tile_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
                       &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_aux, &ctx->w_flags,

@@ -27,6 +27,7 @@ enum : uint32_t {
     ERRB_FORMAT = 1u << 5,     // device record decode: malformed BAM record
     ERRB_NOXM = 1u << 6,       // device record decode: record without XM:Z
     ERRB_CRC = 1u << 8,        // device inflate: CRC32 of an inflated BGZF block does not match its trailer
+    ERRB_TAGPANIC = 1u << 9,   // tag: a record on which the reference's determine_xm_tag_string panics (tag.rs:24, 155-170, 297)
     ERRB_UNALIGNED = 1u << 7,  // device record walk: a record straddles two BGZF blocks (take the host walk)
 };
 

@@ -51,6 +51,13 @@ struct mth_ctx {
     uint64_t dec_reads = 0, dec_cpgs = 0;
     // device-side BGZF inflate + per-block record walk (mth_inflate.hip)
     mth::DevBuf inf_file, inf_tab, inf_raw, inf_cnt, inf_base, inf_recoff, crc_mat;
+    // `tag` (mth_tag.hip): the genome (contigs back to back), per-contig offsets + header lengths, per-record work arrays,
+    // and the host copies mth_tag_records hands out
+    mth::DevBuf tag_genome, tag_goff, tag_ncol, tag_coloff, tag_xmlen, tag_cols, tag_xm;
+    int32_t tag_n_refs = -1;
+    std::vector<uint64_t> tag_h_off;
+    std::vector<uint32_t> tag_h_len;
+    std::vector<uint8_t> tag_h_xm;
     // results (PDR columns)
     mth::DevBuf out_pos, out_pdr, out_nc, out_nd;
     uint64_t out_cap = 0;        // rows

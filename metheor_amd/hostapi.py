@@ -12,7 +12,8 @@ SYMBOLS = [
     "mth_host_ref_len", "mth_host_ref_tid", "mth_host_set_xm_min_mapq", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_plan_region", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
     "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
     "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32", "mth_host_write_synthetic_bam",
-    "mth_host_write_synthetic_bam_multi",
+    "mth_host_write_synthetic_bam_multi", "mth_host_header_text", "mth_host_sam_format", "mth_host_fasta_open", "mth_host_fasta_close",
+    "mth_host_fasta_last_error", "mth_host_fasta_fetch",
 ]
 
 
@@ -24,6 +25,9 @@ class _Bgzf(C.Structure):      # mth_host_bgzf_t
 class _Shard(C.Structure):     # mth_host_shard_t
     _fields_ = [("block_beg", C.c_uint64), ("block_end", C.c_uint64), ("first_byte", C.c_uint64),
                 ("tid_beg", C.c_int32), ("pos_beg", C.c_int32), ("tid_end", C.c_int32), ("pos_end", C.c_int32)]
+
+
+WINDOW_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)   # mth_host_window_cb
 
 
 class HostError(RuntimeError):
@@ -62,6 +66,13 @@ def lib():
         L.mth_host_format_f32.argtypes = [C.c_float, C.c_char_p]
         L.mth_host_write_synthetic_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int32] + [vp] * 6 + [C.c_uint64, C.c_int]
         L.mth_host_write_synthetic_bam_multi.argtypes = [C.c_char_p, C.c_int32, vp, vp, C.c_int64, C.c_int32] + [vp] * 7 + [C.c_uint64, C.c_int]
+        L.mth_host_header_text.argtypes = [vp, C.POINTER(C.c_uint64)]; L.mth_host_header_text.restype = vp
+        L.mth_host_sam_format.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int64]; L.mth_host_sam_format.restype = C.c_int64
+        L.mth_host_decode_stream.argtypes = [vp, WINDOW_CB, vp]
+        L.mth_host_fasta_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int]
+        L.mth_host_fasta_close.argtypes = [vp]; L.mth_host_fasta_close.restype = None
+        L.mth_host_fasta_last_error.argtypes = [vp]; L.mth_host_fasta_last_error.restype = C.c_char_p
+        L.mth_host_fasta_fetch.argtypes = [vp, C.c_char_p, C.c_int64, C.POINTER(vp), C.POINTER(C.c_int64)]
         _LIB = L
     return _LIB
 
@@ -174,3 +185,60 @@ class BamFile:
                     end=arr("read_end", np.int32, n), mapq=arr("read_mapq", np.uint8, n),
                     fwd=arr("read_fwd", np.uint8, n), cpg_off=arr("cpg_off", np.uint64, n + 1),
                     cpg_pos=arr("cpg_pos", np.uint32, nc), cpg_rel=arr("cpg_rel", np.uint16, nc))
+
+    def header_text(self):
+        n = C.c_uint64(0)
+        p = self.L.mth_host_header_text(self.h, C.byref(n))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def windows(self):
+        """mth_host_decode_stream: [(bytes of the window, record offsets uint64[n_rec + 1])] -- host inflate + record walk only"""
+        out = []
+
+        def cb(_user, buf, off, n_rec):
+            o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), shape=(n_rec + 1,)).copy()
+            out.append((C.string_at(buf, int(o[-1])), o))
+            return 0
+        rc = self.L.mth_host_decode_stream(self.h, WINDOW_CB(cb), None)
+        if rc != 0:
+            raise HostError(rc, self.L.mth_host_last_error(self.h).decode())
+        return out
+
+    def sam_line(self, raw, o0, o1, xm=None):
+        """the record at raw[o0:o1] (block_size field included) as a SAM line; xm (bytes) is appended as XM:Z"""
+        rec = (C.c_uint8 * (o1 - o0 - 4)).from_buffer_copy(raw[o0 + 4:o1])
+        cap = 4 * (o1 - o0) + 256 + (len(xm) if xm else 0)
+        buf = C.create_string_buffer(cap)
+        n = self.L.mth_host_sam_format(self.h, rec, o1 - o0 - 4, xm, len(xm) if xm else 0, buf, cap)
+        if n < 0 or n > cap:
+            raise HostError(int(n), "cannot format the record")
+        return buf.raw[:n]
+
+
+class Fasta:
+    def __init__(self, path):
+        self.L = lib()
+        self.h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = self.L.mth_host_fasta_open(os.fsencode(path), C.byref(self.h), err, 1024)
+        if rc != 0:
+            self.h = None
+            raise HostError(rc, err.value.decode())
+
+    def fetch(self, name, end_incl):
+        p, n = C.c_void_p(), C.c_int64(0)
+        rc = self.L.mth_host_fasta_fetch(self.h, name.encode(), int(end_incl), C.byref(p), C.byref(n))
+        if rc != 0:
+            raise HostError(rc, self.L.mth_host_fasta_last_error(self.h).decode())
+        return C.string_at(p, n.value) if n.value else b""
+
+    def close(self):
+        if self.h:
+            self.L.mth_host_fasta_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -86,6 +86,31 @@ def test_tag_missing_reference(tmp_path):        # :246-259
     assert r.returncode != 0 and "required" in r.stderr
 
 
+# ---- tests/tag-cli.rs (the three failure cases need no device: they end before the first kernel) ----
+def test_tag_input_file_doesnt_exist(tmp_path):  # tag-cli.rs:7-23
+    r = run("tag", "-i", "tests/no_such_input.bam", "-o", str(tmp_path / "out.bam"), "-g", "tests/hg38.chr19.fa")
+    assert r.returncode != 0 and "file not found" in r.stderr and "no_such_input.bam" in r.stderr
+
+
+def test_tag_output_directory_doesnt_exist(tmp_path):   # tag-cli.rs:24-40, tag.rs:396-403
+    sam = os.path.join(ROOT, "tests", "golden", "test.chr19.XM.sam")
+    r = run("tag", "-i", sam, "-o", "no_such_dir/out.bam", "-g", "tests/hg38.chr19.fa")
+    assert r.returncode == 101 and "No such directory" in r.stderr and "no_such_dir" in r.stderr
+    # PathBuf::from("out.sam").parent() is "" -- not a directory: the reference refuses a bare file name too
+    r = run("tag", "-i", sam, "-o", "out_bare_name.sam", "-g", "tests/hg38.chr19.fa")
+    assert r.returncode == 101 and "No such directory" in r.stderr
+    assert not os.path.exists(os.path.join(ROOT, "out_bare_name.sam"))
+
+
+def test_tag_reference_genome_doesnt_exist(tmp_path):   # tag-cli.rs:41-58; tag.rs:386-390 error_when_reference_genome_is_not_found
+    sam = os.path.join(ROOT, "tests", "golden", "test.chr19.XM.sam")
+    out = tmp_path / "out.sam"
+    r = run("tag", "-i", sam, "-o", str(out), "-g", "tests/no_such.fa")
+    assert r.returncode == 101 and "file not found" in r.stderr and "no_such.fa" in r.stderr
+    # the writer is created (and the header written) before the genome is opened (tag.rs:405-417)
+    assert out.read_text().startswith("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr19\tLN:58617616\n")
+
+
 def test_subcommand_help_texts():                # :277-311
     r = run("pdr", "--help")
     assert r.returncode == 0 and "PDR" in r.stdout and "--input" in r.stdout and "--output" in r.stdout
