@@ -268,6 +268,14 @@ int  mth_bgzf_inflate(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const 
  * MTH_ERR_FORMAT. */
 int  mth_bgzf_decode(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
                      const uint32_t *isize, uint64_t n_blocks, uint64_t first_byte, int append, mth_decoded_t *out);
+/* Overlap of the NEXT chunk's host-to-device copy with the current chunk's kernels: announces file[0, n_bytes) (host memory
+ * that stays valid) as the chunk after the one the next mth_bgzf_decode / mth_bgzf_inflate call is given.  That call starts a
+ * helper thread which copies the announced bytes into a second staging buffer on a side stream while its own kernels run;
+ * the following call, given the SAME pointer and size, uses them instead of copying.  n_bytes = 0 withdraws the announcement. */
+int  mth_bgzf_stage(mth_ctx_t *ctx, const void *file, uint64_t n_bytes);
+/* size the decoded arrays for n_reads / n_cpgs in total (what is decoded so far is kept): spares the appending calls their
+ * reallocations when the caller can estimate the file's totals */
+int  mth_decode_reserve(mth_ctx_t *ctx, uint64_t n_reads, uint64_t n_cpgs);
 /* copy the decoded arrays to the host (any pointer may be NULL) */
 int  mth_decoded_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *start, int32_t *end, uint8_t *mapq, uint8_t *fwd,
                        uint64_t *cpg_off, uint32_t *cpg_pos, uint16_t *cpg_rel);

@@ -16,7 +16,7 @@ SYMBOLS = [
     "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
     "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
-    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
+    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_bgzf_stage", "mth_decode_reserve", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -127,6 +127,8 @@ def lib():
         L.mth_decode_set_xm_min_mapq.argtypes = [vp, C.c_uint32]
         L.mth_bgzf_inflate.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]
         L.mth_bgzf_decode.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(mth_decoded_t)]
+        L.mth_bgzf_stage.argtypes = [vp, vp, C.c_uint64]
+        L.mth_decode_reserve.argtypes = [vp, C.c_uint64, C.c_uint64]
         L.mth_tag_set_genome.argtypes = [vp, C.c_int32, vp, vp, vp]
         L.mth_tag_records.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(mth_tag_out_t)]
         L.mth_decoded_fetch.argtypes = [vp] * 9

@@ -369,23 +369,39 @@ bool load_bgzf_on_device(Input &in) {
         bz.header_bytes = g_shard.plan.first_byte;
     }
     Phase ph("  device inflate + walk + decode");
-    // chunks of whole blocks, <= ~1 GiB of file bytes each (bounds the staging buffers, not the decoded SoA)
-    size_t chunk = (size_t)1 << 30;
-    if (const char *e = getenv("METHEOR_DEVICE_CHUNK_MB")) { const long k = atol(e); if (k >= 1 && k <= 65536) chunk = (size_t)k << 20; }
+    // Chunks of whole blocks.  The first is small (<= 512 MiB of file bytes) so that the GPU starts early; every later chunk
+    // (<= 2 GiB) is copied to the device by a helper thread on a side stream (mth_bgzf_stage) while the chunk before it is
+    // being inflated and decoded -- only the first copy is exposed.  METHEOR_DEVICE_CHUNK_MB sets both sizes,
+    // METHEOR_NO_STAGE=1 copies every chunk in line.
+    size_t chunk_first = (size_t)512 << 20, chunk = (size_t)2 << 30;
+    if (const char *e = getenv("METHEOR_DEVICE_CHUNK_MB")) { const long k = atol(e); if (k >= 1 && k <= 65536) chunk_first = chunk = (size_t)k << 20; }
+    if (const char *e = getenv("METHEOR_FIRST_CHUNK_MB")) { const long k = atol(e); if (k >= 1 && k <= 65536) chunk_first = (size_t)k << 20; }
+    const bool stage = !getenv("METHEOR_NO_STAGE");
+    struct Chunk { uint64_t b0, b1, base, nbytes, ubytes; };
+    std::vector<Chunk> chunks;
+    uint64_t total_u = 0;
+    for (uint64_t b0 = blk_beg; b0 < bz.n_blocks;) {
+        const size_t lim = chunks.empty() ? chunk_first : chunk;
+        uint64_t b1 = b0, ubytes = 0;
+        while (b1 < bz.n_blocks && (b1 == b0 || bz.coff[b1] + bz.csize[b1] - bz.coff[b0] <= lim)) { ubytes += bz.isize[b1]; ++b1; }
+        chunks.push_back(Chunk{b0, b1, bz.coff[b0], bz.coff[b1 - 1] + bz.csize[b1 - 1] + 8 - bz.coff[b0], ubytes});   // incl. the last block's CRC32 + ISIZE trailer
+        total_u += ubytes;
+        b0 = b1;
+    }
+    if (chunks.empty()) chunks.push_back(Chunk{blk_beg, blk_beg, 0, 0, 0});
     bool first = true;
     uint64_t hdr_left = bz.header_bytes;      // header bytes still ahead of the next chunk's inflated stream
-    for (uint64_t b0 = blk_beg; b0 < bz.n_blocks || first;) {
-        uint64_t b1 = b0;
-        uint64_t ubytes = 0;
-        while (b1 < bz.n_blocks && (b1 == b0 || bz.coff[b1] + bz.csize[b1] - bz.coff[b0] <= chunk)) { ubytes += bz.isize[b1]; ++b1; }
-        std::vector<uint64_t> rel((size_t)(b1 - b0));
-        const uint64_t base = b1 > b0 ? bz.coff[b0] : 0;
-        for (uint64_t k = b0; k < b1; ++k) rel[(size_t)(k - b0)] = bz.coff[k] - base;
-        const uint64_t nbytes = b1 > b0 ? bz.coff[b1 - 1] + bz.csize[b1 - 1] + 8 - base : 0;   // incl. the last block's CRC32 + ISIZE trailer
-        const uint64_t first_byte = std::min<uint64_t>(hdr_left, ubytes);
-        if (b1 > b0 && hdr_left > ubytes && b1 < bz.n_blocks) { hdr_left -= ubytes; b0 = b1; continue; }   // a chunk made of header only
+    uint64_t done_u = 0;
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+        const Chunk &c = chunks[ci];
+        const uint64_t first_byte = std::min<uint64_t>(hdr_left, c.ubytes);
+        if (c.b1 > c.b0 && hdr_left > c.ubytes && ci + 1 < chunks.size()) { hdr_left -= c.ubytes; continue; }   // a chunk made of header only
+        if (stage && ci + 1 < chunks.size() && chunks[ci + 1].nbytes)
+            check(in.ctx, mth_bgzf_stage(in.ctx, bz.file + chunks[ci + 1].base, chunks[ci + 1].nbytes));
+        std::vector<uint64_t> rel((size_t)(c.b1 - c.b0));
+        for (uint64_t k = c.b0; k < c.b1; ++k) rel[(size_t)(k - c.b0)] = bz.coff[k] - c.base;
         mth_decoded_t d;
-        const int rc = mth_bgzf_decode(in.ctx, bz.file + base, nbytes, rel.data(), bz.csize + b0, bz.isize + b0, b1 - b0, first_byte, first ? 0 : 1, &d);
+        const int rc = mth_bgzf_decode(in.ctx, bz.file + c.base, c.nbytes, rel.data(), bz.csize + c.b0, bz.isize + c.b0, c.b1 - c.b0, first_byte, first ? 0 : 1, &d);
         hdr_left -= first_byte;
         if (rc == MTH_ERR_UNALIGNED) { check(in.ctx, mth_reset(in.ctx)); return false; }
         if (rc == MTH_ERR_FORMAT) {
@@ -394,9 +410,13 @@ bool load_bgzf_on_device(Input &in) {
             die("Error reading BAM record. corrupt BGZF block or BAM record");
         }
         check(in.ctx, rc);
+        done_u += c.ubytes;
+        if (first && ci + 1 < chunks.size() && done_u) {
+            // size the decoded arrays once from the first chunk's yield (reads and calls per inflated byte, +3 %)
+            const double f = 1.03 * (double)total_u / (double)done_u;
+            check(in.ctx, mth_decode_reserve(in.ctx, (uint64_t)((double)d.n_reads * f) + 4096, (uint64_t)((double)d.n_cpgs * f) + 4096));
+        }
         first = false;
-        b0 = b1;
-        if (b1 >= bz.n_blocks) break;
     }
     return true;
 }
@@ -409,6 +429,8 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
         mth_host_bgzf_t bz;                      // builds (and caches) the block table while the context is being created
         if (!getenv("METHEOR_HOST_INFLATE") && mth_host_bgzf_blocks(in.h, &bz) != 0) { cf.wait(); die(mth_host_last_error(in.h)); }
     }
+    // (touching the mapped file's pages from 16 threads while the HIP runtime starts was measured: it slows the start-up
+    // it competes with and the copies gain nothing, profiles/r02_e2e.md)
     in.ctx = cf.get();
     if (cpg_set) check(in.ctx, mth_decode_set_cpg_filter(in.ctx, keys, n_keys, 1));
     check(in.ctx, mth_decode_set_xm_min_mapq(in.ctx, (uint32_t)g_shard.xm_min_mapq));

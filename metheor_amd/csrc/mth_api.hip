@@ -175,12 +175,13 @@ int mth_ctx_create(int device_id, mth_ctx_t **out) {
 void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stage_thread.joinable()) ctx->stage_thread.join();
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rccl_release(ctx);
     for (DevBuf *b : {&ctx->st_start, &ctx->st_end, &ctx->st_mapq, &ctx->st_fwd, &ctx->st_off, &ctx->st_pos,
                       &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_bucket, &ctx->scratch, &ctx->dec_raw, &ctx->dec_recoff, &ctx->dec_tid, &ctx->dec_start, &ctx->dec_end,
                       &ctx->dec_mapq, &ctx->dec_fwd, &ctx->dec_n, &ctx->dec_off, &ctx->dec_pos, &ctx->dec_rel, &ctx->dec_blk, &ctx->dec_off32, &ctx->dec_runs, &ctx->dec_xm, &ctx->dec_filter,
-                      &ctx->inf_file, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff, &ctx->crc_mat,
+                      &ctx->inf_file, &ctx->inf_file2, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff, &ctx->crc_mat,
                       &ctx->tag_genome, &ctx->tag_goff, &ctx->tag_ncol, &ctx->tag_coloff, &ctx->tag_xmlen, &ctx->tag_cols, &ctx->tag_xm,
                       &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
                       &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_tflag, &ctx->q_tile_row0, &ctx->q_tile_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
@@ -195,6 +196,8 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (ctx->d_state2) (void)hipFree(ctx->d_state2);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_words) (void)hipHostFree(ctx->h_words);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->staged_ev) (void)hipEventDestroy(ctx->staged_ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mth_common.h"
@@ -51,6 +52,16 @@ struct mth_ctx {
     uint64_t dec_reads = 0, dec_cpgs = 0;
     // device-side BGZF inflate + per-block record walk (mth_inflate.hip)
     mth::DevBuf inf_file, inf_tab, inf_raw, inf_cnt, inf_base, inf_recoff, crc_mat;
+    // mth_bgzf_stage: the NEXT chunk's file bytes, copied on a side stream while the current chunk is being inflated
+    mth::DevBuf inf_file2;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t staged_ev = nullptr;
+    const void *staged_src = nullptr;
+    uint64_t staged_bytes = 0;
+    const void *next_src = nullptr;      // announced by mth_bgzf_stage, copied by a helper thread the next inflate call starts
+    uint64_t next_bytes = 0;
+    std::thread stage_thread;
+    int stage_rc = 0;
     // `tag` (mth_tag.hip): the genome (contigs back to back), per-contig offsets + header lengths, per-record work arrays,
     // and the host copies mth_tag_records hands out
     mth::DevBuf tag_genome, tag_goff, tag_ncol, tag_coloff, tag_xmlen, tag_cols, tag_xm;

@@ -426,6 +426,22 @@ int mth_decode_set_cpg_filter(mth_ctx_t *ctx, const uint64_t *keys_sorted, uint6
     return MTH_OK;
 }
 
+int mth_decode_reserve(mth_ctx_t *ctx, uint64_t n_reads, uint64_t n_cpgs) {
+    if (!ctx) return MTH_ERR_INVALID;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t R0 = (size_t)ctx->dec_reads, C0 = (size_t)ctx->dec_cpgs, R = (size_t)n_reads, C = (size_t)n_cpgs;
+    MTH_HIP(ctx, ctx->dec_tid.reserve(R * 4 + 4, s, R0 > 0, R0 * 4));
+    MTH_HIP(ctx, ctx->dec_start.reserve(R * 4 + 4, s, R0 > 0, R0 * 4));
+    MTH_HIP(ctx, ctx->dec_end.reserve(R * 4 + 4, s, R0 > 0, R0 * 4));
+    MTH_HIP(ctx, ctx->dec_mapq.reserve(R + 4, s, R0 > 0, R0));
+    MTH_HIP(ctx, ctx->dec_fwd.reserve(R + 4, s, R0 > 0, R0));
+    MTH_HIP(ctx, ctx->dec_off.reserve((R + 1) * 8, s, R0 > 0, R0 ? (R0 + 1) * 8 : 0));
+    MTH_HIP(ctx, ctx->dec_pos.reserve(C * 4 + 4, s, C0 > 0, C0 * 4));
+    MTH_HIP(ctx, ctx->dec_rel.reserve(C * 2 + 4, s, C0 > 0, C0 * 2));
+    return MTH_OK;
+}
+
 int mth_decode_set_xm_min_mapq(mth_ctx_t *ctx, uint32_t min_mapq) {
     if (!ctx) return MTH_ERR_INVALID;
     ctx->dec_xm_min_mapq = min_mapq;

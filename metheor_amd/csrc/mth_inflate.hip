@@ -374,11 +374,47 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
     }
     total = uoff[nb];
     // stage: compressed bytes (padded: the bit reader loads whole words), the table, the inflated stream
-    MTH_HIP(ctx, ctx->inf_file.reserve((size_t)n_bytes + 64, s));
+    // the helper thread of the previous call (copying THIS call's bytes, if they were announced) has to be done first
+    if (ctx->stage_thread.joinable()) {
+        ctx->stage_thread.join();
+        if (ctx->stage_rc != MTH_OK) return fail(ctx, MTH_ERR_HIP, "staging the next chunk's file bytes failed");
+    }
+    const bool staged = ctx->staged_src && ctx->staged_src == file && ctx->staged_bytes == n_bytes;
+    if (staged) {
+        // copied on the side stream while the previous chunk was in flight: take that buffer
+        std::swap(ctx->inf_file, ctx->inf_file2);
+        MTH_HIP(ctx, hipStreamWaitEvent(s, ctx->staged_ev, 0));
+    } else {
+        MTH_HIP(ctx, ctx->inf_file.reserve((size_t)n_bytes + 64, s));
+    }
+    ctx->staged_src = nullptr;
     MTH_HIP(ctx, ctx->inf_tab.reserve(nb * 24 + 64, s));
     MTH_HIP(ctx, ctx->inf_raw.reserve((size_t)total + 64, s));
-    if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->inf_file.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, s));
-    MTH_HIP(ctx, hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file.p) + n_bytes, 0, 64, s));
+    if (!staged) {
+        if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->inf_file.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, s));
+        MTH_HIP(ctx, hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file.p) + n_bytes, 0, 64, s));
+    }
+    // the chunk announced by mth_bgzf_stage: its bytes travel on the side stream, from a helper thread (a pageable copy
+    // blocks its caller), while this call's kernels run.  The thread owns inf_file2 / copy_stream / staged_* until joined.
+    if (ctx->next_src && ctx->next_bytes) {
+        if (!ctx->copy_stream) {
+            MTH_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            MTH_HIP(ctx, hipEventCreateWithFlags(&ctx->staged_ev, hipEventDisableTiming));
+        }
+        const void *src = ctx->next_src;
+        const uint64_t nbytes = ctx->next_bytes;
+        ctx->next_src = nullptr;
+        ctx->stage_rc = MTH_OK;
+        ctx->stage_thread = std::thread([ctx, src, nbytes] {
+            auto ok = [&](hipError_t e) { if (e != hipSuccess) ctx->stage_rc = MTH_ERR_HIP; return e == hipSuccess; };
+            if (!ok(hipSetDevice(ctx->device))) return;
+            if (!ok(ctx->inf_file2.reserve((size_t)nbytes + 64, ctx->copy_stream))) return;
+            if (!ok(hipMemcpyAsync(ctx->inf_file2.p, src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->copy_stream))) return;
+            if (!ok(hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file2.p) + nbytes, 0, 64, ctx->copy_stream))) return;
+            if (!ok(hipEventRecord(ctx->staged_ev, ctx->copy_stream))) return;
+            ctx->staged_src = src; ctx->staged_bytes = nbytes;
+        });
+    }
     uint8_t *tab = static_cast<uint8_t *>(ctx->inf_tab.p);
     uint64_t *d_coff = reinterpret_cast<uint64_t *>(tab);
     d_uoff = reinterpret_cast<uint64_t *>(tab + nb * 8);
@@ -416,6 +452,13 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
 }
 
 extern "C" {
+
+int mth_bgzf_stage(mth_ctx_t *ctx, const void *file, uint64_t n_bytes) {
+    if (!ctx || (n_bytes && !file)) return MTH_ERR_INVALID;
+    ctx->next_src = n_bytes ? file : nullptr;
+    ctx->next_bytes = n_bytes;
+    return MTH_OK;
+}
 
 int mth_bgzf_inflate(mth_ctx_t *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
                      const uint32_t *isize, uint64_t n_blocks, void *dst_host, uint64_t *n_out) {
