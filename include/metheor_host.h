@@ -45,6 +45,8 @@ const char *mth_host_ref_name(const mth_host_t *h, int tid);
 int64_t mth_host_ref_len(const mth_host_t *h, int tid);
 int  mth_host_ref_tid(const mth_host_t *h, const char *name);   /* -1 if unknown */
 
+/* the path the loaders read: the input itself for a BAM, the in-memory BAM a SAM text input was converted into otherwise */
+const char *mth_host_path(const mth_host_t *h);
 /* the header text as the file holds it (what bam::Header::from_template copies into a writer, tag.rs:403-406) */
 const char *mth_host_header_text(const mth_host_t *h, uint64_t *n_bytes);
 /* One BAM record (the bytes after its block_size field) as a SAM line ending in '\n' -- what bam::Writer with Format::Sam

@@ -139,6 +139,8 @@ int mth_host_ref_tid(const mth_host_t *h, const char *name) {
     return it == h->name2tid.end() ? -1 : it->second;
 }
 
+const char *mth_host_path(const mth_host_t *h) { return h ? h->path.c_str() : ""; }
+
 const char *mth_host_header_text(const mth_host_t *h, uint64_t *n_bytes) {
     if (n_bytes) *n_bytes = h ? h->reader.header_text().size() : 0;
     return h ? h->reader.header_text().data() : "";

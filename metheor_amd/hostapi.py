@@ -12,7 +12,7 @@ SYMBOLS = [
     "mth_host_ref_len", "mth_host_ref_tid", "mth_host_set_xm_min_mapq", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_plan_region", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
     "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
     "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32", "mth_host_write_synthetic_bam",
-    "mth_host_write_synthetic_bam_multi", "mth_host_header_text", "mth_host_sam_format", "mth_host_fasta_open", "mth_host_fasta_close",
+    "mth_host_write_synthetic_bam_multi", "mth_host_header_text", "mth_host_path", "mth_host_sam_format", "mth_host_fasta_open", "mth_host_fasta_close",
     "mth_host_fasta_last_error", "mth_host_fasta_fetch",
 ]
 
@@ -66,6 +66,7 @@ def lib():
         L.mth_host_format_f32.argtypes = [C.c_float, C.c_char_p]
         L.mth_host_write_synthetic_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int32] + [vp] * 6 + [C.c_uint64, C.c_int]
         L.mth_host_write_synthetic_bam_multi.argtypes = [C.c_char_p, C.c_int32, vp, vp, C.c_int64, C.c_int32] + [vp] * 7 + [C.c_uint64, C.c_int]
+        L.mth_host_path.argtypes = [vp]; L.mth_host_path.restype = C.c_char_p
         L.mth_host_header_text.argtypes = [vp, C.POINTER(C.c_uint64)]; L.mth_host_header_text.restype = vp
         L.mth_host_sam_format.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int64]; L.mth_host_sam_format.restype = C.c_int64
         L.mth_host_decode_stream.argtypes = [vp, WINDOW_CB, vp]
@@ -185,6 +186,11 @@ class BamFile:
                     end=arr("read_end", np.int32, n), mapq=arr("read_mapq", np.uint8, n),
                     fwd=arr("read_fwd", np.uint8, n), cpg_off=arr("cpg_off", np.uint64, n + 1),
                     cpg_pos=arr("cpg_pos", np.uint32, nc), cpg_rel=arr("cpg_rel", np.uint16, nc))
+
+    def staged_path(self):
+        """SAM input: the path of the in-memory BAM the text was converted into (valid while this object lives)"""
+        p = self.L.mth_host_path(self.h)
+        return p.decode()
 
     def header_text(self):
         n = C.c_uint64(0)

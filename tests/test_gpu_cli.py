@@ -499,3 +499,29 @@ def test_region_from_the_bam_index(tmp_path):
     assert r.returncode == 101 and "BAM index" in r.stderr
     r = run("pdr", "-i", bam, "-o", str(o), "--region", "gA:10-1")
     assert r.returncode == 2
+
+
+def test_sam_text_input_runs_like_bam_input(golden_dir, tmp_path):
+    """bam::Reader::from_path opens SAM text as readily as BAM (bamutil.rs:4-11): every subcommand given the reference's
+    .sam fixture directly == given the same records as a BAM == the oracle's text"""
+    sam = os.path.join(golden_dir, "test.chr19.XM.sam")
+    rec = bamio.read_sam(sam)
+    bam = str(tmp_path / "rrbs.bam")
+    bamio.write_bam(bam, rec)
+    reads = pyoracle.Reads.decode(rec)
+    a, b = tmp_path / "a.tsv", tmp_path / "b.tsv"
+    for sub, extra in (("pdr", ["-d", "3", "-p", "2"]), ("mhl", ["-d", "2", "-p", "2"]), ("me", ["-d", "2"]), ("pm", ["-d", "2"]),
+                       ("fdrp", ["-d", "2", "-l", "10"]), ("qfdrp", ["-d", "2", "-l", "10"])):
+        r1 = run(sub, "-i", sam, "-o", str(a), *extra)
+        r2 = run(sub, "-i", bam, "-o", str(b), *extra)
+        assert r1.returncode == 0 and r2.returncode == 0, (sub, r1.stderr, r2.stderr)
+        assert a.read_bytes() == b.read_bytes() and a.stat().st_size > 100, sub
+    r = run("pdr", "-i", sam, "-o", str(a), "-d", "3", "-p", "2")
+    assert a.read_text() == util.oracle_tsv_pdr(reads, ["chr19"], min_depth=3, min_cpgs=2, min_qual=10)
+    r = run("lpmd", "-i", sam, "-o", str(a))
+    assert r.returncode == 0 and a.read_text() == util.oracle_tsv_lpmd(reads, sam)
+    # a SAM record without XM:Z panics like a BAM record without it (readutil.rs:46)
+    noxm = tmp_path / "noxm.sam"
+    noxm.write_text("".join(l.split("\tXM:Z:")[0] + "\n" if not l.startswith("@") else l for l in open(sam)))
+    r = run("pdr", "-i", str(noxm), "-o", str(a))
+    assert r.returncode == 101 and "Error reading XM tag in BAM record" in r.stderr

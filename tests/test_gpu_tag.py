@@ -168,3 +168,15 @@ def test_cli_tag_fasta_contig_missing(tmp_path):
     tag_util.write_fasta(fa, "c0", b"ACGTACGT", with_fai=False)
     r = subprocess.run([EXE, "tag", "-i", str(p), "-o", str(tmp_path / "o.sam"), "-g", fa], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 101 and "Error fetching reference genome sequence" in r.stderr
+
+
+def test_cli_tag_bam_input_equals_sam_input(chr19, tmp_path):
+    # the same 1000 records as a BAM file (seq / qual / every aux field carried by the host library's SAM -> BAM
+    # conversion, written out here): the tagged SAM is the same bytes
+    f = hostapi.BamFile(chr19["noxm"])
+    bam = tmp_path / "noxm.bam"
+    bam.write_bytes(open(f.staged_path(), "rb").read())
+    out = tmp_path / "from_bam.sam"
+    r = subprocess.run([EXE, "tag", "-i", str(bam), "-o", str(out), "-g", chr19["fa"]], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == chr19["want"]
