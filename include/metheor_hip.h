@@ -191,7 +191,8 @@ int  mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int
 /* ---- MHL: methylation haplotype load per site (mhl.rs:135-208, 43-73) -------------------------
  * Exact stream semantics of the reference, including its flush / re-open of sites:
  * flush on strict '<' by any read with >= 1 CpG, before the mapq / min_cpgs filters.  Reads with
- * more than 512 CpGs covering a site are refused (MTH_ERR_CAPACITY). */
+ * more than 16384 CpGs covering a site are refused (MTH_ERR_CAPACITY); reads with 513..16384 take a walk whose
+ * histograms live in 256 MB of HBM scratch. */
 typedef struct {
     uint32_t min_depth;  /* -d 10 */
     uint32_t min_cpgs;   /* -p 4  */

@@ -95,7 +95,7 @@ struct mth_ctx {
     // site-walk measures (mth_sites.hip): discovery sink, per-candidate work arrays, MHL result rows
     mth::DevState *d_state2 = nullptr;
     mth::DevBuf s_pos, s_pdr, s_nc, s_nd, s_batch_cnt;
-    mth::DevBuf w_val, w_cov, w_aux, w_flags, w_blk;
+    mth::DevBuf w_val, w_cov, w_aux, w_flags, w_blk, w_huge;
     mth::DevBuf m_state, m_pos, m_val, m_cov, m_batch_rows;
     uint64_t m_cap = 0, m_rows_bound = 0;
     std::vector<mth::BatchMeta> m_batches;

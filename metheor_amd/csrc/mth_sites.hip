@@ -31,7 +31,8 @@ struct WalkArgs {
     DevState *st;               // main state (error bits)
     float    *val;              // per candidate site
     uint32_t *cov;
-    uint32_t *flags;            // bit0 keep (some segment reached min_depth), bit1 needs the big variant
+    uint32_t *flags;            // bit0 keep (some segment reached min_depth), bit1 needs the big variant, 8 = needs the HBM-scratch variant
+    uint32_t *huge_any;         // set by k_mhl_walk_big when it hands a site to k_mhl_walk_huge
     int32_t idx_base, max_span;
     uint32_t n_reads, min_depth, min_cpgs;
     uint8_t min_qual;
@@ -319,6 +320,59 @@ __global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
     }
 }
 
+// The sequential per-site walk (mhl.rs:155-205 literally) over caller-provided histograms of lcap entries: S[l-1] = sum over
+// the covering reads of count_l (mhl.rs:36-41), D[l-1] = sum over the covering reads with n_r >= l of (n_r - l + 1) as f32
+// (mhl.rs:53-58).  Returns true if a covering read has more than lcap CpGs (the caller redoes the site with larger arrays).
+__device__ __forceinline__ bool mhl_seq_walk(const WalkArgs &a, const int32_t c, const uint32_t lo, const uint32_t hi, uint32_t *S, float *D,
+                                             const uint32_t lcap, float &res, uint32_t &res_cov, bool &have) {
+    // (only the first maxn entries of a segment's histograms are ever touched: they are zeroed when a longer read arrives)
+    uint32_t seg_cov = 0, maxn = 0;
+    bool overflow = false;
+    auto finalize = [&]() {   // compute_mhl, mhl.rs:43-73
+        float l_sum = 0.0f;
+        for (uint32_t l = 1; l < maxn + 1; ++l) l_sum = l_sum + (float)l;
+        float mhl = 0.0f;
+        for (uint32_t l = 1; l <= min(maxn, lcap); ++l)
+            if (S[l - 1] > 0) { const float t = ((float)l * (float)S[l - 1]) / D[l - 1]; mhl = mhl + t; }
+        return mhl / l_sum;
+    };
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+        const uint32_t n = o1 - o0;
+        if (n == 0) continue;                                          // no first CpG: neither flushes nor contributes
+        const int32_t first = (int32_t)(a.cpg_pos[o0] & 0x7fffffffu);
+        if (c < first && seg_cov > 0) {                                // mhl.rs:163-171 (strict '<', before the filters)
+            if (seg_cov >= a.min_depth) { res = finalize(); res_cov = seg_cov; have = true; }
+            seg_cov = 0; maxn = 0;
+        }
+        if (a.read_mapq[i] < a.min_qual) continue;                     // mhl.rs:176
+        if (n < a.min_cpgs) continue;                                  // mhl.rs:181
+        bool hit = false;                                              // does the read call c ?
+        for (uint32_t k = o0; k < o1; ++k) {
+            const int32_t p = (int32_t)(a.cpg_pos[k] & 0x7fffffffu);
+            if (p == c) { hit = true; break; }
+            if (p > c) break;
+        }
+        if (!hit) continue;
+        if (n > lcap) { overflow = true; continue; }         // refused below
+        seg_cov += 1;                                                   // add_num_cpgs, mhl.rs:75-80
+        for (uint32_t l = maxn; l < n; ++l) { S[l] = 0; D[l] = 0.0f; }
+        maxn = max(maxn, n);
+        for (uint32_t l = 1; l <= n; ++l) D[l - 1] = D[l - 1] + (float)(n - l + 1);
+        uint32_t cur = 0;                                               // get_stretch_info, readutil.rs:147-164
+        for (uint32_t k = o0; k < o1; ++k) {
+            if (a.cpg_pos[k] >> 31) {
+                cur += 1;
+                for (uint32_t l = 1; l <= cur; ++l) S[l - 1] += 1u;
+            } else {
+                cur = 0;
+            }
+        }
+    }
+    if (seg_cov > 0 && seg_cov >= a.min_depth) { res = finalize(); res_cov = seg_cov; have = true; }   // mhl.rs:201-205
+    return overflow;
+}
+
 // What k_mhl_walk_lds left: (flags == 4) the sites of groups whose candidate reads did not fit the LDS staging -- deep data --
 // take the same per-site walk straight from global memory, with the 32-bit spill accumulators (exact at any depth); (flags == 2)
 // a covering read with more than 16 CpGs, or a segment too deep for the 16-bit counters / for the f32 denominators to stay
@@ -344,54 +398,40 @@ __global__ __launch_bounds__(256) void k_mhl_walk_big(const WalkArgs a) {
         }
         uint32_t S[LCAP];      // S[l-1] = sum over covering reads of count_l   (mhl.rs:36-41)
         float D[LCAP];         // D[l-1] = sum over covering reads with n_r >= l of (n_r-l+1) as f32   (mhl.rs:53-58)
-        for (int l = 0; l < LCAP; ++l) { S[l] = 0; D[l] = 0.0f; }
-        uint32_t seg_cov = 0, maxn = 0, res_cov = 0;
         float res = 0.0f;
-        bool have = false, overflow = false;
-        auto finalize = [&]() {   // compute_mhl, mhl.rs:43-73
-            float l_sum = 0.0f;
-            for (uint32_t l = 1; l < maxn + 1; ++l) l_sum = l_sum + (float)l;
-            float mhl = 0.0f;
-            for (uint32_t l = 1; l <= min(maxn, (uint32_t)LCAP); ++l)
-                if (S[l - 1] > 0) { const float t = ((float)l * (float)S[l - 1]) / D[l - 1]; mhl = mhl + t; }
-            return mhl / l_sum;
-        };
-        for (uint32_t i = lo; i < hi; ++i) {
-            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
-            const uint32_t n = o1 - o0;
-            if (n == 0) continue;                                          // no first CpG: neither flushes nor contributes
-            const int32_t first = (int32_t)(a.cpg_pos[o0] & 0x7fffffffu);
-            if (c < first && seg_cov > 0) {                                // mhl.rs:163-171 (strict '<', before the filters)
-                if (seg_cov >= a.min_depth) { res = finalize(); res_cov = seg_cov; have = true; }
-                seg_cov = 0; maxn = 0;
-                for (int l = 0; l < LCAP; ++l) { S[l] = 0; D[l] = 0.0f; }
-            }
-            if (a.read_mapq[i] < a.min_qual) continue;                     // mhl.rs:176
-            if (n < a.min_cpgs) continue;                                  // mhl.rs:181
-            bool hit = false;                                              // does the read call c ?
-            for (uint32_t k = o0; k < o1; ++k) {
-                const int32_t p = (int32_t)(a.cpg_pos[k] & 0x7fffffffu);
-                if (p == c) { hit = true; break; }
-                if (p > c) break;
-            }
-            if (!hit) continue;
-            if (n > (uint32_t)LCAP) { overflow = true; continue; }         // refused below
-            seg_cov += 1;                                                   // add_num_cpgs, mhl.rs:75-80
-            maxn = max(maxn, n);
-            for (uint32_t l = 1; l <= n; ++l) D[l - 1] = D[l - 1] + (float)(n - l + 1);
-            uint32_t cur = 0;                                               // get_stretch_info, readutil.rs:147-164
-            for (uint32_t k = o0; k < o1; ++k) {
-                if (a.cpg_pos[k] >> 31) {
-                    cur += 1;
-                    for (uint32_t l = 1; l <= cur; ++l) S[l - 1] += 1u;
-                } else {
-                    cur = 0;
-                }
-            }
+        uint32_t res_cov = 0;
+        bool have = false;
+        const bool overflow = mhl_seq_walk(a, c, lo, hi, S, D, (uint32_t)LCAP, res, res_cov, have);
+        if (overflow) {                                                     // a read with > LCAP CpGs covers the site:
+            a.flags[j] = 8u;                                                // k_mhl_walk_huge redoes it with arrays in HBM
+            atomicOr(a.huge_any, 1u);
+            continue;
         }
-        if (seg_cov > 0 && seg_cov >= a.min_depth) { res = finalize(); res_cov = seg_cov; have = true; }   // mhl.rs:201-205
-        if (overflow) {
-            atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);                 // a read with > LCAP CpGs covers the site
+        a.val[j] = res;
+        a.cov[j] = res_cov;
+        a.flags[j] = have ? 1u : 0u;
+    }
+}
+
+// Sites with a covering read of more than 512 CpGs (long reads): the same walk with the two histograms in an HBM scratch
+// slice per thread (lcap entries each; the reference has no limit, mhl.rs:185-192).  The launch is unconditional and ends
+// at once unless k_mhl_walk_big flagged a site.  A read beyond lcap CpGs is still refused (ERRB_CAPACITY).
+__global__ __launch_bounds__(64) void k_mhl_walk_huge(const WalkArgs a, uint32_t *__restrict__ S_all, float *__restrict__ D_all, const uint32_t lcap) {
+    if (*a.huge_any == 0u) return;
+    const uint32_t gtid = blockIdx.x * 64 + threadIdx.x, nthreads = gridDim.x * 64;
+    uint32_t *S = S_all + (size_t)gtid * lcap;
+    float *D = D_all + (size_t)gtid * lcap;
+    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    for (uint32_t j = gtid; j < n_sites; j += nthreads) {
+        if (a.flags[j] != 8u) continue;
+        const int32_t c = a.site_pos[j];
+        const uint32_t lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
+        const uint32_t hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        float res = 0.0f;
+        uint32_t res_cov = 0;
+        bool have = false;
+        if (mhl_seq_walk(a, c, lo, hi, S, D, lcap, res, res_cov, have)) {
+            atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);
             a.flags[j] = 0u;
             continue;
         }
@@ -632,6 +672,10 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
     a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.n_reads = d.n_reads;
     a.min_depth = params->min_depth; a.min_cpgs = params->min_cpgs; a.min_qual = params->min_qual;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 255) / 256, 8192);
+    // [0] = "some site needs the HBM-scratch walk" (set by k_mhl_walk_big), cleared per batch; the scratch follows
+    MTH_HIP(ctx, ctx->w_huge.reserve((size_t)2048 * 16384 * 8, s));
+    MTH_HIP(ctx, hipMemsetAsync(&ctx->d_state2->pad_, 0, 4, s));
+    a.huge_any = &ctx->d_state2->pad_;
     {
         LaunchTimer lt(ctx, K_MHLWALK);
         hipLaunchKernelGGL(k_mhl_walk_lds, dim3(grid), dim3(256), 0, s, a);
@@ -639,6 +683,10 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
     {
         LaunchTimer lt(ctx, K_MHLWALKBIG);
         hipLaunchKernelGGL((k_mhl_walk_big<512>), dim3(grid), dim3(256), 0, s, a);
+        // long reads (> 512 CpGs): 2048 threads, 16384 histogram entries each in 256 MB of HBM scratch
+        constexpr uint32_t HUGE_THREADS = 2048, HUGE_LCAP = 16384;
+        hipLaunchKernelGGL(k_mhl_walk_huge, dim3(HUGE_THREADS / 64), dim3(64), 0, s, a, ctx->w_huge.as<uint32_t>(),
+                           reinterpret_cast<float *>(ctx->w_huge.as<uint32_t>() + (size_t)HUGE_THREADS * HUGE_LCAP), HUGE_LCAP);
     }
     unsigned long long *ms = ctx->m_state.as<unsigned long long>();   // [0] total rows [1] base of the batch
     const uint32_t nblk = (uint32_t)((bound + 256 * SCAN_PER - 1) / (256 * SCAN_PER));

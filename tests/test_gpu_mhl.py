@@ -169,11 +169,27 @@ def test_reset_empty_and_capacity(eng):
     b = Batch(0, 0, 1000, z4, z4, np.zeros(0, np.uint8), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8))
     eng.mhl_accumulate(b)
     assert len(eng.mhl_fetch()["pos"]) == 0
-    # reads with > 512 CpGs are beyond the histogram capacity: loud MTH_ERR_CAPACITY, never a wrong value
-    c = synth.make_contig(0, 100_000, 60, 0.3, np.random.default_rng(5), read_len=6000)
+    # reads with > 16384 CpGs are beyond the histogram capacity: loud MTH_ERR_CAPACITY, never a wrong value
+    c = synth.make_contig(0, 400_000, 6, 0.45, np.random.default_rng(5), read_len=60_000)
+    assert np.diff(c["cpg_off"].astype(np.int64)).max() > 16384
     eng.reset()
     eng.mhl_accumulate(util.device_batch(c), min_depth=0, min_cpgs=0, min_qual=0)
     with pytest.raises(MthError) as e:
         eng.mhl_fetch()
     assert e.value.status == -8
     eng.reset()
+
+
+def test_long_reads_beyond_512_cpgs(eng):
+    """mhl.rs:185-192 has no limit on a read's CpG count: reads with up to 16384 CpGs take the walk whose histograms live in
+    HBM scratch (k_mhl_walk_huge); rows equal to the oracle's, mixed with ordinary reads in the same batch"""
+    from metheor_amd import synth
+    rng = np.random.default_rng(77)
+    long_c = synth.make_contig(0, 120_000, 70, 0.3, rng, read_len=6000)          # ~1800 CpGs per read
+    n = np.diff(long_c["cpg_off"].astype(np.int64))
+    assert n.max() > 1000 and n.max() < 16384
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(long_c))
+    for kw in (dict(min_depth=0, min_cpgs=0, min_qual=0), dict(min_depth=3, min_cpgs=4, min_qual=10)):
+        d = run_device(eng, [long_c], kw)
+        nd, nrows = check(d, reads, kw)
+        assert nrows > 1000
