@@ -173,8 +173,9 @@ int  mth_lpmd_pairs_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_
                           uint32_t *n_concordant, uint32_t *n_discordant);
 
 /* ---- ME / PM: per-quartet 16-bin epiallele histograms (me.rs:90-132, pm.rs:85-128) ------------
- * One accumulate serves both measures (they share the histogram).  Requires consecutive CpGs of
- * a read to be < 2048 bp apart (MTH_ERR_CAPACITY otherwise). */
+ * One accumulate serves both measures (they share the histogram).  Windows whose consecutive CpGs are >= 2048 bp
+ * apart (reference skips, long reads) are aggregated under a 128-bit key on a side path; the calls of a read must be in
+ * ascending position order (MTH_ERR_SPAN otherwise). */
 typedef struct {
     uint8_t min_qual;   /* -q 10 (lib.rs:66-68, 90-92) */
 } mth_quartet_params_t;

@@ -72,7 +72,7 @@ int sync_and_check(mth_ctx *ctx) {
     if (e & ERRB_UNSORTED) return fail(ctx, MTH_ERR_UNSORTED, "reads of a batch are not sorted by start position");
     if (e & ERRB_SPAN) return fail(ctx, MTH_ERR_SPAN, "a read spans more reference bases than batch.max_span");
     if (e & ERRB_RANGE) return fail(ctx, MTH_ERR_RANGE, "CpG position outside the declared range");
-    if (e & ERRB_CAPACITY) return fail(ctx, MTH_ERR_CAPACITY, "capacity exceeded (CpGs of a read >= 2048 bp apart in a quartet, a read with more than 16384 CpGs in MHL, or FDRP max_depth above 16384)");
+    if (e & ERRB_CAPACITY) return fail(ctx, MTH_ERR_CAPACITY, "capacity exceeded (a read with more than 16384 CpGs in MHL, or FDRP max_depth above 16384)");
     if (e & ERRB_CRC) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block (CRC32 mismatch)");
     if (e & ERRB_FORMAT) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block or malformed BAM record (DEFLATE / ISIZE / block_size / field lengths inconsistent)");
     if (e & ERRB_TAGPANIC) return fail(ctx, MTH_ERR_FORMAT, "tag: a record the reference cannot tag either (unplaced or outside its contig / the FASTA, a base without a complement, or a C whose context ends in a deletion): determine_xm_tag_string panics there");
@@ -135,7 +135,7 @@ const char *mth_strerror(int s) {
         case MTH_ERR_SPAN: return "read span exceeds batch.max_span";
         case MTH_ERR_REOPEN: return "input needs flush re-open semantics not implemented on this path";
         case MTH_ERR_RANGE: return "CpG position out of declared range";
-        case MTH_ERR_CAPACITY: return "capacity exceeded (CpGs of a read >= 2048 bp apart in a quartet, a read with more than 16384 CpGs in MHL, or FDRP max_depth above 16384)";
+        case MTH_ERR_CAPACITY: return "capacity exceeded (a read with more than 16384 CpGs in MHL, or FDRP max_depth above 16384)";
         case MTH_ERR_STATE: return "call order violated";
         case MTH_ERR_FORMAT: return "malformed BAM record or record without XM:Z";
         case MTH_ERR_UNALIGNED: return "BAM records straddle BGZF blocks";
@@ -184,7 +184,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
                       &ctx->inf_file, &ctx->inf_file2, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff, &ctx->crc_mat,
                       &ctx->tag_genome, &ctx->tag_goff, &ctx->tag_ncol, &ctx->tag_coloff, &ctx->tag_xmlen, &ctx->tag_cols, &ctx->tag_xm,
                       &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
-                      &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_tflag, &ctx->q_tile_row0, &ctx->q_tile_rows, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
+                      &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_tflag, &ctx->q_tile_row0, &ctx->q_tile_rows, &ctx->q_wpos, &ctx->q_wpat, &ctx->q_wk0, &ctx->q_wk1, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
                       &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_aux, &ctx->w_flags,
                       &ctx->w_blk, &ctx->w_huge, &ctx->m_state, &ctx->m_pos, &ctx->m_val, &ctx->m_cov, &ctx->m_batch_rows,
                       &ctx->f_state, &ctx->f_pos, &ctx->f_val, &ctx->f_qval, &ctx->f_n, &ctx->f_batch_rows, &ctx->f_rows,

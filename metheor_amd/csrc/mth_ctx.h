@@ -77,7 +77,7 @@ struct mth_ctx {
     size_t batch_cnt_cap = 0;
 
     // ME / PM (mth_quartet.hip): hash table of the batch in flight + appended result rows
-    mth::DevBuf q_state, q_keys, q_hist, q_blk, q_batch_rows, q_tflag, q_tile_row0, q_tile_rows;
+    mth::DevBuf q_state, q_keys, q_hist, q_blk, q_batch_rows, q_tflag, q_tile_row0, q_tile_rows, q_wpos, q_wpat, q_wk0, q_wk1;
     // a batch of the tile-kernel measures (quartets, pairs): heavy0 = first row of the global path's rows, tile_end = tiles of
     // all batches up to and including it
     struct TileBatch { int32_t tid; uint64_t rows, heavy0, tile_end; };

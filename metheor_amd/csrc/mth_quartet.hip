@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void k_quartet_insert(const uint32_t *__restri
                                                         uint32_t *__restrict__ hist, unsigned long long mask,
                                                         unsigned long long *__restrict__ overflow, DevState *__restrict__ st,
                                                         const uint32_t *__restrict__ tile_flag /* nullptr: every quartet */,
-                                                        int tile_shift /* log2 of the tile width the flags were made with */) {
+                                                        int tile_shift /* log2 of the tile width the flags were made with */,
+                                                        uint4 *__restrict__ wide_pos, uint32_t *__restrict__ wide_pat,
+                                                        unsigned long long wide_cap, unsigned long long *__restrict__ wide_n) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_reads) return;
     const uint32_t o0 = cpg_off[i], o1 = cpg_off[i + 1];
@@ -84,10 +86,18 @@ __global__ __launch_bounds__(256) void k_quartet_insert(const uint32_t *__restri
                            d4 = (d & 0x7fffffffu) - (c & 0x7fffffffu);
             const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 33) | ((unsigned long long)d2 << 22) |
                                            ((unsigned long long)d3 << 11) | (unsigned long long)d4;
-            if (d2 - 1u >= 2047u || d3 - 1u >= 2047u || d4 - 1u >= 2047u || key == QKEY_EMPTY) {
-                atomicOr(&st->err, (uint32_t)ERRB_CAPACITY);
+            const uint32_t pat = ((a >> 31) << 3) | ((b >> 31) << 2) | ((c >> 31) << 1) | (d >> 31);
+            if (d2 - 1u >= 0x7fffffffu || d3 - 1u >= 0x7fffffffu || d4 - 1u >= 0x7fffffffu) {
+                atomicOr(&st->err, (uint32_t)ERRB_SPAN);                 // calls of a read not in ascending position order
+            } else if (d2 >= 2048u || d3 >= 2048u || d4 >= 2048u || key == QKEY_EMPTY) {
+                // CpGs of the window >= 2048 bp apart do not fit the packed key: the instance goes to the wide list
+                // (aggregated by k_quartet_wide_insert under a 128-bit key); counted even when the list is full (the host redoes)
+                const unsigned long long w = atomicAdd(wide_n, 1ull);
+                if (w < wide_cap) {
+                    wide_pos[w] = make_uint4((uint32_t)p1, b & 0x7fffffffu, c & 0x7fffffffu, d & 0x7fffffffu);
+                    wide_pat[w] = pat;
+                }
             } else {
-                const uint32_t pat = ((a >> 31) << 3) | ((b >> 31) << 2) | ((c >> 31) << 1) | (d >> 31);
                 unsigned long long h = qhash(key) & mask;
                 // The table is sized for the DISTINCT quartets one expects (half the instances), not for the instances:
                 // a bounded probe, and a flag that makes the host redo the pass with a larger table, keep that safe.
@@ -104,6 +114,32 @@ __global__ __launch_bounds__(256) void k_quartet_insert(const uint32_t *__restri
         }
         a = b; b = c; c = d;
     }
+}
+
+// Wide quartets (some pair of consecutive CpGs >= 2048 bp apart: reference skips, deletions, long reads) under a 128-bit
+// key: k0 = p1 << 32 | p2 claims the slot with a CAS, k1 = p3 << 32 | p4 is published right after by the claimer.  A lane that
+// finds its k0 in a slot waits for the slot's k1 to appear and compares; the claimer's store comes before every wait in
+// program order (same iteration, straight-line), so lanes of one wave cannot wait on each other's unpublished slot.
+__global__ __launch_bounds__(256) void k_quartet_wide_insert(const uint4 *__restrict__ wide_pos, const uint32_t *__restrict__ wide_pat,
+                                                             unsigned long long n, unsigned long long *__restrict__ k0,
+                                                             unsigned long long *__restrict__ k1, uint32_t *__restrict__ hist,
+                                                             unsigned long long mask, unsigned long long *__restrict__ overflow) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 p = wide_pos[i];
+    const unsigned long long key0 = ((unsigned long long)p.x << 32) | p.y, key1 = ((unsigned long long)p.z << 32) | p.w;
+    unsigned long long h = qhash(key0 ^ qhash(key1)) & mask;
+    for (uint32_t probes = 0; probes < QPROBE_MAX; ++probes) {
+        const unsigned long long cur = atomicCAS(&k0[h], QKEY_EMPTY, key0);
+        if (cur == QKEY_EMPTY) __hip_atomic_store(&k1[h], key1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == QKEY_EMPTY || cur == key0) {
+            unsigned long long v;
+            do { v = __hip_atomic_load(&k1[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (v == QKEY_EMPTY);
+            if (v == key1) { atomicAdd(&hist[h * 16 + wide_pat[i]], 1u); return; }
+        }
+        h = (h + 1) & mask;
+    }
+    *overflow = 1ull;
 }
 
 // rows per block of 256*8 slots
@@ -148,6 +184,7 @@ __device__ __forceinline__ void quartet_values(const uint32_t *c, float &me, flo
 }
 
 __global__ __launch_bounds__(256) void k_quartet_emit(const unsigned long long *__restrict__ keys,
+                                                      const unsigned long long *__restrict__ keys1 /* wide table: p3 << 32 | p4; else nullptr */,
                                                       const uint32_t *__restrict__ hist, unsigned long long n_slots,
                                                       const uint32_t *__restrict__ blk,
                                                       const unsigned long long *__restrict__ q_base,
@@ -179,9 +216,14 @@ __global__ __launch_bounds__(256) void k_quartet_emit(const unsigned long long *
     for (int k = 0; k < QE_PER; ++k) {
         if (kk[k] == QKEY_EMPTY) continue;
         const unsigned long long key = kk[k];
-        const int32_t p1 = (int32_t)(key >> 33);
-        const int32_t p2 = p1 + (int32_t)((key >> 22) & 2047u), p3 = p2 + (int32_t)((key >> 11) & 2047u),
-                      p4 = p3 + (int32_t)(key & 2047u);
+        int32_t p1, p2, p3, p4;
+        if (keys1) {
+            const unsigned long long key1 = keys1[s0 + k];
+            p1 = (int32_t)(key >> 32); p2 = (int32_t)(uint32_t)key; p3 = (int32_t)(key1 >> 32); p4 = (int32_t)(uint32_t)key1;
+        } else {
+            p1 = (int32_t)(key >> 33);
+            p2 = p1 + (int32_t)((key >> 22) & 2047u); p3 = p2 + (int32_t)((key >> 11) & 2047u); p4 = p3 + (int32_t)(key & 2047u);
+        }
         reinterpret_cast<int4 *>(out_pos)[o] = make_int4(p1, p2, p3, p4);
         uint32_t c[16];
         const uint4 *src = reinterpret_cast<const uint4 *>(hist + (s0 + k) * 16);
@@ -290,7 +332,7 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
                         const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 33) | ((unsigned long long)d2 << 22) |
                                                        ((unsigned long long)d3 << 11) | (unsigned long long)d4;
                         if (d2 - 1u >= 2047u || d3 - 1u >= 2047u || d4 - 1u >= 2047u || key == QKEY_EMPTY) {
-                            atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);
+                            s_heavy = 1u;                                        // CpGs >= 2048 bp apart (or out of order): the global path sorts it out
                         } else {
                             const uint32_t pat = ((x >> 31) << 3) | ((y >> 31) << 2) | ((z >> 31) << 1) | (w >> 31);
                             uint32_t h = qslot(key), probes = 0;
@@ -508,6 +550,7 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
         MTH_HIP(ctx, hipStreamSynchronize(s));
         unsigned long long n_slots = 1024;
         while (n_slots < bound / 2) n_slots <<= 1;
+        unsigned long long wide_cap = std::max<unsigned long long>(ctx->q_wpat.cap / 4, 65536), wide_n = 0;
         if (const char *e = getenv("MTH_QUARTET_SLOTS_MIN")) { const unsigned long long k = strtoull(e, nullptr, 10); if (k >= 16) { n_slots = 16; while (n_slots < k) n_slots <<= 1; } }   // tests: force the retry
         for (;;) {
             MTH_HIP(ctx, ctx->q_keys.reserve(n_slots * 8, s));
@@ -515,16 +558,22 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
             MTH_HIP(ctx, hipMemsetAsync(ctx->q_keys.p, 0xFF, n_slots * 8, s));
             MTH_HIP(ctx, hipMemsetAsync(ctx->q_hist.p, 0, n_slots * 64, s));
             MTH_HIP(ctx, hipMemsetAsync(qs + 3, 0, sizeof(unsigned long long), s));
+            MTH_HIP(ctx, hipMemsetAsync(qs + 7, 0, sizeof(unsigned long long), s));
+            MTH_HIP(ctx, ctx->q_wpos.reserve(wide_cap * 16, s));
+            MTH_HIP(ctx, ctx->q_wpat.reserve(wide_cap * 4, s));
             {
                 LaunchTimer lt(ctx, K_QINSERT);
                 hipLaunchKernelGGL(k_quartet_insert, dim3((d.n_reads + 255) / 256), dim3(256), 0, s, d.cpg_off, d.cpg_pos,
                                    d.read_mapq, d.n_reads, params->min_qual, d.region_beg, d.region_end,
                                    ctx->q_keys.as<unsigned long long>(), ctx->q_hist.as<uint32_t>(), n_slots - 1, qs + 3,
-                                   ctx->d_state, (const uint32_t *)ctx->q_tflag.as<uint32_t>(), tile_shift);
+                                   ctx->d_state, (const uint32_t *)ctx->q_tflag.as<uint32_t>(), tile_shift,
+                                   ctx->q_wpos.as<uint4>(), ctx->q_wpat.as<uint32_t>(), wide_cap, qs + 7);
             }
             unsigned long long ovf = 0;
             MTH_HIP(ctx, hipMemcpyAsync(&ovf, qs + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
+            MTH_HIP(ctx, hipMemcpyAsync(&wide_n, qs + 7, sizeof wide_n, hipMemcpyDeviceToHost, s));
             MTH_HIP(ctx, hipStreamSynchronize(s));
+            if (wide_n > wide_cap) { wide_cap = wide_n; continue; }        // the wide list was too short: same table, again
             if (!ovf) break;
             n_slots <<= 2;
         }
@@ -539,6 +588,7 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
             hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->q_blk.as<uint32_t>(), nblk, qs + 1, qs + 2,
                                ctx->q_batch_rows.as<uint32_t>(), 0u);
             hipLaunchKernelGGL(k_quartet_emit, dim3(nblk), dim3(256), 0, s, ctx->q_keys.as<unsigned long long>(),
+                               (const unsigned long long *)nullptr,
                                ctx->q_hist.as<uint32_t>(), n_slots, ctx->q_blk.as<uint32_t>(), qs + 2,
                                ctx->q_pos.as<int32_t>(), ctx->q_cnt.as<uint32_t>(), ctx->q_me.as<float>(),
                                ctx->q_pm.as<float>(), ctx->q_depth.as<uint32_t>());
@@ -547,6 +597,42 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
         MTH_HIP(ctx, hipMemcpyAsync(&t2, qs + 1, sizeof t2, hipMemcpyDeviceToHost, s));
         MTH_HIP(ctx, hipStreamSynchronize(s));
         total = t2;
+        if (wide_n) {
+            // the wide instances under their 128-bit keys: same emit, rows appended after the packed-key rows of the batch
+            unsigned long long w_slots = 1024;
+            while (w_slots < 2 * wide_n) w_slots <<= 1;
+            for (;;) {
+                MTH_HIP(ctx, ctx->q_wk0.reserve(w_slots * 8, s));
+                MTH_HIP(ctx, ctx->q_wk1.reserve(w_slots * 8, s));
+                MTH_HIP(ctx, ctx->q_hist.reserve(w_slots * 64, s));
+                MTH_HIP(ctx, hipMemsetAsync(ctx->q_wk0.p, 0xFF, w_slots * 8, s));
+                MTH_HIP(ctx, hipMemsetAsync(ctx->q_wk1.p, 0xFF, w_slots * 8, s));
+                MTH_HIP(ctx, hipMemsetAsync(ctx->q_hist.p, 0, w_slots * 64, s));
+                MTH_HIP(ctx, hipMemsetAsync(qs + 3, 0, sizeof(unsigned long long), s));
+                hipLaunchKernelGGL(k_quartet_wide_insert, dim3((uint32_t)((wide_n + 255) / 256)), dim3(256), 0, s, ctx->q_wpos.as<uint4>(),
+                                   ctx->q_wpat.as<uint32_t>(), wide_n, ctx->q_wk0.as<unsigned long long>(), ctx->q_wk1.as<unsigned long long>(),
+                                   ctx->q_hist.as<uint32_t>(), w_slots - 1, qs + 3);
+                unsigned long long ovf = 0;
+                MTH_HIP(ctx, hipMemcpyAsync(&ovf, qs + 3, sizeof ovf, hipMemcpyDeviceToHost, s));
+                MTH_HIP(ctx, hipStreamSynchronize(s));
+                if (!ovf) break;
+                w_slots <<= 2;
+            }
+            if (total + wide_n > ctx->q_cap) MTH_HIP(ctx, grow_rows(total + wide_n, total));
+            const uint32_t wblk = (uint32_t)((w_slots + 256 * QE_PER - 1) / (256 * QE_PER));
+            MTH_HIP(ctx, ctx->q_blk.reserve((size_t)wblk * 4, s));
+            hipLaunchKernelGGL(k_quartet_blockcount, dim3(wblk), dim3(256), 0, s, ctx->q_wk0.as<unsigned long long>(), w_slots, ctx->q_blk.as<uint32_t>());
+            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->q_blk.as<uint32_t>(), wblk, qs + 1, qs + 2,
+                               ctx->q_batch_rows.as<uint32_t>(), 0u);
+            hipLaunchKernelGGL(k_quartet_emit, dim3(wblk), dim3(256), 0, s, ctx->q_wk0.as<unsigned long long>(),
+                               (const unsigned long long *)ctx->q_wk1.as<unsigned long long>(),
+                               ctx->q_hist.as<uint32_t>(), w_slots, ctx->q_blk.as<uint32_t>(), qs + 2,
+                               ctx->q_pos.as<int32_t>(), ctx->q_cnt.as<uint32_t>(), ctx->q_me.as<float>(),
+                               ctx->q_pm.as<float>(), ctx->q_depth.as<uint32_t>());
+            MTH_HIP(ctx, hipMemcpyAsync(&t2, qs + 1, sizeof t2, hipMemcpyDeviceToHost, s));
+            MTH_HIP(ctx, hipStreamSynchronize(s));
+            total = t2;
+        }
     }
     MTH_HIP(ctx, hipGetLastError());
     meta.rows = total - rows_before;

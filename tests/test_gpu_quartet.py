@@ -119,19 +119,53 @@ def test_reset_and_empty(eng):
     assert len(eng.quartet_fetch(0)["tid"]) == 0
 
 
-def test_wide_quartet_is_refused(eng):
-    """consecutive CpGs of a read >= 2048 bp apart do not fit the packed key: loud MTH_ERR_CAPACITY"""
-    from metheor_amd import Batch, MthError
+def test_wide_quartets_take_the_128_bit_key(eng):
+    """consecutive CpGs of a read >= 2048 bp apart do not fit the packed 64-bit key (reference skips, big deletions, long
+    reads): the reference has no such limit (readutil.rs:97-132), so these windows are aggregated under a 128-bit key
+    (k_quartet_wide_insert) and come out as ordinary rows"""
+    from metheor_amd import Batch, synth
     st = np.array([100], np.int32)
-    pos = np.array([100, 200, 5000, 5100], np.uint32)
+    pos = np.array([100, 200, 5000 | (1 << 31), 5100], np.uint32)
     b = Batch(0, 0, 100_000, st, st + 5100, np.array([42], np.uint8), np.array([0, 4], np.uint32), pos,
               np.array([0, 100, 4900, 5000], np.uint16))
     eng.reset()
     eng.quartet_accumulate(b)
-    with pytest.raises(MthError) as e:
-        eng.quartet_fetch(0)
-    assert e.value.status == -8
-    eng.reset()
+    d = eng.quartet_fetch(0)
+    assert d["pos"].tolist() == [[100, 200, 5000, 5100]]
+    assert d["cnt"][0].tolist() == [0, 0, 1] + [0] * 13                      # pattern 0b0010: only the third CpG methylated
+    # long sparse reads (most windows wide) on top of ordinary 150-bp reads, the same window seen by many reads
+    rng = np.random.default_rng(404)
+    sites = synth.make_sites(300_000, 0.0012, rng)
+    long_c = synth.make_contig(0, 300_000, 900, 0.0012, rng, read_len=9000, sites=sites)
+    n = np.diff(long_c["cpg_off"].astype(np.int64))
+    gaps = np.diff(sites)
+    assert (gaps >= 2048).sum() > 20 and n.max() >= 8
+    short_c = synth.make_contig(0, 300_000, 40_000, 0.03, rng)
+    # one coordinate-sorted batch holding both kinds
+    def merged(a, b):
+        order = np.argsort(np.concatenate([a["read_start"], b["read_start"]]), kind="stable")
+        out = dict(a)
+        cnt = np.concatenate([np.diff(a["cpg_off"].astype(np.int64)), np.diff(b["cpg_off"].astype(np.int64))])[order]
+        off = np.zeros(len(order) + 1, np.int64); np.cumsum(cnt, out=off[1:])
+        src_off = np.concatenate([a["cpg_off"][:-1].astype(np.int64), b["cpg_off"][:-1].astype(np.int64) + int(a["cpg_off"][-1])])[order]
+        idx = np.repeat(src_off - off[:-1], cnt) + np.arange(off[-1])
+        for k in ("read_start", "read_end", "read_mapq", "read_fwd"):
+            out[k] = np.concatenate([a[k], b[k]])[order]
+        out["cpg_off"] = off.astype(np.uint32)
+        out["cpg_pos"] = np.concatenate([a["cpg_pos"], b["cpg_pos"]])[idx]
+        out["cpg_rel"] = np.concatenate([a["cpg_rel"].astype(np.uint16), b["cpg_rel"].astype(np.uint16)])[idx]
+        return out
+    c = merged(long_c, short_c)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    for mq, md in ((10, 0), (0, 3)):
+        d = run_device(eng, [c], mq, md)
+        check(d, reads, mq, md)
+    wide = (np.diff(d["pos"].astype(np.int64), axis=1) >= 2048).any(axis=1)
+    assert wide.sum() > 20 and (~wide).sum() > 1000
+    # and split into regions (a wide quartet is owned by the region of its first CpG)
+    from metheor_amd import shard
+    d2 = run_device(eng, [c], 0, 3, regions=[shard.plan_regions(c, 3)])
+    check(d2, reads, 0, 3)
 
 
 def test_table_overflow_retry(eng, monkeypatch):
