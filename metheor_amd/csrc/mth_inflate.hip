@@ -27,6 +27,7 @@ struct InflArgs {
     uint32_t n_blocks;
     uint8_t *out;
     uint32_t *err;
+    int fast_literals;                         // the hand-written literal loop (METHEOR_INFLATE_ASM=0 turns it off: A/B)
 };
 
 __constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -82,14 +83,39 @@ __device__ bool huff_build(const Huff &h, const uint8_t *lens, int n, uint16_t *
     return true;
 }
 
+// The bit reader.  Wave-uniform by construction: every field lives in scalar registers and the input is read with SCALAR
+// loads of aligned dwords (the file bytes are not written by this launch), so a refill neither occupies a vector lane nor
+// waits for the literal stores in flight (a vector load's s_waitcnt vmcnt does).
+// (the decoder state IS wave-uniform, but values that came through LDS or a vector load look divergent to the compiler:
+// readfirstlane states the fact at the scalar-asm boundaries)
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uni64(uint64_t x) { return (uint64_t)uni((uint32_t)x) | ((uint64_t)uni((uint32_t)(x >> 32)) << 32); }
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p) { return reinterpret_cast<T *>(uni64(reinterpret_cast<uint64_t>(p))); }
+__device__ __forceinline__ uint32_t sload_dword(const uint8_t *p) {   // p: wave-uniform, 4-byte aligned
+    uint32_t w;
+    const uint8_t *q = uni_ptr(p);
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(q) : "memory");
+#ifndef MTH_INFLATE_DIVERGENT_STATE
+    w = uni(w);                          // (an asm result counts as divergent: say it is not, or the whole decoder moves to the vector unit)
+#endif
+    return w;
+}
 struct Bits {
-    const uint8_t *in, *end;     // end: first byte past the payload (reads may run a few bytes beyond: the file is padded)
+    const uint8_t *file;         // the compressed bytes (a kernel argument: loads through file + offset stay global, uniform loads --
+                                 // a pointer that came back from the scalar asm would be a flat one, and flat loads count as divergent)
+    uint64_t in, end;            // byte offsets in file: next aligned dword to load; first byte past the payload (reads run a few bytes beyond: the file is padded)
     uint64_t bb;
     int bc;
+    __device__ __forceinline__ void seek(uint64_t p) {          // start reading at byte offset p
+        const uint32_t skip = ((uint32_t)(reinterpret_cast<uintptr_t>(file) + p) & 3u) * 8u;
+        in = p - (skip >> 3);
+        const uint32_t w = sload_dword(file + in);
+        in += 4;
+        bb = w >> skip; bc = 32 - (int)skip;
+    }
     __device__ __forceinline__ void refill() {
         if (bc < 32) {
-            uint32_t w;
-            __builtin_memcpy(&w, in, 4);
+            const uint32_t w = sload_dword(file + in);
             bb |= (uint64_t)w << bc;
             in += 4; bc += 32;
         }
@@ -97,9 +123,68 @@ struct Bits {
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
     __device__ __forceinline__ void drop(int n) { bb >>= n; bc -= n; }
     __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = peek(n); drop(n); return v; }
-    // bytes consumed so far (whole bytes of the bit buffer given back)
-    __device__ __forceinline__ const uint8_t *cursor() const { return in - (bc >> 3); }
+    // bytes consumed so far (whole bytes of the bit buffer given back), as an offset in file
+    __device__ __forceinline__ uint64_t cursor() const { return in - (uint64_t)(bc >> 3); }
 };
+
+// A run of literals in hand-written ISA: while the next code is a direct-table hit for a literal and the output has room,
+// decode it, store it and go on -- refilling from scalar memory as it goes.  22 instructions per literal (15 scalar) against
+// the ~45 (30 scalar) the compiler made of the general symbol loop; the scalar unit, one per CU, is what k_inflate is bound by
+// (PMC: 10.8 G scalar / 5.8 G vector instructions per 13 441 blocks).  Leaves at anything else (length code, end of block,
+// long code, output full) with the state as the general loop expects it.
+__device__ __forceinline__ void literal_run(Bits &b, uint32_t &pos, const uint32_t isize, uint8_t *out0, const uint32_t ltab_lds) {
+    uint64_t bb = uni64(b.bb), tmp;
+    const uint64_t base = uni64(reinterpret_cast<uint64_t>(b.file));
+    uint64_t in = base + uni64(b.in);                   // the address as an integer: scalar registers s[42:43]
+    int32_t bc = (int32_t)uni((uint32_t)b.bc);
+    uint32_t t, e, l, vt, ve;
+    uint32_t upos = uni(pos);
+    const uint32_t u_isize = uni(isize), u_lt = uni(ltab_lds);
+    uint8_t *const u_out = uni_ptr(out0);
+    asm volatile(
+        "L_top_%=:\n\t"
+        "s_cmp_lt_i32 %[bc], 32\n\t"
+        "s_cbranch_scc0 L_look_%=\n\t"
+        "s_load_dword s44, s[42:43], 0x0\n\t"
+        "s_add_u32 s42, s42, 4\n\t"
+        "s_addc_u32 s43, s43, 0\n\t"
+        "s_mov_b32 s45, 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_lshl_b64 s[44:45], s[44:45], %[bc]\n\t"
+        "s_or_b64 s[40:41], s[40:41], s[44:45]\n\t"
+        "s_add_u32 %[bc], %[bc], 32\n\t"
+        "L_look_%=:\n\t"
+        "s_and_b32 %[t], s40, 0x3ff\n\t"
+        "s_lshl1_add_u32 %[t], %[t], %[lt]\n\t"
+        "v_mov_b32 %[vt], %[t]\n\t"
+        "ds_read_u16 %[ve], %[vt]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[e], %[ve]\n\t"
+        "s_sub_u32 %[t], %[e], 1\n\t"
+        "s_cmp_ge_u32 %[t], 0xfff\n\t"          // e == 0: no short code here; e >= 0x1000: not a literal
+        "s_cbranch_scc1 L_exit_%=\n\t"
+        "s_cmp_ge_u32 %[pos], %[isize]\n\t"
+        "s_cbranch_scc1 L_exit_%=\n\t"
+        "s_and_b32 %[l], %[e], 15\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], %[l]\n\t"
+        "s_sub_u32 %[bc], %[bc], %[l]\n\t"
+        "s_lshr_b32 %[e], %[e], 4\n\t"
+        "v_mov_b32 %[ve], %[e]\n\t"
+        "v_mov_b32 %[vt], %[pos]\n\t"
+        "global_store_byte %[vt], %[ve], %[out]\n\t"
+        "s_add_u32 %[pos], %[pos], 1\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_exit_%=:\n\t"
+        : "+{s[40:41]}"(bb), "+{s[42:43]}"(in), [bc] "+s"(bc), [pos] "+s"(upos), "=&{s[44:45]}"(tmp), [t] "=&s"(t), [e] "=&s"(e), [l] "=&s"(l),
+          [vt] "=&v"(vt), [ve] "=&v"(ve)
+        : [lt] "s"(u_lt), [isize] "s"(u_isize), [out] "s"(u_out)
+        : "memory", "scc");
+#ifndef MTH_INFLATE_DIVERGENT_STATE
+    b.bb = uni64(bb); b.in = uni64(in) - base; b.bc = (int)uni((uint32_t)bc); pos = uni(upos);
+#else
+    b.bb = bb; b.in = in - base; b.bc = bc; pos = upos;
+#endif
+}
 
 // decode one symbol; -1 on an invalid code
 __device__ __forceinline__ int huff_decode(const Huff &h, Bits &b) {
@@ -107,6 +192,7 @@ __device__ __forceinline__ int huff_decode(const Huff &h, Bits &b) {
     if (e) { b.drop((int)(e & 15u)); return (int)(e >> 4); }
     // longer than root bits (or invalid): canonical walk, one bit at a time (RFC 1951 3.2.2; MSB of the code first)
     int code = 0, first = 0, index = 0;
+#pragma unroll 1                                       // rare path: unrolled 15 deep it tripled the kernel and cost it a wave per SIMD
     for (int l = 1; l < 16; ++l) {
         code |= (int)b.take(1);
         const int c = h.count[l];
@@ -127,7 +213,10 @@ __global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
     uint8_t *const out0 = a.out + a.uoff[blk];
     const uint32_t isize = a.isize[blk];
     Bits b;
-    b.in = a.file + a.coff[blk]; b.end = b.in + a.csize[blk]; b.bb = 0; b.bc = 0;
+    b.file = a.file;
+    b.end = a.coff[blk] + a.csize[blk];
+    b.seek(a.coff[blk]);
+    const uint32_t ltab_lds = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint16_t *)s_ltab);
     const Huff HL{s_ltab, s_lsorted, s_lcount, LROOT, s_tmp}, HD{s_dtab, s_dsorted, s_dcount, DROOT, s_tmp};
     uint32_t pos = 0;
     bool bad = false, last = false;
@@ -137,13 +226,14 @@ __global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
         const uint32_t type = b.take(2);
         if (type == 0) {                                   // stored
             b.drop(b.bc & 7);                              // to the byte boundary
-            const uint8_t *p = b.cursor();
+            const uint64_t po = b.cursor();
+            const uint8_t *p = a.file + po;
             const uint32_t len = (uint32_t)p[0] | ((uint32_t)p[1] << 8), nlen = (uint32_t)p[2] | ((uint32_t)p[3] << 8);
             p += 4;
-            if ((len ^ nlen) != 0xffffu || pos + len > isize || p + len > b.end) { bad = true; break; }
+            if ((len ^ nlen) != 0xffffu || pos + len > isize || po + 4 + len > b.end) { bad = true; break; }
             for (uint32_t i = lane; i < len; i += 64) out0[pos + i] = p[i];
             pos += len;
-            b.in = p + len; b.bb = 0; b.bc = 0;
+            b.seek(po + 4 + len);
             continue;
         }
         if (type == 3) { bad = true; break; }
@@ -194,6 +284,7 @@ __global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
         }
         // ---- symbols ----
         for (;;) {
+            if (a.fast_literals) literal_run(b, pos, isize, out0, ltab_lds);
             b.refill();
             const int sym = huff_decode(HL, b);
             if (sym < 0) { bad = true; break; }
@@ -429,6 +520,7 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
         InflArgs ia{};
         ia.file = ctx->inf_file.as<uint8_t>(); ia.coff = d_coff; ia.csize = d_csize; ia.isize = d_isize; ia.uoff = d_uoff;
         ia.n_blocks = (uint32_t)nb; ia.out = ctx->inf_raw.as<uint8_t>(); ia.err = &ctx->d_state->err;
+        { static const int fast = [] { const char *e = getenv("METHEOR_INFLATE_ASM"); return e ? atoi(e) : 1; }(); ia.fast_literals = fast; }
         {
             LaunchTimer lt(ctx, K_INFLATE);
             hipLaunchKernelGGL(k_inflate, dim3((uint32_t)nb), dim3(64), 0, s, ia);
