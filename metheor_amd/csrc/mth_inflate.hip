@@ -43,7 +43,7 @@ struct Huff {
 
 // wave-cooperative build; returns false for an over-subscribed code (incomplete codes are accepted as zlib does for
 // the single-distance-code case; an unused entry decodes as an error later)
-__device__ bool huff_build(const Huff &h, const uint8_t *lens, int n, uint16_t *code_of /* scratch, n entries */) {
+__device__ bool huff_build(const Huff &h, const uint8_t *lens, int n, uint16_t *code_of /* scratch, n entries */, bool flag_literals = false) {
     const int lane = threadIdx.x & 63;
     if (lane < 16) h.count[lane] = 0;
     for (int i = lane; i < (1 << h.root); i += 64) h.tab[i] = 0;
@@ -74,7 +74,7 @@ __device__ bool huff_build(const Huff &h, const uint8_t *lens, int n, uint16_t *
         const int l = lens[s];
         if (l == 0 || l > h.root) continue;
         const uint32_t rev = __builtin_bitreverse32((uint32_t)code_of[s]) >> (32 - l);
-        const uint16_t e = (uint16_t)((s << 4) | l);
+        const uint16_t e = (uint16_t)((s << 4) | l | ((flag_literals && s < 256) ? 0x8000 : 0));   // bit 15: a literal (the asm loop tests it)
         for (uint32_t k = rev; k < (1u << h.root); k += (1u << l)) h.tab[k] = e;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -127,24 +127,46 @@ struct Bits {
     __device__ __forceinline__ uint64_t cursor() const { return in - (uint64_t)(bc >> 3); }
 };
 
-// A run of literals in hand-written ISA: while the next code is a direct-table hit for a literal and the output has room,
-// decode it, store it and go on -- refilling from scalar memory as it goes.  22 instructions per literal (15 scalar) against
-// the ~45 (30 scalar) the compiler made of the general symbol loop; the scalar unit, one per CU, is what k_inflate is bound by
-// (PMC: 10.8 G scalar / 5.8 G vector instructions per 13 441 blocks).  Leaves at anything else (length code, end of block,
-// long code, output full) with the state as the general loop expects it.
+// A run of literals in hand-written ISA: while the next code is a direct-table hit for a literal (bit 15 of the entry), decode
+// it, store it and go on -- three per trip around the loop (a refill leaves >= 32 bits, a table hit takes <= 10), refilling
+// from scalar memory as it goes.  ~11 scalar + 5 vector instructions per literal against the ~30 + 15 the compiler made of the
+// general symbol loop; the scalar unit, one per CU, is what k_inflate is bound by (PMC: 10.8 G scalar / 5.8 G vector
+// instructions per 13 441 blocks before, profiles/r02_e2e.md).  The output bound is checked where the bits are refilled: at
+// most 63 + 2 literals can follow a refill, so the loop only runs while 72 bytes of room are left and the block's last bytes
+// go through the general loop.  Leaves at anything else (length code, end of block, long code) with the state as the general
+// loop expects it.
+#define MTH_LIT_STEP                                     \
+    "s_and_b32 %[t], s40, 0x3ff\n\t"                     \
+    "s_lshl1_add_u32 %[t], %[t], %[lt]\n\t"              \
+    "v_mov_b32 %[vt], %[t]\n\t"                          \
+    "ds_read_u16 %[ve], %[vt]\n\t"                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                           \
+    "v_readfirstlane_b32 %[e], %[ve]\n\t"                \
+    "s_bitcmp1_b32 %[e], 15\n\t"                         \
+    "s_cbranch_scc0 L_exit_%=\n\t"                       \
+    "s_and_b32 %[e], %[e], 15\n\t"                       \
+    "s_lshr_b64 s[40:41], s[40:41], %[e]\n\t"            \
+    "s_sub_u32 %[bc], %[bc], %[e]\n\t"                   \
+    "v_lshrrev_b32 %[ve], 4, %[ve]\n\t"                  \
+    "global_store_byte %[vpos], %[ve], %[out]\n\t"       \
+    "v_add_u32 %[vpos], 1, %[vpos]\n\t"
 __device__ __forceinline__ void literal_run(Bits &b, uint32_t &pos, const uint32_t isize, uint8_t *out0, const uint32_t ltab_lds) {
     uint64_t bb = uni64(b.bb), tmp;
     const uint64_t base = uni64(reinterpret_cast<uint64_t>(b.file));
     uint64_t in = base + uni64(b.in);                   // the address as an integer: scalar registers s[42:43]
     int32_t bc = (int32_t)uni((uint32_t)b.bc);
-    uint32_t t, e, l, vt, ve;
-    uint32_t upos = uni(pos);
+    uint32_t t, e, vt, ve;
+    uint32_t vpos = pos;
     const uint32_t u_isize = uni(isize), u_lt = uni(ltab_lds);
     uint8_t *const u_out = uni_ptr(out0);
     asm volatile(
         "L_top_%=:\n\t"
         "s_cmp_lt_i32 %[bc], 32\n\t"
-        "s_cbranch_scc0 L_look_%=\n\t"
+        "s_cbranch_scc0 L_go_%=\n\t"
+        "v_readfirstlane_b32 %[t], %[vpos]\n\t"
+        "s_add_u32 %[t], %[t], 72\n\t"
+        "s_cmp_gt_u32 %[t], %[isize]\n\t"
+        "s_cbranch_scc1 L_exit_%=\n\t"
         "s_load_dword s44, s[42:43], 0x0\n\t"
         "s_add_u32 s42, s42, 4\n\t"
         "s_addc_u32 s43, s43, 0\n\t"
@@ -153,43 +175,26 @@ __device__ __forceinline__ void literal_run(Bits &b, uint32_t &pos, const uint32
         "s_lshl_b64 s[44:45], s[44:45], %[bc]\n\t"
         "s_or_b64 s[40:41], s[40:41], s[44:45]\n\t"
         "s_add_u32 %[bc], %[bc], 32\n\t"
-        "L_look_%=:\n\t"
-        "s_and_b32 %[t], s40, 0x3ff\n\t"
-        "s_lshl1_add_u32 %[t], %[t], %[lt]\n\t"
-        "v_mov_b32 %[vt], %[t]\n\t"
-        "ds_read_u16 %[ve], %[vt]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 %[e], %[ve]\n\t"
-        "s_sub_u32 %[t], %[e], 1\n\t"
-        "s_cmp_ge_u32 %[t], 0xfff\n\t"          // e == 0: no short code here; e >= 0x1000: not a literal
-        "s_cbranch_scc1 L_exit_%=\n\t"
-        "s_cmp_ge_u32 %[pos], %[isize]\n\t"
-        "s_cbranch_scc1 L_exit_%=\n\t"
-        "s_and_b32 %[l], %[e], 15\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], %[l]\n\t"
-        "s_sub_u32 %[bc], %[bc], %[l]\n\t"
-        "s_lshr_b32 %[e], %[e], 4\n\t"
-        "v_mov_b32 %[ve], %[e]\n\t"
-        "v_mov_b32 %[vt], %[pos]\n\t"
-        "global_store_byte %[vt], %[ve], %[out]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n\t"
+        "L_go_%=:\n\t"
+        MTH_LIT_STEP MTH_LIT_STEP MTH_LIT_STEP
         "s_branch L_top_%=\n\t"
         "L_exit_%=:\n\t"
-        : "+{s[40:41]}"(bb), "+{s[42:43]}"(in), [bc] "+s"(bc), [pos] "+s"(upos), "=&{s[44:45]}"(tmp), [t] "=&s"(t), [e] "=&s"(e), [l] "=&s"(l),
+        : "+{s[40:41]}"(bb), "+{s[42:43]}"(in), [bc] "+s"(bc), [vpos] "+v"(vpos), "=&{s[44:45]}"(tmp), [t] "=&s"(t), [e] "=&s"(e),
           [vt] "=&v"(vt), [ve] "=&v"(ve)
         : [lt] "s"(u_lt), [isize] "s"(u_isize), [out] "s"(u_out)
         : "memory", "scc");
 #ifndef MTH_INFLATE_DIVERGENT_STATE
-    b.bb = uni64(bb); b.in = uni64(in) - base; b.bc = (int)uni((uint32_t)bc); pos = uni(upos);
+    b.bb = uni64(bb); b.in = uni64(in) - base; b.bc = (int)uni((uint32_t)bc); pos = uni(vpos);
 #else
-    b.bb = bb; b.in = in - base; b.bc = bc; pos = upos;
+    b.bb = bb; b.in = in - base; b.bc = bc; pos = vpos;
 #endif
 }
+#undef MTH_LIT_STEP
 
 // decode one symbol; -1 on an invalid code
 __device__ __forceinline__ int huff_decode(const Huff &h, Bits &b) {
     const uint32_t e = h.tab[b.peek(h.root)];
-    if (e) { b.drop((int)(e & 15u)); return (int)(e >> 4); }
+    if (e) { b.drop((int)(e & 15u)); return (int)((e >> 4) & 0x7ffu); }
     // longer than root bits (or invalid): canonical walk, one bit at a time (RFC 1951 3.2.2; MSB of the code first)
     int code = 0, first = 0, index = 0;
 #pragma unroll 1                                       // rare path: unrolled 15 deep it tripled the kernel and cost it a wave per SIMD
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
         if (type == 1) {                                   // fixed codes (RFC 1951 3.2.6)
             for (int s = lane; s < 288; s += 64) s_lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (!huff_build(HL, s_lens, 288, s_code)) { bad = true; break; }
+            if (!huff_build(HL, s_lens, 288, s_code, true)) { bad = true; break; }
             for (int s = lane; s < 30; s += 64) s_lens[s] = 5;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (!huff_build(HD, s_lens, 30, s_code)) { bad = true; break; }
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
             // the distance lengths follow the literal/length ones: build the distance code first (it lives in s_dtab,
             // which the code-length code no longer needs), from a copy at the front of a scratch region
             if (!huff_build(HD, s_lens + hlit, hdist, s_code)) { bad = true; break; }
-            if (!huff_build(HL, s_lens, hlit, s_code)) { bad = true; break; }
+            if (!huff_build(HL, s_lens, hlit, s_code, true)) { bad = true; break; }
         }
         // ---- symbols ----
         for (;;) {
