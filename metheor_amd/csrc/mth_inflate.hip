@@ -129,22 +129,23 @@ struct Bits {
 
 // A run of literals in hand-written ISA: while the next code is a direct-table hit for a literal (bit 15 of the entry), decode
 // it, store it and go on -- three per trip around the loop (a refill leaves >= 32 bits, a table hit takes <= 10), refilling
-// from scalar memory as it goes.  ~11 scalar + 5 vector instructions per literal against the ~30 + 15 the compiler made of the
+// from scalar memory as it goes; table index, literal test and code length are worked out on the vector side (the scalar unit
+// is the busy one): ~5 scalar + 8 vector instructions per literal against the ~30 + 15 the compiler made of the
 // general symbol loop; the scalar unit, one per CU, is what k_inflate is bound by (PMC: 10.8 G scalar / 5.8 G vector
 // instructions per 13 441 blocks before, profiles/r02_e2e.md).  The output bound is checked where the bits are refilled: at
 // most 63 + 2 literals can follow a refill, so the loop only runs while 72 bytes of room are left and the block's last bytes
 // go through the general loop.  Leaves at anything else (length code, end of block, long code) with the state as the general
 // loop expects it.
 #define MTH_LIT_STEP                                     \
-    "s_and_b32 %[t], s40, 0x3ff\n\t"                     \
-    "s_lshl1_add_u32 %[t], %[t], %[lt]\n\t"              \
-    "v_mov_b32 %[vt], %[t]\n\t"                          \
+    "v_mov_b32 %[vt], s40\n\t"                           \
+    "v_and_b32 %[vt], 0x3ff, %[vt]\n\t"                  \
+    "v_lshl_add_u32 %[vt], %[vt], 1, %[vlt]\n\t"         \
     "ds_read_u16 %[ve], %[vt]\n\t"                       \
     "s_waitcnt lgkmcnt(0)\n\t"                           \
-    "v_readfirstlane_b32 %[e], %[ve]\n\t"                \
-    "s_bitcmp1_b32 %[e], 15\n\t"                         \
-    "s_cbranch_scc0 L_exit_%=\n\t"                       \
-    "s_and_b32 %[e], %[e], 15\n\t"                       \
+    "v_cmp_gt_u32 vcc, 0x8000, %[ve]\n\t"                \
+    "v_and_b32 %[vt], 15, %[ve]\n\t"                     \
+    "s_cbranch_vccnz L_exit_%=\n\t"                      \
+    "v_readfirstlane_b32 %[e], %[vt]\n\t"                \
     "s_lshr_b64 s[40:41], s[40:41], %[e]\n\t"            \
     "s_sub_u32 %[bc], %[bc], %[e]\n\t"                   \
     "v_lshrrev_b32 %[ve], 4, %[ve]\n\t"                  \
@@ -181,8 +182,8 @@ __device__ __forceinline__ void literal_run(Bits &b, uint32_t &pos, const uint32
         "L_exit_%=:\n\t"
         : "+{s[40:41]}"(bb), "+{s[42:43]}"(in), [bc] "+s"(bc), [vpos] "+v"(vpos), "=&{s[44:45]}"(tmp), [t] "=&s"(t), [e] "=&s"(e),
           [vt] "=&v"(vt), [ve] "=&v"(ve)
-        : [lt] "s"(u_lt), [isize] "s"(u_isize), [out] "s"(u_out)
-        : "memory", "scc");
+        : [vlt] "v"(u_lt), [isize] "s"(u_isize), [out] "s"(u_out)
+        : "memory", "scc", "vcc");
 #ifndef MTH_INFLATE_DIVERGENT_STATE
     b.bb = uni64(bb); b.in = uni64(in) - base; b.bc = (int)uni((uint32_t)bc); pos = uni(vpos);
 #else
@@ -207,14 +208,66 @@ __device__ __forceinline__ int huff_decode(const Huff &h, Bits &b) {
     return -1;
 }
 
-__global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
+// The symbols of one DEFLATE block (RFC 1951 3.2.3-3.2.5) up to its end-of-block code; true = the stream is invalid.
+// Early returns instead of loop-carried error flags: the flags were most of what the compiler's version spent per symbol.
+__device__ __forceinline__ bool inflate_symbols(Bits &b, const Huff &HL, const Huff &HD, uint32_t &pos, const uint32_t isize, uint8_t *out0,
+                                                const uint32_t ltab_lds, const bool fast_literals, const int lane, const uint32_t *s_lbx,
+                                                const uint32_t *s_dbx) {
+    for (;;) {
+        if (fast_literals) literal_run(b, pos, isize, out0, ltab_lds);
+        b.refill();
+        const int sym = huff_decode(HL, b);
+        if (sym < 0) return true;
+        if (sym < 256) {
+            if (pos >= isize) return true;
+            out0[pos] = (uint8_t)sym;          // every lane, same address, same value: no exec-mask juggling for lane 0
+            ++pos;
+            continue;
+        }
+        if (sym == 256) return false;
+        if (sym > 285) return true;
+        const int li = sym - 257;
+        // base and extra bits of a length / distance symbol (RFC 1951 3.2.5) from two small LDS tables built at kernel start:
+        // by arithmetic they were ~25 scalar instructions per match, on the unit the kernel is bound by
+        const uint32_t lbx = s_lbx[li];
+        const uint32_t len = (lbx & 0xffffu) + b.take((int)(lbx >> 16));
+        b.refill();
+        const int ds = huff_decode(HD, b);
+        if (ds < 0 || ds > 29) return true;
+        const uint32_t dbx = s_dbx[ds];
+        const uint32_t dist = (dbx & 0xffffu) + b.take((int)(dbx >> 16));
+        if (dist > pos || pos + len > isize) return true;
+        // the bytes written so far must be visible to the loads below (same wave, but loads and stores return
+        // out of order with respect to each other)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (dist >= len) {                              // no overlap: all lanes copy at once
+            for (uint32_t k = lane; k < len; k += 64) out0[pos + k] = out0[pos - dist + k];
+        } else {                                        // overlapping run: the source repeats with period dist
+            for (uint32_t k = lane; k < len; k += 64) out0[pos + k] = out0[pos - dist + (k % dist)];
+        }
+        pos += len;
+    }
+}
+
+__global__ __launch_bounds__(64, 8) void k_inflate(const InflArgs a) {
     __shared__ uint16_t s_ltab[1 << LROOT], s_dtab[1 << DROOT];
     __shared__ uint16_t s_lsorted[288], s_dsorted[32], s_lcount[16], s_dcount[16], s_code[320];
     __shared__ uint8_t s_lens[320];
     __shared__ uint16_t s_tmp[32];
+    __shared__ uint32_t s_lbx[32], s_dbx[32];     // length / distance symbols: base | extra bits << 16 (RFC 1951 3.2.5)
     const uint32_t blk = blockIdx.x;
     if (blk >= a.n_blocks) return;
     const int lane = threadIdx.x;
+    if (lane < 29) {                               // from the 9th length symbol on, four symbols per extra-bit count
+        const uint32_t li = (uint32_t)lane, lx = (li < 8 || li == 28) ? 0u : (li >> 2) - 1u;
+        s_lbx[lane] = (li < 8 ? li + 3u : (li == 28 ? 258u : ((4u + (li & 3u)) << lx) + 3u)) | (lx << 16);
+    }
+    if (lane < 30) {                               // from the 5th distance symbol on, two per extra-bit count
+        const uint32_t ds = (uint32_t)lane, dx = ds < 4 ? 0u : (ds >> 1) - 1u;
+        s_dbx[lane] = (ds < 4 ? ds + 1u : ((2u + (ds & 1u)) << dx) + 1u) | (dx << 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     uint8_t *const out0 = a.out + a.uoff[blk];
     const uint32_t isize = a.isize[blk];
     Bits b;
@@ -288,44 +341,7 @@ __global__ __launch_bounds__(64) void k_inflate(const InflArgs a) {
             if (!huff_build(HL, s_lens, hlit, s_code, true)) { bad = true; break; }
         }
         // ---- symbols ----
-        for (;;) {
-            if (a.fast_literals) literal_run(b, pos, isize, out0, ltab_lds);
-            b.refill();
-            const int sym = huff_decode(HL, b);
-            if (sym < 0) { bad = true; break; }
-            if (sym < 256) {
-                if (pos >= isize) { bad = true; break; }
-                out0[pos] = (uint8_t)sym;          // every lane, same address, same value: no exec-mask juggling for lane 0
-                ++pos;
-                continue;
-            }
-            if (sym == 256) break;
-            if (sym > 285) { bad = true; break; }
-            const int li = sym - 257;
-            // base and extra bits of a length / distance symbol by arithmetic (RFC 1951 3.2.5: from the 9th symbol on, four -- two
-            // for distances -- symbols per extra-bit count): the tables lived in constant memory and cost two dependent global
-            // loads per match each
-            const uint32_t lx = (li < 8 || li == 28) ? 0u : (uint32_t)(li >> 2) - 1u;
-            const uint32_t lbase = li < 8 ? (uint32_t)li + 3u : (li == 28 ? 258u : ((4u + ((uint32_t)li & 3u)) << lx) + 3u);
-            const uint32_t len = lbase + b.take((int)lx);
-            b.refill();
-            const int ds = huff_decode(HD, b);
-            if (ds < 0 || ds > 29) { bad = true; break; }
-            const uint32_t dx = ds < 4 ? 0u : (uint32_t)(ds >> 1) - 1u;
-            const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u;
-            const uint32_t dist = dbase + b.take((int)dx);
-            if (dist > pos || pos + len > isize) { bad = true; break; }
-            // the bytes written so far must be visible to the loads below (same wave, but loads and stores return
-            // out of order with respect to each other)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (dist >= len) {                              // no overlap: all lanes copy at once
-                for (uint32_t k = lane; k < len; k += 64) out0[pos + k] = out0[pos - dist + k];
-            } else {                                        // overlapping run: the source repeats with period dist
-                for (uint32_t k = lane; k < len; k += 64) out0[pos + k] = out0[pos - dist + (k % dist)];
-            }
-            pos += len;
-        }
+        if (inflate_symbols(b, HL, HD, pos, isize, out0, ltab_lds, a.fast_literals != 0, lane, s_lbx, s_dbx)) { bad = true; break; }
     }
     if (!bad && (pos != isize || b.cursor() > b.end)) bad = true;
     if (bad && lane == 0) atomicOr(a.err, (uint32_t)ERRB_FORMAT);
