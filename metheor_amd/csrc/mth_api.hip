@@ -1,5 +1,6 @@
 // mth_api.hip -- C ABI (include/metheor_hip.h) over the gfx950 kernels: context, buffers,
 // staging of host batches, result getters, per-kernel event timing.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -149,25 +150,45 @@ const char *mth_last_error(const mth_ctx_t *ctx) { return ctx ? ctx->last_error.
 int mth_ctx_create(int device_id, mth_ctx_t **out) {
     if (!out) return MTH_ERR_INVALID;
     *out = nullptr;
+    // METHEOR_TIMING=1: what the 70-140 ms of start-up are made of (stderr)
+    const bool tm = getenv("METHEOR_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    auto lap = [&](const char *what) {
+        if (!tm) return;
+        const auto t1 = now();
+        fprintf(stderr, "[metheor timing]     ctx/%-22s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    };
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return MTH_ERR_NO_DEVICE;
+    lap("hipGetDeviceCount");
+    // (hipDeviceGetAttribute-free: the architecture name is all that is needed, but only the properties call gives it)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return MTH_ERR_NO_DEVICE;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MTH_ERR_NO_DEVICE;  // kernels are built for gfx950 only
+    lap("hipGetDeviceProperties");
     auto *ctx = new mth_ctx;
     ctx->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_state, sizeof(DevState)) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_words, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+    bool ok = hipSetDevice(device_id) == hipSuccess;
+    lap("hipSetDevice");
+    ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
+    lap("hipStreamCreate");
+    ok = ok && hipMalloc((void **)&ctx->d_state, sizeof(DevState)) == hipSuccess;
+    lap("hipMalloc");
+    ok = ok && hipHostMalloc((void **)&ctx->h_state, sizeof(DevState) + 16 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess;
+    lap("hipHostMalloc");
+    if (!ok) {
         mth_ctx_destroy(ctx);
         return MTH_ERR_HIP;
     }
+    ctx->h_words = reinterpret_cast<unsigned long long *>(ctx->h_state + 1);      // one pinned allocation for both
     ctx->stream = ctx->own_stream;
     if (hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream) != hipSuccess) {
         mth_ctx_destroy(ctx);
         return MTH_ERR_HIP;
     }
+    lap("first memset");
     *out = ctx;
     return MTH_OK;
 }
@@ -195,7 +216,6 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (ctx->d_state) (void)hipFree(ctx->d_state);
     if (ctx->d_state2) (void)hipFree(ctx->d_state2);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
-    if (ctx->h_words) (void)hipHostFree(ctx->h_words);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->staged_ev) (void)hipEventDestroy(ctx->staged_ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
