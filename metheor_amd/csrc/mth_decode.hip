@@ -36,6 +36,7 @@ struct DecArgs {
     uint32_t xm_min_mapq;         // a record WITHOUT XM:Z is an error only if its mapq >= this (lpmd.rs:176-181 filters on mapq first)
 };
 
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint32_t ld_u16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 
@@ -51,7 +52,13 @@ __device__ __forceinline__ bool dev_find_xm(const uint8_t *aux, uint32_t len, co
             case 'i': case 'I': case 'f': o += 4; break;
             case 'Z': case 'H': {
                 const uint32_t b = o;
-                // NUL search four bytes at a time (global memory takes unaligned dword loads), bytewise at the very end
+                // NUL search sixteen, then four bytes at a time (global memory takes unaligned loads), bytewise at the very end
+                for (; o + 16 <= len; o += 16) {
+                    const u32x4_a1 w4 = *reinterpret_cast<const u32x4_a1 *>(aux + o);
+                    const uint32_t z = (((w4.x - 0x01010101u) & ~w4.x) | ((w4.y - 0x01010101u) & ~w4.y) | ((w4.z - 0x01010101u) & ~w4.z) |
+                                        ((w4.w - 0x01010101u) & ~w4.w)) & 0x80808080u;
+                    if (z) break;                                   // a NUL somewhere in these 16 bytes: the 4-byte loop below finds it
+                }
                 for (;;) {
                     if (o >= len) return false;
                     if (o + 4 > len) { if (aux[o] == 0) break; ++o; continue; }
@@ -157,6 +164,21 @@ __global__ __launch_bounds__(256) void k_decode(const DecArgs a) {
                     if (ln) { if (first < 0) first = (int32_t)r; last = (int32_t)(r + ln - 1); }
                     const uint32_t qe = min(q + ln, xm_len);                   // (XM shorter than the query: nothing beyond it)
                     uint32_t qq = q;
+                    // sixteen XM characters per load (the lanes of a wave read 64 different cache lines and nothing stays in L1:
+                    // every load is an L2 round trip); a window without z / Z (72 % of them at 2 % CpG density) is skipped at once
+                    for (; qq + 16 <= qe; qq += 16) {
+                        const u32x4_a1 x4 = *reinterpret_cast<const u32x4_a1 *>(xm + qq);
+                        uint32_t any = 0;
+                        const uint32_t xw[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const uint32_t y = (xw[j] | 0x20202020u) ^ 0x7a7a7a7au; any |= (y - 0x01010101u) & ~y & 0x80808080u; }
+                        if (any == 0u) continue;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const uint8_t ch = (uint8_t)(xw[k >> 2] >> (8 * (k & 3)));
+                            if (ch == 'z' || ch == 'Z') call(qq + k, r + (qq + k - q), ch);
+                        }
+                    }
                     // four XM characters per load; a word without z / Z (most of them) is skipped at once
                     for (; qq + 4 <= qe; qq += 4) {
                         const uint32_t x = ld_u32(xm + qq) | 0x20202020u;      // 'Z' -> 'z'
