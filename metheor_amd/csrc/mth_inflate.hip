@@ -481,6 +481,8 @@ static void crc_zero_operators(uint32_t (*mat)[32]) {
     for (int k = 1; k < 17; ++k) square(mat[k], mat[k - 1]);
 }
 
+// (Splitting a pageable host-to-device copy over 4 / 8 host threads that enqueue slices into the same stream was measured:
+// no gain at 4, slower at 8 -- profiles/r02_e2e.md.)
 // stage the file bytes + block table and launch the inflate; on return d_uoff / d_isize point at the device table
 static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
                           const uint32_t *isize, uint64_t n_blocks, uint64_t &total, uint64_t *&d_uoff, uint32_t *&d_isize) {
@@ -515,6 +517,14 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
     if (!staged) {
         if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->inf_file.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, s));
         MTH_HIP(ctx, hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file.p) + n_bytes, 0, 64, s));
+    }
+    // (before the inflate is launched: allocating it afterwards synchronised with the inflate and delayed the first CRC launch by ~7 ms)
+    if (!ctx->crc_mat.p) {
+        uint32_t mat[17][32];
+        crc_zero_operators(mat);
+        MTH_HIP(ctx, ctx->crc_mat.reserve(sizeof mat, s));
+        MTH_HIP(ctx, hipMemcpyAsync(ctx->crc_mat.p, mat, sizeof mat, hipMemcpyHostToDevice, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));            // mat is a local
     }
     // the chunk announced by mth_bgzf_stage: its bytes travel on the side stream, from a helper thread (a pageable copy
     // blocks its caller), while this call's kernels run.  The thread owns inf_file2 / copy_stream / staged_* until joined.
@@ -557,12 +567,6 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
             hipLaunchKernelGGL(k_inflate, dim3((uint32_t)nb), dim3(64), 0, s, ia);
         }
         // CRC32 of every inflated block against the gzip trailer (the 4 bytes after the payload)
-        if (!ctx->crc_mat.p) {
-            uint32_t mat[17][32];
-            crc_zero_operators(mat);
-            MTH_HIP(ctx, ctx->crc_mat.reserve(sizeof mat, s));
-            MTH_HIP(ctx, hipMemcpy(ctx->crc_mat.p, mat, sizeof mat, hipMemcpyHostToDevice));
-        }
         for (size_t i = 0; i < nb; ++i)
             if (coff[i] + (uint64_t)csize[i] + 4 > n_bytes) return fail(ctx, MTH_ERR_INVALID, "BGZF block table: the CRC trailer of a block lies outside the file bytes");
         CrcArgs ca{};

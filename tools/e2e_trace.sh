@@ -20,7 +20,7 @@ rows.sort()
 if rows:
     t0 = rows[0][0]
     for a, b, n in rows:
-        if b - a > 1_000_000: print("%8.1f ms  +%7.1f ms  %s" % ((a - t0) / 1e6, (b - a) / 1e6, n))
+        if b - a > 300_000: print("%8.1f ms  +%7.1f ms  %s" % ((a - t0) / 1e6, (b - a) / 1e6, n))
     print("span ms %.1f, %d events" % ((rows[-1][1] - t0) / 1e6, len(rows)))
 else:
     print("no events")
