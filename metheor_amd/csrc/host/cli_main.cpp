@@ -370,18 +370,20 @@ bool load_bgzf_on_device(Input &in) {
     }
     Phase ph("  device inflate + walk + decode");
     // Chunks of whole blocks.  The first is small (<= 512 MiB of file bytes) so that the GPU starts early; every later chunk
-    // (<= 2 GiB) is copied to the device by a helper thread on a side stream (mth_bgzf_stage) while the chunk before it is
+    // (<= 2 GiB; METHEOR_CHUNK_GROWTH makes the sizes grow geometrically instead -- measured slower, profiles/r02_e2e.md) is copied to the device by a helper thread on a side stream (mth_bgzf_stage) while the chunk before it is
     // being inflated and decoded -- only the first copy is exposed.  METHEOR_DEVICE_CHUNK_MB sets both sizes,
     // METHEOR_NO_STAGE=1 copies every chunk in line.
-    size_t chunk_first = (size_t)512 << 20, chunk = (size_t)2 << 30;
-    if (const char *e = getenv("METHEOR_DEVICE_CHUNK_MB")) { const long k = atol(e); if (k >= 1 && k <= 65536) chunk_first = chunk = (size_t)k << 20; }
+    size_t chunk_first = (size_t)512 << 20, chunk = (size_t)2 << 30, growth = 64;
+    if (const char *e = getenv("METHEOR_DEVICE_CHUNK_MB")) { const long k = atol(e); if (k >= 1 && k <= 65536) { chunk_first = chunk = (size_t)k << 20; growth = 1; } }
     if (const char *e = getenv("METHEOR_FIRST_CHUNK_MB")) { const long k = atol(e); if (k >= 1 && k <= 65536) chunk_first = (size_t)k << 20; }
+    if (const char *e = getenv("METHEOR_CHUNK_GROWTH")) { const long k = atol(e); if (k >= 1 && k <= 64) growth = (size_t)k; }
     const bool stage = !getenv("METHEOR_NO_STAGE");
     struct Chunk { uint64_t b0, b1, base, nbytes, ubytes; };
     std::vector<Chunk> chunks;
     uint64_t total_u = 0;
     for (uint64_t b0 = blk_beg; b0 < bz.n_blocks;) {
-        const size_t lim = chunks.empty() ? chunk_first : chunk;
+        size_t lim = chunk_first;
+        for (size_t k = 0; k < chunks.size() && lim < chunk; ++k) lim = std::min(chunk, lim * growth);
         uint64_t b1 = b0, ubytes = 0;
         while (b1 < bz.n_blocks && (b1 == b0 || bz.coff[b1] + bz.csize[b1] - bz.coff[b0] <= lim)) { ubytes += bz.isize[b1]; ++b1; }
         chunks.push_back(Chunk{b0, b1, bz.coff[b0], bz.coff[b1 - 1] + bz.csize[b1 - 1] + 8 - bz.coff[b0], ubytes});   // incl. the last block's CRC32 + ISIZE trailer
