@@ -29,6 +29,7 @@
 #ifndef METHEOR_HIP_H
 #define METHEOR_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -124,6 +125,11 @@ int  mth_pdr_count(mth_ctx_t *ctx, uint64_t *n_sites);
  * submitted in that order; any pointer may be NULL; buffers hold >= mth_pdr_count entries */
 int  mth_pdr_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *pos, float *pdr,
                    uint32_t *n_concordant, uint32_t *n_discordant);
+/* page-locked host memory for the *_fetch destinations: device-to-host copies into it run at the link's rate (pageable
+ * destinations work too, through the runtime's bounce buffers -- ~4x slower on a 700 k-row table).  Freed by
+ * mth_result_buffer_free or with the context's process. */
+int  mth_result_buffer_alloc(mth_ctx_t *ctx, size_t bytes, void **out);
+int  mth_result_buffer_free(mth_ctx_t *ctx, void *p);
 /* device pointers of the same columns (valid until the next accumulate/reset) */
 int  mth_pdr_device_view(mth_ctx_t *ctx, uint64_t *n_sites, const int32_t **pos,
                          const float **pdr, const uint32_t **n_concordant,

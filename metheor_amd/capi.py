@@ -13,7 +13,7 @@ MTH_MEM_HOST, MTH_MEM_DEVICE = 0, 1
 SYMBOLS = [
     "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
-    "mth_pdr_fetch", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
+    "mth_pdr_fetch", "mth_result_buffer_alloc", "mth_result_buffer_free", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
     "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
     "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_bgzf_stage", "mth_decode_reserve", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
@@ -104,6 +104,8 @@ def lib():
         L.mth_pdr_lpmd_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_pdr_lpmd_params_t)]
         L.mth_pdr_count.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.mth_pdr_fetch.argtypes = [vp] * 6
+        L.mth_result_buffer_alloc.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.mth_result_buffer_free.argtypes = [vp, vp]
         L.mth_pdr_device_view.argtypes = [vp, C.POINTER(C.c_uint64)] + [C.POINTER(vp)] * 4
         L.mth_lpmd_global.argtypes = [vp, C.POINTER(C.c_int64 * 4), C.POINTER(C.c_float)]
         L.mth_lpmd_from_counts.restype = C.c_float

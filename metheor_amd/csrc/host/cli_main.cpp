@@ -610,6 +610,8 @@ void write_rows(FILE *f, uint64_t n, Row &&row) {
         for (uint64_t i = r0; i < r1; ++i) row(parts[(size_t)t], i);
     };
     if (nt == 1) { work(0); parts[0].flush(); return; }
+    // (every thread writing its own part with pwrite at its offset was measured SLOWER than this ordered append on tmpfs:
+    // 22 against 15 ms for the 25-MB PDR table, profiles/r02_e2e.md)
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
     for (auto &x : th) x.join();
@@ -668,10 +670,13 @@ int run_pdr(const Args &a) {
     }
     {
         Phase ph3("fetch + TSV write");
-        std::vector<int32_t> tid(n), pos(n);
-        std::vector<float> pdr(n);
-        std::vector<uint32_t> nc(n), nd(n);
-        { Phase pf("  fetch"); check(ctx, mth_pdr_fetch(ctx, tid.data(), pos.data(), pdr.data(), nc.data(), nd.data())); }
+        // the five columns in one page-locked allocation (device-to-host at the link's rate; nothing to zero-fill)
+        void *pin = nullptr;
+        check(ctx, mth_result_buffer_alloc(ctx, (size_t)n * 20, &pin));
+        int32_t *tid = (int32_t *)pin, *pos = tid + n;
+        float *pdr = (float *)(pos + n);
+        uint32_t *nc = (uint32_t *)(pdr + n), *nd = nc + n;
+        { Phase pf("  fetch"); check(ctx, mth_pdr_fetch(ctx, tid, pos, pdr, nc, nd)); }
         Phase pw("  format + write");
         FILE *f = open_output(a.s.at("output"));
         write_rows(f, n, [&](LineWriter &w, uint64_t i) {   // pdr.rs:102-116
@@ -679,6 +684,7 @@ int run_pdr(const Args &a) {
             w.f32(pdr[i]); w.ch('\t'); w.u32(nc[i]); w.ch('\t'); w.u32(nd[i]); w.eol();
         });
         if (fclose(f) != 0) die("Error writing to output file.");
+        if (getenv("METHEOR_TEARDOWN")) check(ctx, mth_result_buffer_free(ctx, pin));   // (unpinning is a few ms: left to the process's end otherwise)
     }
     return finish(ctx, in.h);
 }
@@ -934,6 +940,10 @@ int main(int argc, char **argv) {
         usage_error(nullptr, "unrecognized subcommand '" + sub + "'");
     }
     const Args a = parse_args(*cmd, argc, argv, 2);
+    // HIP runtime setting for a process that keeps one or two streams busy per device (read by the runtime at its first call; a value
+    // from the caller's environment wins): one hardware queue per device shortens the load phase by ~25 ms on the 10 M-read file
+    // (profiles/r02_e2e.md, "Runtime settings"; HIP_FORCE_DEV_KERNARG, HSA_ENABLE_INTERRUPT=0, HSA_ENABLE_SDMA=0 and others: no gain)
+    setenv("GPU_MAX_HW_QUEUES", "1", 0);
     auto run = [&]() -> int {
         if (sub == "pdr") return run_pdr(a);
         if (sub == "lpmd") return run_lpmd(a);

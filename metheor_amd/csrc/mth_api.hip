@@ -330,10 +330,13 @@ int mth_pdr_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *pos, float *pdr, uint32
     if (rc) return rc;
     const uint64_t n = ctx->h_state->n_sites;
     if (n == 0) return MTH_OK;
-    if (pos) MTH_HIP(ctx, hipMemcpy(pos, ctx->out_pos.p, n * 4, hipMemcpyDeviceToHost));
-    if (pdr) MTH_HIP(ctx, hipMemcpy(pdr, ctx->out_pdr.p, n * 4, hipMemcpyDeviceToHost));
-    if (nc) MTH_HIP(ctx, hipMemcpy(nc, ctx->out_nc.p, n * 4, hipMemcpyDeviceToHost));
-    if (nd) MTH_HIP(ctx, hipMemcpy(nd, ctx->out_nd.p, n * 4, hipMemcpyDeviceToHost));
+    // four copies in flight, one wait (into mth_result_buffer_alloc memory they run at the link's rate; pageable destinations
+    // go through the runtime's bounce buffers as before)
+    if (pos) MTH_HIP(ctx, hipMemcpyAsync(pos, ctx->out_pos.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (pdr) MTH_HIP(ctx, hipMemcpyAsync(pdr, ctx->out_pdr.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (nc) MTH_HIP(ctx, hipMemcpyAsync(nc, ctx->out_nc.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (nd) MTH_HIP(ctx, hipMemcpyAsync(nd, ctx->out_nd.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (tid) {
         std::vector<uint32_t> cnt(ctx->batches.size());
         if (!cnt.empty()) MTH_HIP(ctx, hipMemcpy(cnt.data(), ctx->batch_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
@@ -342,6 +345,21 @@ int mth_pdr_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *pos, float *pdr, uint32
             for (uint32_t j = 0; j < cnt[b] && o < n; ++j) tid[o++] = ctx->batches[b].tid;
         if (o != n) return fail(ctx, MTH_ERR_STATE, "per-batch row counts do not add up to the row count");
     }
+    return MTH_OK;
+}
+
+int mth_result_buffer_alloc(mth_ctx_t *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return MTH_ERR_INVALID;
+    *out = nullptr;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    const hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(ctx, MTH_ERR_HIP, "hipHostMalloc (result buffer)", e); }
+    return MTH_OK;
+}
+
+int mth_result_buffer_free(mth_ctx_t *ctx, void *p) {
+    if (!ctx) return MTH_ERR_INVALID;
+    if (p) MTH_HIP(ctx, hipHostFree(p));
     return MTH_OK;
 }
 

@@ -515,6 +515,8 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
     MTH_HIP(ctx, ctx->inf_tab.reserve(nb * 24 + 64, s));
     MTH_HIP(ctx, ctx->inf_raw.reserve((size_t)total + 64, s));
     if (!staged) {
+        // (copying through own page-locked pieces from 2-8 worker threads was measured: no faster than the runtime's pageable path,
+        // profiles/r02_e2e.md -- the page-cache reads bound both)
         if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->inf_file.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, s));
         MTH_HIP(ctx, hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file.p) + n_bytes, 0, 64, s));
     }

@@ -12,6 +12,8 @@ exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 wall = [[] for _ in arms]
 load = [[] for _ in arms]
 ctxt = [[] for _ in arms]
+fetch = [[] for _ in arms]
+fmtw = [[] for _ in arms]
 try:
     for rep in range(reps + 1):
         for k, arm in enumerate(arms):
@@ -26,10 +28,14 @@ try:
             load[k].append(float(m.group(1)) if m else float("nan"))
             m = re.search(r"device context \(overlapped\)\s+([0-9.]+) s", r.stderr)
             ctxt[k].append(float(m.group(1)) if m else float("nan"))
+            m = re.search(r"fetch \+ TSV write\s+([0-9.]+) s", r.stderr)
+            fetch[k].append(float(m.group(1)) if m else float("nan"))
+            m = re.search(r"  format \+ write\s+([0-9.]+) s", r.stderr)
+            fmtw[k].append(float(m.group(1)) if m else float("nan"))
     for k, arm in enumerate(arms):
         w, l, x = sorted(wall[k]), sorted(load[k]), sorted(ctxt[k])
         q = lambda v, f: v[int(f * (len(v) - 1))]
-        print("%-44s wall min %.3f q25 %.3f med %.3f | load min %.3f q25 %.3f med %.3f | ctx min %.3f med %.3f | best %.1f M reads/s" %
-              (arm or "default", w[0], q(w, .25), q(w, .5), l[0], q(l, .25), q(l, .5), x[0], q(x, .5), 10 / w[0]), flush=True)
+        print("%-44s wall min %.3f q25 %.3f med %.3f | load min %.3f q25 %.3f med %.3f | ctx min %.3f med %.3f | fetch+write med %.3f (write %.3f) | best %.1f M reads/s" %
+              (arm or "default", w[0], q(w, .25), q(w, .5), l[0], q(l, .25), q(l, .5), x[0], q(x, .5), q(sorted(fetch[k]), .5), q(sorted(fmtw[k]), .5), 10 / w[0]), flush=True)
 finally:
     os.remove(bam)
