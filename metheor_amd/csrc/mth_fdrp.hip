@@ -58,9 +58,11 @@ struct FdrpArgs {
     unsigned long long seed;
     int32_t idx_base, max_span, tid, min_overlap;
     int32_t region_beg, region_end;   // sites are discovered for [region_beg, region_end) only
-    uint32_t n_reads, min_depth, max_depth;
+    uint32_t n_reads, n_cpgs, min_depth, max_depth;
     uint8_t min_qual;
     uint32_t *rows_scratch;           // SLOTS = 0: slots_cap rows of (4 + FD_NB) words per wave of the launch
+    int32_t ablate;                   // TEMPORARY measurement switch
+    const uint16_t *pair_tab;         // SLOTS = 64: (i | j << 8) of the k-th pair of n reads at [n (n-1) (n-2) / 6 + k], n <= 64
     uint32_t slots_cap;
 };
 
@@ -84,7 +86,7 @@ __device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_r
 __device__ __forceinline__ int32_t sgpr(int32_t x) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)x); }
 
 template <int FD_NB, int SLOTS>
-__global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
+__global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fdrp_walk(const FdrpArgs a) {
     const int FD_SLOTS = SLOTS ? SLOTS : (int)a.slots_cap;
     const int lane = threadIdx.x & 63;
     const uint32_t wave_id = sgpr((uint32_t)((blockIdx.x * 256 + threadIdx.x) >> 6)), n_waves = (gridDim.x * 256) >> 6;
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
     uint32_t *const rows = SLOTS ? s_rows[threadIdx.x >> 6] : a.rows_scratch + (size_t)wave_id * a.slots_cap * ROW;
     for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
         const int32_t c = sgpr(a.site_pos[j]);
-        // the 64-site window of the compact finalize depends on j alone: requested here, a full walk before it is used (it
-        // used to be the fifth dependent round trip of a site; on sparse WGBS a site is ~6 us of such round trips)
+        // the 64-site window of the compact finalize depends on j alone: requested here, a full walk before it is used.
+        // (Requesting the position two sites ahead and the index entries + window one site ahead changes nothing, measured
+        // twice: 1.4856 vs 1.4861 ms -- a site's time is instruction issue, not this chain's latency.)
         const uint32_t j0w = (j >= 32u) ? min(j - 32u, n_sites > 64u ? n_sites - 64u : 0u) : 0u;
         const int32_t spw = (j0w + (uint32_t)lane < n_sites) ? a.site_pos[j0w + lane] : 0x7fffffff;
         const uint32_t lo = sgpr(min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads));
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
 
         auto finalize = [&]() {   // compute_fdrp / compute_qfdrp over slots 0..sampled-1
             const int nS = sampled;
+            if (a.ablate == 1) { have = true; res_n = (uint32_t)nS; return; }
             uint32_t disc = 0;     // per lane j: discordant pairs (i, j)
             float q = 0.0f;
             // lane = slot: the slot's row; calls are packed words (position | state << 31), FD_NOPOS = none
@@ -151,20 +155,25 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    auto add_call = [&](const uint32_t w, const bool valid) {
-                        const uint32_t p = w & 0x7fffffffu;
-                        const uint32_t rel_p = valid ? (uint32_t)((int32_t)p - (c - FD_WIN)) : 0u;
-                        const unsigned long long b = valid ? (1ull << bit_of[rel_p]) : 0ull;
-                        const bool cov = (int32_t)p >= r_s;                    // a call lies in [start-1, end]
+                    // mC: the positions the read calls; mM: those it calls methylated.  A read calls positions in
+                    // [start - 1, end] only, so the one call that can lie outside the covered bases is its first, at start - 1
+                    // (mA below).  Registers past the last call repeat it (see the walk): the same bit again.
+                    auto add_call = [&](const uint32_t w) {
+                        const uint32_t rel_p = (w & 0x7fffffffu) - (uint32_t)(c - FD_WIN);
+                        const unsigned long long b = 1ull << bit_of[rel_p];
                         mC |= b;
-                        mA |= cov ? b : 0ull;
-                        mM |= (cov && (w >> 31)) ? b : 0ull;
+                        mM |= b & (unsigned long long)((long long)(int32_t)w >> 31);
                     };
-                    const bool live = lane < nS;
+                    if (lane < nS) {
 #pragma unroll
-                    for (int k = 0; k < FD_NB; ++k) add_call(vw[k], live && vw[k] != FD_NOPOS);
-                    if (any_long && live)
-                        for (uint32_t t = FD_NB; t < r_n; ++t) add_call(a.cpg_pos[r_o0 + t], true);
+                        for (int k = 0; k < FD_NB; ++k) add_call(vw[k]);
+                        if (any_long)
+                            for (uint32_t t = FD_NB; t < r_n; ++t) add_call(a.cpg_pos[r_o0 + t]);
+                        const uint32_t p0 = vw[0] & 0x7fffffffu;
+                        const unsigned long long b0 = 1ull << bit_of[p0 - (uint32_t)(c - FD_WIN)];
+                        mA = ((int32_t)p0 >= r_s) ? mC : mC & ~b0;
+                        mM &= mA;
+                    }
                 }
             }
 #define MTH_FD_DPP x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)) + term;
@@ -183,19 +192,15 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int P = (nS * (nS - 1)) >> 1;
-                const int twoN = 2 * nS;
-                const float bq = (float)(twoN - 1);
+                const int P = a.ablate == 2 ? 0 : (nS * (nS - 1)) >> 1;
+                // k -> (i, j) from a table (the closed form -- a square root, three 32-bit multiplies, two corrections -- was more
+                // than half of a round's vector instructions); the next round's entry is requested a round ahead
+                const uint16_t *const tab = a.pair_tab + (uint32_t)(nS * (nS - 1) * (nS - 2)) / 6u;
+                uint32_t ent_next = tab[min(lane, P - 1)];
                 for (int k0 = 0; k0 < P; k0 += 64) {
-                    const int k = min(k0 + lane, P - 1);
-                    // row i of the strict upper triangle starts at off(i) = i * (2 nS - i - 1) / 2
-                    int pi = (int)((bq - __builtin_sqrtf(bq * bq - 8.0f * (float)k)) * 0.5f);
-                    pi = max(0, min(pi, nS - 2));
-                    int off = (pi * (twoN - pi - 1)) >> 1;
-                    if (k < off) { pi -= 1; off = (pi * (twoN - pi - 1)) >> 1; }
-                    const int off1 = ((pi + 1) * (twoN - pi - 2)) >> 1;
-                    if (k >= off1) { pi += 1; off = off1; }
-                    const int pj = k - off + pi + 1;
+                    const uint32_t ent = ent_next;
+                    if (k0 + 64 < P) ent_next = tab[min(k0 + 64 + lane, P - 1)];
+                    const int pi = (int)(ent & 0xffu), pj = (int)(ent >> 8);
                     const uint32_t *ri = rows + pi * ROW, *rj = rows + pj * ROW;
                     const int32_t si = (int32_t)ri[0], ei = (int32_t)ri[1], sj = (int32_t)rj[0], ej = (int32_t)rj[1];
                     const int32_t ov = min(ei, ej) - max(si, sj) + 1;        // get_num_overlap_bases, fdrp.rs:97-107
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
                     // VALU per term and was ~30 % of a VALU-bound kernel; most pairs of a site agree and contribute +0.0.)
                     const unsigned long long nz = __ballot(term0 != 0.0f);
                     const int m_nz = __popcll(nz);
-                    if (m_nz == 0) continue;                                 // wave-uniform
+                    if (m_nz == 0 || a.ablate == 3) continue;                                 // wave-uniform
                     if (term0 != 0.0f) s_term[__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u))] = term0;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -383,18 +388,47 @@ __global__ __launch_bounds__(256) void k_fdrp_walk(const FdrpArgs a) {
             const uint32_t i = base + (uint32_t)lane;
             const bool valid = i < hi;
             const uint32_t ii = valid ? i : lo;                              // (lo < hi here) every lane loads: no dependent round trip
-            const uint32_t o0 = valid ? a.cpg_off[ii] : 0u, o1 = valid ? a.cpg_off[ii + 1] : 0u;
+            // (all five loads unconditional and issued together: written as `valid ? load : 0` each became its own exec-masked
+            // block with a wait inside, three round trips per chunk instead of two)
+            const uint32_t o0 = a.cpg_off[ii], o1 = a.cpg_off[ii + 1];
             const int32_t cs_raw = a.read_start[ii], ce_raw = a.read_end[ii];
+            const uint32_t mq = a.read_mapq[ii];
             const uint32_t n = o1 - o0;
-            const bool pass = valid && a.read_mapq[ii] >= a.min_qual && n > 0;   // fdrp.rs:205, 208
+            const bool pass = valid & (mq >= (uint32_t)a.min_qual) & (n > 0u);   // fdrp.rs:205, 208
             const int32_t cs = pass ? cs_raw : 0, ce = pass ? ce_raw : 0;
             uint32_t cw[FD_NB];
             bool hit = false;                                                // does the candidate call c ?
+            // The first FD_NB calls of a candidate, four per load (a read's calls are consecutive words; the quads past its
+            // fourth call are fetched only when some candidate of the chunk has that many).  Registers past the read's last call
+            // repeat its first call: a repeated call changes nothing below (same position, same state -- the same bit in the
+            // compact masks, the same key in the min-chain).  Lanes without a candidate load valid words that `pass` discards.
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
-            for (int k = 0; k < FD_NB; ++k) {
-                cw[k] = (pass && (uint32_t)k < n) ? a.cpg_pos[o0 + k] : FD_NOPOS;
-                hit = hit || (cw[k] & 0x7fffffffu) == (uint32_t)c;
+            for (int q = 0; q < FD_NB / 4; ++q) {
+                const bool want = q == 0 || __any(pass && n > (uint32_t)(4 * q));      // wave-uniform
+                if (want) {
+                    // (the address is clamped so that the quad lies inside the array; the few candidates at the batch's end whose
+                    // quad would cross it are re-read word by word afterwards -- as an if / else the two arms shared registers and
+                    // the compiler waited for the quad right behind its load)
+                    const uint32_t oq = o0 + (uint32_t)(4 * q);
+                    const uint32_t oq_safe = a.n_cpgs >= 4u ? min(oq, a.n_cpgs - 4u) : 0u;
+                    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + oq_safe);
+                    cw[4 * q] = v.x; cw[4 * q + 1] = v.y; cw[4 * q + 2] = v.z; cw[4 * q + 3] = v.w;
+                    if (__builtin_expect(__any(oq != oq_safe || a.n_cpgs < 4u), 0)) {
+                        if (oq != oq_safe || a.n_cpgs < 4u) {
+#pragma unroll
+                            for (int k = 4 * q; k < 4 * q + 4; ++k) cw[k] = (o0 + (uint32_t)k < a.n_cpgs) ? a.cpg_pos[o0 + k] : 0u;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 4 * q; k < 4 * q + 4; ++k) cw[k] = 0u;
+                }
             }
+#pragma unroll
+            for (int k = 1; k < FD_NB; ++k) cw[k] = ((uint32_t)k < n) ? cw[k] : cw[0];
+#pragma unroll
+            for (int k = 0; k < FD_NB; ++k) hit = hit || (cw[k] & 0x7fffffffu) == (uint32_t)c;
             if (pass && n > (uint32_t)FD_NB)
                 for (uint32_t k = FD_NB; k < n; ++k) hit = hit || (a.cpg_pos[o0 + k] & 0x7fffffffu) == (uint32_t)c;
             const unsigned long long m_hit = __ballot(pass && hit);
@@ -549,10 +583,24 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     a.fdrp = ctx->w_val.as<float>(); a.qfdrp = reinterpret_cast<float *>(ctx->w_aux.p); a.nreads = ctx->w_cov.as<uint32_t>();
     a.flags = ctx->w_flags.as<uint32_t>();
     a.seed = params->seed; a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.tid = d.tid;
-    a.min_overlap = params->min_overlap; a.n_reads = d.n_reads; a.region_beg = d.region_beg; a.region_end = d.region_end;
+    a.min_overlap = params->min_overlap; a.n_reads = d.n_reads; a.n_cpgs = d.n_cpgs; a.region_beg = d.region_beg; a.region_end = d.region_end;
     a.min_depth = (uint32_t)std::min<uint64_t>(params->min_depth, 0xffffffffull); a.max_depth = params->max_depth;
     a.min_qual = params->min_qual;
     a.rows_scratch = nullptr; a.slots_cap = 0;
+    if (!ctx->f_pairtab.p) {
+        // the pairs of n stored reads in the reference's (i, j) loop order (fdrp.rs:129-141), n = 2..64, one after the other
+        std::vector<uint16_t> t;
+        t.reserve(43680 + 64);
+        for (int n = 0; n <= 64; ++n)
+            for (int i = 0; i + 1 < n; ++i)
+                for (int j = i + 1; j < n; ++j) t.push_back((uint16_t)(i | (j << 8)));
+        t.resize(t.size() + 64, 0);
+        MTH_HIP(ctx, ctx->f_pairtab.reserve(t.size() * 2, s));
+        MTH_HIP(ctx, hipMemcpyAsync(ctx->f_pairtab.p, t.data(), t.size() * 2, hipMemcpyHostToDevice, s));
+        MTH_HIP(ctx, hipStreamSynchronize(s));            // t is a local
+    }
+    a.pair_tab = ctx->f_pairtab.as<uint16_t>();
+    { const char *e = getenv("METHEOR_FDRP_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     if (params->max_depth > FD_DEPTH_MAX) return fail(ctx, MTH_ERR_CAPACITY, "FDRP / qFDRP max_depth above 16384 (the pair index of one site is 32-bit arithmetic)");
     const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 3) / 4, 16384);   // 4 waves (sites) per block
     {
