@@ -61,7 +61,6 @@ struct FdrpArgs {
     uint32_t n_reads, n_cpgs, min_depth, max_depth;
     uint8_t min_qual;
     uint32_t *rows_scratch;           // SLOTS = 0: slots_cap rows of (4 + FD_NB) words per wave of the launch
-    int32_t ablate;                   // TEMPORARY measurement switch
     const uint16_t *pair_tab;         // SLOTS = 64: (i | j << 8) of the k-th pair of n reads at [n (n-1) (n-2) / 6 + k], n <= 64
     uint32_t slots_cap;
 };
@@ -100,6 +99,13 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
     constexpr int ROW = 4 + FD_NB;
     __shared__ __attribute__((aligned(16))) uint32_t s_rows[4][(SLOTS ? SLOTS : 1) * ROW];
     uint32_t *const rows = SLOTS ? s_rows[threadIdx.x >> 6] : a.rows_scratch + (size_t)wave_id * a.slots_cap * ROW;
+    // ham / ncpg for ncpg <= 16, computed here by the same f32 division the pair loop would do (17 instructions per round otherwise)
+    constexpr int FD_QN = 17;
+    __shared__ float s_quot[SLOTS == 64 ? FD_QN * FD_QN : 1];
+    if (SLOTS == 64) {
+        for (int t = threadIdx.x; t < FD_QN * FD_QN; t += 256) s_quot[t] = (float)(t / FD_QN) / (float)(t % FD_QN);
+        __syncthreads();
+    }
     for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
         const int32_t c = sgpr(a.site_pos[j]);
         // the 64-site window of the compact finalize depends on j alone: requested here, a full walk before it is used.
@@ -120,7 +126,6 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
 
         auto finalize = [&]() {   // compute_fdrp / compute_qfdrp over slots 0..sampled-1
             const int nS = sampled;
-            if (a.ablate == 1) { have = true; res_n = (uint32_t)nS; return; }
             uint32_t disc = 0;     // per lane j: discordant pairs (i, j)
             float q = 0.0f;
             // lane = slot: the slot's row; calls are packed words (position | state << 31), FD_NOPOS = none
@@ -192,7 +197,8 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int P = a.ablate == 2 ? 0 : (nS * (nS - 1)) >> 1;
+                const int P = (nS * (nS - 1)) >> 1;
+                const bool lut_ok = !__any(lane < nS && r_n >= (uint32_t)FD_QN);   // wave-uniform: every ncpg of the site is in the table
                 // k -> (i, j) from a table (the closed form -- a square root, three 32-bit multiplies, two corrections -- was more
                 // than half of a round's vector instructions); the next round's entry is requested a round ahead
                 const uint16_t *const tab = a.pair_tab + (uint32_t)(nS * (nS - 1) * (nS - 2)) / 6u;
@@ -209,13 +215,14 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
                     const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) +
                                          __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));                      // fdrp.rs:114-115
                     disc += (pair_ok && ham != 0u) ? 1u : 0u;                // fdrp.rs:138-140
-                    const float term0 = pair_ok ? (float)ham / (float)ncpg : 0.0f;  // qfdrp.rs:152; +0.0 for skipped pairs
+                    const float quot = lut_ok ? s_quot[ham * FD_QN + ncpg] : (float)ham / (float)ncpg;
+                    const float term0 = pair_ok ? quot : 0.0f;               // qfdrp.rs:152; +0.0 for skipped pairs
                     // x + 0.0 == x, so only the non-zero terms (NaN included: 0 / 0 when two reads share no CpG) have to be
                     // chained, in their order: they are packed into the low lanes through LDS first.  (The chain is one dependent
                     // VALU per term and was ~30 % of a VALU-bound kernel; most pairs of a site agree and contribute +0.0.)
                     const unsigned long long nz = __ballot(term0 != 0.0f);
                     const int m_nz = __popcll(nz);
-                    if (m_nz == 0 || a.ablate == 3) continue;                                 // wave-uniform
+                    if (m_nz == 0) continue;                                 // wave-uniform
                     if (term0 != 0.0f) s_term[__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u))] = term0;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -427,8 +434,12 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
             }
 #pragma unroll
             for (int k = 1; k < FD_NB; ++k) cw[k] = ((uint32_t)k < n) ? cw[k] : cw[0];
+            {   // "some register holds position c" as an integer min-chain (a chain of compares becomes scalar and-masks per call)
+                uint32_t mn = 0xffffffffu;
 #pragma unroll
-            for (int k = 0; k < FD_NB; ++k) hit = hit || (cw[k] & 0x7fffffffu) == (uint32_t)c;
+                for (int k = 0; k < FD_NB; ++k) mn = min(mn, (cw[k] ^ (uint32_t)c) & 0x7fffffffu);
+                hit = mn == 0u;
+            }
             if (pass && n > (uint32_t)FD_NB)
                 for (uint32_t k = FD_NB; k < n; ++k) hit = hit || (a.cpg_pos[o0 + k] & 0x7fffffffu) == (uint32_t)c;
             const unsigned long long m_hit = __ballot(pass && hit);
@@ -456,13 +467,9 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
                     total += n_hit; sampled += n_hit;
                     deep = deep || total > FD_SLOTS;                          // only reachable with max_depth > 64
                 }
-                if (m_flush) {                                                // fdrp.rs:212-223
-                    if (entry) {
-                        if ((uint32_t)sampled >= a.min_depth && !deep) MTH_FD_FINISH();
-                        entry = false; total = 0; sampled = 0;
-                    }
-                    break;   // reads are sorted by start: none from here on can call c, and further flushes find no entry
-                }
+                // fdrp.rs:212-223.  Reads are sorted by start: none from here on can call c, and further flushes find no entry --
+                // the flush is the one after the loop (same condition; one inlined copy of finalize less)
+                if (m_flush) break;
                 continue;
             }
             unsigned long long ev = m_hit | m_flush;                          // a read calling c has first <= c: never both
@@ -600,7 +607,6 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         MTH_HIP(ctx, hipStreamSynchronize(s));            // t is a local
     }
     a.pair_tab = ctx->f_pairtab.as<uint16_t>();
-    { const char *e = getenv("METHEOR_FDRP_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     if (params->max_depth > FD_DEPTH_MAX) return fail(ctx, MTH_ERR_CAPACITY, "FDRP / qFDRP max_depth above 16384 (the pair index of one site is 32-bit arithmetic)");
     const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 3) / 4, 16384);   // 4 waves (sites) per block
     {
