@@ -11,7 +11,7 @@ namespace mth {
 // A tile is TILE_W consecutive reference positions of one contig; one workgroup owns the sites
 // of one tile and keeps their accumulators in LDS.  The read index has one entry per IDX_Q bp.
 // (the tile width is a template parameter of the tile kernel: 1024 / 2048 / 4096)
-constexpr int IDX_QSHIFT = 8;
+constexpr int IDX_QSHIFT = 5;   // 32-bp quanta (256 until round 2: up to 362 bp of useless candidates per tile / site)
 constexpr int IDX_Q = 1 << IDX_QSHIFT;
 constexpr int BLOCK = 256;
 

@@ -160,7 +160,8 @@ int decode_core(mth_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_off, uint6
 int launch_pdr_exact(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p);
 // site discovery (tile pipeline into the private sink): positions called by >= 1 read with
 // mapq >= min_qual and n_cpgs >= max(min_cpgs,1); bound = host-known upper bound of the site count
-int discover_sites(mth_ctx *ctx, const mth_batch_t &dev_batch, uint32_t min_cpgs, uint8_t min_qual, uint64_t &bound);
+int discover_sites(mth_ctx *ctx, const mth_batch_t &dev_batch, uint32_t min_cpgs, uint8_t min_qual, uint64_t &bound,
+                   uint32_t min_cov = 0);
 
 // implemented in mth_pdr_lpmd.hip.  sink == nullptr: rows go to the ctx's PDR result columns.
 struct TileSink {

@@ -52,6 +52,7 @@ struct FdrpArgs {
     const uint32_t *idx;
     const DevState *sites_st;
     const int32_t  *site_pos;
+    const uint32_t *site_nc, *site_nd;   // discovery's per-site read counts (reads passing mapq that call the site)
     DevState *st;
     float    *fdrp, *qfdrp;     // per candidate site
     uint32_t *nreads, *flags;
@@ -106,7 +107,22 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
         for (int t = threadIdx.x; t < FD_QN * FD_QN; t += 256) s_quot[t] = (float)(t / FD_QN) / (float)(t % FD_QN);
         __syncthreads();
     }
+    // A site's segments hold at most the reads that call it and pass mapq -- the count the discovery pass left beside the
+    // position -- so a site whose count is below min_depth cannot produce a row (fdrp.rs:239-243) and is not walked: at
+    // WGBS depths (config 3: 9.7x against -d 10) that is more than half of the sites.  The count of the wave's NEXT site is
+    // requested one site ahead, so a run of skipped sites is not a run of exposed round trips.
+    uint32_t cov_j = 0;
+    if (SLOTS == 64 && wave_id < n_sites) cov_j = a.site_nc[wave_id] + a.site_nd[wave_id];
     for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
+        if (SLOTS == 64) {
+            const uint32_t cov = sgpr(cov_j);
+            const uint32_t jn = j + n_waves;
+            if (jn < n_sites) cov_j = a.site_nc[jn] + a.site_nd[jn];
+            if (cov < a.min_depth) {
+                if (lane == 0) { a.fdrp[j] = 0.0f; a.qfdrp[j] = 0.0f; a.nreads[j] = 0u; a.flags[j] = 0u; }
+                continue;
+            }
+        }
         const int32_t c = sgpr(a.site_pos[j]);
         // the 64-site window of the compact finalize depends on j alone: requested here, a full walk before it is used.
         // (Requesting the position two sites ahead and the index entries + window one site ahead changes nothing, measured
@@ -587,6 +603,7 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     FdrpArgs a;
     a.read_start = d.read_start; a.read_end = d.read_end; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
     a.idx = ctx->idx.as<uint32_t>(); a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>(); a.st = ctx->d_state;
+    a.site_nc = ctx->s_nc.as<uint32_t>(); a.site_nd = ctx->s_nd.as<uint32_t>();
     a.fdrp = ctx->w_val.as<float>(); a.qfdrp = reinterpret_cast<float *>(ctx->w_aux.p); a.nreads = ctx->w_cov.as<uint32_t>();
     a.flags = ctx->w_flags.as<uint32_t>();
     a.seed = params->seed; a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.tid = d.tid;

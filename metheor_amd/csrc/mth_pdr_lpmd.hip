@@ -51,6 +51,7 @@ struct TileArgs {
 // idx[q] = first read i with read_start[i] >= idx_base + q*IDX_Q   (q = 0..nq)
 // One thread handles 4 consecutive reads (one 16-byte load + the element before them); the thread
 // whose group contains index n_reads also plays the sentinel that closes the index.
+constexpr int IDX_GROUPS = 1;   // groups of 4 reads per thread; 4 (all loads hoisted) measured slower: 0.0177 against 0.0157 ms on config 2
 __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict__ read_start,
                                                        uint32_t n_reads, int32_t idx_base,
                                                        uint32_t nq, int aligned16,
@@ -80,41 +81,70 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
         for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 64));
         if (gtid == 0) st->safe_hi = best;
     }
-    const uint32_t i0 = gtid * 4u;
-    if (i0 > n_reads) return;
-    auto bucket = [&](int32_t s) -> int64_t {  // floor((s-base)/Q), -1 below the base
+    auto bucket = [&](int32_t s) -> int32_t {  // min(floor((s-base)/Q), nq), -1 below the base
         const int64_t d = (int64_t)s - idx_base;
-        return d < 0 ? -1 : (d >> IDX_QSHIFT);
+        return d < 0 ? -1 : (int32_t)min(d >> IDX_QSHIFT, (int64_t)nq);
     };
-    int32_t sv[4];
-    if (aligned16 && i0 + 4 <= n_reads) {
-        const int4 x = *reinterpret_cast<const int4 *>(read_start + i0);
-        sv[0] = x.x; sv[1] = x.y; sv[2] = x.z; sv[3] = x.w;
-    } else {
+    // IDX_GROUPS groups of 4 reads per thread, BLOCK groups apart (coalesced); all their loads are requested before the
+    // first is used
+    int32_t sv[IDX_GROUPS][4], sp[IDX_GROUPS];
+    uint32_t gi[IDX_GROUPS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sv[k] = (i0 + k < n_reads) ? read_start[i0 + k] : 0;
+    for (int u = 0; u < IDX_GROUPS; ++u) {
+        const uint32_t i0 = ((blockIdx.x * IDX_GROUPS + u) * BLOCK + threadIdx.x) * 4u;
+        gi[u] = i0;
+        sp[u] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sv[u][k] = 0;
+        if (i0 > n_reads) continue;
+        if (aligned16 && i0 + 4 <= n_reads) {
+            const int4 x = *reinterpret_cast<const int4 *>(read_start + i0);
+            sv[u][0] = x.x; sv[u][1] = x.y; sv[u][2] = x.z; sv[u][3] = x.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[u][k] = (i0 + k < n_reads) ? read_start[i0 + k] : 0;
+        }
+        if (i0 > 0) sp[u] = read_start[i0 - 1];
     }
-    int64_t g_prev = -1;
-    int32_t s_prev = 0;
-    bool have_prev = false;
-    if (i0 > 0) { s_prev = read_start[i0 - 1]; g_prev = bucket(s_prev); have_prev = true; }
+    // The quantum is 32 bp (it was 256: the candidates of a tile or a site then carried up to 362 bp of reads that cannot
+    // touch it, 8 % of a 4096-bp tile's loop iterations), so a read usually opens an entry or two; a stretch without reads
+    // (assembly gaps: megabases) is filled by the whole wave, 64 entries per step, not by the one lane that found it.
+    const int lane = threadIdx.x & 63;
     uint32_t err = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t i = i0 + k;
-        if (i > n_reads) break;
-        int64_t g_cur;
-        if (i < n_reads) {
-            const int32_t s = sv[k];
-            g_cur = bucket(s);
-            if (have_prev && s < s_prev) err |= ERRB_UNSORTED;
-            s_prev = s; have_prev = true;
-        } else {
-            g_cur = nq;   // sentinel closes the index
+    for (int u = 0; u < IDX_GROUPS; ++u) {
+        const uint32_t i0 = gi[u];
+        const bool gact = i0 <= n_reads;
+        int32_t g_prev = -1, s_prev = 0;
+        bool have_prev = false;
+        if (gact && i0 > 0) { s_prev = sp[u]; g_prev = bucket(s_prev); have_prev = true; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + k;
+            const bool act = gact && i <= n_reads;
+            int32_t g_cur = g_prev;
+            if (act) {
+                if (i < n_reads) {
+                    const int32_t s = sv[u][k];
+                    g_cur = bucket(s);
+                    if (have_prev && s < s_prev) err |= ERRB_UNSORTED;
+                    s_prev = s; have_prev = true;
+                } else {
+                    g_cur = (int32_t)nq;   // sentinel closes the index
+                }
+            }
+            const bool big = act && g_cur - g_prev > 32;
+            if (act && !big) for (int32_t q = g_prev + 1; q <= g_cur; ++q) idx[q] = i;
+            unsigned long long m = __ballot(big);
+            while (m) {
+                const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                m &= m - 1;
+                const int32_t gp = __builtin_amdgcn_readlane(g_prev, l), gc = __builtin_amdgcn_readlane(g_cur, l);
+                const uint32_t ii = (uint32_t)__builtin_amdgcn_readlane((int)i, l);
+                for (int32_t q = gp + 1 + lane; q <= gc; q += 64) idx[q] = ii;
+            }
+            if (g_cur > g_prev) g_prev = g_cur;
         }
-        if (g_cur > (int64_t)nq) g_cur = nq;
-        for (int64_t q = g_prev + 1; q <= g_cur; ++q) idx[q] = i;
-        if (g_cur > g_prev) g_prev = g_cur;
     }
     if (err) atomicOr(&st->err, err);
 }
@@ -143,13 +173,29 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 constexpr int TILE_BUCKET_SHIFT = 8;   // 256 tiles per bucket
 // LPMD per-tile partials: wave DPP reduce -> LDS -> one atomic per counter into the tile's bucket (256 tiles share
 // an address; the per-read counts never touch global memory)
-template <int B>
+// A wave reduction is ~50 issue cycles (4 DPP adds, 4 readlanes) and a tile is only ~3 reads per lane: the four sums are taken
+// as two where their sizes allow it.  SMALL (tiles with <= 65535 candidate reads): a wave's read counts fit 16 bits, so n_read
+// and n_valid share a word; the pair counts share one when no lane of the wave has more than 1023 of either (the usual case:
+// 64 x 1023 < 2^16), decided by one ballot.
+template <int B, bool SMALL>
 __device__ __forceinline__ void tile_lpmd_partials(const TileArgs &a, const uint32_t t, uint32_t (*red)[B / 64],
                                                    uint32_t lp_c, uint32_t lp_d, uint32_t n_read, uint32_t n_valid) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t r0 = wave_sum(lp_c), r1 = wave_sum(lp_d), r2 = wave_sum(n_read), r3 = wave_sum(n_valid);
+    uint32_t r0, r1, r2, r3;
+    if (SMALL) {
+        const uint32_t rv = wave_sum(n_read | (n_valid << 16));
+        r2 = rv & 0xffffu; r3 = rv >> 16;
+        if (!__any((lp_c | lp_d) > 1023u)) {
+            const uint32_t cd = wave_sum(lp_c | (lp_d << 16));
+            r0 = cd & 0xffffu; r1 = cd >> 16;
+        } else { r0 = wave_sum(lp_c); r1 = wave_sum(lp_d); }
+    } else { r0 = wave_sum(lp_c); r1 = wave_sum(lp_d); r2 = wave_sum(n_read); r3 = wave_sum(n_valid); }
     if (lane == 0) { red[0][wave] = r0; red[1][wave] = r1; red[2][wave] = r2; red[3][wave] = r3; }
-    __syncthreads();
+}
+// second half, after the workgroup barrier that follows (the one the compaction needs anyway)
+template <int B>
+__device__ __forceinline__ void tile_lpmd_commit(const TileArgs &a, const uint32_t t, uint32_t (*red)[B / 64]) {
+    const int tid = threadIdx.x;
     if (tid < 4) {
         uint32_t s = 0;
         for (int w = 0; w < B / 64; ++w) s += red[tid][w];
@@ -170,21 +216,31 @@ __device__ __forceinline__ uint32_t tile_compact(const TileArgs &a, const uint32
     constexpr int PER = NPOS / B;
     static_assert(PER % 4 == 0 && PER <= 32, "uint4 LDS reads, 32-bit mask");
     uint32_t qual = 0;
+    if (WIDE) {
 #pragma unroll
-    for (int q = 0; q < PER / 4; ++q) {
-        const uint4 x = reinterpret_cast<const uint4 *>(cnt)[tid * (PER / 4) + q];
-        uint4 cov;
-        if (WIDE) {
+        for (int q = 0; q < PER / 4; ++q) {
+            const uint4 x = reinterpret_cast<const uint4 *>(cnt)[tid * (PER / 4) + q];
             const uint4 y = reinterpret_cast<const uint4 *>(cnt + W / 2)[tid * (PER / 4) + q];
-            cov = make_uint4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
-        } else {
-            cov = make_uint4((x.x & 0xffffu) + (x.x >> 16), (x.y & 0xffffu) + (x.y >> 16), (x.z & 0xffffu) + (x.z >> 16),
-                             (x.w & 0xffffu) + (x.w >> 16));
+            const uint4 cov = make_uint4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+            qual |= (cov.x >= a.min_cov ? 1u : 0u) << (4 * q);
+            qual |= (cov.y >= a.min_cov ? 1u : 0u) << (4 * q + 1);
+            qual |= (cov.z >= a.min_cov ? 1u : 0u) << (4 * q + 2);
+            qual |= (cov.w >= a.min_cov ? 1u : 0u) << (4 * q + 3);
         }
-        qual |= (cov.x >= a.min_cov ? 1u : 0u) << (4 * q);
-        qual |= (cov.y >= a.min_cov ? 1u : 0u) << (4 * q + 1);
-        qual |= (cov.z >= a.min_cov ? 1u : 0u) << (4 * q + 2);
-        qual |= (cov.w >= a.min_cov ? 1u : 0u) << (4 * q + 3);
+    } else {
+        // packed word = coverage | discordant << 16.  Per position: coverage - min_cov (the sign says "below"), shifted into the
+        // mask from the right by one funnel shift, last position first -- 3 instructions against the compare / select / or chain's
+        // 5 (half-rate, profiles/r02_ubench_valu.md) of the form that kept concordant | discordant and had to add the halves first.
+        uint32_t below = 0;
+#pragma unroll
+        for (int q = PER / 4 - 1; q >= 0; --q) {
+            const uint4 x = reinterpret_cast<const uint4 *>(cnt)[tid * (PER / 4) + q];
+            below = __builtin_amdgcn_alignbit(below, (x.w & 0xffffu) - a.min_cov, 31);
+            below = __builtin_amdgcn_alignbit(below, (x.z & 0xffffu) - a.min_cov, 31);
+            below = __builtin_amdgcn_alignbit(below, (x.y & 0xffffu) - a.min_cov, 31);
+            below = __builtin_amdgcn_alignbit(below, (x.x & 0xffffu) - a.min_cov, 31);
+        }
+        qual = ~below & (PER == 32 ? 0xffffffffu : (1u << PER) - 1u);
     }
     {   // only the pass's positions [0, Wp) exist (the last tile of a region is short)
         const int32_t left = (int32_t)Wp - tid * PER;
@@ -192,24 +248,24 @@ __device__ __forceinline__ uint32_t tile_compact(const TileArgs &a, const uint32
     }
     const uint32_t mine = __builtin_popcount(qual);
     const uint32_t incl = wave_scan_incl(mine);
-    if (lane == 63) wave_off[wave + 1] = incl;
+    static_assert(B == 256, "four wave totals in one 16-byte LDS word");
+    if (lane == 63) wave_off[wave] = incl;
     __syncthreads();
-    if (tid == 0) {
-        wave_off[0] = 0;
-        for (int w = 1; w <= B / 64; ++w) wave_off[w] += wave_off[w - 1];
-    }
-    __syncthreads();
-    uint32_t o = out_base + wave_off[wave] + incl - mine;
+    // every thread adds up the totals of the waves before its own (a single thread doing the prefix cost a second barrier)
+    const uint4 wt = *reinterpret_cast<const uint4 *>(wave_off);
+    const uint32_t before = (wave > 0 ? wt.x : 0u) + (wave > 1 ? wt.y : 0u) + (wave > 2 ? wt.z : 0u);
+    const uint32_t total = wt.x + wt.y + wt.z + wt.w;
+    uint32_t o = out_base + before + incl - mine;
     SiteRec *__restrict__ out = a.scratch + (size_t)t * W;
     while (qual) {
         const uint32_t idx = (uint32_t)tid * PER + (uint32_t)__builtin_ctz(qual);
         qual &= qual - 1;
         SiteRec rr; rr.pos = P0 + (int32_t)idx; rr.pad = 0;
         if (WIDE) { rr.n_conc = cnt[idx]; rr.n_disc = cnt[W / 2 + idx]; }
-        else { const uint32_t x = cnt[idx]; rr.n_conc = x & 0xffffu; rr.n_disc = x >> 16; }
+        else { const uint32_t x = cnt[idx]; rr.n_disc = x >> 16; rr.n_conc = (x & 0xffffu) - rr.n_disc; }
         out[o++] = rr;
     }
-    return wave_off[B / 64];
+    return total;
 }
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -268,12 +324,16 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 // One pass of a tile over its candidate reads [lo, hi): LDS counters for the reference positions
 // [P0, P0 + Wp), then compaction.  do_lp: also the LPMD pair counts and read totals of the reads the tile owns
 // (first pass only).  Returns the number of rows the pass appended at scratch[out_base..].
-template <int W, int B, int NB, typename RelT, bool WIDE, bool CLAMP>
+// MG > 0 (batches with max_span <= MG): the counter array has MG margin words on either side of the tile's W, so every call of a
+// read that can touch the tile has a word of its own and the scatter address needs no clamp (see the scatter below).
+template <int W, int B, int NB, typename RelT, bool WIDE, bool CLAMP, int MG>
 __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t t, const int32_t T0, const int32_t T1,
                                               const int32_t P0, const uint32_t Wp, const uint32_t lo, const uint32_t hi,
-                                              const bool do_lp, const uint32_t out_base, uint32_t *cnt,
+                                              const bool do_lp, const uint32_t out_base, uint32_t *cnt_raw,
                                               uint32_t (*red)[B / 64], uint32_t *wave_off, SlotTabs &tabs) {
     const int tid = threadIdx.x;
+    uint32_t *const cnt = cnt_raw + MG;                         // the tile's first position
+    constexpr bool MARGIN = MG > 0 && !WIDE;
     const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
     constexpr bool PACKED = sizeof(RelT) == 1 && NB == 8;      // the table / packed-field forms below (8-bit relpos)
     // (the caller has cleared the counters and built the slot tables)
@@ -335,7 +395,9 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         // Span check (every call in [start-1, start+max_span-1] -- this is what makes the halo complete,
         // checked on the calls themselves instead of trusting read_end): max over the live slots.
         const uint32_t sm1 = (uint32_t)(s - 1);
-        const uint32_t dead_w = (((uint32_t)T0 + (1u << 28)) & 0x7fffffffu) | (v[0] & 0x80000000u);   // 2^28 bp past the tile
+        // dead call word: a position 2^28 bp past the tile (clamped to the trash word by the scatter), or -- with margins -- the
+        // lane's own word at the start of the low margin; the first call's state either way (concordant)
+        const uint32_t dead_w = ((MARGIN ? (uint32_t)(P0 - MG + (tid & 63)) : (uint32_t)T0 + (1u << 28)) & 0x7fffffffu) | (v[0] & 0x80000000u);
         const uint32_t n_lp = lp_ok ? min(n, (uint32_t)NB) : 0u;       // calls whose pairs are evaluated from the registers
         uint32_t acc = 0, xmax = (v[0] & 0x7fffffffu) - sm1;
         if constexpr (PACKED) {
@@ -347,9 +409,13 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
             xs[0] = xmax;
 #pragma unroll
             for (int k = 1; k < 8; ++k) {
-                xs[k] = ((v[k] & 0x7fffffffu) - sm1) & mk[k];
-                v[k] = bfi(mk[k], v[k], dead_w);
-                acc |= v[k] ^ v[0];
+                // v_bitop3_b32 (gfx950: any three-input bit function in one instruction; the compiler expanded the select
+                // into not / and / and / or for six of the seven slots).  The state bit rides through the subtraction (no
+                // borrow for a call at or after start - 1; a call before it leaves a huge value either way) and is masked
+                // together with the liveness.
+                xs[k] = __builtin_amdgcn_bitop3_b32(v[k] - sm1, mk[k], 0x7fffffffu, 0x80);       // a & b & c
+                v[k] = __builtin_amdgcn_bitop3_b32(v[k], dead_w, mk[k], 0xe4);                    // c ? a : b
+                acc = __builtin_amdgcn_bitop3_b32(acc, v[k], v[0], 0xf6);                         // a | (b ^ c)
             }
             xmax = max(max(max(xs[0], xs[1]), max(xs[2], xs[3])), max(max(xs[4], xs[5]), max(xs[6], xs[7])));
         } else {
@@ -366,7 +432,7 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
                 for (int k = 0; k < NB; ++k) r[k] = ((uint32_t)k < n_lp) ? r[k] : (int32_t)((k + 1) << 24);
             }
         }
-        bad |= (xmax > (uint32_t)a.max_span) ? 1u : 0u;
+        uint32_t bad_it = (xmax > (uint32_t)a.max_span) ? 1u : 0u;      // this read's span violations
         uint32_t disc = acc >> 31;
         const bool any_long = __any(n > (uint32_t)NB);   // wave-uniform: the three tails below are rare
         if (any_long && n > (uint32_t)NB) {
@@ -374,9 +440,10 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
             for (uint32_t k = NB; k < n; ++k) {
                 const uint32_t x = a.cpg_pos[o0 + k];
                 disc |= (x >> 31) ^ first;
-                bad |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+                bad_it |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
             }
         }
+        bad |= bad_it;
         // windowed pair counts (readutil.rs:166-224): pairs (j<k) with min <= rel_k - rel_j <= max.
         // The calls are sorted by relpos, so the distance at call-index gap g+1 is >= the distance at gap g:
         // walk the pair matrix by diagonals g = 1, 2, .. and stop once NO lane of the wave has a pair
@@ -418,17 +485,16 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
                         const uint32_t later = (g & 1) ? O[li] : Q[li], sl = (g & 1) ? SO[li] : SQ[li];
                         const uint32_t D = later - Q[m];
                         const uint32_t Bw = KB - D;
-                        const uint32_t IN = (D + KA) & Bw & 0x80008000u;               // min <= distance <= max (readutil.rs:184, 196)
+                        const uint32_t IN = __builtin_amdgcn_bitop3_b32(D + KA, Bw, 0x80008000u, 0x80);   // min <= distance <= max (readutil.rs:184, 196)
                         const uint32_t DD = IN & (sl ^ SQ[m]);
-                        accIN += IN >> 15;
-                        accDD += DD >> 15;
+                        accIN += __builtin_popcount(IN);        // v_bcnt_u32_b32 adds its second operand: one instruction per count
+                        accDD += __builtin_popcount(DD);
                         orB |= Bw;
                     }
                     if (!__any((orB & 0x80008000u) != 0u)) break;      // no lane has a pair within max_distance on this diagonal
                 }
-                const uint32_t lp_n = (accIN & 0xffffu) + (accIN >> 16), lp_dd = (accDD & 0xffffu) + (accDD >> 16);
-                lp_c += lp_n - lp_dd;
-                lp_d += lp_dd;
+                lp_c += accIN - accDD;
+                lp_d += accDD;
             }
         } else if (any_lp) {
             const uint32_t span_ok = (uint32_t)(maxd - a.min_dist);
@@ -466,14 +532,33 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         }
         // scatter +1 to the pass's sites (pdr.rs:180-191), branch-free: a slot that is dead, outside the pass's
         // positions or belongs to a read PDR skips adds into a trash word instead (no exec juggling).
-        // Packed: one word per position, concordant count in the low half, discordant in the high half; the
+        // Packed: one word per position, coverage (concordant + discordant reads) in the low half, discordant in the high half; the
         // address is formed in byte units modulo 2^32 -- (word << 2) drops the state bit, candidates lie within
         // W + max_span of the tile, dead words 2^28 bp away and PDR-skipped reads get a base shifted by 2^28 bp --
         // and clamped with one min to the thread's trash word (3 VALU per slot).  Positions of the tile past
         // the region end may collect adds that way; the compaction masks them.
         // Wide: concordant at [0, W/2), discordant at [W/2, W); explicit range test.
-        if (!WIDE) {
-            const uint32_t one = disc ? 0x10000u : 1u;
+        // With margins (MG): a read that passes the span check and starts in [P0 - MG + 1, P0 + W] has all its calls in
+        // [P0 - MG, P0 + W + MG), a word each; dead slots point at the lane's word in the low margin; reads outside that
+        // start range (the index hands out whole 256-bp quanta) cannot call a position of the tile and skip the scatter
+        // together with the reads PDR skips and the span violators: one branch per read instead of a clamp per slot
+        // (1 VALU per slot).  Margin words are never read.
+        if (MARGIN) {
+            if (pdr_ok && !bad_it && (uint32_t)(s - (P0 - MG + 1)) <= (uint32_t)(W + MG - 1)) {
+                const uint32_t one = disc ? 0x10001u : 1u;           // coverage in the low half, discordant reads in the high half
+                const uint32_t base4 = (uint32_t)(P0 - MG) << 2;
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt_raw) + ((v[k] << 2) - base4)), one);
+                if (any_long) {
+                    for (uint32_t k = NB; k < n; ++k) {
+                        const uint32_t pk = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)P0;
+                        if (pk < Wp) atomicAdd(cnt + pk, one);
+                    }
+                }
+            }
+        } else if (!WIDE) {
+            const uint32_t one = disc ? 0x10001u : 1u;           // coverage in the low half, discordant reads in the high half
             const uint32_t base4 = ((uint32_t)P0 << 2) - (pdr_ok ? 0u : (1u << 30));
             const uint32_t trash4 = (uint32_t)(W + (tid & 63)) << 2;
 #pragma unroll
@@ -510,8 +595,9 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         i = inext;
     }
     if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
-    if (do_lp) tile_lpmd_partials<B>(a, t, red, lp_c, lp_d, n_read, n_valid);
+    if (do_lp) tile_lpmd_partials<B, !WIDE>(a, t, red, lp_c, lp_d, n_read, n_valid);
     __syncthreads();
+    if (do_lp) tile_lpmd_commit<B>(a, t, red);
     if (!a.want_pdr) return 0u;
     return tile_compact<W, B, WIDE>(a, t, P0, Wp, cnt, wave_off, out_base);
 }
@@ -529,11 +615,12 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
 // is called at most once per candidate read, so while the tile has <= 65535 candidates both counts fit 16 bits
 // (packed).  Heavier tiles (deep amplicons) take two passes over their reads with 32-bit counters, each
 // covering half of the tile's positions -- same LDS footprint, no extra launch, exact.
-template <int W, int B, int NB, typename RelT>
+template <int W, int B, int NB, typename RelT, int MG>
 __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[W + 64];   // counters, then one trash word per lane
+    static_assert(MG == 0 || (MG >= 64 && MG % 4 == 0), "the wide passes keep their trash words in the high margin");
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[MG ? MG + W + MG : W + 64];   // [margin,] counters, then margin / one trash word per lane
     __shared__ uint32_t red[4][B / 64];
-    __shared__ uint32_t wave_off[B / 64 + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t wave_off[B / 64];
     __shared__ __attribute__((aligned(16))) SlotTabs tabs;
 
     // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
@@ -556,7 +643,7 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
     // k_build_index left the last read index that is safe for every tile ending at or before it
     const uint32_t safe_hi = a.st->safe_hi;
     auto clear = [&]() {
-        for (int i = threadIdx.x; i < W / 4; i += B) reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < W / 4; i += B) reinterpret_cast<uint4 *>(cnt + MG)[i] = make_uint4(0, 0, 0, 0);
     };
     clear();
     slot_tabs_init(tabs, threadIdx.x);
@@ -566,16 +653,16 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
     if (hi - lo <= 65535u) {
         static_assert(NB == 8, "safe_hi is computed for 8 call slots");
         if (hi <= safe_hi)
-            rows = tile_pass<W, B, NB, RelT, false, false>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
+            rows = tile_pass<W, B, NB, RelT, false, false, MG>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
         else
-            rows = tile_pass<W, B, NB, RelT, false, true>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
+            rows = tile_pass<W, B, NB, RelT, false, true, MG>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
     } else {
         const int32_t Tm = (int32_t)min((int64_t)T0 + W / 2, (int64_t)T1);
-        rows = tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
+        rows = tile_pass<W, B, NB, RelT, true, true, MG>(a, t, T0, T1, T0, (uint32_t)(Tm - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
         __syncthreads();
         clear();
         __syncthreads();
-        rows += tile_pass<W, B, NB, RelT, true, true>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off, tabs);
+        rows += tile_pass<W, B, NB, RelT, true, true, MG>(a, t, T0, T1, Tm, (uint32_t)(T1 - Tm), lo, hi, false, rows, cnt, red, wave_off, tabs);
     }
     if (threadIdx.x == 0) {
         a.tile_cnt[t] = rows;
@@ -610,6 +697,8 @@ __global__ __launch_bounds__(64) void k_gather(const SiteRec *__restrict__ scrat
     const uint64_t cur = st->cur_base;
     const uint64_t base = cur + before;
     if (!fin_only) {
+        // (requesting the tile's first 64 rows together with the words that say where they go -- one round trip less -- was
+        // measured: 0.0126-0.0131 against 0.0127 ms, no change)
         const SiteRec *__restrict__ src = scratch + (size_t)t * tile_w;
         for (uint32_t j = lane; j < n; j += 64) {
             const SiteRec r = src[j];
@@ -639,10 +728,13 @@ __global__ __launch_bounds__(64) void k_gather(const SiteRec *__restrict__ scrat
 }
 
 // ---------------------------------------------------------------------------------------------
+constexpr int TILE_MARGIN = 256;   // counter margins on either side of a tile for batches with max_span <= 256
 template <int W, int B, typename RelT>
 static void launch_tile(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
     const uint32_t grid = ((ntiles + 7) / 8) * 8;   // whole rows of 8 XCDs (remap in the kernel)
-    hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT>), dim3(grid), dim3(B), 0, s, a, ntiles);
+    static const bool no_margin = getenv("MTH_TILE_NO_MARGIN") != nullptr;   // A/B switch
+    if (a.max_span <= TILE_MARGIN && !no_margin) hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT, TILE_MARGIN>), dim3(grid), dim3(B), 0, s, a, ntiles);
+    else hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT, 0>), dim3(grid), dim3(B), 0, s, a, ntiles);
 }
 
 // the linear read index alone (for kernels that find a tile's candidate reads without running the PDR/LPMD pass):
@@ -656,7 +748,7 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &id
     const uint32_t nq = (uint32_t)(((int64_t)ntiles * tile_w + ext) >> IDX_QSHIFT) + 2;
     MTH_HIP(ctx, ctx->idx.reserve((size_t)(nq + 1) * 4, s));
     LaunchTimer lt(ctx, K_INDEX);
-    const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK - 1) / BLOCK;
+    const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK * IDX_GROUPS - 1) / (BLOCK * IDX_GROUPS);
     hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, idx_base, nq,
                        (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0), ctx->idx.as<uint32_t>(), ctx->d_state,
                        ctx->d_state, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr, 0u);   // cur_base is rewritten by the next PDR batch's own index build
@@ -690,7 +782,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
 
     {
         LaunchTimer lt(ctx, K_INDEX);
-        const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK - 1) / BLOCK;
+        const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK * IDX_GROUPS - 1) / (BLOCK * IDX_GROUPS);
         hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start,
                            b.n_reads, idx_base, nq, (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0),
                            ctx->idx.as<uint32_t>(), ctx->d_state, cst, ctx->tile_bucket.as<unsigned long long>(), nbk * 5u,

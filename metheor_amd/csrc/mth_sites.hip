@@ -28,6 +28,7 @@ struct WalkArgs {
     const uint32_t *idx;
     const DevState *sites_st;   // n_sites of the discovery pass
     const int32_t  *site_pos;
+    const uint32_t *site_nc, *site_nd;   // discovery's per-site counts: contributors (reads passing the filters that call the site)
     DevState *st;               // main state (error bits)
     float    *val;              // per candidate site
     uint32_t *cov;
@@ -232,6 +233,15 @@ __global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
     __shared__ uint16_t s_st[MW_RC];          // read start relative to the block's base
     __shared__ uint32_t s_wv[4][8];           // per wave: lo, hi, first / last site position, has sites, call offsets at lo / hi
     __shared__ __attribute__((aligned(16))) uint32_t s_vtab[17 * 8];   // row m: max(0, m-l+1) for l = 1..16 as 16-bit pairs
+    // A site whose contributors (all of them, over the whole batch: the discovery pass counted them) number fewer than
+    // min_depth cannot produce a row: no segment holds more than that (mhl.rs:163-171, 201-205).  At WGBS depths that is most
+    // sites (config 3: 601 k rows from several million sites).  The group still stages the candidates of its 256
+    // consecutive sites -- filtering the site list instead makes the groups sparse and the staging miss (measured: config 2
+    // 0.56 -> 0.75 ms) -- but only the sites that can reach min_depth are walked, packed into as few waves as they need:
+    // wave w lists its walkable sites at s_l*[w * 64 ..], and thread k takes the k-th of the run.
+    __shared__ uint32_t s_lj[256], s_llo[256], s_lhi[256];
+    __shared__ int32_t s_lc[256];
+    __shared__ uint32_t s_wcnt[4];
     const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
     const int tid = threadIdx.x;
     if (tid < 17 * 8) {
@@ -243,8 +253,10 @@ __global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
         const bool valid = j < n_sites;
         int32_t c = 0;
         uint32_t lo = 0, hi = 0;
+        bool active = false;
         if (valid) {
             c = a.site_pos[j];
+            active = a.site_nc[j] + a.site_nd[j] >= a.min_depth;
             lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
             hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
         }
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
         }
         parts = __builtin_amdgcn_readfirstlane(parts);
         if (!parts) {
-            if (valid) a.flags[j] = 4u;                 // deep data: k_mhl_walk_big walks these sites from global memory
+            if (valid) a.flags[j] = active ? 4u : 0u;   // deep data: k_mhl_walk_big walks these sites from global memory
         } else {
             const int per = 4 / parts;
             for (int q = 0; q * per < nw; ++q) {
@@ -290,6 +302,18 @@ __global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
                 const uint32_t c0 = __builtin_amdgcn_readfirstlane(s_wv[w0][5]);
                 const uint32_t ncall = __builtin_amdgcn_readfirstlane(s_wv[w1][6]) - c0;
                 if (q) __syncthreads();                 // the previous run's walks are done with the buffers
+                {   // the run's walkable sites, listed per wave
+                    const bool in_run = valid && wv >= w0 && wv <= w1;
+                    const bool mine = in_run && active;
+                    const unsigned long long bal = __ballot(mine);
+                    const int ln = tid & 63;
+                    if (mine) {
+                        const uint32_t e = (uint32_t)wv * 64u + (uint32_t)__builtin_popcountll(bal & ((1ull << ln) - 1ull));
+                        s_lj[e] = j; s_lc[e] = c; s_llo[e] = lo; s_lhi[e] = hi;
+                    }
+                    if (ln == 0) s_wcnt[wv] = (uint32_t)__builtin_popcountll(bal);
+                    if (in_run && !active) a.flags[j] = 0u;
+                }
                 for (uint32_t k = tid; k <= bhi - blo; k += 256) s_ofs[k] = (uint16_t)(a.cpg_off[blo + k] - c0);
                 for (uint32_t k = tid; k < bhi - blo; k += 256) {
                     s_mq[k] = a.read_mapq[blo + k];
@@ -300,7 +324,18 @@ __global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
                     s_call[w] = (uint16_t)((((x & 0x7fffffffu) - (uint32_t)base) & 0x7fffu) | ((x >> 31) << 15));
                 }
                 __syncthreads();
-                if (valid && wv >= w0 && wv <= w1) {
+                uint32_t e = 0xffffffffu;                // this thread's entry of the run's list, if any
+                {
+                    uint32_t k = (uint32_t)tid;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t cw = s_wcnt[w];
+                        if (e == 0xffffffffu) { if (k < cw) e = (uint32_t)w * 64u + k; else k -= cw; }
+                    }
+                }
+                if (e != 0xffffffffu) {
+                    const uint32_t j = s_lj[e], lo = s_llo[e], hi = s_lhi[e];
+                    const int32_t c = s_lc[e];
                     // The index hands out whole 256-bp quanta (~110 candidates); only reads starting in
                     // [c - max_span + 1, c + 1] matter (~35): an earlier read cannot call c and comes before every
                     // contributor (its flush finds nothing open), and the first later read can only flush what the
@@ -566,7 +601,9 @@ __global__ void k_bump_batches(DevState *st) { st->n_batches += 1; }
 
 // run the tile pipeline as a site-discovery pass: positions called by >= 1 read that passes
 // (mapq >= min_qual, n_cpgs >= max(min_cpgs,1)) -> ctx->s_pos (sorted), count in ctx->d_state2
-int discover_sites(mth_ctx *ctx, const mth_batch_t &d, uint32_t min_cpgs, uint8_t min_qual, uint64_t &bound) {
+// min_cov > 1: only sites that at least min_cov such reads call.  A segment of the walks below holds a subset of those reads,
+// so a site below the measure's min_depth cannot produce a row and need not be walked (at WGBS depths that is most sites).
+int discover_sites(mth_ctx *ctx, const mth_batch_t &d, uint32_t min_cpgs, uint8_t min_qual, uint64_t &bound, uint32_t min_cov) {
     hipStream_t s = ctx->stream;
     const uint64_t region_len = (uint64_t)((int64_t)d.region_end - d.region_beg);
     bound = d.n_cpgs < region_len ? d.n_cpgs : region_len;
@@ -579,7 +616,7 @@ int discover_sites(mth_ctx *ctx, const mth_batch_t &d, uint32_t min_cpgs, uint8_
     MTH_HIP(ctx, ctx->s_batch_cnt.reserve(16, s));
     mth_pdr_lpmd_params_t p;
     memset(&p, 0, sizeof p);
-    p.pdr_min_depth = 0; p.pdr_min_cpgs = min_cpgs; p.pdr_min_qual = min_qual; p.want_pdr = 1;
+    p.pdr_min_depth = min_cov; p.pdr_min_cpgs = min_cpgs; p.pdr_min_qual = min_qual; p.want_pdr = 1;
     TileSink sink{ctx->d_state2, ctx->s_pos.as<int32_t>(), ctx->s_pdr.as<float>(), ctx->s_nc.as<uint32_t>(),
                   ctx->s_nd.as<uint32_t>(), ctx->s_batch_cnt.as<uint32_t>()};
     return launch_pdr_lpmd(ctx, d, p, &sink);
@@ -589,7 +626,7 @@ int discover_sites(mth_ctx *ctx, const mth_batch_t &d, uint32_t min_cpgs, uint8_
 int launch_pdr_exact(mth_ctx *ctx, const mth_batch_t &d, const mth_pdr_lpmd_params_t &p) {
     hipStream_t s = ctx->stream;
     uint64_t bound = 0;
-    int rc = discover_sites(ctx, d, p.pdr_min_cpgs, p.pdr_min_qual, bound);
+    int rc = discover_sites(ctx, d, p.pdr_min_cpgs, p.pdr_min_qual, bound, p.pdr_min_depth);
     if (rc) return rc;
     if (bound == 0) bound = 1;
     MTH_HIP(ctx, ctx->w_val.reserve(bound * 4, s));
@@ -639,6 +676,7 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
     if (rc) return rc;
     hipStream_t s = ctx->stream;
     uint64_t bound = 0;
+        // (the site list is NOT filtered by min_depth here: the walk skips such sites itself and keeps its staging dense)
     if ((rc = discover_sites(ctx, d, params->min_cpgs, params->min_qual, bound))) return rc;
     if (bound == 0) { ctx->m_batches.push_back(BatchMeta{batch->tid}); bound = 1; }
     else ctx->m_batches.push_back(BatchMeta{batch->tid});
@@ -668,6 +706,7 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
     WalkArgs a;
     a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
     a.idx = ctx->idx.as<uint32_t>(); a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>();
+    a.site_nc = ctx->s_nc.as<uint32_t>(); a.site_nd = ctx->s_nd.as<uint32_t>();
     a.st = ctx->d_state; a.val = ctx->w_val.as<float>(); a.cov = ctx->w_cov.as<uint32_t>(); a.flags = ctx->w_flags.as<uint32_t>();
     a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.n_reads = d.n_reads;
     a.min_depth = params->min_depth; a.min_cpgs = params->min_cpgs; a.min_qual = params->min_qual;
