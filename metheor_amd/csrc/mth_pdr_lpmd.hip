@@ -25,6 +25,10 @@
 // contraction here).  Algorithmic bytes: 16 B/read + 5 B/CpG call in, 12 B/site out.
 #include "mth_ctx.h"
 
+#ifndef MTH_TILE_PF
+#define MTH_TILE_PF 1
+#endif
+
 namespace mth {
 
 struct TileArgs {
@@ -342,10 +346,34 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
     uint32_t i = lo + tid;
     int32_t s = 0;
     uint32_t o0 = 0, n = 0, mq = 0;
-    if (i < hi) { s = a.read_start[i]; o0 = a.cpg_off[i]; n = a.cpg_off[i + 1] - o0; mq = a.read_mapq[i]; }
+    // PF (the plain-load instantiation with 8-bit relpos): ONE round trip per iteration.  Only the read's two call offsets are
+    // fetched ahead (two registers); its calls, relative positions, start and mapq are then requested together -- the calls
+    // unconditionally: every read of such a tile has its 8-slot window inside the arrays (safe_hi) -- and the NEXT read's
+    // offsets right behind them, so that they travel during this read's arithmetic.  (The version that fetched the whole next
+    // record ahead cost the registers of the 8th wave; profiles/r02_tile_latency.md.)
+    constexpr bool PF = MTH_TILE_PF && !CLAMP && sizeof(RelT) == 1 && NB == 8;
+    uint32_t o1 = 0;
+    if (PF) { if (i < hi) { o0 = a.cpg_off[i]; o1 = a.cpg_off[i + 1]; } }
+    else if (i < hi) { s = a.read_start[i]; o0 = a.cpg_off[i]; n = a.cpg_off[i + 1] - o0; mq = a.read_mapq[i]; }
     while (i < hi) {
         const uint32_t inext = i + B;
         const bool more = inext < hi;
+        uint32_t v[NB];
+        int32_t r[NB];
+        uint32_t rraw0 = 0, rraw1 = 0;                         // PACKED, !CLAMP: the 8 relpos bytes as loaded
+        uint32_t o0n = 0, o1n = 0;
+        if constexpr (PF) {
+            n = o1 - o0;
+            const uint32_t *__restrict__ cp = a.cpg_pos + o0;
+#pragma unroll
+            for (int k4 = 0; k4 < NB / 4; ++k4) {
+                const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(cp + 4 * k4);
+                v[4 * k4] = x.x; v[4 * k4 + 1] = x.y; v[4 * k4 + 2] = x.z; v[4 * k4 + 3] = x.w;
+            }
+            if (do_lp) { const u32x2_a1 x = *reinterpret_cast<const u32x2_a1 *>(reinterpret_cast<const RelT *>(a.cpg_rel) + o0); rraw0 = x.x; rraw1 = x.y; }
+            s = a.read_start[i]; mq = a.read_mapq[i];
+            if (more) { o0n = a.cpg_off[inext]; o1n = a.cpg_off[inext + 1]; }
+        }
         const bool owned = (s >= T0) && (s < T1);
         // lpmd.rs:176-179
         const bool lp_ok = do_lp && owned && (mq >= a.lpmd_min_qual);
@@ -357,9 +385,6 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         const int32_t maxd = PACKED ? min(a.max_dist, 255) : min(a.max_dist, 1 << 20);   // 8-bit relpos: no distance beyond 255
         const int32_t mind = max(a.min_dist, 0);
         const bool any_lp = maxd >= a.min_dist && maxd >= 0 && __any(work && lp_ok && n > 1);   // min > max: no pair can qualify (and the range trick below would wrap)
-        uint32_t v[NB];
-        int32_t r[NB];
-        uint32_t rraw0 = 0, rraw1 = 0;                         // PACKED, !CLAMP: the 8 relpos bytes as loaded
         // All calls of the read in flight at once: two 16-byte loads from a per-read base (dword alignment
         // is all global_load_dwordx4 needs) and one 8/16-byte load of the relative positions.  Slots k >= n
         // read the NEXT reads' calls and are neutralised below; only the batch's last few reads could run
@@ -368,7 +393,9 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         if (work) {
             const uint32_t *__restrict__ cp = a.cpg_pos + o0;
             const RelT *__restrict__ rp = rel + o0;
-            if (!CLAMP) {
+            if (PF) {
+                (void)cp; (void)rp;                    // requested at the top of the iteration
+            } else if (!CLAMP) {
 #pragma unroll
                 for (int k4 = 0; k4 < NB / 4; ++k4) {
                     const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(cp + 4 * k4);
@@ -591,7 +618,8 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         }   // work
         // the thread's next read.  (Requesting it together with the calls above and parking it in LDS -- one round
         // trip per iteration instead of two -- was built and measured: no change, profiles/r02_tile_latency.md.)
-        if (more) { s = a.read_start[inext]; o0 = a.cpg_off[inext]; n = a.cpg_off[inext + 1] - o0; mq = a.read_mapq[inext]; }
+        if (PF) { o0 = o0n; o1 = o1n; }
+        else if (more) { s = a.read_start[inext]; o0 = a.cpg_off[inext]; n = a.cpg_off[inext + 1] - o0; mq = a.read_mapq[inext]; }
         i = inext;
     }
     if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
