@@ -571,7 +571,7 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         // together with the reads PDR skips and the span violators: one branch per read instead of a clamp per slot
         // (1 VALU per slot).  Margin words are never read.
         if (MARGIN) {
-            if (pdr_ok && !bad_it && (uint32_t)(s - (P0 - MG + 1)) <= (uint32_t)(W + MG - 1)) {
+            if (pdr_ok && !bad_it && (uint32_t)s - (uint32_t)(P0 - MG + 1) <= (uint32_t)(W + MG - 1)) {      // unsigned: starts near 2^31 do not overflow
                 const uint32_t one = disc ? 0x10001u : 1u;           // coverage in the low half, discordant reads in the high half
                 const uint32_t base4 = (uint32_t)(P0 - MG) << 2;
 #pragma unroll
@@ -706,7 +706,8 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
 // launch reads what it writes (cur_base is set by the next batch's k_build_index).
 // fin_only (LPMD-only passes): a single wave that only commits.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_gather(const SiteRec *__restrict__ scratch,
+constexpr int GATHER_WAVES = 4;   // tiles per workgroup (one wave each)
+__global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(const SiteRec *__restrict__ scratch,
                                                const uint32_t *__restrict__ tile_cnt,
                                                const unsigned long long *__restrict__ bucket, uint32_t nbk,
                                                uint32_t ntiles, int fin_only, int want_lpmd,
@@ -714,22 +715,32 @@ __global__ __launch_bounds__(64) void k_gather(const SiteRec *__restrict__ scrat
                                                uint32_t tile_w,
                                                int32_t *__restrict__ out_pos, float *__restrict__ out_pdr,
                                                uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
-    const uint32_t t = fin_only ? ntiles - 1 : blockIdx.x;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t t = fin_only ? ntiles - 1 : blockIdx.x * GATHER_WAVES + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t bk = t >> TILE_BUCKET_SHIFT;
-    uint32_t part = 0;                                  // rows of one batch fit 32 bits (<= region positions)
-    for (uint32_t b = lane; b < bk; b += 64) part += (uint32_t)bucket[b];
-    for (uint32_t u = (bk << TILE_BUCKET_SHIFT) + lane; u < t; u += 64) part += tile_cnt[u];
-    const uint32_t before = wave_sum(part);
+    // Everything the wave needs first is requested before anything is used: its own row count, the batch's base, the bucket
+    // sums before its bucket, the (up to 255 = 4 x 64) earlier tiles of its bucket and -- speculatively, scratch holds tile_w
+    // >= 64 rows per tile whether or not the tile wrote them -- its first 64 rows.  (The earlier-tiles loop used to wait for
+    // each of its four loads in turn: five dependent round trips per wave.)
+    static_assert(TILE_BUCKET_SHIFT == 8, "a bucket's earlier tiles are four loads per lane");
+    const SiteRec *__restrict__ src = scratch + (size_t)t * tile_w;
+    SiteRec r0; r0.pos = 0; r0.n_conc = 0; r0.n_disc = 0; r0.pad = 0;
+    if (!fin_only) r0 = src[lane];
     const uint32_t n = tile_cnt[t];
     const uint64_t cur = st->cur_base;
+    const uint32_t u0 = (bk << TILE_BUCKET_SHIFT) + lane;
+    uint32_t x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = (u0 + 64u * k < t) ? tile_cnt[u0 + 64u * k] : 0u;
+    uint32_t part = 0;                                  // rows of one batch fit 32 bits (<= region positions)
+    for (uint32_t b = lane; b < bk; b += 64) part += (uint32_t)bucket[b];
+    part += (x[0] + x[1]) + (x[2] + x[3]);
+    const uint32_t before = wave_sum(part);
     const uint64_t base = cur + before;
     if (!fin_only) {
-        // (requesting the tile's first 64 rows together with the words that say where they go -- one round trip less -- was
-        // measured: 0.0126-0.0131 against 0.0127 ms, no change)
-        const SiteRec *__restrict__ src = scratch + (size_t)t * tile_w;
         for (uint32_t j = lane; j < n; j += 64) {
-            const SiteRec r = src[j];
+            const SiteRec r = j < 64 ? r0 : src[j];
             out_pos[base + j] = r.pos;
             out_nc[base + j] = r.n_conc;
             out_nd[base + j] = r.n_disc;
@@ -836,7 +847,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     }
     {
         LaunchTimer lt(ctx, K_GATHER);
-        hipLaunchKernelGGL(k_gather, dim3(p.want_pdr ? ntiles : 1u), dim3(64), 0, s, ctx->scratch.as<SiteRec>(),
+        hipLaunchKernelGGL(k_gather, dim3(p.want_pdr ? (ntiles + GATHER_WAVES - 1) / GATHER_WAVES : 1u), dim3(p.want_pdr ? 64 * GATHER_WAVES : 64), 0, s, ctx->scratch.as<SiteRec>(),
                            ctx->tile_cnt.as<uint32_t>(), ctx->tile_bucket.as<unsigned long long>(), nbk, ntiles,
                            p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, bcnt, (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
     }
