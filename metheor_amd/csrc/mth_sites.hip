@@ -314,14 +314,41 @@ __global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
                     if (ln == 0) s_wcnt[wv] = (uint32_t)__builtin_popcountll(bal);
                     if (in_run && !active) a.flags[j] = 0u;
                 }
-                for (uint32_t k = tid; k <= bhi - blo; k += 256) s_ofs[k] = (uint16_t)(a.cpg_off[blo + k] - c0);
-                for (uint32_t k = tid; k < bhi - blo; k += 256) {
-                    s_mq[k] = a.read_mapq[blo + k];
-                    s_st[k] = (uint16_t)((uint32_t)(a.read_start[blo + k] - base) & 0x7fffu);
-                }
-                for (uint32_t w = tid; w < ncall; w += 256) {
-                    const uint32_t x = a.cpg_pos[c0 + w];
-                    s_call[w] = (uint16_t)((((x & 0x7fffffffu) - (uint32_t)base) & 0x7fffu) | ((x >> 31) << 15));
+                // Staging, eight elements per thread requested before the first is stored: written as plain loops these were one
+                // load -> wait -> LDS store per trip (ISA checked), ~23 dependent round trips per group -- a quarter of the kernel.
+                {
+                    const uint32_t nr = bhi - blo;
+                    for (uint32_t k0 = tid; k0 <= nr; k0 += 256 * 8) {
+                        uint32_t x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) x[u] = (k0 + 256u * u <= nr) ? a.cpg_off[blo + k0 + 256u * u] : 0u;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (k0 + 256u * u <= nr) s_ofs[k0 + 256u * u] = (uint16_t)(x[u] - c0);
+                    }
+                    for (uint32_t k0 = tid; k0 < nr; k0 += 256 * 4) {
+                        uint32_t q[4]; int32_t st4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool in = k0 + 256u * u < nr;
+                            q[u] = in ? (uint32_t)a.read_mapq[blo + k0 + 256u * u] : 0u;
+                            st4[u] = in ? a.read_start[blo + k0 + 256u * u] : 0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (k0 + 256u * u < nr) {
+                                s_mq[k0 + 256u * u] = (uint8_t)q[u];
+                                s_st[k0 + 256u * u] = (uint16_t)((uint32_t)(st4[u] - base) & 0x7fffu);
+                            }
+                    }
+                    for (uint32_t w0 = tid; w0 < ncall; w0 += 256 * 8) {
+                        uint32_t x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) x[u] = (w0 + 256u * u < ncall) ? a.cpg_pos[c0 + w0 + 256u * u] : 0u;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (w0 + 256u * u < ncall)
+                                s_call[w0 + 256u * u] = (uint16_t)((((x[u] & 0x7fffffffu) - (uint32_t)base) & 0x7fffu) | ((x[u] >> 31) << 15));
+                    }
                 }
                 __syncthreads();
                 uint32_t e = 0xffffffffu;                // this thread's entry of the run's list, if any
