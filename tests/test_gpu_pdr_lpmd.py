@@ -277,6 +277,28 @@ def test_pdr_long_spans_vs_oracle(eng):
     assert (p3["pos"] == p2["pos"]).all() and (p3["n_discordant"] == p2["n_discordant"]).all()
 
 
+@pytest.mark.parametrize("read_len", [120, 200, 255, 256, 257])
+def test_counter_margin_boundary_spans(eng, read_len):
+    """the tile kernel keeps 256 margin words on either side of a tile for batches with max_span <= 256 (no clamp per
+    call slot) and falls back to the clamped form above that: spans on both sides of the switch, whole contigs and region
+    splits (halo reads call positions on both sides of a region), PDR via the tile kernel (<= 150) or the exact walk fed by
+    the tile kernel's site discovery (> 150), LPMD always via the tile kernel"""
+    from metheor_amd import PdrLpmdParams, shard, synth
+    rng = np.random.default_rng(9000 + read_len)
+    cs = [synth.make_contig(0, 150_000, 24_000, 0.03, rng, read_len=read_len), synth.make_contig(1, 9_000, 900, 0.05, rng, read_len=read_len)]
+    assert all(int((c["read_end"] - c["read_start"]).max()) + 1 == read_len for c in cs)
+    reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
+    for kw, lkw in ((dict(min_depth=10, min_cpgs=4, min_qual=10), dict()), (dict(min_depth=0, min_cpgs=0, min_qual=0), dict(min_distance=1, max_distance=40, min_qual=0)),
+                    (dict(min_depth=3, min_cpgs=1, min_qual=20), dict(min_distance=2, max_distance=300, min_qual=20))):
+        params = PdrLpmdParams(lpmd_min_qual=lkw.get("min_qual", 10), min_distance=lkw.get("min_distance", 2), max_distance=lkw.get("max_distance", 16), **kw)
+        p, l = run_device(eng, cs, params)
+        check_against_oracle(p, l, reads, kw, lkw)
+        assert len(p["pos"]) > 100
+        regions = [shard.plan_regions(cs[0], 5), [(0, 4097), (4097, cs[1]["length"])]]
+        p2, l2 = run_device(eng, cs, params, regions=regions)
+        check_against_oracle(p2, l2, reads, kw, lkw)
+
+
 # ---- BASELINE config 2 at full size: size-independent properties ----------------------------------
 def test_full_size_properties(eng):
     """10 M reads: device totals vs closed forms computed with numpy on the SoA"""
