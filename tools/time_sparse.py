@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ME/PM and the pairs table on ONE sparse WGBS-like contig (config-3 density): ms per pass and per kernel.
+"""Every measure on ONE sparse WGBS-like contig (config-3 density): ms per pass and per kernel.
 Usage: python tools/time_sparse.py [--len 248956422] [--reads 16000000] [--density 0.0091]"""
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +22,8 @@ def main():
     c = synth.make_contig(0, args.len, args.reads, args.density, np.random.default_rng(3))
     bt = util.device_batch(c, device="cuda:0")
     for name, fn in (("me/pm", lambda: eng.quartet_accumulate(bt)), ("pairs", lambda: eng.lpmd_pairs_accumulate(bt)),
-                     ("pdr+lpmd", lambda: eng.pdr_lpmd_accumulate(bt, metheor_amd.PdrLpmdParams()))):
+                     ("pdr+lpmd", lambda: eng.pdr_lpmd_accumulate(bt, metheor_amd.PdrLpmdParams())),
+                     ("mhl", lambda: eng.mhl_accumulate(bt)), ("fdrp+qfdrp", lambda: eng.fdrp_accumulate(bt))):
         dt, k = timed(eng, fn, 5)
         print(json.dumps({"measure": name, "reads": args.reads, "ms_per_pass": round(dt * 1e3, 3), "kernels_ms": k}), flush=True)
 
