@@ -31,10 +31,6 @@
 #include "mth_ctx.h"
 #include "mth_scan.h"
 
-#ifndef MTH_FD_PIPE
-#define MTH_FD_PIPE 1
-#endif
-
 namespace mth {
 
 constexpr int FD_WIN = 201;   // MAX_READ_LEN, fdrp.rs:10
@@ -117,29 +113,11 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
     // requested one site ahead, so a run of skipped sites is not a run of exposed round trips.
     uint32_t cov_j = 0;
     if (SLOTS == 64 && wave_id < n_sites) cov_j = a.site_nc[wave_id] + a.site_nd[wave_id];
-    // Site pipeline (MTH_FD_PIPE): a site's chain is position -> two index entries -> candidate fields -> calls, four dependent
-    // round trips.  On dense data (config 2) the waves of a SIMD cover them with arithmetic and requesting them ahead changed
-    // nothing (1.4856 vs 1.4861 ms); at WGBS depths (config 3: a dozen stored reads, one pair round) a site is mostly that
-    // chain.  So the first two links are taken out of it: the wave holds, as scalars, this site's position and index entries
-    // and the next site's position; at the top of a site it requests the next site's index entries and the position two sites
-    // ahead, and turns them into scalars on the way to the next site (three vector registers live across a site).
-    auto idx_lo = [&](int32_t cc) { return (uint32_t)(cc - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT; };
-    auto idx_hi = [&](int32_t cc) { return ((uint32_t)(cc + 1 - a.idx_base) >> IDX_QSHIFT) + 1; };
-    int32_t c_cur = 0, c_nxt = 0, c_v = 0;
-    uint32_t lo_cur = 0, hi_cur = 0, lo_v = 0, hi_v = 0;
-    if (MTH_FD_PIPE && wave_id < n_sites) {
-        c_cur = sgpr(a.site_pos[wave_id]);
-        if (wave_id + n_waves < n_sites) c_nxt = a.site_pos[wave_id + n_waves];
-        lo_cur = a.idx[idx_lo(c_cur)]; hi_cur = a.idx[idx_hi(c_cur)];
-        c_nxt = sgpr(c_nxt); lo_cur = sgpr(lo_cur); hi_cur = sgpr(hi_cur);
-    }
-    for (uint32_t j = wave_id; j < n_sites;
-         j += n_waves, c_cur = c_nxt, lo_cur = sgpr(lo_v), hi_cur = sgpr(hi_v), c_nxt = sgpr(c_v)) {
-        if (MTH_FD_PIPE) {
-            const uint32_t jn = j + n_waves, jnn = jn + n_waves;
-            if (jn < n_sites) { lo_v = a.idx[idx_lo(c_nxt)]; hi_v = a.idx[idx_hi(c_nxt)]; }
-            if (jnn < n_sites) c_v = a.site_pos[jnn];
-        }
+    // (A site pipeline -- the wave holding this site's position and index entries and the next site's position as scalars,
+    // requesting the next site's index entries and the position two sites ahead at the top of a site -- was built twice: on dense
+    // data it changes nothing (1.4856 vs 1.4861 ms; 1.3456 vs 1.3383), at WGBS depth it is slower (0.880 -> 0.930 ms on a
+    // 16 M-read chr1-sized contig): a site's time is instruction issue, not this chain's latency.)
+    for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
         if (SLOTS == 64) {
             const uint32_t cov = sgpr(cov_j);
             const uint32_t jn = j + n_waves;
@@ -149,12 +127,12 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
                 continue;
             }
         }
-        const int32_t c = MTH_FD_PIPE ? c_cur : sgpr(a.site_pos[j]);
+        const int32_t c = sgpr(a.site_pos[j]);
         // the 64-site window of the compact finalize depends on j alone: requested here, a full walk before it is used
         const uint32_t j0w = (j >= 32u) ? min(j - 32u, n_sites > 64u ? n_sites - 64u : 0u) : 0u;
         const int32_t spw = (j0w + (uint32_t)lane < n_sites) ? a.site_pos[j0w + lane] : 0x7fffffff;
-        const uint32_t lo = MTH_FD_PIPE ? min(lo_cur, a.n_reads) : sgpr(min(a.idx[idx_lo(c)], a.n_reads));
-        const uint32_t hi = MTH_FD_PIPE ? min(hi_cur, a.n_reads) : sgpr(min(a.idx[idx_hi(c)], a.n_reads));
+        const uint32_t lo = sgpr(min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads));
+        const uint32_t hi = sgpr(min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads));
         // wave-uniform segment state
         int32_t total = 0, sampled = 0;
         bool entry = false, have = false, deep = false;
