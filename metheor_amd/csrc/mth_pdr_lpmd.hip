@@ -5,7 +5,7 @@
 // concordant / discordant CpG-pair counts inside a query-distance window.
 //
 // How (MI355X-first, nothing like the reference's hash maps):
-//   k_build_index   one thread per read: a linear index "first read starting at or after q*256 bp"
+//   k_build_index   one thread per read: a linear index "first read starting at or after q*32 bp"
 //                   (reads are coordinate sorted) + sortedness validation.
 //   k_pdr_lpmd_tile one 256-thread workgroup per 4096-bp tile of the contig.  The tile's site
 //                   accumulators are DENSE in LDS (one 32-bit word per reference position holding both
@@ -570,7 +570,7 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         // Wide: concordant at [0, W/2), discordant at [W/2, W); explicit range test.
         // With margins (MG): a read that passes the span check and starts in [P0 - MG + 1, P0 + W] has all its calls in
         // [P0 - MG, P0 + W + MG), a word each; dead slots point at the lane's word in the low margin; reads outside that
-        // start range (the index hands out whole 256-bp quanta) cannot call a position of the tile and skip the scatter
+        // start range (the index hands out whole 32-bp quanta) cannot call a position of the tile and skip the scatter
         // together with the reads PDR skips and the span violators: one branch per read instead of a clamp per slot
         // (1 VALU per slot).  Margin words are never read.
         if (MARGIN) {

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
                 const int w0 = q * per, w1 = min(w0 + per, nw) - 1;
                 const uint32_t blo = __builtin_amdgcn_readfirstlane(s_wv[w0][0]), bhi = __builtin_amdgcn_readfirstlane(s_wv[w1][1]);
                 const int32_t c_first = (int32_t)__builtin_amdgcn_readfirstlane(s_wv[w0][2]);
-                // the index hands out whole 256-bp quanta: a staged read starts in [c_first - max_span - 255, c_last + 257]
+                // the index hands out whole IDX_Q-bp quanta: a staged read starts in [c_first - max_span - (IDX_Q - 1), c_last + IDX_Q + 1]
                 // and calls positions in [start-1, start+max_span-1] (the tile pipeline that discovered the sites has
                 // checked that on every call)
                 const int32_t base = c_first - a.max_span - (IDX_Q + 1);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_mhl_walk_lds(const WalkArgs a) {
                 if (e != 0xffffffffu) {
                     const uint32_t j = s_lj[e], lo = s_llo[e], hi = s_lhi[e];
                     const int32_t c = s_lc[e];
-                    // The index hands out whole 256-bp quanta (~110 candidates); only reads starting in
+                    // The index hands out whole quanta (32 bp; 256 bp and ~110 candidates when this was written); only reads starting in
                     // [c - max_span + 1, c + 1] matter (~35): an earlier read cannot call c and comes before every
                     // contributor (its flush finds nothing open), and the first later read can only flush what the
                     // end-of-range flush below finalises identically.  Two binary searches over the staged starts.
