@@ -740,7 +740,8 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
     const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 255) / 256, 8192);
     // [0] = "some site needs the HBM-scratch walk" (set by k_mhl_walk_big), cleared per batch; the scratch follows
     MTH_HIP(ctx, ctx->w_huge.reserve((size_t)2048 * 16384 * 8, s));
-    MTH_HIP(ctx, hipMemsetAsync(&ctx->d_state2->pad_, 0, 4, s));
+    // (d_state2 was cleared as a whole by discover_sites a moment ago and nothing of the tile pipeline writes this word: no
+    // second fill kernel for it)
     a.huge_any = &ctx->d_state2->pad_;
     {
         LaunchTimer lt(ctx, K_MHLWALK);
