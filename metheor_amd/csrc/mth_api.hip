@@ -218,6 +218,8 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->staged_ev) (void)hipEventDestroy(ctx->staged_ev);
+    if (ctx->piece_stream) (void)hipStreamDestroy(ctx->piece_stream);
+    for (hipEvent_t e : ctx->piece_ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

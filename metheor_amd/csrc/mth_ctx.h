@@ -56,6 +56,8 @@ struct mth_ctx {
     mth::DevBuf inf_file2;
     hipStream_t copy_stream = nullptr;
     hipEvent_t staged_ev = nullptr;
+    hipStream_t piece_stream = nullptr;  // an in-line chunk's file bytes travel here in pieces, each piece's blocks inflate as it lands
+    std::vector<hipEvent_t> piece_ev;
     const void *staged_src = nullptr;
     uint64_t staged_bytes = 0;
     const void *next_src = nullptr;      // announced by mth_bgzf_stage, copied by a helper thread the next inflate call starts

@@ -514,7 +514,14 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
     ctx->staged_src = nullptr;
     MTH_HIP(ctx, ctx->inf_tab.reserve(nb * 24 + 64, s));
     MTH_HIP(ctx, ctx->inf_raw.reserve((size_t)total + 64, s));
-    if (!staged) {
+    // METHEOR_COPY_PIECE_MB=k (default 0 = off): an in-line copy (the first chunk of a file, or every chunk under METHEOR_NO_STAGE)
+    // of two pieces or more travels on its own stream piece by piece, and the blocks of a piece are inflated as soon as the piece
+    // has landed.  Built to hide the first chunk's inflate behind its copy; measured slower (profiles/r02_e2e.md, last section):
+    // a pageable copy pins, moves and unpins inside the call, ~2.5 ms of that per call is not overlapped with anything, and the
+    // runtime pipelines one large copy better than the caller can pipeline several small ones.  Kept as a switch, parity-tested.
+    static const size_t piece_bytes = [] { const char *e = getenv("METHEOR_COPY_PIECE_MB"); const long k = e ? atol(e) : 0; return k > 0 ? (size_t)k << 20 : (size_t)0; }();
+    const bool pieced = !staged && piece_bytes && n_bytes >= 2 * (uint64_t)piece_bytes && nb >= 2;
+    if (!staged && !pieced) {
         // (copying through own page-locked pieces from 2-8 worker threads was measured: no faster than the runtime's pageable path,
         // profiles/r02_e2e.md -- the page-cache reads bound both)
         if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->inf_file.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, s));
@@ -564,9 +571,49 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
         ia.file = ctx->inf_file.as<uint8_t>(); ia.coff = d_coff; ia.csize = d_csize; ia.isize = d_isize; ia.uoff = d_uoff;
         ia.n_blocks = (uint32_t)nb; ia.out = ctx->inf_raw.as<uint8_t>(); ia.err = &ctx->d_state->err;
         { static const int fast = [] { const char *e = getenv("METHEOR_INFLATE_ASM"); return e ? atoi(e) : 1; }(); ia.fast_literals = fast; }
-        {
+        auto launch = [&](size_t b0, size_t b1) {       // blocks [b0, b1): absolute output offsets, so a launch is any run of blocks
+            InflArgs x = ia;
+            x.coff = d_coff + b0; x.csize = d_csize + b0; x.isize = d_isize + b0; x.uoff = d_uoff + b0; x.n_blocks = (uint32_t)(b1 - b0);
             LaunchTimer lt(ctx, K_INFLATE);
-            hipLaunchKernelGGL(k_inflate, dim3((uint32_t)nb), dim3(64), 0, s, ia);
+            hipLaunchKernelGGL(k_inflate, dim3(x.n_blocks), dim3(64), 0, s, x);
+        };
+        if (pieced) {
+            if (!ctx->piece_stream) MTH_HIP(ctx, hipStreamCreateWithFlags(&ctx->piece_stream, hipStreamNonBlocking));
+            auto event = [&](size_t k) -> hipError_t {
+                while (ctx->piece_ev.size() <= k) {
+                    hipEvent_t e = nullptr;
+                    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                    if (rc != hipSuccess) return rc;
+                    ctx->piece_ev.push_back(e);
+                }
+                return hipSuccess;
+            };
+            // whatever the compute stream still runs on the old contents of the buffer comes first
+            MTH_HIP(ctx, event(0));
+            MTH_HIP(ctx, hipEventRecord(ctx->piece_ev[0], s));
+            MTH_HIP(ctx, hipStreamWaitEvent(ctx->piece_stream, ctx->piece_ev[0], 0));
+            uint8_t *const dst = static_cast<uint8_t *>(ctx->inf_file.p);
+            const uint8_t *const src = static_cast<const uint8_t *>(file);
+            size_t off = 0, bl = 0, k = 1;
+            while (off < (size_t)n_bytes) {
+                size_t len = std::min(piece_bytes, (size_t)n_bytes - off);
+                if ((size_t)n_bytes - off - len < piece_bytes / 2) len = (size_t)n_bytes - off;     // no stub piece at the end
+                MTH_HIP(ctx, hipMemcpyAsync(dst + off, src + off, len, hipMemcpyHostToDevice, ctx->piece_stream));
+                off += len;
+                const bool last = off == (size_t)n_bytes;
+                if (last) MTH_HIP(ctx, hipMemsetAsync(dst + n_bytes, 0, 64, ctx->piece_stream));
+                MTH_HIP(ctx, event(k));
+                MTH_HIP(ctx, hipEventRecord(ctx->piece_ev[k], ctx->piece_stream));
+                MTH_HIP(ctx, hipStreamWaitEvent(s, ctx->piece_ev[k], 0));
+                ++k;
+                // the blocks whose payload -- and the 64 bytes the bit reader may load past it -- have arrived
+                size_t b1 = bl;
+                while (b1 < nb && (last || coff[b1] + (uint64_t)csize[b1] + 64u <= (uint64_t)off)) ++b1;
+                if (b1 > bl) launch(bl, b1);
+                bl = b1;
+            }
+        } else {
+            launch(0, nb);
         }
         // CRC32 of every inflated block against the gzip trailer (the 4 bytes after the payload)
         for (size_t i = 0; i < nb; ++i)
