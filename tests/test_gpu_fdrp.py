@@ -271,3 +271,18 @@ def test_max_depth_above_64(eng):
         run_device(eng, [very], dict(min_qual=10, min_depth=5, max_depth=16385, min_overlap=20))
     assert e.value.status == -8
     eng.reset()
+
+
+def test_wgbs_depth(eng):
+    """BASELINE config 3 in small (density 0.0091, ~10x, a dozen candidate reads per site): bit for bit the oracle's fdrp / qfdrp
+    columns, including max_depth below the depth (reservoir, shared draw) and min_depth 1 (one-read sites: 0 / 0 = NaN rows)"""
+    from metheor_amd import synth
+    c = synth.make_contig(2, 3_000_000, 200_000, 0.0091, np.random.default_rng(77))
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    for kw in (dict(min_qual=10, min_depth=10, max_depth=40, min_overlap=35),
+               dict(min_qual=10, min_depth=4, max_depth=40, min_overlap=35),
+               dict(min_qual=0, min_depth=1, max_depth=64, min_overlap=0),
+               dict(min_qual=10, min_depth=2, max_depth=5, min_overlap=20, seed=99)):
+        n, nf, nq = check(run_device(eng, [c], kw, device="cuda:0"), reads, kw)
+        print("wgbs depth", kw, "rows", n, "not bit-identical:", nf, nq)
+        assert n > 10000 and nf == 0 and nq == 0
