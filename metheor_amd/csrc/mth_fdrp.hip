@@ -64,6 +64,7 @@ struct FdrpArgs {
     uint32_t *rows_scratch;           // SLOTS = 0: slots_cap rows of (4 + FD_NB) words per wave of the launch
     const uint16_t *pair_tab;         // SLOTS = 64: (i | j << 8) of the k-th pair of n reads at [n (n-1) (n-2) / 6 + k], n <= 64
     uint32_t slots_cap;
+    uint32_t only_flag;               // SLOTS = 64: 0 = every site, else only the sites k_fdrp_walk4 left with this flag
 };
 
 // the oracle's orc_sample_j: splitmix64 over (seed, tid, pos, total) -> 1..=total
@@ -111,8 +112,12 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
     // position -- so a site whose count is below min_depth cannot produce a row (fdrp.rs:239-243) and is not walked: at
     // WGBS depths (config 3: 9.7x against -d 10) that is more than half of the sites.  The count of the wave's NEXT site is
     // requested one site ahead, so a run of skipped sites is not a run of exposed round trips.
+    // (after k_fdrp_walk4 -- only_flag set -- the prefetched word says "handed back" instead: 0 = not this pass's site)
+    auto site_key = [&](const uint32_t jx) -> uint32_t {
+        return a.only_flag ? (a.flags[jx] == a.only_flag ? 0xffffffffu : 0u) : a.site_nc[jx] + a.site_nd[jx];
+    };
     uint32_t cov_j = 0;
-    if (SLOTS == 64 && wave_id < n_sites) cov_j = a.site_nc[wave_id] + a.site_nd[wave_id];
+    if (SLOTS == 64 && wave_id < n_sites) cov_j = site_key(wave_id);
     // (A site pipeline -- the wave holding this site's position and index entries and the next site's position as scalars,
     // requesting the next site's index entries and the position two sites ahead at the top of a site -- was built twice: on dense
     // data it changes nothing (1.4856 vs 1.4861 ms; 1.3456 vs 1.3383), at WGBS depth it is slower (0.880 -> 0.930 ms on a
@@ -121,8 +126,9 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
         if (SLOTS == 64) {
             const uint32_t cov = sgpr(cov_j);
             const uint32_t jn = j + n_waves;
-            if (jn < n_sites) cov_j = a.site_nc[jn] + a.site_nd[jn];
-            if (cov < a.min_depth) {
+            if (jn < n_sites) cov_j = site_key(jn);
+            if (a.only_flag) { if (cov == 0u) continue; }                   // k_fdrp_walk4 ran first: only what it handed back
+            else if (cov < a.min_depth) {
                 if (lane == 0) { a.fdrp[j] = 0.0f; a.qfdrp[j] = 0.0f; a.nreads[j] = 0u; a.flags[j] = 0u; }
                 continue;
             }
@@ -531,6 +537,220 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
 
 #undef MTH_FD_FINISH
 
+// ---------------------------------------------------------------------------------------------
+// WGBS depth (config 3: ~10x, a dozen candidate reads per site): the wave-per-site walk above fills a fifth of its lanes
+// and pays its whole chain of dependent round trips -- site, index entries, candidate fields, calls -- per site.  Here a wave
+// takes 64 / GL consecutive sites (GL = 16 or 32 lanes each): lane = candidate read of its site, the hit lanes turn their
+// calls into the three 64-bit masks of the compact finalize themselves and store them at slot = arrival order, then lane k
+// of a site takes the site's k-th, (k + GL)-th ... pair (pair index from an LDS copy of the pair table: no load in the
+// round loop).  The qFDRP terms of a round are chained in the reference's (i, j) order inside each site's lanes (DPP
+// wave_shr:1: x[l] = x[l-1] + term[l], a skipped pair adds +0.0; the lane read after s steps depends on the s lanes below
+// it only, all of its own site).
+// Only the common shape is handled: one chunk (<= GL candidates), calls in registers (<= 8 per candidate), the "hits, then
+// reads past c + 1" order, at most max_depth hits, spans <= 200 bp (host side), the 64 sites around c covering +-200 bp.
+// Anything else is handed back (flags = 4) and done by k_fdrp_walk<8, 64> with only_flag = 4 -- same results either way.
+constexpr uint32_t FD_REDO = 4u;
+template <int GL>      // lanes (= candidate reads, stored reads, pairs per round) of a site: 16 or 32
+__global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
+    constexpr int NG = 64 / GL, WS = 64 / GL;      // sites per wave; sites of the 64-site window per lane
+    constexpr uint32_t GMASK = GL == 32 ? 0xffffffffu : (1u << GL) - 1u;
+    constexpr int NTAB = (GL + 1) * GL * (GL - 1) / 6;   // pairs of n = 2..GL stored reads, one list after the other
+    const int lane = threadIdx.x & 63, gl = lane & (GL - 1), row0 = lane & ~(GL - 1), g = lane / GL, wave = threadIdx.x >> 6;
+    const uint32_t wave_id = sgpr((uint32_t)((blockIdx.x * 256 + threadIdx.x) >> 6)), n_waves = (gridDim.x * 256) >> 6;
+    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    __shared__ uint8_t s_bit[4][NG][2 * FD_WIN + 1 + 13];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[4][NG][GL * 8];   // per slot: start, end, mC, mA, mM
+    __shared__ uint16_t s_tab[NTAB + 1];
+    for (int t = threadIdx.x; t < NTAB; t += 256) s_tab[t] = a.pair_tab[t];
+    if (threadIdx.x == 0) s_tab[NTAB] = 0;
+    __syncthreads();
+    uint8_t *const bit_of = s_bit[wave][g];
+    uint32_t *const rows = s_rows[wave][g];
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    __shared__ uint32_t s_list[4][64];
+    uint32_t *const list = s_list[wave];
+    // A wave takes 64 consecutive sites at a time, lane = site: the sites whose count is below min_depth cannot produce a row
+    // (fdrp.rs:239-243; more than half of them at config-3 depth) and get their empty result here, the others are packed into
+    // a list and walked NG at a time -- every site of a step is one that needs the walk.
+    for (uint32_t blk = wave_id; (uint64_t)blk * 64u < n_sites; blk += n_waves) {
+        uint32_t n_act;
+        {
+            const uint32_t jl = blk * 64u + (uint32_t)lane;
+            const bool in = jl < n_sites;
+            const uint32_t cov_l = in ? a.site_nc[jl] + a.site_nd[jl] : 0u;
+            const bool active = in && cov_l >= a.min_depth;
+            if (in && !active) { a.fdrp[jl] = 0.0f; a.qfdrp[jl] = 0.0f; a.nreads[jl] = 0u; a.flags[jl] = 0u; }
+            const unsigned long long m_act = __ballot(active);
+            n_act = (uint32_t)__popcll(m_act);
+            __builtin_amdgcn_wave_barrier();                                     // the previous block's list reads are done
+            if (active) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_act, 0u))] = jl;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    for (uint32_t t0 = 0; t0 < n_act; t0 += (uint32_t)NG) {
+        const bool jv = t0 + (uint32_t)g < n_act;
+        const uint32_t j = list[jv ? t0 + (uint32_t)g : t0];
+        const uint32_t jj = j;
+        const int32_t c = a.site_pos[jj];
+        const bool act = jv;                                                // site-uniform (as everything named per site below)
+        bool redo = false;
+        // the 64 sites around c, WS per lane
+        const uint32_t j0w = (jj >= 32u) ? min(jj - 32u, n_sites > 64u ? n_sites - 64u : 0u) : 0u;
+        int32_t sp[WS];
+#pragma unroll
+        for (int t = 0; t < WS; ++t) { const uint32_t si = j0w + (uint32_t)(WS * gl + t); sp[t] = si < n_sites ? a.site_pos[si] : 0x7fffffff; }
+        const uint32_t lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
+        const uint32_t hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        redo = redo || hi - lo > 2u * (uint32_t)GL || a.n_cpgs < 8u;
+        {
+            const int32_t sp_first = __shfl(sp[0], row0, 64), sp_last = __shfl(sp[WS - 1], row0 | (GL - 1), 64);
+            const bool compact = (int64_t)c - 200 >= a.region_beg && (int64_t)c + 200 < a.region_end &&
+                                 (j0w == 0u || sp_first < c - 200) && (int64_t)sp_last > (int64_t)c + 200;   // absent sites read as +inf
+            redo = redo || !compact;
+        }
+#pragma unroll
+        for (int t = 0; t < WS; ++t) {
+            const uint32_t rel = (uint32_t)(sp[t] - (c - FD_WIN));
+            if (rel <= 2u * FD_WIN) bit_of[rel] = (uint8_t)(WS * gl + t);
+        }
+        // Candidates.  The index hands out whole 32-bp quanta: up to 2 GL reads, two per lane, of which those starting before
+        // c - max_span + 1 (they end before c: neither a call at c nor a first call past it) and those starting past c + 1 (a read
+        // calls [start - 1, end]: no call at c; they could only flush after every hit, which changes nothing here) are inert.
+        // Reads are sorted by start, so the inert ones are a prefix and a suffix; the rest -- GL at most, else the site is handed
+        // back -- moves to lanes 0.. of the site by two lane permutes per field.
+        const uint32_t n_idx = hi - lo;
+        const bool vA = act && !redo && (uint32_t)gl < n_idx, vB = act && !redo && (uint32_t)(GL + gl) < n_idx;
+        const uint32_t iA = vA ? lo + (uint32_t)gl : 0u, iB = vB ? lo + (uint32_t)(GL + gl) : 0u;
+        const uint32_t oA0 = a.cpg_off[iA], oA1 = a.cpg_off[iA + 1], oB0 = a.cpg_off[iB], oB1 = a.cpg_off[iB + 1];
+        const int32_t sA = a.read_start[iA], sB = a.read_start[iB], eA = a.read_end[iA], eB = a.read_end[iB];
+        const uint32_t mqA = a.read_mapq[iA], mqB = a.read_mapq[iB];
+        const int32_t s_min = c - a.max_span + 1;
+        auto site_count = [&](const bool p) { return (uint32_t)__builtin_popcount((uint32_t)(__ballot(p) >> row0) & GMASK); };
+        const uint32_t below = site_count(vA && sA < s_min) + site_count(vB && sB < s_min);
+        const uint32_t above = site_count(vA && sA > c + 1) + site_count(vB && sB > c + 1);
+        const uint32_t n_c = (act && !redo) ? n_idx - below - above : 0u;
+        redo = redo || n_c > (uint32_t)GL;
+        const uint32_t kk = below + (uint32_t)gl;
+        const bool fromB = kk >= (uint32_t)GL;
+        const int src = row0 | (int)(kk & (uint32_t)(GL - 1));
+        auto pick = [&](const uint32_t xa, const uint32_t xb) { const uint32_t ya = __shfl(xa, src, 64), yb = __shfl(xb, src, 64); return fromB ? yb : ya; };
+        const bool valid = act && !redo && (uint32_t)gl < n_c;
+        const uint32_t o0 = pick(oA0, oB0), o1 = pick(oA1, oB1);
+        const int32_t cs_raw = (int32_t)pick((uint32_t)sA, (uint32_t)sB), ce_raw = (int32_t)pick((uint32_t)eA, (uint32_t)eB);
+        const uint32_t mq = pick(mqA, mqB);
+        const uint32_t n = o1 - o0;
+        const bool pass = valid & (mq >= (uint32_t)a.min_qual) & (n > 0u);  // fdrp.rs:205, 208
+        const int32_t cs = pass ? cs_raw : 0, ce = pass ? ce_raw : 0;
+        uint32_t cw[8];
+        {
+            // (a candidate whose 8-word window would cross the end of the call array, or with more than 8 calls: handed back)
+            const bool edge = pass && ((uint64_t)o0 + 8u > (uint64_t)a.n_cpgs || n > 8u);
+            const uint32_t ob = a.n_cpgs >= 8u ? min(o0, a.n_cpgs - 8u) : 0u;
+            u32x4_a4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+            if (a.n_cpgs >= 8u) {                                               // wave-uniform
+                v0 = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + ob);
+                if (__any(pass && n > 4u)) v1 = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + ob + 4u);
+            }
+            cw[0] = v0.x; cw[1] = v0.y; cw[2] = v0.z; cw[3] = v0.w; cw[4] = v1.x; cw[5] = v1.y; cw[6] = v1.z; cw[7] = v1.w;
+            const unsigned long long m_edge = __ballot(edge);
+            redo = redo || ((uint32_t)(m_edge >> row0) & GMASK) != 0u;
+        }
+#pragma unroll
+        for (int k = 1; k < 8; ++k) cw[k] = ((uint32_t)k < n) ? cw[k] : cw[0];
+        bool hit;
+        {
+            uint32_t mn = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mn = min(mn, (cw[k] ^ (uint32_t)c) & 0x7fffffffu);
+            hit = mn == 0u;
+        }
+        const uint32_t mh = (uint32_t)(__ballot(pass && hit) >> row0) & GMASK;
+        const uint32_t mf = (uint32_t)(__ballot(pass && c < (int32_t)(cw[0] & 0x7fffffffu)) >> row0) & GMASK;   // c < first call, fdrp.rs:212
+        const int n_hit = __builtin_popcount(mh);
+        const int first_flush = mf ? __builtin_ctz(mf) : GL;
+        const int32_t cs_flush = __shfl(cs, row0 | (first_flush & (GL - 1)), 64);
+        const bool fast = (uint32_t)n_hit <= a.max_depth && (mh == 0u || 31 - __builtin_clz(mh) < first_flush) && (mf == 0u || cs_flush > c + 1);
+        redo = redo || !fast;
+        // fdrp.rs:239-243: the open segment is evaluated when it holds >= min_depth reads (and exists at all)
+        const bool fin = act && !redo && mh != 0u && (uint32_t)n_hit >= a.min_depth;
+        const int nS = fin ? n_hit : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (fin && pass && hit) {
+            unsigned long long mC = 0, mM = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t rel_p = (cw[k] & 0x7fffffffu) - (uint32_t)(c - FD_WIN);
+                const unsigned long long b = 1ull << bit_of[rel_p];
+                mC |= b;
+                mM |= b & (unsigned long long)((long long)(int32_t)cw[k] >> 31);
+            }
+            const uint32_t p0 = cw[0] & 0x7fffffffu;
+            const unsigned long long b0 = 1ull << bit_of[p0 - (uint32_t)(c - FD_WIN)];
+            const unsigned long long mA = ((int32_t)p0 >= cs) ? mC : mC & ~b0;   // the one call that can lie outside the covered bases: start - 1
+            mM &= mA;
+            uint32_t *r = rows + 8 * __builtin_popcount(mh & ((1u << gl) - 1u));   // slot = arrival order
+            r[0] = (uint32_t)cs; r[1] = (uint32_t)ce;
+            r[2] = (uint32_t)mC; r[3] = (uint32_t)(mC >> 32); r[4] = (uint32_t)mA; r[5] = (uint32_t)(mA >> 32);
+            r[6] = (uint32_t)mM; r[7] = (uint32_t)(mM >> 32);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // pairs: lane k of the site takes pairs k, k + GL, ... of the reference's (i, j) order (fdrp.rs:129-141)
+        const int P = (nS * (nS - 1)) >> 1;
+        const int rg = (P + GL - 1) / GL;
+        int rounds = 0;
+#pragma unroll
+        for (int w = 0; w < NG; ++w) rounds = max(rounds, __builtin_amdgcn_readlane(rg, w * GL));
+        const uint16_t *const tab = s_tab + (uint32_t)(nS > 2 ? nS * (nS - 1) * (nS - 2) : 0) / 6u;
+        uint32_t disc = 0;
+        float q = 0.0f;
+        for (int r = 0; r < rounds; ++r) {
+            const int k = GL * r + gl;
+            const uint32_t ent = tab[P ? min(k, P - 1) : 0];
+            const int pi = (int)(ent & 0xffu) & (GL - 1), pj = (int)(ent >> 8) & (GL - 1);
+            const uint32_t *ri = rows + pi * 8, *rj = rows + pj * 8;
+            const int32_t si = (int32_t)ri[0], ei = (int32_t)ri[1], sj = (int32_t)rj[0], ej = (int32_t)rj[1];
+            const int32_t ov = min(ei, ej) - max(si, sj) + 1;                  // get_num_overlap_bases, fdrp.rs:97-107
+            const bool pair_ok = (k < P) & (max(ov, 0) >= a.min_overlap);        // fdrp.rs:134
+            const uint32_t ncpg = __builtin_popcount(ri[2] & rj[2]) + __builtin_popcount(ri[3] & rj[3]);   // qfdrp.rs:109-119
+            const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) +
+                                 __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));                      // fdrp.rs:114-115
+            disc += (pair_ok && ham != 0u) ? 1u : 0u;                            // fdrp.rs:138-140
+            const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;        // qfdrp.rs:152; +0.0 for skipped pairs
+            const unsigned long long nz = __ballot(term != 0.0f);
+            if (nz == 0ull) continue;                                            // wave-uniform: x + 0.0 == x
+            // chain length: the highest lane of any site that holds a non-zero term (later lanes add +0.0: exact)
+            int steps = 0;
+#pragma unroll
+            for (int w = 0; w < NG; ++w) { const uint32_t m = (uint32_t)(nz >> (GL * w)) & GMASK; steps = max(steps, m ? 31 - __builtin_clz(m) : 0); }
+            float x = (gl == 0) ? q + term : term;
+            for (int st = 0; st < steps; ++st)
+                x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)) + term;
+            q = __shfl(x, row0 | steps, 64);
+        }
+        uint32_t n_disc = disc;
+#pragma unroll
+        for (int o = GL / 2; o > 0; o >>= 1) n_disc += __shfl_xor(n_disc, o, 64);  // within the site's lanes
+        if (gl == 0 && jv) {
+            float res_f = 0.0f, res_q = 0.0f;
+            uint32_t res_n = 0u, fl = 0u;
+            if (fin) {
+                // (num_reads * (num_reads - 1)) as f32 / 2.0 in usize arithmetic (fdrp.rs:143)
+                const unsigned long long prod = (unsigned long long)(long long)nS * (unsigned long long)((long long)nS - 1);
+                const float den = (float)prod / 2.0f;
+                res_f = (float)n_disc / den; res_q = q / den; res_n = (uint32_t)nS; fl = 1u;
+            } else if (act && redo) fl = FD_REDO;
+            a.fdrp[j] = res_f; a.qfdrp[j] = res_q; a.nreads[j] = res_n; a.flags[j] = fl;
+        }
+        __builtin_amdgcn_wave_barrier();                                         // LDS reads done before the next sites' writes
+    }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fdrp_emit(const uint32_t *__restrict__ flags, const int32_t *__restrict__ site_pos,
                                                    const float *__restrict__ f, const float *__restrict__ q,
                                                    const uint32_t *__restrict__ nr, const DevState *__restrict__ sites_st,
@@ -633,8 +853,24 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         // dense CpGs (hotspots, RRBS): 16 call registers per stored read keep the per-call match out of
         // the memory loop; sparse WGBS keeps 8 (half the compares per call)
         const bool dense = d.n_reads && ((double)d.n_cpgs / (double)d.n_reads) > 6.0;
+        // WGBS depth: when a site has about a dozen reads that can call it (reads starting in [c - max_span + 1, c + 1]), four
+        // sites share a wave (k_fdrp_walk4<16>) and the general walk only redoes what that kernel handed back.  Measured on a
+        // chr1-sized contig (profiles/r02_fdrp_walk4.md): ~10 such reads per site 0.887 -> 0.568 ms, ~19.5 per site 1.95 -> 2.17
+        // (16 lanes) / 2.13 (32 lanes) -- deeper sites are bound by their pair rounds and keep the wave-per-site walk.
+        // METHEOR_FDRP_WALK4=0 / 16 / 32 (1 = 16) forces the choice (A/B, tests).
+        const double cand = (double)d.n_reads * ((double)d.max_span + 2.0) / std::max<double>(1.0, (double)d.region_end - (double)d.region_beg);
+        int walk4 = (!dense && d.max_span <= 200 && cand <= 12.0) ? 16 : 0;                                 // lanes per site
+        if (const char *e = getenv("METHEOR_FDRP_WALK4")) { const int k = atoi(e); walk4 = d.max_span <= 200 ? (k == 1 ? 16 : (k == 16 || k == 32 ? k : 0)) : 0; }
+        a.only_flag = 0u;
+        if (walk4) {
+            const uint32_t grid4 = (uint32_t)std::min<uint64_t>((bound + 255) / 256, 16384);   // 4 waves x 64 sites per block and step
+            if (walk4 == 16) hipLaunchKernelGGL(k_fdrp_walk4<16>, dim3(grid4), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(k_fdrp_walk4<32>, dim3(grid4), dim3(256), 0, s, a);
+            a.only_flag = FD_REDO;
+        }
         if (dense) hipLaunchKernelGGL((k_fdrp_walk<16, 64>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_fdrp_walk<8, 64>), dim3(grid), dim3(256), 0, s, a);
+        a.only_flag = 0u;
         // max_depth > 64: the sites that held more than 64 reads at once were flagged, not computed: 256-slot pass over them
         if (params->max_depth > 64) hipLaunchKernelGGL((k_fdrp_walk<8, FD_SLOTS_DEEP>), dim3(grid), dim3(256), 0, s, a);
         // max_depth > 256: what the 256-slot pass flagged again, with max_depth rows per wave in HBM scratch (as many waves as

@@ -17,6 +17,17 @@ f32 = np.float32
 TOL = 1e-6
 
 
+@pytest.fixture(autouse=True, params=["auto", "walk16", "walk32"])
+def walk_choice(request, monkeypatch):
+    """every case three times: with the host's own choice between the wave-per-site walk and k_fdrp_walk4 (16 or 32 lanes per
+    site, the rest handed back to the general walk), and with either width forced -- on dense data mostly the hand-back path"""
+    if request.param != "auto":
+        monkeypatch.setenv("METHEOR_FDRP_WALK4", request.param[4:])
+    else:
+        monkeypatch.delenv("METHEOR_FDRP_WALK4", raising=False)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def eng():
     import metheor_amd
