@@ -74,6 +74,24 @@ def scenario(seed):
     return rng, cs, regions, read_len
 
 
+def fdrp_checked(eng, cs, fk, regions, reads):
+    """FDRP / qFDRP against the oracle, then once more with k_fdrp_walk4 (four sites per wave, hand-back to the general walk) forced
+    on: the same rows bit for bit"""
+    import os
+    d0 = T_fdrp.run_device(eng, cs, fk, regions=regions)
+    T_fdrp.check(d0, reads, fk)
+    os.environ["METHEOR_FDRP_WALK4"] = "16"
+    try:
+        d1 = T_fdrp.run_device(eng, cs, fk, regions=regions)
+    finally:
+        del os.environ["METHEOR_FDRP_WALK4"]
+    assert len(d0["pos"]) == len(d1["pos"])
+    for k in ("tid", "pos", "n_reads"):
+        assert (d0[k] == d1[k]).all(), k
+    for k in ("fdrp", "qfdrp"):
+        assert (d0[k].view(np.uint32) == d1[k].view(np.uint32)).all(), k
+
+
 @pytest.mark.parametrize("seed", range(96))
 def test_random_scenario_all_measures(eng, seed):
     from metheor_amd import PdrLpmdParams, synth
@@ -111,7 +129,7 @@ def test_random_scenario_all_measures(eng, seed):
     if regions is not None and fcs is not cs:
         from metheor_amd import shard
         fregions = [[(b, e) for (b, e) in r] for r in regions]
-    T_fdrp.check(T_fdrp.run_device(eng, fcs, fk, regions=fregions), freads, fk)
+    fdrp_checked(eng, fcs, fk, fregions, freads)
 
 
 def shift_contig(c, off):
@@ -149,4 +167,4 @@ def test_high_coordinates(eng, seed, top):
     T_mhl.check(T_mhl.run_device(eng, [hc], mk, regions=region), reads, mk)
     if read_len <= 200:
         fk = dict(min_qual=mq, min_depth=2, max_depth=40, min_overlap=10, seed=1)
-        T_fdrp.check(T_fdrp.run_device(eng, [hc], fk, regions=region), reads, fk)
+        fdrp_checked(eng, [hc], fk, region, reads)
