@@ -855,11 +855,12 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         const bool dense = d.n_reads && ((double)d.n_cpgs / (double)d.n_reads) > 6.0;
         // WGBS depth: when a site has about a dozen reads that can call it (reads starting in [c - max_span + 1, c + 1]), four
         // sites share a wave (k_fdrp_walk4<16>) and the general walk only redoes what that kernel handed back.  Measured on a
-        // chr1-sized contig (profiles/r02_fdrp_walk4.md): ~10 such reads per site 0.887 -> 0.568 ms, ~19.5 per site 1.95 -> 2.17
+        // chr1-sized contig (profiles/r02_fdrp_walk4.md): ~10 such reads per site 0.887 -> 0.568 ms, 12 1.29 -> 0.94, 14.6 1.58 -> 1.39,
+        // 17 1.79 -> 1.83 (the switch is at 16), ~19.5 per site 1.95 -> 2.17
         // (16 lanes) / 2.13 (32 lanes) -- deeper sites are bound by their pair rounds and keep the wave-per-site walk.
         // METHEOR_FDRP_WALK4=0 / 16 / 32 (1 = 16) forces the choice (A/B, tests).
         const double cand = (double)d.n_reads * ((double)d.max_span + 2.0) / std::max<double>(1.0, (double)d.region_end - (double)d.region_beg);
-        int walk4 = (!dense && d.max_span <= 200 && cand <= 12.0) ? 16 : 0;                                 // lanes per site
+        int walk4 = (!dense && d.max_span <= 200 && cand <= 16.0) ? 16 : 0;                                 // lanes per site
         if (const char *e = getenv("METHEOR_FDRP_WALK4")) { const int k = atoi(e); walk4 = d.max_span <= 200 ? (k == 1 ? 16 : (k == 16 || k == 32 ? k : 0)) : 0; }
         a.only_flag = 0u;
         if (walk4) {
