@@ -669,8 +669,10 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
         const uint32_t mf = (uint32_t)(__ballot(pass && c < (int32_t)(cw[0] & 0x7fffffffu)) >> row0) & GMASK;   // c < first call, fdrp.rs:212
         const int n_hit = __builtin_popcount(mh);
         const int first_flush = mf ? __builtin_ctz(mf) : GL;
-        const int32_t cs_flush = __shfl(cs, row0 | (first_flush & (GL - 1)), 64);
-        const bool fast = (uint32_t)n_hit <= a.max_depth && (mh == 0u || 31 - __builtin_clz(mh) < first_flush) && (mf == 0u || cs_flush > c + 1);
+        // (the wave-per-site walk also wants the first flusher to start past c + 1, because it stops looking at that read; here the
+        // site's lanes hold EVERY read that starts at or before c + 1, so "no hit after the first flusher" is checked, not inferred:
+        // the segment the flusher closes is the one evaluated, nothing re-opens it -- fdrp.rs:212-223)
+        const bool fast = (uint32_t)n_hit <= a.max_depth && (mh == 0u || 31 - __builtin_clz(mh) < first_flush);
         redo = redo || !fast;
         // fdrp.rs:239-243: the open segment is evaluated when it holds >= min_depth reads (and exists at all)
         const bool fin = act && !redo && mh != 0u && (uint32_t)n_hit >= a.min_depth;
