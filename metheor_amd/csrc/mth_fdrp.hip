@@ -64,7 +64,8 @@ struct FdrpArgs {
     uint32_t *rows_scratch;           // SLOTS = 0: slots_cap rows of (4 + FD_NB) words per wave of the launch
     const uint16_t *pair_tab;         // SLOTS = 64: (i | j << 8) of the k-th pair of n reads at [n (n-1) (n-2) / 6 + k], n <= 64
     uint32_t slots_cap;
-    uint32_t only_flag;               // SLOTS = 64: 0 = every site, else only the sites k_fdrp_walk4 left with this flag
+    uint32_t only_flag;               // SLOTS = 64: 0 = every site, else only the sites k_fdrp_walk4 handed back
+    unsigned long long *redo_mask;    // per block of 64 consecutive sites: the sites k_fdrp_walk4 handed back (written for every block)
 };
 
 // the oracle's orc_sample_j: splitmix64 over (seed, tid, pos, total) -> 1..=total
@@ -112,23 +113,39 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
     // position -- so a site whose count is below min_depth cannot produce a row (fdrp.rs:239-243) and is not walked: at
     // WGBS depths (config 3: 9.7x against -d 10) that is more than half of the sites.  The count of the wave's NEXT site is
     // requested one site ahead, so a run of skipped sites is not a run of exposed round trips.
-    // (after k_fdrp_walk4 -- only_flag set -- the prefetched word says "handed back" instead: 0 = not this pass's site)
-    auto site_key = [&](const uint32_t jx) -> uint32_t {
-        return a.only_flag ? (a.flags[jx] == a.only_flag ? 0xffffffffu : 0u) : a.site_nc[jx] + a.site_nd[jx];
-    };
+    // (after k_fdrp_walk4 -- only_flag set -- the pass walks the set bits of that kernel's per-block hand-back masks instead: one
+    // word per 64 sites to look at, not one per site)
+    const bool listed = SLOTS == 64 && a.only_flag != 0u;
     uint32_t cov_j = 0;
-    if (SLOTS == 64 && wave_id < n_sites) cov_j = site_key(wave_id);
+    if (SLOTS == 64 && !listed && wave_id < n_sites) cov_j = a.site_nc[wave_id] + a.site_nd[wave_id];
+    uint32_t l_blk = wave_id, l_cur = 0;
+    unsigned long long l_m = 0;
     // (A site pipeline -- the wave holding this site's position and index entries and the next site's position as scalars,
     // requesting the next site's index entries and the position two sites ahead at the top of a site -- was built twice: on dense
     // data it changes nothing (1.4856 vs 1.4861 ms; 1.3456 vs 1.3383), at WGBS depth it is slower (0.880 -> 0.930 ms on a
     // 16 M-read chr1-sized contig): a site's time is instruction issue, not this chain's latency.)
-    for (uint32_t j = wave_id; j < n_sites; j += n_waves) {
-        if (SLOTS == 64) {
+    for (uint32_t it = wave_id;; it += n_waves) {
+        uint32_t j;
+        if (listed) {
+            bool end = false;
+            while (l_m == 0ull) {
+                if ((uint64_t)l_blk * 64u >= n_sites) { end = true; break; }
+                const unsigned long long w = a.redo_mask[l_blk];
+                l_m = ((unsigned long long)sgpr((uint32_t)(w >> 32)) << 32) | sgpr((uint32_t)w);
+                l_cur = l_blk; l_blk += n_waves;
+            }
+            if (end) break;
+            j = l_cur * 64u + (uint32_t)__builtin_ctzll(l_m);
+            l_m &= l_m - 1ull;
+        } else {
+            j = it;
+            if (j >= n_sites) break;
+        }
+        if (SLOTS == 64 && !listed) {
             const uint32_t cov = sgpr(cov_j);
             const uint32_t jn = j + n_waves;
-            if (jn < n_sites) cov_j = site_key(jn);
-            if (a.only_flag) { if (cov == 0u) continue; }                   // k_fdrp_walk4 ran first: only what it handed back
-            else if (cov < a.min_depth) {
+            if (jn < n_sites) cov_j = a.site_nc[jn] + a.site_nd[jn];
+            if (cov < a.min_depth) {
                 if (lane == 0) { a.fdrp[j] = 0.0f; a.qfdrp[j] = 0.0f; a.nreads[j] = 0u; a.flags[j] = 0u; }
                 continue;
             }
@@ -588,6 +605,7 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+    unsigned long long redo_bits = 0;
     for (uint32_t t0 = 0; t0 < n_act; t0 += (uint32_t)NG) {
         const bool jv = t0 + (uint32_t)g < n_act;
         const uint32_t j = list[jv ? t0 + (uint32_t)g : t0];
@@ -748,8 +766,14 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
             } else if (act && redo) fl = FD_REDO;
             a.fdrp[j] = res_f; a.qfdrp[j] = res_q; a.nreads[j] = res_n; a.flags[j] = fl;
         }
+        {   // the step's handed-back sites, as bits of the block's mask (wave-uniform)
+            const uint32_t rel = (act && redo) ? (j - blk * 64u) + 1u : 0u;
+#pragma unroll
+            for (int w = 0; w < NG; ++w) { const uint32_t r1 = __builtin_amdgcn_readlane(rel, w * GL); if (r1) redo_bits |= 1ull << (r1 - 1u); }
+        }
         __builtin_amdgcn_wave_barrier();                                         // LDS reads done before the next sites' writes
     }
+        if (lane == 0) a.redo_mask[blk] = redo_bits;
     }
 }
 
@@ -864,8 +888,10 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         const double cand = (double)d.n_reads * ((double)d.max_span + 2.0) / std::max<double>(1.0, (double)d.region_end - (double)d.region_beg);
         int walk4 = (!dense && d.max_span <= 200 && cand <= 16.0) ? 16 : 0;                                 // lanes per site
         if (const char *e = getenv("METHEOR_FDRP_WALK4")) { const int k = atoi(e); walk4 = d.max_span <= 200 ? (k == 1 ? 16 : (k == 16 || k == 32 ? k : 0)) : 0; }
-        a.only_flag = 0u;
+        a.only_flag = 0u; a.redo_mask = nullptr;
         if (walk4) {
+            MTH_HIP(ctx, ctx->f_redo.reserve((bound / 64 + 2) * 8, s));
+            a.redo_mask = ctx->f_redo.as<unsigned long long>();
             const uint32_t grid4 = (uint32_t)std::min<uint64_t>((bound + 255) / 256, 16384);   // 4 waves x 64 sites per block and step
             if (walk4 == 16) hipLaunchKernelGGL(k_fdrp_walk4<16>, dim3(grid4), dim3(256), 0, s, a);
             else hipLaunchKernelGGL(k_fdrp_walk4<32>, dim3(grid4), dim3(256), 0, s, a);
