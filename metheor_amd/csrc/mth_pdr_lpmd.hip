@@ -24,6 +24,7 @@
 // Roofline: integer streaming + LDS atomics, HBM-bound by design (no MFMA: there is no
 // contraction here).  Algorithmic bytes: 16 B/read + 5 B/CpG call in, 12 B/site out.
 #include "mth_ctx.h"
+#include "mth_tile_dev.h"
 
 #ifndef MTH_TILE_PF
 #define MTH_TILE_PF 1
@@ -157,27 +158,6 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// DPP controls (gfx9 family): no LDS traffic, one VALU per step
-#define MTH_DPP(v, ctrl, rmask, bctl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, (bctl)))
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {   // wave-uniform result
-    v += MTH_DPP(v, 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, true);
-    v += MTH_DPP(v, 0x4e /*quad_perm [2,3,0,1]*/, 0xf, true);
-    v += MTH_DPP(v, 0x141 /*row_half_mirror*/, 0xf, true);
-    v += MTH_DPP(v, 0x140 /*row_mirror*/, 0xf, true);          // every lane: sum of its row of 16
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
-           __builtin_amdgcn_readlane(v, 48);
-}
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
-    v += MTH_DPP(v, 0x111 /*row_shr:1*/, 0xf, true);
-    v += MTH_DPP(v, 0x112 /*row_shr:2*/, 0xf, true);
-    v += MTH_DPP(v, 0x114 /*row_shr:4*/, 0xf, true);
-    v += MTH_DPP(v, 0x118 /*row_shr:8*/, 0xf, true);
-    v += MTH_DPP(v, 0x142 /*row_bcast:15*/, 0xa, false);
-    v += MTH_DPP(v, 0x143 /*row_bcast:31*/, 0xc, false);
-    return v;
-}
-
-constexpr int TILE_BUCKET_SHIFT = 8;   // 256 tiles per bucket
 // LPMD per-tile partials: wave DPP reduce -> LDS -> one atomic per counter into the tile's bucket (256 tiles share
 // an address; the per-read counts never touch global memory)
 // A wave reduction is ~50 issue cycles (4 DPP adds, 4 readlanes) and a tile is only ~3 reads per lane: the four sums are taken
@@ -275,9 +255,6 @@ __device__ __forceinline__ uint32_t tile_compact(const TileArgs &a, const uint32
     return total;
 }
 
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
-typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
 // NB relative positions of a read with one load (global memory takes unaligned vector loads)
 template <typename RelT, int NB>
 __device__ __forceinline__ void load_rel(const RelT *__restrict__ rp, int32_t (&r)[NB]) {
@@ -299,34 +276,6 @@ __device__ __forceinline__ void load_rel(const RelT *__restrict__ rp, int32_t (&
         }
     }
 }
-
-// ---- per-slot liveness without compare + select (profiles/r02_ubench_valu.md: v_cmp, v_cndmask, v_min/max are half rate) ----
-// The live call slots of a read are a PREFIX (k < n), so everything that depends on "slot k is dead" is a function of n
-// alone and comes from two 9-row LDS tables (n = 0..8; built once per pass, 576 bytes):
-//   mtab[n][k]   0xffffffff if k < n else 0                       -> masks for the span check / dead-word insertion
-//   dtab[n][c]   relpos offsets of the packed fields (below) that push every dead slot 0x400 * (k + 1) past the live
-//                ones, so that any distance involving a dead slot is >= 0x400 - 255 and all distances stay >= 0
-// ---- windowed pair counts, two pairs per instruction (8-bit relpos) ----
-// Slots are packed two per register as 16-bit fields: Q_e = (slot 2e, slot 2e+1), O_e = (slot 2e+1, slot 2e+2), slot 8
-// being a dummy that is always dead.  The pairs at call-index gap g are then  later - earlier  with earlier = Q_m and
-// later = O_{(g-1)/2+m} (g odd) or Q_{g/2+m} (g even): one 32-bit subtraction gives two distances (no borrows: relpos
-// ascends with the slot, dead offsets ascend faster).  With A = D + (0x8000 - min) and B = (0x8000 + max) - D per
-// field, bit 15 of A & B says "min <= distance <= max"; the call states sit in bit 15 of a second set of packed words,
-// so one xor + and gives "in the window and discordant".  Only full-rate VALU ops (add / sub / and / xor / or / shift).
-struct SlotTabs {
-    uint32_t mtab[9][8];
-    uint32_t dtab[9][8];
-};
-__device__ __forceinline__ void slot_tabs_init(SlotTabs &T, const int tid) {
-    if (tid < 72) {
-        const uint32_t nn = (uint32_t)tid >> 3, c = (uint32_t)tid & 7u;
-        T.mtab[nn][c] = c < nn ? 0xffffffffu : 0u;
-        auto dead = [&](uint32_t k) { return k >= 8u ? 0x2400u : (k >= nn ? 0x400u * (k + 1u) : 0u); };
-        const uint32_t lo = c < 4 ? 2u * c : 2u * (c - 4u) + 1u;       // first slot of the packed register Q_c / O_(c-4)
-        T.dtab[nn][c] = dead(lo) | (dead(lo + 1u) << 16);
-    }
-}
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   // v_bfi_b32
 
 // One pass of a tile over its candidate reads [lo, hi): LDS counters for the reference positions
 // [P0, P0 + Wp), then compaction.  do_lp: also the LPMD pair counts and read totals of the reads the tile owns
@@ -798,6 +747,7 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &id
 }
 
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_params_t &p, const TileSink *sink) {
+    if (stream_eligible(b)) return launch_pdr_lpmd_stream(ctx, b, p, sink);
     hipStream_t s = ctx->stream;
     // where the compacted rows and their counters go: the PDR result columns by default, or a
     // caller-supplied sink (site discovery for the site-walk measures)

@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--len", type=int, default=248_956_422)
     ap.add_argument("--reads", type=int, default=16_000_000)
     ap.add_argument("--density", type=float, default=0.0091)
+    ap.add_argument("--only", default="", help="substring of the measure names to run")
     args = ap.parse_args()
     import metheor_amd
     from metheor_amd import synth
@@ -24,7 +25,9 @@ def main():
     for name, fn in (("me/pm", lambda: eng.quartet_accumulate(bt)), ("pairs", lambda: eng.lpmd_pairs_accumulate(bt)),
                      ("pdr+lpmd", lambda: eng.pdr_lpmd_accumulate(bt, metheor_amd.PdrLpmdParams())),
                      ("mhl", lambda: eng.mhl_accumulate(bt)), ("fdrp+qfdrp", lambda: eng.fdrp_accumulate(bt))):
-        dt, k = timed(eng, fn, 5)
+        if args.only and args.only not in name:
+            continue
+        dt, k = timed(eng, fn, 20 if args.only else 5)
         print(json.dumps({"measure": name, "reads": args.reads, "ms_per_pass": round(dt * 1e3, 3), "kernels_ms": k}), flush=True)
 
 
