@@ -12,9 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmetheor_hip.so")
 ARCH = "gfx950"
+# MTH_EXTRA_HIPFLAGS: experiment builds (-DMTH_STREAM_TRACE ...); the recorded BUILD_INFO carries the flags
 # -ffp-contract=off: every float this engine emits must equal the reference's UNFUSED f32 expressions (Rust never contracts
 # a*b+c); hipcc's default is contract=fast
-HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off", "-Wno-unused-result"]
+HIP_FLAGS = os.environ.get("MTH_EXTRA_HIPFLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off", "-Wno-unused-result"]
 
 HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip", "mth_stream.hip", "mth_quartet.hip", "mth_scan.hip", "mth_sites.hip", "mth_fdrp.hip", "mth_pairs.hip", "mth_decode.hip", "mth_inflate.hip", "mth_rccl.hip", "mth_tag.hip"]
 HOST_LIB = os.path.join(HERE, "libmetheor_host.so")

@@ -757,7 +757,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     float *o_pdr = sink ? sink->pdr : ctx->out_pdr.as<float>();
     uint32_t *o_nc = sink ? sink->nc : ctx->out_nc.as<uint32_t>();
     uint32_t *o_nd = sink ? sink->nd : ctx->out_nd.as<uint32_t>();
-    constexpr int tile_w = 4096;
+    constexpr int tile_w = 4096;   // (8192-bp tiles, 4 workgroups per CU: config 3 0.1655 -> 0.1956 ms, config 2 0.0858 -> 0.1069; profiles/r03_stream_kernel.md)
     const int64_t region_len = (int64_t)b.region_end - b.region_beg;
     const uint32_t ntiles = (uint32_t)((region_len + tile_w - 1) / tile_w);
     if (ntiles == 0) return MTH_OK;

@@ -46,6 +46,9 @@ struct StreamArgs {
     uint32_t min_cov, min_cpgs;
     int32_t  min_dist, max_dist;
     uint8_t  pdr_min_qual, lpmd_min_qual, want_pdr, want_lpmd;
+#ifdef MTH_STREAM_TRACE
+    unsigned long long *trace;       // experiment build: per-wave begin / end ticks and placement (tools/stream_trace.py)
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -374,6 +377,10 @@ __global__ __launch_bounds__(64 * ST_WAVES, 8) void k_pdr_lpmd_stream(const Stre
     constexpr uint32_t R = 1u << RSH;
     __shared__ __attribute__((aligned(16))) uint32_t ring_all[ST_WAVES][R];
     __shared__ __attribute__((aligned(16))) SlotTabs tabs;
+#ifdef MTH_ST_PADLDS
+    __shared__ uint32_t pad_lds[MTH_ST_PADLDS / 4];      // experiment build: fewer workgroups per CU
+    if (a.n_reads == 0xffffffffu) pad_lds[threadIdx.x] = 1;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
     slot_tabs_init(tabs, tid);
@@ -385,6 +392,9 @@ __global__ __launch_bounds__(64 * ST_WAVES, 8) void k_pdr_lpmd_stream(const Stre
     const uint32_t blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const uint32_t w = blk * ST_WAVES + wv;
     if (w >= a.nwaves) return;
+#ifdef MTH_STREAM_TRACE
+    const unsigned long long t_beg = __builtin_readcyclecounter();
+#endif
     if (w == 0 && lane == 0) a.cst->cur_base = a.cst->n_sites;   // this batch's rows go after everything emitted so far (read by the gather)
 
     const uint32_t b0 = w * a.C, e = min(b0 + a.C, a.n_reads);
@@ -412,6 +422,17 @@ __global__ __launch_bounds__(64 * ST_WAVES, 8) void k_pdr_lpmd_stream(const Stre
     // a position is called at most once per read: 16-bit counters are exact while the wave sees <= 65535 reads
     if (e - h <= 65535u) stream_wave<RSH, PER, false>(a, w, ring, wvoff, &ring_all[0][0], tabs, h, b0, e, emit_lo, emit_hi, owns, s_prev);
     else stream_wave<RSH, PER, true>(a, w, ring, wvoff, &ring_all[0][0], tabs, h, b0, e, emit_lo, emit_hi, owns, s_prev);
+#ifdef MTH_STREAM_TRACE
+    if (lane == 0 && a.trace) {
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.trace[4 * (size_t)w + 0] = t_beg;
+        a.trace[4 * (size_t)w + 1] = __builtin_readcyclecounter();
+        a.trace[4 * (size_t)w + 2] = ((unsigned long long)xcc << 32) | hwid;
+        a.trace[4 * (size_t)w + 3] = ((unsigned long long)(b0 - h) << 32) | (e - b0);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -526,6 +547,11 @@ int launch_pdr_lpmd_stream(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpm
     a.min_dist = p.lpmd_min_distance; a.max_dist = p.lpmd_max_distance;
     a.pdr_min_qual = p.pdr_min_qual; a.lpmd_min_qual = p.lpmd_min_qual;
     a.want_pdr = p.want_pdr; a.want_lpmd = p.want_lpmd;
+#ifdef MTH_STREAM_TRACE
+    static unsigned long long *d_trace = nullptr;
+    if (!d_trace) (void)hipMalloc((void **)&d_trace, 4 * 8 * 65536);
+    a.trace = d_trace;
+#endif
     {
         LaunchTimer lt(ctx, K_STREAM);
         const uint32_t nblk = ((nwaves + ST_WAVES - 1) / ST_WAVES + 7) / 8 * 8;   // whole rows of 8 XCDs (remap in the kernel)
@@ -539,6 +565,15 @@ int launch_pdr_lpmd_stream(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpm
                            other, (uint32_t)need_words, o_pos, o_pdr, o_nc, o_nd);
     }
     MTH_HIP(ctx, hipGetLastError());
+#ifdef MTH_STREAM_TRACE
+    if (getenv("MTH_STREAM_TRACE_OUT") && nwaves <= 65536) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> t(4 * (size_t)nwaves);
+        (void)hipMemcpy(t.data(), d_trace, t.size() * 8, hipMemcpyDeviceToHost);
+        FILE *f = fopen(getenv("MTH_STREAM_TRACE_OUT"), "wb");
+        if (f) { fwrite(t.data(), 8, t.size(), f); fclose(f); }
+    }
+#endif
     if (sink) {
         // site discovery for the site walks (MHL, FDRP / qFDRP, exact PDR): they find a site's candidate reads through the linear
         // read index, which the tile pipeline used to leave behind

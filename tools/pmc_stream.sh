@@ -1,0 +1,29 @@
+#!/bin/bash
+# PMC counters of the PDR+LPMD kernels (streaming and tile) on config 2 or on a config-3-density contig; separate --pmc passes.
+# usage (GPU box, repo root): bash tools/pmc_stream.sh <outdir> [cfg2|cfg3]
+out=${1:-gpurun_out/pmc_stream}; mkdir -p $out
+cfg=${2:-cfg2}
+export TMPDIR=/tmp
+if [ "$cfg" = cfg2 ]; then cmd="python tools/time_tile.py 10"; else cmd="python tools/time_sparse.py --only pdr"; fi
+run() {  # $1 tag, rest counters
+  tag=$1; shift 1
+  MTH_STREAM=1 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/s$tag -- $cmd > $out/s$tag.log 2>&1
+  MTH_NO_STREAM=1 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/t$tag -- $cmd > $out/t$tag.log 2>&1
+}
+run a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES
+run b SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT
+run c GRBM_GUI_ACTIVE SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM
+python - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+for d in sorted(glob.glob(out + "/[st][abc]")):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0][:40]
+            if "pdr_lpmd" not in k: continue
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            n[(k, r["Counter_Name"])] += 1
+    for k in acc:
+        print(d.split("/")[-1], k, {c: round(v / max(n[(k, c)], 1)) for c, v in acc[k].items()})
+PY

@@ -9,11 +9,12 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 c = synth.chr19_10m()
 eng = metheor_amd.Engine(0)
 bt = util.device_batch(c, device="cuda:0")
-p = metheor_amd.PdrLpmdParams()
+only = os.environ.get("ONLY", "both")
+p = metheor_amd.PdrLpmdParams(want_pdr=only != "lpmd", want_lpmd=only != "pdr")
 for _ in range(5):
     eng.reset(); eng.pdr_lpmd_accumulate(bt, p)
 eng.sync(); eng.timing_enable(True); eng.timing_reset()
 for _ in range(steps):
     eng.reset(); eng.pdr_lpmd_accumulate(bt, p)
 t = eng.timing()
-print("ablate", os.environ.get("MTH_DEBUG_ABLATE", "0"), {k: round(v[0], 4) for k, v in t.items() if v[1] > 0})
+print("only", only, {k: round(v[0], 4) for k, v in t.items() if v[1] > 0})
