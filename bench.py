@@ -51,6 +51,10 @@ def parse_args(argv=None):
                          "reduced with gloo on the host and the line says \"valid\": false)")
     ap.add_argument("--reduce-every-step", action="store_true",
                     help="N > 1: all-reduce the LPMD counters after every step (default: once per job, after the last step, inside the timed region)")
+    ap.add_argument("--no-wgbs", action="store_true", help="skip the WGBS-depth legs (roofline_wgbs, all7, fdrp_pairs; N = 1 only)")
+    ap.add_argument("--wgbs-reads", type=int, default=200_000_000, help="reads of the config-3 leg (24 hg38-sized contigs)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 even when it is on PATH")
+    ap.add_argument("--traffic-probe", default="", help="INTERNAL: run a few steps on the arrays saved in this .npz and exit (the process rocprofv3 wraps)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="no GPU work: run only the N-rank scaffolding (spawn, rendezvous, barrier, max over ranks, one JSON line)")
     return ap.parse_args(argv)
@@ -165,8 +169,177 @@ def e2e_leg(c, n_reads):
                 os.remove(p)
 
 
+def timed_kernels(eng, fn, reps):
+    """per-kernel mean ms over reps calls of fn() (HIP events on the engine's stream)"""
+    eng.timing_enable(True)
+    eng.timing_reset()
+    for _ in range(reps):
+        eng.reset()
+        fn()
+    tm = eng.timing()
+    eng.timing_enable(False)
+    eng.timing_reset()
+    return {k: v[0] for k, v in tm.items() if v[1] > 0}
+
+
+def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
+    """The workload the metric is named after (WGBS depth), all device-generated (metheor_amd/synth_device.py):
+    roofline_wgbs -- PDR+LPMD on one chr1-sized contig at config-3 density, dominant kernel against 24.5 B/read;
+    all7 -- BASELINE config 3, every measure over the 24 contigs queued the way the CLI queues them, one sync;
+    fdrp_pairs -- BASELINE config 4 (50x hotspots, -D 64): read pairs per second of the FDRP / qFDRP pass."""
+    from metheor_amd import synth, synth_device
+    out = {}
+    P0 = metheor_amd.PdrLpmdParams()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    n1 = int(round(n_reads_total * synth.HG38_LENGTHS[0] / float(sum(synth.HG38_LENGTHS))))
+    bt, info = synth_device.make_contig(0, synth.HG38_LENGTHS[0], n1, 0.0091, gen, dev)
+    for _ in range(3):
+        eng.reset(); eng.pdr_lpmd_accumulate(bt, P0)
+    eng.sync()
+    tm = timed_kernels(eng, lambda: eng.pdr_lpmd_accumulate(bt, P0), 20)
+    eng.reset(); eng.pdr_lpmd_accumulate(bt, metheor_amd.PdrLpmdParams(min_depth=0, min_cpgs=0))
+    sites_all = eng.pdr_count()
+    dom = max(tm, key=lambda k: tm[k])
+    alg = 16.0 * info["n_reads"] + 5.0 * info["n_calls"] + 12.0 * sites_all + 32.0
+    step_ms = sum(tm.values())
+    out["roofline_wgbs"] = {"workload": "one chr1-sized contig at S-WGBS (config 3) density: %d x 150bp reads on %.1f Mbp, %.2f calls/read, fused PDR+LPMD, CLI defaults"
+                                        % (info["n_reads"], info["length"] / 1e6, info["n_calls"] / info["n_reads"]),
+                            "bound": "hbm", "kernel": dom, "kernel_ms": round(tm[dom], 5), "algorithmic_bytes_per_launch": alg,
+                            "bytes_per_read": round(alg / info["n_reads"], 3), "achieved": round(alg / (tm[dom] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": round(alg / (tm[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                            "whole_step_kernels_ms": round(step_ms, 5), "whole_step_frac": round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                            "all_kernels_ms": {k: round(v, 5) for k, v in tm.items()}}
+    del bt
+    # ---- config 3, all seven measures ----
+    t0 = time.perf_counter()
+    resident, n_tot, c_tot = [], 0, 0
+    for b, inf in synth_device.wgbs(n_reads=n_reads_total, device=dev):
+        resident.append(b); n_tot += inf["n_reads"]; c_tot += inf["n_calls"]
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    passes = {"pdr+lpmd": lambda b: eng.pdr_lpmd_accumulate(b, P0), "me/pm": lambda b: eng.quartet_accumulate(b),
+              "mhl": lambda b: eng.mhl_accumulate(b), "fdrp+qfdrp": lambda b: eng.fdrp_accumulate(b),
+              "lpmd --pairs": lambda b: eng.lpmd_pairs_accumulate(b)}
+    per = {}
+    for name, fn in passes.items():
+        best = None
+        for _ in range(3):
+            eng.reset(); eng.sync()
+            t0 = time.perf_counter()
+            for b in resident:
+                fn(b)
+            eng.sync()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        per[name] = best
+    best_all = None
+    for _ in range(3):
+        eng.reset(); eng.sync()
+        t0 = time.perf_counter()
+        for fn in passes.values():
+            for b in resident:
+                fn(b)
+        eng.sync()
+        dt = time.perf_counter() - t0
+        best_all = dt if best_all is None else min(best_all, dt)
+    seven = {k: v for k, v in per.items() if k != "lpmd --pairs"}
+    lg = eng.lpmd_global()
+    assert lg["n_read"] == n_tot, (lg, n_tot)
+    out["all7"] = {"workload": "S-WGBS-200M (BASELINE config 3): %d x 150bp reads over 24 hg38-sized contigs, %.2f calls/read, every contig's batch resident, "
+                               "each measure's 24 batches queued back to back (as the CLI queues them); four passes give the seven measures "
+                               "(PDR+LPMD fused, ME+PM from one quartet pass, MHL, FDRP+qFDRP from one walk), a fifth the LPMD --pairs table" % (n_tot, c_tot / n_tot),
+                   "reads": n_tot, "per_pass_ms_one_sync_each": {k: round(v * 1e3, 3) for k, v in per.items()},
+                   "seven_measures_ms": round(sum(seven.values()) * 1e3, 3), "all_five_passes_one_sync_ms": round(best_all * 1e3, 3),
+                   "G_reads_per_s_seven": round(n_tot / sum(seven.values()) / 1e9, 3),
+                   "variant": "unfused: one pass per measure group, each rebuilding the read index",
+                   "frac_of_hbm_at_188B_per_read_unfused": round(188.0 * n_tot / sum(seven.values()) / 1e9 / HBM_PEAK_GBPS, 4),
+                   "frac_of_hbm_at_39B_per_read_fused": round(39.0 * n_tot / sum(seven.values()) / 1e9 / HBM_PEAK_GBPS, 4),
+                   "generate_s": round(t_gen, 2)}
+    del resident
+    torch.cuda.empty_cache()
+    # ---- config 4 ----
+    hb, hinf = synth_device.hotspots(device=dev)
+    for _ in range(2):
+        eng.reset(); eng.fdrp_accumulate(hb, max_depth=64)
+    eng.sync()
+    best = None
+    for _ in range(5):
+        eng.reset(); eng.sync()
+        t0 = time.perf_counter()
+        eng.fdrp_accumulate(hb, max_depth=64)
+        eng.sync()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    f = eng.fdrp_fetch()
+    nst = f["n_reads"].astype(np.int64)
+    pairs = int((nst * (nst - 1) // 2).sum())
+    tk = timed_kernels(eng, lambda: eng.fdrp_accumulate(hb, max_depth=64), 3)
+    out["fdrp_pairs"] = {"workload": "S-hotspot-50x (BASELINE config 4): %d reads in 20000 1-kbp windows at 50x, FDRP + qFDRP, -D 64 (no sampling)" % hinf["n_reads"],
+                         "sites": int(len(nst)), "read_pairs": pairs, "pass_ms": round(best * 1e3, 3), "G_pairs_per_s": round(pairs / best / 1e9, 2),
+                         "kernels_ms": {k: round(v, 4) for k, v in tk.items()}}
+    return out
+
+
+def traffic_probe(path):
+    """the process rocprofv3 wraps: the arrays of the bench's own batch, a few steps, nothing else"""
+    import torch
+    import metheor_amd
+    from metheor_amd import batches
+    z = np.load(path)
+    c = {k: z[k] for k in z.files}
+    c["tid"] = 0
+    c["length"] = int(c.pop("length_"))
+    eng = metheor_amd.Engine(0)
+    bt = batches.device_batch(c, device="cuda:0")
+    p = metheor_amd.PdrLpmdParams()
+    for _ in range(8):
+        eng.reset(); eng.pdr_lpmd_accumulate(bt, p)
+    eng.sync()
+    eng.close()
+    return 0
+
+
+def measure_traffic(c, dom):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+    WRITE_SIZE in separate --pmc passes (kernel-trace only), FETCH_SIZE doubled (gfx950: it reports half of a wide coalesced
+    read).  Returns (bytes, source) or (None, reason)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    d = tempfile.mkdtemp(prefix="metheor_pmc_", dir="/tmp")
+    npz = os.path.join(d, "batch.npz")
+    np.savez(npz, length_=np.int64(c["length"]), **{k: c[k] for k in ("read_start", "read_end", "read_mapq", "read_fwd", "cpg_off", "cpg_pos", "cpg_rel")})
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            od = os.path.join(d, ctr)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", od, "--", sys.executable, os.path.abspath(__file__),
+                                "--traffic-probe", npz], env=env, capture_output=True, text=True, timeout=600)
+            acc = []
+            for f in glob.glob(od + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr and dom in row["Kernel_Name"]:
+                        acc.append(float(row["Counter_Value"]))
+            if not acc:
+                return None, "rocprofv3 pass %s gave no rows for %s (rc %d)" % (ctr, dom, r.returncode)
+            vals[ctr] = sum(acc) / len(acc)
+    except Exception as ex:
+        return None, "rocprofv3 failed: %s" % str(ex)[:120]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    b = int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
+    return b, ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 8 launches; FETCH_SIZE %.0f KB doubled "
+               "(gfx950 correction), WRITE_SIZE %.0f KB" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+
+
+
 def main():
     args = parse_args()
+    if args.traffic_probe:
+        return traffic_probe(args.traffic_probe)
     in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not in_rank:
         return relaunch(args)
@@ -205,7 +378,7 @@ def main():
 
     import metheor_amd
     from metheor_amd import synth
-    from tests import util
+    from metheor_amd import batches
 
     # ---- synthetic input, resident in HBM before the timed region --------------------------------
     c = synth.chr19_10m(n_reads=args.reads, seed=1234 + rank)
@@ -214,7 +387,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)          # a dedicated non-default stream: the engine enqueues on it
     torch.cuda.set_stream(stream)
     eng = metheor_amd.Engine(device_index, stream=stream.cuda_stream)
-    batch = util.device_batch(c, device=dev)
+    batch = batches.device_batch(c, device=dev)
     params = metheor_amd.PdrLpmdParams(want_pdr=args.only != "lpmd", want_lpmd=args.only != "pdr")  # reference CLI defaults
     collective = "none"
     if use_dist and not shared:
@@ -318,6 +491,33 @@ def main():
             except Exception:
                 traffic = None
         ceiling = copy_ceiling_gbps(torch, dev, stream)
+        # the same leg over TWO resident batches taken in turn (the second from the device generator, same distributions): one
+        # batch's traffic (~250 MB) is the size of the 256-MiB Infinity Cache, two are not -- an HBM statement needs the set to exceed it
+        two = None
+        if world == 1:
+            from metheor_amd import synth_device
+            g2 = torch.Generator(device=dev)
+            g2.manual_seed(4321)
+            batch_b, info_b = synth_device.make_contig(0, synth.CHR19_LEN, n_reads, 0.02, g2, dev)
+            for _ in range(2):
+                eng.reset(); eng.pdr_lpmd_accumulate(batch_b, params)
+            eng.sync()
+            eng.timing_enable(True)
+            eng.timing_reset()
+            for k in range(2 * args.roofline_steps):
+                eng.reset()
+                eng.pdr_lpmd_accumulate(batch if k % 2 == 0 else batch_b, params)
+            tm2 = eng.timing()
+            eng.timing_enable(False)
+            eng.timing_reset()
+            eng.reset(); eng.pdr_lpmd_accumulate(batch_b, metheor_amd.PdrLpmdParams(min_depth=0, min_cpgs=0))
+            alg_b = 16.0 * info_b["n_reads"] + 5.0 * info_b["n_calls"] + 12.0 * eng.pdr_count() + 32.0
+            alg2 = 0.5 * (alg_bytes + alg_b)
+            ms2 = tm2[dom][0]
+            two = {"what": "the same kernel timed over two resident batches taken in turn (working set ~2 x %.0f MB > 256 MiB L3)" % (alg_bytes / 1e6),
+                   "kernel_ms": round(ms2, 5), "algorithmic_bytes_per_launch_mean": alg2,
+                   "achieved": round(alg2 / (ms2 * 1e-3) / 1e9, 2), "frac": round(alg2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
+            del batch_b
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                            "copy_ceiling_GBps": round(ceiling, 1), "frac_of_copy_ceiling": round(achieved / ceiling, 5),
@@ -325,7 +525,7 @@ def main():
                            "bytes_per_read": round(alg_bytes / n_reads, 3), "kernel_ms": round(ms, 5),
                            "whole_step_kernels_ms": round(step_kernels_ms, 5),
                            "whole_step_frac": round(alg_bytes / (step_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if step_kernels_ms > 0 else None,
-                           "all_kernels_ms": {k: round(v[0], 5) for k, v in tm.items() if v[1] > 0}}
+                           "all_kernels_ms": {k: round(v[0], 5) for k, v in tm.items() if v[1] > 0}, "two_batches": two}
 
     # ---- soak: untimed passes so that an external sampler (rocm-smi every few seconds) can see the GPU working ------
     # ---- the exchange step on its own: latency of one all-reduce of the 32 bytes (every rank takes part) ---------------
@@ -357,6 +557,13 @@ def main():
             n_soak += 200
         out["soak"] = {"seconds": round(time.perf_counter() - t0, 2), "steps": n_soak,
                        "ms_per_step": round((time.perf_counter() - t0) / n_soak * 1e3, 4)}
+
+    # ---- WGBS depth (the workload the metric is named after): roofline_wgbs, all seven measures on config 3, config-4 pairs/s --
+    if rank == 0 and world == 1 and not args.no_wgbs:
+        try:
+            out.update(wgbs_legs(eng, torch, dev, metheor_amd, args.wgbs_reads))
+        except Exception as ex:       # a secondary leg must never cost the bench line
+            out["wgbs_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
 
     # ---- end to end from a BAM file (N = 1): the north_star's 50 M reads/s clause ------------------------------------
     if rank == 0 and world == 1 and not args.no_e2e:
@@ -417,6 +624,15 @@ def main():
                                                "sample": "%d-read BAM of the same generator: 1-thread zlib inflate + BAM/XM decode (libmetheor_host) + oracle pdr + lpmd" % len(rd1)}
         except Exception as ex:       # the baseline's second figure must never cost the bench line
             out["cpu_baseline"]["from_bam"] = {"error": str(ex)[:200]}
+    if rank == 0 and world == 1 and not args.no_traffic and "roofline" in out:
+        if eng is not None:
+            eng.close()
+            eng = None
+        b, src = measure_traffic(c, out["roofline"]["kernel"])
+        if b is not None:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = b, src
+        else:
+            out["roofline"]["traffic_note"] = src
     if rank == 0:
         print(json.dumps(out), flush=True)
     if eng is not None:

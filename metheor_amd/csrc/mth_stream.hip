@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64 * SGATHER_WAVES) void k_gather_stream(const Site
 bool stream_eligible(const mth_batch_t &b) {
     // A/B switches: MTH_STREAM=1 takes the streaming kernel, MTH_NO_STREAM=1 keeps the tile pipeline (the default while the
     // streaming kernel is still the slower of the two on config 2)
-    static const bool off = getenv("MTH_NO_STREAM") != nullptr || getenv("MTH_STREAM") == nullptr;
+    const bool off = getenv("MTH_NO_STREAM") != nullptr || getenv("MTH_STREAM") == nullptr;      // read per batch: the tests run both forms in one process
     return !off && b.cpg_rel != nullptr && b.max_span >= 1 && b.max_span <= 256 && b.n_reads > 0;
 }
 

@@ -16,6 +16,17 @@ pytestmark = pytest.mark.gpu
 f32 = np.float32
 
 
+@pytest.fixture(autouse=True, params=["tile", "stream"])
+def kernel_form(request, monkeypatch):
+    """every case runs through the tile pipeline (the default) and through the streaming kernel (mth_stream.hip, MTH_STREAM=1;
+    batches it does not take -- 16-bit relpos, spans > 256 -- fall back to the tile pipeline by themselves)"""
+    if request.param == "stream":
+        monkeypatch.setenv("MTH_STREAM", "1")
+    else:
+        monkeypatch.delenv("MTH_STREAM", raising=False)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def eng():
     import metheor_amd

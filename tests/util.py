@@ -23,26 +23,7 @@ def contig_from_oracle_soa(soa, tid, length):
                 cpg_rel=rel.astype(np.uint8) if (len(rel) == 0 or rel.max() < 256) else rel)
 
 
-def device_batch(c, region=None, device=None, rel16=False):
-    """contig dict -> metheor_amd.Batch (host numpy, or torch tensors on `device`)"""
-    from metheor_amd import Batch
-    beg, end = region if region is not None else c.get("region", (0, c["length"]))
-    rel = c["cpg_rel"].astype(np.uint16) if rel16 else c["cpg_rel"]
-    arrs = dict(read_start=c["read_start"], read_end=c["read_end"], read_mapq=c["read_mapq"],
-                cpg_off=c["cpg_off"], cpg_pos=c["cpg_pos"], cpg_rel=rel)
-    if device is not None:
-        import torch
-        t = {}
-        for k, a in arrs.items():
-            a = np.ascontiguousarray(a)
-            if a.dtype == np.uint32:
-                t[k] = torch.from_numpy(a.view(np.int32)).to(device)
-            elif a.dtype == np.uint16:
-                t[k] = torch.from_numpy(a.view(np.int16)).to(device)
-            else:
-                t[k] = torch.from_numpy(a).to(device)
-        arrs = t
-    return Batch(c["tid"], beg, end, max_span=shard.max_span(c), **arrs)
+from metheor_amd.batches import device_batch  # noqa: E402,F401  (moved into the package: bench.py and smoke() must not import tests)
 
 
 def contig_to_records(c, name="chrS"):
