@@ -35,8 +35,14 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None, help="default 2000 (weak) / 20 (strong)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 50 (weak) / 3 (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's contract): BASELINE config 2 per GPU.  strong: ONE whole-genome WGBS input (BASELINE config 5 "
+                         "shape, --strong-reads reads over 24 hg38-sized contigs) region-sharded over the N ranks, one RCCL all-reduce per job")
+    ap.add_argument("--strong-reads", type=int, default=1_000_000_000, help="reads of the strong-scaling genome (config 5 = 1 B)")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="strong mode without a GPU: generate (torch on the CPU), plan, slice and report the partition; everything up to the engine calls")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (config 2 = 10 M)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="reads of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,7 +63,12 @@ def parse_args(argv=None):
     ap.add_argument("--traffic-probe", default="", help="INTERNAL: run a few steps on the arrays saved in this .npz and exit (the process rocprofv3 wraps)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="no GPU work: run only the N-rank scaffolding (spawn, rendezvous, barrier, max over ranks, one JSON line)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.steps is None:
+        a.steps = 20 if a.scaling == "strong" else 2000
+    if a.warmup is None:
+        a.warmup = 3 if a.scaling == "strong" else 50
+    return a
 
 
 def free_port():
@@ -336,6 +347,193 @@ def measure_traffic(c, dom):
 
 
 
+def preflight(torch, rank, device_index):
+    """one line per rank on stderr: which device this rank drives (a wrong mapping is the first thing to rule out when RCCL fails)"""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        uuid = getattr(p, "uuid", "?")
+        sys.stderr.write("bench.py preflight: rank %d -> cuda:%d %s uuid %s, %d CUs, %.0f GiB, gcn %s, HSA_ENABLE_IPC_MODE_LEGACY=%s\n"
+                         % (rank, device_index, p.name, uuid, p.multi_processor_count, p.total_memory / 2 ** 30,
+                            getattr(p, "gcnArchName", "?"), os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")))
+    except Exception as ex:
+        sys.stderr.write("bench.py preflight: rank %d: %s\n" % (rank, ex))
+
+
+def strong_main(args, rank, world, local_rank, in_rank):
+    """--scaling strong: ONE genome (BASELINE config 5 shape), the reads in genome order cut into `world` equal runs
+    (metheor_amd.shard.plan_genome: whole contigs, and regions of the contigs a cut falls into), every rank keeps the reads that
+    can touch its regions (halo reads re-read, as `metheor --gpus N` does with BGZF blocks), runs the fused PDR+LPMD pass over its
+    pieces, and the genome-wide LPMD counters are all-reduced ONCE per job over RCCL (lpmd.rs:51-55)."""
+    import torch
+    import torch.distributed as dist
+    from metheor_amd import shard, synth, synth_device
+
+    use_dist = in_rank
+    plan_only = args.plan_only
+    if use_dist:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if plan_only:
+        dev = torch.device("cpu")
+        device_index = -1
+    else:
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            sys.stderr.write("bench.py: no GPU visible (the engine is HIP-only, there is no CPU fallback)\n")
+            return 3
+        if world > ndev and not args.share_devices:
+            sys.stderr.write("bench.py: --gpus %d needs %d devices, %d visible\n" % (world, world, ndev))
+            return 3
+        device_index = local_rank % ndev
+        torch.cuda.set_device(device_index)
+        dev = torch.device("cuda", device_index)
+        preflight(torch, rank, device_index)
+
+    lens = synth.HG38_LENGTHS
+    tot_len = float(sum(lens))
+    contig_reads = [int(round(args.strong_reads * ln / tot_len)) for ln in lens]
+    total_reads = sum(contig_reads)
+    plan = shard.plan_genome(contig_reads, world)
+    mine = {tid: (a, b) for tid, a, b in plan[rank]}
+
+    eng = None
+    if not plan_only:
+        import metheor_amd
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        eng = metheor_amd.Engine(device_index, stream=stream.cuda_stream)
+        params = metheor_amd.PdrLpmdParams()
+    rccl = False
+    if eng is not None and use_dist and world <= torch.cuda.device_count():
+        import metheor_amd
+        ids = [metheor_amd.Engine.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        try:
+            eng.rccl_init_rank(ids[0], rank, world)
+            rccl = True
+        except Exception as ex:
+            sys.stderr.write("bench.py: rank %d: RCCL communicator could not be created (ncclCommInitRank): %s\n" % (rank, ex))
+            return 4
+
+    # every rank generates the same genome (same seed, same generator) contig by contig and keeps its slices
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5000)
+    pieces, owned, loaded, calls = [], 0, 0, 0
+    t0 = time.perf_counter()
+    for tid, (ln, n) in enumerate(zip(lens, contig_reads)):
+        t, info = synth_device.make_contig_tensors(tid, ln, n, 0.0091, gen, dev)
+        if tid in mine:
+            a, b = mine[tid]
+            beg = 0 if a == 0 else int(t["read_start"][a].item())
+            end = ln if b == n else int(t["read_start"][b].item())
+            if end > beg:
+                sl, n_own = synth_device.slice_region(t, beg, end)
+                owned += n_own
+                loaded += int(sl["read_start"].shape[0])
+                calls += int(sl["cpg_pos"].shape[0])
+                pieces.append(sl if plan_only else synth_device.to_batch(sl))
+        del t
+    t_gen = time.perf_counter() - t0
+
+    def gather_scalar(x, dtype):
+        v = torch.tensor([x], dtype=dtype)
+        if not use_dist:
+            return [v.item()]
+        got = [torch.zeros(1, dtype=dtype) for _ in range(world)]
+        dist.all_gather(got, v)
+        return [g.item() for g in got]
+
+    per_rank_reads = gather_scalar(owned, torch.int64)
+    per_rank_loaded = gather_scalar(loaded, torch.int64)
+    if plan_only:
+        if rank == 0:
+            assert sum(per_rank_reads) == total_reads, (per_rank_reads, total_reads)
+            print(json.dumps({"metric": "plan only (no GPU work)", "scaling": "strong", "n_gpus": world, "world_seen": world, "reads": total_reads,
+                              "per_rank_reads": per_rank_reads, "per_rank_reads_loaded_with_halo": per_rank_loaded,
+                              "imbalance_reads": round(max(per_rank_reads) / (sum(per_rank_reads) / world), 4),
+                              "per_rank_pieces": gather_scalar(len(pieces), torch.int64)}), flush=True)
+        else:
+            gather_scalar(len(pieces), torch.int64)
+        if use_dist:
+            dist.destroy_process_group()
+        return 0
+
+    def step(last=False):
+        eng.reset()
+        for b in pieces:
+            eng.pdr_lpmd_accumulate(b, params)
+        if rccl and last:
+            eng.allreduce_lpmd_rank()
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(last=(k == args.warmup - 1))
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(last=(k == args.steps - 1))
+    fence()
+    dt_mine = time.perf_counter() - t0
+    # a rank's own time without the others (no barrier inside): what the imbalance is computed from
+    eng.sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        eng.reset()
+        for b in pieces:
+            eng.pdr_lpmd_accumulate(b, params)
+    eng.sync()
+    own_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    per_rank_dt = gather_scalar(dt_mine, torch.float64)
+    per_rank_own = gather_scalar(own_ms, torch.float64)
+    lg = eng.lpmd_global()
+    sites = gather_scalar(int(eng.pdr_count()), torch.int64)
+    if rccl or world == 1:
+        assert lg["n_read"] == total_reads, (lg, total_reads)
+    coll = None
+    if rccl:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step(last=True)
+            eng.lpmd_global()
+        t_with = (time.perf_counter() - t0) / 10
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step(last=False)
+            eng.lpmd_global()
+        t_without = (time.perf_counter() - t0) / 10
+        coll = {"serialised_step_with": round(t_with * 1e3, 4), "serialised_step_without": round(t_without * 1e3, 4),
+                "all_reduce": round((t_with - t_without) * 1e3, 4)}
+    if rank == 0:
+        dt = max(per_rank_dt)
+        out = {"metric": "M reads/sec (PDR+LPMD, 150bp WGBS)", "value": round(total_reads * args.steps / dt / 1e6, 3), "unit": "M reads/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+               "config": {"workload": "S-WG (BASELINE config 5 shape): ONE genome, %d x 150bp reads over 24 hg38-sized contigs, %.2f calls/read on rank 0, "
+                                      "region-sharded over %d rank(s) by equal read runs in genome order (halo reads re-read), fused PDR+LPMD, CLI defaults"
+                                      % (total_reads, calls / max(loaded, 1), world),
+                          "reads_total": total_reads, "parallelism": "region-sharded x%d" % world},
+               "world_seen": world, "devices_visible": torch.cuda.device_count(),
+               "collective": ("RCCL ncclAllReduce(int64 x 4, sum) via mth_allreduce_lpmd_rank, world %d, once per job: after the last step, inside the timed region" % world)
+                             if rccl else "none",
+               "per_rank_reads": per_rank_reads, "per_rank_reads_loaded_with_halo": per_rank_loaded,
+               "per_rank_ms_per_step": [round(x / args.steps * 1e3, 4) for x in per_rank_dt],
+               "per_rank_own_ms_per_step": [round(x, 4) for x in per_rank_own],
+               "imbalance": round(max(per_rank_own) / (sum(per_rank_own) / world), 4),
+               "imbalance_reads": round(max(per_rank_reads) / (sum(per_rank_reads) / world), 4),
+               "sites_emitted_total": int(sum(sites)), "collective_ms": coll, "generate_s": round(t_gen, 2), "timed_region_s": round(dt, 4)}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if use_dist:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse_args()
     if args.traffic_probe:
@@ -355,6 +553,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.selftest_launcher:
         return selftest(args, rank, world)
+    if args.scaling == "strong":
+        return strong_main(args, rank, world, local_rank, in_rank)
 
     import torch
     import torch.distributed as dist

@@ -40,3 +40,23 @@ def slice_region(c, beg, end, halo=None):
     out["cpg_rel"] = c["cpg_rel"][o0:o1]
     out["region"] = (beg, end)
     return out
+
+
+def plan_genome(contig_reads, world):
+    """Region sharding of one genome over `world` ranks: the reads in genome order are cut into `world` runs of equal
+    length, so a rank owns a contiguous stretch of the genome -- whole contigs and, where a cut falls inside one, a region of it.
+    contig_reads: reads per contig, in tid order.  Returns, per rank, a list of (tid, first_read, end_read) with contig-local read
+    indices; the caller turns the indices into positions (region = [start[first_read] or 0, start[end_read] or contig length)),
+    which is what makes ownership a property of the POSITION (a read is owned by the rank whose region holds its start)."""
+    total = int(sum(contig_reads))
+    cuts = [(total * r) // world for r in range(world + 1)]
+    plan = [[] for _ in range(world)]
+    base = 0
+    for tid, n in enumerate(contig_reads):
+        n = int(n)
+        for r in range(world):
+            a, b = max(cuts[r], base), min(cuts[r + 1], base + n)
+            if b > a:
+                plan[r].append((tid, a - base, b - base))
+        base += n
+    return plan

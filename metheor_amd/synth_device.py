@@ -22,9 +22,9 @@ def make_sites(length, density, gen, device):
     return pos[pos < length - 2]
 
 
-def make_contig(tid, length, n_reads, density, gen, device, read_len=150, low_mapq_frac=0.05,
-                levels=((0.1, 0.3), (0.9, 0.7)), starts=None):
-    """one contig's reads as device tensors; returns (Batch, info dict)"""
+def make_contig_tensors(tid, length, n_reads, density, gen, device, read_len=150, low_mapq_frac=0.05,
+                        levels=((0.1, 0.3), (0.9, 0.7)), starts=None):
+    """one contig's reads as device tensors (the SoA of include/metheor_hip.h); returns (tensor dict, info dict)"""
     sites = make_sites(length, density, gen, device)
     lv = torch.tensor([l for l, _ in levels], dtype=torch.float32, device=device)
     pw = torch.tensor([w for _, w in levels], dtype=torch.float64)
@@ -53,11 +53,43 @@ def make_contig(tid, length, n_reads, density, gen, device, read_len=150, low_ma
     meth = torch.rand(total, generator=gen, device=device) < site_level[site_idx]
     cpg_pos = (pos | (meth.to(torch.int64) << 31)).to(torch.int32)       # wraps into the sign bit: the 32-bit pattern is what counts
     rs = starts.to(torch.int32)
-    bt = Batch(tid, 0, int(length), read_start=rs, read_end=rs + (read_len - 1), read_mapq=mapq,
-               cpg_off=cpg_off.to(torch.int32), cpg_pos=cpg_pos, cpg_rel=rel, max_span=read_len)
+    t = dict(tid=tid, length=int(length), max_span=read_len, read_start=rs, read_end=rs + (read_len - 1), read_mapq=mapq,
+             cpg_off=cpg_off, cpg_pos=cpg_pos, cpg_rel=rel)
     info = dict(tid=tid, length=int(length), n_reads=n_reads, n_calls=total, n_sites_possible=int(len(sites)),
                 n_mapq_ok_with_calls=int(((mapq >= 10) & (cnt > 0)).sum().item()), n_mapq_ok=int((mapq >= 10).sum().item()))
-    return bt, info
+    return t, info
+
+
+def to_batch(t, region=None):
+    """tensor dict (make_contig_tensors / slice_region) -> Batch"""
+    beg, end = region if region is not None else t.get("region", (0, t["length"]))
+    return Batch(t["tid"], int(beg), int(end), read_start=t["read_start"], read_end=t["read_end"], read_mapq=t["read_mapq"],
+                 cpg_off=t["cpg_off"].to(torch.int32), cpg_pos=t["cpg_pos"], cpg_rel=t["cpg_rel"], max_span=t["max_span"])
+
+
+def make_contig(tid, length, n_reads, density, gen, device, **kw):
+    """one contig's reads as a device-resident Batch; returns (Batch, info dict)"""
+    t, info = make_contig_tensors(tid, length, n_reads, density, gen, device, **kw)
+    return to_batch(t), info
+
+
+def slice_region(t, beg, end, halo=None):
+    """shard.slice_region on the device: the reads that can touch sites in [beg, end) -- start in [beg - halo, end] -- CSR rebased;
+    returns (tensor dict, number of reads OWNED by the region: start in [beg, end))"""
+    if halo is None:
+        halo = t["max_span"]
+    s = t["read_start"]
+    key = torch.tensor([beg - halo, end + 1, beg, end], dtype=s.dtype, device=s.device)
+    i0, i1, a0, a1 = [int(x) for x in torch.searchsorted(s, key, right=False).tolist()]
+    o0, o1 = int(t["cpg_off"][i0].item()), int(t["cpg_off"][i1].item())
+    out = dict(t)
+    for k in ("read_start", "read_end", "read_mapq"):
+        out[k] = t[k][i0:i1].contiguous()
+    out["cpg_off"] = (t["cpg_off"][i0:i1 + 1] - o0).contiguous()
+    out["cpg_pos"] = t["cpg_pos"][o0:o1].contiguous()
+    out["cpg_rel"] = t["cpg_rel"][o0:o1].contiguous()
+    out["region"] = (int(beg), int(end))
+    return out, a1 - a0
 
 
 def wgbs(n_reads=200_000_000, seed=2000, density=0.0091, contigs=None, device="cuda:0"):

@@ -47,3 +47,50 @@ def test_single_gpu_without_device_fails_loudly():
         pytest.skip("GPU present")
     r = subprocess.run([sys.executable, BENCH, "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+# ---- --scaling strong: ONE genome region-sharded over the ranks; everything up to the engine calls on CPU ---
+def test_strong_scaling_partition_two_ranks_under_torchrun():
+    """generate (torch on the CPU) -> plan_genome -> slice per rank -> gloo gather: the code path of the real run up to the engine /
+    RCCL calls.  The partition must be exact (every read owned once) and balanced."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", BENCH, "--gpus", "2", "--scaling", "strong", "--plan-only", "--strong-reads", "400000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _one_line(r.stdout)
+    assert j["scaling"] == "strong" and j["world_seen"] == 2 and len(j["per_rank_reads"]) == 2
+    assert sum(j["per_rank_reads"]) == j["reads"]
+    assert j["imbalance_reads"] < 1.01
+    assert all(l >= o for l, o in zip(j["per_rank_reads_loaded_with_halo"], j["per_rank_reads"]))      # halo reads are re-read, never dropped
+
+
+def test_strong_scaling_plain_invocation_five_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "5", "--scaling", "strong", "--plan-only", "--strong-reads", "300000"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _one_line(r.stdout)
+    assert j["world_seen"] == 5 and sum(j["per_rank_reads"]) == j["reads"] and j["imbalance_reads"] < 1.01
+    assert sum(j["per_rank_pieces"]) >= 24          # every contig is somebody's, cut contigs twice
+
+
+def test_plan_genome_covers_every_read_once():
+    from metheor_amd import shard
+    import random
+    rnd = random.Random(7)
+    for _ in range(200):
+        contigs = [rnd.randrange(0, 5000) for _ in range(rnd.randrange(1, 30))]
+        world = rnd.randrange(1, 65)
+        plan = shard.plan_genome(contigs, world)
+        assert len(plan) == world
+        seen = [0] * len(contigs)
+        prev = (-1, 0)
+        for r in plan:
+            for tid, a, b in r:
+                assert 0 <= a < b <= contigs[tid]
+                assert (tid, a) >= prev          # genome order, no overlap
+                assert seen[tid] == a            # contiguous per contig
+                seen[tid] = b
+                prev = (tid, b)
+        assert seen == contigs
+        sizes = [sum(b - a for _, a, b in r) for r in plan]
+        assert max(sizes) - min(sizes) <= 1
