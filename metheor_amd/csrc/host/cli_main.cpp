@@ -862,8 +862,12 @@ int tag_window(void *user, const uint8_t *buf, const uint64_t *rec_off, uint64_t
         const uint32_t len = (uint32_t)(rec_off[i + 1] - rec_off[i] - 4);
         const int64_t cap = 4 * (int64_t)len + 256 + t.xm_len[i];
         if ((int64_t)b.size() < cap) b.resize((size_t)cap);
-        const int64_t n = mth_host_sam_format(st->h, rec, len, t.xm + t.xm_off[i], t.xm_len[i], b.data(), (int64_t)b.size());
-        if (n < 0 || n > (int64_t)b.size()) { st->fail = "Error writing to output file."; return 1; }
+        int64_t n = mth_host_sam_format(st->h, rec, len, t.xm + t.xm_off[i], t.xm_len[i], b.data(), (int64_t)b.size());
+        if (n > (int64_t)b.size()) {      // B:c / B:s arrays print up to 7 characters per 1-2 byte element: the formatter says how much it needs
+            b.resize((size_t)n);
+            n = mth_host_sam_format(st->h, rec, len, t.xm + t.xm_off[i], t.xm_len[i], b.data(), (int64_t)b.size());
+        }
+        if (n < 0 || n > (int64_t)b.size()) { st->fail = "metheor: cannot format a record as SAM (malformed BAM record)"; return 1; }
         if (fwrite(b.data(), 1, (size_t)n, st->out) != (size_t)n) { st->fail = "Error writing to output file."; return 1; }
     }
     return 0;

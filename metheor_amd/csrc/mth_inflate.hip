@@ -18,6 +18,11 @@
 
 namespace mth {
 
+// Reads of a CORRUPT last block can run past the staged file bytes: garbage keeps decoding as literals until the output bound
+// (isize <= 64 KiB) stops it, <= 10 bits each -- 80 KiB of input at most.  The staging buffers carry that much padding, so the
+// scalar loads of the bit reader always stay inside the allocation (the CRC / ISIZE checks then flag the block).
+constexpr size_t INF_FILE_PAD = 96 * 1024;
+
 constexpr int LROOT = 10, DROOT = 9;          // direct-lookup bits of the literal/length and distance tables
 struct InflArgs {
     const uint8_t *file;                      // the compressed file, padded by >= 16 readable bytes
@@ -152,6 +157,9 @@ struct Bits {
     "global_store_byte %[vpos], %[ve], %[out]\n\t"       \
     "v_add_u32 %[vpos], 1, %[vpos]\n\t"
 __device__ __forceinline__ void literal_run(Bits &b, uint32_t &pos, const uint32_t isize, uint8_t *out0, const uint32_t ltab_lds) {
+    // The loop checks the output bound where it refills; entered with >= 32 bits in hand it would store up to 63 + 2 literals
+    // before its first check: same bound here, once per call (a corrupt stream must not write into the next block's output).
+    if (pos + 72u > isize) return;
     uint64_t bb = uni64(b.bb), tmp;
     const uint64_t base = uni64(reinterpret_cast<uint64_t>(b.file));
     uint64_t in = base + uni64(b.in);                   // the address as an integer: scalar registers s[42:43]
@@ -509,7 +517,7 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
         std::swap(ctx->inf_file, ctx->inf_file2);
         MTH_HIP(ctx, hipStreamWaitEvent(s, ctx->staged_ev, 0));
     } else {
-        MTH_HIP(ctx, ctx->inf_file.reserve((size_t)n_bytes + 64, s));
+        MTH_HIP(ctx, ctx->inf_file.reserve((size_t)n_bytes + INF_FILE_PAD, s));
     }
     ctx->staged_src = nullptr;
     MTH_HIP(ctx, ctx->inf_tab.reserve(nb * 24 + 64, s));
@@ -549,7 +557,7 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
         ctx->stage_thread = std::thread([ctx, src, nbytes] {
             auto ok = [&](hipError_t e) { if (e != hipSuccess) ctx->stage_rc = MTH_ERR_HIP; return e == hipSuccess; };
             if (!ok(hipSetDevice(ctx->device))) return;
-            if (!ok(ctx->inf_file2.reserve((size_t)nbytes + 64, ctx->copy_stream))) return;
+            if (!ok(ctx->inf_file2.reserve((size_t)nbytes + INF_FILE_PAD, ctx->copy_stream))) return;
             if (!ok(hipMemcpyAsync(ctx->inf_file2.p, src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->copy_stream))) return;
             if (!ok(hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file2.p) + nbytes, 0, 64, ctx->copy_stream))) return;
             if (!ok(hipEventRecord(ctx->staged_ev, ctx->copy_stream))) return;

@@ -174,25 +174,31 @@ int mth_allreduce_lpmd(mth_ctx_t **ctxs, int n) {
         if (!r) { cleanup(); return rccl_fail(ctxs[0], "RCCL is not available", ncclSuccess); }
         std::vector<int> devs;
         for (int i : leaders) devs.push_back(ctxs[i]->device);
-        CommSet *set = nullptr;
+        // the communicators of this device list, copied out while the lock is held: g_sets may grow (and move) under another
+        // thread's call with another list as soon as it is released
+        std::vector<ncclComm_t> comms;
         {
             std::lock_guard<std::mutex> g(g_sets_mu);
-            for (CommSet &s : g_sets) if (s.devs == devs) set = &s;
-            if (!set) {
+            for (CommSet &s : g_sets) if (s.devs == devs) comms = s.comms;
+            if (comms.empty()) {
                 CommSet s;
                 s.devs = devs;
-                s.comms.resize(devs.size());
+                s.comms.assign(devs.size(), (ncclComm_t) nullptr);
                 const ncclResult_t e = r->CommInitAll(s.comms.data(), (int)devs.size(), devs.data());
-                if (e != ncclSuccess) { cleanup(); return rccl_fail(ctxs[0], "ncclCommInitAll", e); }
+                if (e != ncclSuccess) {
+                    for (ncclComm_t c : s.comms) if (c) (void)r->CommDestroy(c);      // whatever was created before the failure
+                    cleanup();
+                    return rccl_fail(ctxs[0], "ncclCommInitAll", e);
+                }
+                comms = s.comms;
                 g_sets.push_back(std::move(s));
-                set = &g_sets.back();
             }
         }
         ncclResult_t e = r->GroupStart();
         for (size_t k = 0; k < leaders.size() && e == ncclSuccess; ++k) {
             mth_ctx *c = ctxs[leaders[k]];
             if (hipSetDevice(c->device) != hipSuccess) { e = ncclUnhandledCudaError; break; }
-            e = r->AllReduce(lp(leaders[k]), lp(leaders[k]), 4, ncclInt64, ncclSum, set->comms[k], c->stream);
+            e = r->AllReduce(lp(leaders[k]), lp(leaders[k]), 4, ncclInt64, ncclSum, comms[k], c->stream);
         }
         const ncclResult_t e2 = r->GroupEnd();
         if (e != ncclSuccess || e2 != ncclSuccess) { cleanup(); return rccl_fail(ctxs[0], "ncclAllReduce", e != ncclSuccess ? e : e2); }

@@ -85,6 +85,45 @@ __device__ __forceinline__ TagRec tg_parse(const TagArgs &a, uint32_t i) {
     return r;
 }
 
+// tag.rs:245-389 with a read column string (nr characters) SHORTER than the reference one (ng): the two target strings are
+// built and indexed independently, exactly as the reference does; any index past a string's end is its panic (-1).
+// Rare (the read ran out before its CIGAR did), so: one plain sequential routine, kept out of line.
+__device__ __noinline__ int64_t tg_xm_unaligned(const uint8_t *R, uint32_t nr, const uint8_t *G, uint32_t ng, bool rc, uint8_t *out) {
+    const uint32_t tlen = nr - 2u, glen = ng - 2u;               // target_read_seq.len(), target_ref_seq.len()
+    if (rc) {                                                    // reverse_complement() maps every character (tag.rs:19-25)
+        for (uint32_t t = 0; t < tlen; ++t) if (!tg_comp(R[t])) return -1;
+        for (uint32_t t = 0; t < glen; ++t) if (!tg_comp(G[t])) return -1;
+    }
+    bool ok = true;
+    auto rd = [&](uint32_t idx) -> uint8_t { if (idx >= tlen) { ok = false; return 0; } return rc ? tg_comp(R[tlen - 1u - idx]) : R[2u + idx]; };
+    auto rf = [&](uint32_t idx) -> uint8_t { if (idx >= glen) { ok = false; return 0; } return rc ? tg_comp(G[glen - 1u - idx]) : G[2u + idx]; };
+    uint32_t nx = 0;
+    for (uint32_t idx = 0; idx + 2u < tlen && ok; ++idx) {       // tag.rs:265
+        const uint8_t r0 = rd(idx);
+        if (r0 == '-') continue;
+        if (r0 == 'N') { out[nx++] = '.'; continue; }
+        if (rf(idx) != 'C') { if (ok) out[nx++] = '.'; continue; }
+        uint8_t c1 = 0, c2 = 0;
+        int n = 1;
+        if ((rd(idx + 1u) == '-' || rd(idx + 2u) == '-') && idx != tlen - 3u && idx != tlen - 4u) {      // tag.rs:271-296
+            for (uint32_t k = 1; n != 3 && idx + k <= tlen - 1u; ++k) {
+                if (rd(idx + k) != '-') { const uint8_t g = rf(idx + k); if (n == 1) c1 = g; else c2 = g; ++n; }
+            }
+            if (n < 2) ok = false;                               // tmp_target_ref_seq[1]
+        } else {                                                 // tag.rs:340-383: skip(idx).take(3) may come up short; [idx + 1] may not
+            c1 = rf(idx + 1u);
+            n = 2;
+            if (idx + 2u < glen) { c2 = rf(idx + 2u); n = 3; }
+        }
+        if (!ok) break;
+        const uint8_t l = tg_letter(c1, c2, n, r0);
+        if (l) out[nx++] = l;
+    }
+    if (!ok) return -1;
+    if (rc) for (uint32_t x = 0, y = nx; x + 1u < y; ++x) { --y; const uint8_t t = out[x]; out[x] = out[y]; out[y] = t; }   // tag.rs:386-389
+    return (int64_t)nx;
+}
+
 __global__ __launch_bounds__(256) void k_tag_count(const TagArgs a) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n_rec) return;
@@ -125,7 +164,11 @@ __global__ __launch_bounds__(256) void k_tag_xm(const TagArgs a) {
     const int64_t have = (int64_t)(a.g_off[r.tid + 1] - a.g_off[r.tid]);      // bases the FASTA actually gave
     const int64_t cs = start - 2 > 0 ? start - 2 : 0, ce = end + 2 < ln ? end + 2 : ln;
     const int64_t pad_s = 2 - start > 0 ? 2 - start : 0, pad_e = end - ln + 2 > 0 ? end - ln + 2 : 0;
-    if (start < 0 || cs > ce || ce > have || pad_s > 2 || pad_e > 2 || qwalk > (int64_t)r.l_seq) { atomicOr(a.err, (uint32_t)ERRB_TAGPANIC); return; }
+    if (start < 0 || cs > ce || ce > have || pad_s > 2 || pad_e > 2) { atomicOr(a.err, (uint32_t)ERRB_TAGPANIC); return; }
+    // A read shorter than its CIGAR's M + I (SEQ '*' beside a CIGAR: secondary alignments of bwa mem -a / bwa-meth) is not a panic in
+    // the reference: chars().skip(a).take(b) just yields fewer characters (tag.rs:190-216), the read column string ends up
+    // shorter than the reference one, and the two are then indexed independently (tag.rs:264-384).
+    const bool short_read = qwalk > (int64_t)r.l_seq;
     const uint8_t *g = a.genome + a.g_off[r.tid];
     const int64_t reflen_str = pad_s + (ce - cs) + pad_e;
     auto ref_at = [&](int64_t k) -> uint8_t {                   // ref_seq[k]
@@ -138,18 +181,27 @@ __global__ __launch_bounds__(256) void k_tag_xm(const TagArgs a) {
     };
     if (reflen_str < 2) { atomicOr(a.err, (uint32_t)ERRB_TAGPANIC); return; }
     // tag.rs:175-243: the gapped columns
-    uint32_t j = 0;
-    R[0] = '-'; R[1] = '-'; G[0] = ref_at(0); G[1] = ref_at(1); j = 2;
-    uint32_t uq = 0;
+    uint32_t j = 2, jr = 2;                                       // next reference / read column (equal unless the read runs out)
+    R[0] = '-'; R[1] = '-'; G[0] = ref_at(0); G[1] = ref_at(1);
+    uint64_t uq = 0;
     int64_t ug = 2;
     for (uint32_t k = 0; k < r.n_cigar; ++k) {
         const uint32_t c = tg_u32(r.cigar + 4 * k), op = c & 15u, len = c >> 4;
-        if (op == 0u) { for (uint32_t t = 0; t < len; ++t) { R[j] = read_at(uq + t); G[j] = ref_at(ug + t); ++j; } uq += len; ug += len; }
-        else if (op == 1u) { for (uint32_t t = 0; t < len; ++t) { R[j] = read_at(uq + t); G[j] = '-'; ++j; } uq += len; }
-        else if (op == 2u) { for (uint32_t t = 0; t < len; ++t) { R[j] = '-'; G[j] = ref_at(ug + t); ++j; } ug += len; }
+        const uint32_t take = (op <= 1u) ? (uint32_t)(uq >= r.l_seq ? 0u : (r.l_seq - uq < len ? r.l_seq - uq : len)) : 0u;   // skip(uq).take(len)
+        if (op == 0u) { for (uint32_t t = 0; t < take; ++t) R[jr++] = read_at((uint32_t)uq + t); for (uint32_t t = 0; t < len; ++t) G[j++] = ref_at(ug + t); uq += len; ug += len; }
+        else if (op == 1u) { for (uint32_t t = 0; t < take; ++t) R[jr++] = read_at((uint32_t)uq + t); for (uint32_t t = 0; t < len; ++t) G[j++] = '-'; uq += len; }
+        else if (op == 2u) { for (uint32_t t = 0; t < len; ++t) { R[jr++] = '-'; G[j++] = ref_at(ug + t); } ug += len; }
     }
-    R[j] = '-'; R[j + 1] = '-'; G[j] = ref_at(reflen_str - 2); G[j + 1] = ref_at(reflen_str - 1);
-    // (j + 2 == ncol by construction)
+    R[jr] = '-'; R[jr + 1] = '-'; G[j] = ref_at(reflen_str - 2); G[j + 1] = ref_at(reflen_str - 1);
+    // (j + 2 == ncol by construction; jr == j unless short_read)
+    if (short_read) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int64_t nx = tg_xm_unaligned(R, jr + 2u, G, j + 2u, rc, a.xm + a.col_off[i]);
+        if (nx < 0) { atomicOr(a.err, (uint32_t)ERRB_TAGPANIC); return; }
+        a.xm_len[i] = (uint32_t)nx;
+        return;
+    }
     if (rc) {                                                    // tag.rs:246-256: every character goes through the table
         for (uint32_t t = 0; t + 2 < ncol; ++t) {
             const uint8_t x = tg_comp(R[t]), y = tg_comp(G[t]);

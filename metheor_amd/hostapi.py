@@ -216,6 +216,10 @@ class BamFile:
         cap = 4 * (o1 - o0) + 256 + (len(xm) if xm else 0)
         buf = C.create_string_buffer(cap)
         n = self.L.mth_host_sam_format(self.h, rec, o1 - o0 - 4, xm, len(xm) if xm else 0, buf, cap)
+        if n > cap:       # large signed B arrays print longer than 4 characters per byte: the formatter returns what it needs
+            cap = int(n)
+            buf = C.create_string_buffer(cap)
+            n = self.L.mth_host_sam_format(self.h, rec, o1 - o0 - 4, xm, len(xm) if xm else 0, buf, cap)
         if n < 0 or n > cap:
             raise HostError(int(n), "cannot format the record")
         return buf.raw[:n]

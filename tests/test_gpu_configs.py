@@ -116,6 +116,7 @@ def test_config3_full_density_chr1_properties(eng):
     p2 = eng.pdr_fetch()
     assert all((p[k] == p2[k]).all() for k in p)
     # exact against the oracle on a 400 k-read prefix and on a 400 k-read slice at the contig's far end
+    slices = []
     for lo_i, hi_i in ((0, 400_000), (n - 400_000, n)):
         beg = 0 if lo_i == 0 else int(c["read_start"][lo_i]) + 200
         end = int(c["read_start"][hi_i]) if hi_i < n else ln
@@ -127,6 +128,70 @@ def test_config3_full_density_chr1_properties(eng):
         assert m.sum() > 30_000 and (p["pos"][m] == o.pos[keep, 0]).all()
         assert (p["n_concordant"][m] == o.cnt[keep, 0]).all() and (p["n_discordant"][m] == o.cnt[keep, 1]).all()
         assert (p["pdr"][m].view(np.uint32) == o.val[keep].view(np.uint32)).all()
+        slices.append((beg, end, reads))
+    # MHL and FDRP / qFDRP over the whole 16.1 M-read contig, exact against the oracle on the same two slices:
+    # a site in [beg, end) only ever sees reads that start within a read length of it, all of them in the slice
+    mk = dict(min_depth=10, min_cpgs=4, min_qual=10)
+    eng.reset()
+    eng.mhl_accumulate(bt, **mk)
+    dm = eng.mhl_fetch()
+    fk = dict(min_qual=10, min_depth=10, max_depth=40, min_overlap=35)
+    eng.fdrp_accumulate(bt, **fk)
+    df = eng.fdrp_fetch()
+    assert len(dm["pos"]) > 20_000 and len(df["pos"]) > 100_000      # (MHL: reads with >= 4 CpGs are rare at 1.35 calls per read)
+    for beg, end, reads in slices:
+        o = reads.mhl(**mk)
+        keep = (o.pos[:, 0] >= beg) & (o.pos[:, 0] < end)
+        m = (dm["pos"] >= beg) & (dm["pos"] < end)
+        assert m.sum() > 300 and (dm["pos"][m] == o.pos[keep, 0]).all() and (dm["cov"][m] == o.cnt[keep, 0]).all()
+        assert np.abs(dm["mhl"][m].astype(np.float64) - o.val[keep].astype(np.float64)).max() <= 1e-6
+        of, oq = reads.fdrp(**fk), reads.qfdrp(**fk)
+        keep = (of.pos[:, 0] >= beg) & (of.pos[:, 0] < end)
+        m = (df["pos"] >= beg) & (df["pos"] < end)
+        assert m.sum() > 5_000 and (df["pos"][m] == of.pos[keep, 0]).all() and (df["n_reads"][m] == of.cnt[keep, 0]).all()
+        assert T_fdrp.same(df["fdrp"][m], of.val[keep]) <= 1e-6 and T_fdrp.same(df["qfdrp"][m], oq.val[keep]) <= 1e-6
+
+
+def test_config4_full_size_hotspots(eng):
+    """BASELINE config 4 at its full size (20 000 windows, 6.66 M reads, 1.40 M sites, 1.8e9 read pairs), -D 64 and the CLI's
+    default -D 40: rows and stored-read counts in closed form from the SoA (a site's depth = the calls it gets from mapq-passing
+    reads; every 150-bp read fits the +-201-bp window of fdrp.rs:58-63), values exact against the oracle on two 30-window slices"""
+    from metheor_amd import shard, synth
+    c = synth.hotspots()                                   # n_windows 20000, depth 50, density 0.08, seed 50
+    n = len(c["read_start"])
+    assert n == 6_660_000
+    bt = util.device_batch(c, device="cuda:0")
+    ncpg = np.diff(c["cpg_off"].astype(np.int64))
+    ok = np.repeat(c["read_mapq"] >= 10, ncpg)
+    pos_ok = (c["cpg_pos"] & 0x7fffffff)[ok].astype(np.int64)
+    sites, depth = np.unique(pos_ok, return_counts=True)
+    want = depth >= 10
+    out = {}
+    for D in (64, 40):
+        fk = dict(min_qual=10, min_depth=10, max_depth=D, min_overlap=35, seed=4)
+        eng.reset()
+        eng.fdrp_accumulate(bt, **fk)
+        d = eng.fdrp_fetch()
+        # (a site flushed by a read that starts on its G and re-opened by a reverse read with the same start reports its LAST
+        # segment, SURVEY Q1: a fraction of a percent of the sites hold fewer reads than their depth, or miss min_depth)
+        idx = np.searchsorted(sites, d["pos"])
+        assert (np.diff(d["pos"]) > 0).all() and (sites[idx] == d["pos"]).all() and want[idx].all()
+        assert len(d["pos"]) >= 0.99 * int(want.sum())
+        cap = np.minimum(depth[idx], D)
+        assert (d["n_reads"] <= cap).all() and (d["n_reads"] == cap).mean() > 0.98      # measured: 98.8 % at this density and depth
+        assert (d["fdrp"] >= 0).all() and (d["fdrp"] <= 1).all() and (d["qfdrp"] >= 0).all() and (d["qfdrp"] <= 1).all()
+        out[D] = d
+    stride = 1000 + 2 * 150 + 404
+    for w0 in (0, 12_345):
+        beg, end = w0 * stride, (w0 + 30) * stride
+        sub = shard.slice_region(c, beg, end)
+        reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(sub))
+        for D in (64, 40):
+            fk = dict(min_qual=10, min_depth=10, max_depth=D, min_overlap=35, seed=4)
+            of, oq = reads.fdrp(**fk), reads.qfdrp(**fk)
+            m = (out[D]["pos"] >= beg) & (out[D]["pos"] < end)
+            assert m.sum() == len(of) > 1500 and (out[D]["pos"][m] == of.pos[:, 0]).all()
+            assert T_fdrp.same(out[D]["fdrp"][m], of.val) <= 1e-6 and T_fdrp.same(out[D]["qfdrp"][m], oq.val) <= 1e-6
 
 
 def test_config5_sharded_8_vs_oracle_text(wgbs24, tmp_path):

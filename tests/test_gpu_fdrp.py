@@ -297,3 +297,49 @@ def test_wgbs_depth(eng):
         n, nf, nq = check(run_device(eng, [c], kw, device="cuda:0"), reads, kw)
         print("wgbs depth", kw, "rows", n, "not bit-identical:", nf, nq)
         assert n > 10000 and nf == 0 and nq == 0
+
+
+# ---- the reservoir as a reservoir (the draw itself: tests/test_reservoir.py) -----------------------------
+def test_reservoir_set_size_and_unbiased_estimates(eng):
+    """BASELINE config 4's hotspots with the CLI's DEFAULT -D 40 (the sampling branch at 50x): every site stores min(depth, 40)
+    reads; FDRP and qFDRP of a uniformly drawn 40-subset are unbiased estimates of the full-depth values (a pair is kept with
+    the same probability whatever its two reads), so over thousands of sampled sites the mean difference to -D 64 must vanish
+    within its standard error -- a reservoir that favoured early (= leftmost) reads would not: neighbours in coordinate order
+    overlap more, fewer of their pairs fall under --min-overlap.  Bound stated in DESIGN section 12: |z| < 5."""
+    from metheor_amd import synth
+    c = synth.hotspots(n_windows=500, window=1000, depth=50, density=0.08, seed=51)
+    full = run_device(eng, [c], dict(min_qual=10, min_depth=10, max_depth=64, min_overlap=35, seed=1))
+    seeds = {}
+    for seed in (1, 2, 3):
+        d = run_device(eng, [c], dict(min_qual=10, min_depth=10, max_depth=40, min_overlap=35, seed=seed))
+        assert (d["pos"] == full["pos"]).all()
+        assert (d["n_reads"] == np.minimum(full["n_reads"], 40)).all()          # stored set size = min(depth, D)
+        seeds[seed] = d
+    deep = full["n_reads"] > 40
+    assert deep.sum() > 5000
+    # the draw depends on the seed: sampled sites change, unsampled ones cannot
+    assert (seeds[1]["fdrp"][~deep].view(np.uint32) == full["fdrp"][~deep].view(np.uint32)).all()
+    assert (seeds[1]["qfdrp"][deep] != seeds[2]["qfdrp"][deep]).mean() > 0.5
+    for key in ("fdrp", "qfdrp"):
+        zs = []
+        for seed, d in seeds.items():
+            diff = d[key][deep].astype(np.float64) - full[key][deep].astype(np.float64)
+            z = diff.mean() / (diff.std(ddof=1) / np.sqrt(len(diff)))
+            zs.append(z)
+            assert abs(z) < 5.0, (key, seed, z, diff.mean())
+        print(key, "z-scores of mean(-D 40 minus -D 64) over", int(deep.sum()), "sites:", [round(z, 2) for z in zs])
+    # what a NON-uniform reservoir looks like to this test: keep each site's first 40 reads (coordinate order) -- the oracle on a
+    # copy of the input from which every site's later reads are gone is not needed: dropping the LAST 10 reads of every window
+    # shifts the mean well outside the bound
+    starts = c["read_start"].astype(np.int64)
+    stride = 1000 + 2 * 150 + 404
+    win = starts // stride
+    order_in_win = np.arange(len(starts)) - np.searchsorted(win, win, side="left")
+    per = np.bincount(win)[win]
+    biased = util.subset_reads(c, order_in_win < per * 0.8)
+    b = run_device(eng, [biased], dict(min_qual=10, min_depth=10, max_depth=64, min_overlap=35, seed=1))
+    common, ia, ib = np.intersect1d(full["pos"][deep], b["pos"], return_indices=True)
+    diff = b["fdrp"][ib].astype(np.float64) - full["fdrp"][deep][ia].astype(np.float64)
+    zb = diff.mean() / (diff.std(ddof=1) / np.sqrt(len(diff)))
+    print("control (first 80 % of every window's reads instead of a uniform subset): z =", round(zb, 1))
+    assert abs(zb) > 8.0

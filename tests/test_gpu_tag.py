@@ -180,3 +180,79 @@ def test_cli_tag_bam_input_equals_sam_input(chr19, tmp_path):
     r = subprocess.run([EXE, "tag", "-i", str(bam), "-o", str(out), "-g", chr19["fa"]], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stderr
     assert out.read_bytes() == chr19["want"]
+
+
+# ---- a read shorter than its CIGAR: chars().skip().take() comes up short in the reference, it does not panic ------
+def _bam_record(tid, pos, flag, cigar, seq, name=b"r"):
+    """one BAM record (block_size included) with an arbitrary l_seq, whatever the CIGAR says"""
+    import struct
+    nib = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    packed = bytearray((len(seq) + 1) // 2)
+    for k, ch in enumerate(seq.decode()):
+        packed[k >> 1] |= nib[ch] << (0 if k & 1 else 4)
+    body = struct.pack("<iiBBHHHIiii", tid, pos, len(name) + 1, 30, 4680, len(cigar), flag, len(seq), -1, -1, 0)
+    body += name + b"\0" + b"".join(struct.pack("<I", c) for c in cigar) + bytes(packed) + b"\xff" * len(seq)
+    return struct.pack("<i", len(body)) + body
+
+
+def test_seq_star_beside_a_cigar_gives_an_empty_xm(eng, tmp_path):
+    # bwa mem -a / bwa-meth secondary alignments: SEQ '*' with a CIGAR.  tag.rs:190-216 take() nothing, every read column is '-'
+    contig = b"ACGTCGCGAACCGGTTACGT" * 20
+    p = tmp_path / "s.sam"
+    p.write_text("@HD\tVN:1.6\n@SQ\tSN:c0\tLN:400\n"
+                 "a\t0\tc0\t10\t30\t20M\t*\t0\t0\tCGCGAACCGGTTACGTACGT\t*\n"
+                 "b\t256\tc0\t10\t30\t20M\t*\t0\t0\t*\t*\n"
+                 "c\t272\tc0\t30\t30\t5M2D10M1I4M\t*\t0\t0\t*\t*\n")
+    got = device_xm(eng, str(p), [(400, contig)])
+    want = [pyoracle.tag_xm(9, 0, [(20 << 4)], b"CGCGAACCGGTTACGTACGT", contig),
+            pyoracle.tag_xm(9, 256, [(20 << 4)], b"", contig),
+            pyoracle.tag_xm(29, 272, [(5 << 4), (2 << 4) | 2, (10 << 4), (1 << 4) | 1, (4 << 4)], b"", contig)]
+    assert want[1] == b"" and want[2] == b"" and len(want[0]) == 20
+    assert got == want
+    fa = str(tmp_path / "g.fa")
+    tag_util.write_fasta(fa, "c0", contig)
+    out = tmp_path / "o.sam"
+    r = subprocess.run([EXE, "tag", "-i", str(p), "-o", str(out), "-g", fa], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = out.read_text().splitlines()[2:]
+    assert lines[1].endswith("\tXM:Z:") and lines[2].endswith("\tXM:Z:") and lines[0].endswith("XM:Z:" + want[0].decode())
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_reads_shorter_than_their_cigar_match_the_oracle(eng, seed):
+    """BAM records whose l_seq is smaller than the CIGAR's M + I (only a BAM can say that; SAM text is refused by htslib and by
+    sam_text.cpp): the device walks the read and reference column strings independently, as tag.rs does, and agrees with the
+    oracle letter for letter -- including the records on which the reference panics"""
+    import metheor_amd
+    rng = np.random.default_rng(seed)
+    contig = bytes(rng.choice(list(b"ACGT") * 8 + list(b"N"), size=600).astype(np.uint8))
+    eng.tag_set_genome([(600, contig)])
+    n_ok = n_panic = 0
+    for i in range(300):
+        ops = []
+        for k in range(int(rng.integers(1, 6))):
+            op = int(rng.choice([0, 0, 0, 1, 2]))
+            if ops and (ops[-1] & 15) == op:
+                continue
+            ops.append((int(rng.integers(1, 25)) << 4) | op)
+        if not any((c & 15) == 0 for c in ops):
+            ops.append((int(rng.integers(1, 25)) << 4))
+        need = sum(c >> 4 for c in ops if (c & 15) in (0, 1))
+        reflen = sum(c >> 4 for c in ops if (c & 15) in (0, 2))
+        l_seq = int(rng.integers(0, need + 1))                    # 0 ... exactly enough
+        seq = bytes(rng.choice(list(b"ACGTN"), size=l_seq).astype(np.uint8))
+        pos = int(rng.integers(0, 600 - reflen))
+        flag = 16 if rng.random() < 0.5 else 0
+        want = pyoracle.tag_xm(pos, flag, ops, seq, contig)
+        raw = _bam_record(0, pos, flag, ops, seq)
+        if want is None:
+            with pytest.raises(metheor_amd.MthError):
+                eng.tag_records(raw, np.array([0, len(raw)], np.uint64))
+            eng.reset()
+            eng.tag_set_genome([(600, contig)])
+            n_panic += 1
+        else:
+            got = eng.tag_records(raw, np.array([0, len(raw)], np.uint64))
+            assert got == [want], (i, ops, l_seq, flag, want, got)
+            n_ok += 1
+    assert n_ok > 150
