@@ -148,32 +148,103 @@ def cpu_info():
     return os.cpu_count(), model
 
 
-def e2e_leg(c, n_reads):
+def _phases(stderr):
+    """[metheor timing] lines of one run (METHEOR_TIMING=1) -> {phase: seconds}"""
+    ph = {}
+    for l in stderr.splitlines():
+        if l.startswith("[metheor timing]"):
+            body = l[len("[metheor timing]"):].rstrip()
+            name, sec = body[:-2].rsplit(None, 1) if body.endswith(" s") else (body, "nan")
+            try:
+                ph[name.strip()] = float(sec)
+            except ValueError:
+                pass
+    return ph
+
+
+def _run_cli(exe, bam, tsv, reps):
+    runs = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "pdr", "-i", bam, "-o", tsv], capture_output=True, text=True, env=dict(os.environ, METHEOR_TIMING="1"))
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return None, r.stderr[-300:]
+        runs.append((dt, _phases(r.stderr)))
+    return runs, None
+
+
+def _split(dt, ph):
+    """a run's wall time by phase: load = BGZF inflate + record walk + XM decode on the device (file -> SoA in HBM, host-to-device copy of
+    the file included), kernels = the measure's passes + sync, tail = fetch + format + write, startup = everything else (process start, HIP
+    runtime start-up -- overlapped with opening the file --, exit)"""
+    load = ph.get("device inflate + walk + decode", ph.get("inflate + device record decode", ph.get("host decode (BGZF+BAM+XM)", 0.0)))
+    kern = ph.get("H2D + kernels (sync)", 0.0)
+    tail = ph.get("fetch", 0.0) + ph.get("format + write", 0.0) + ph.get("fetch + TSV write", 0.0)
+    return {"wall_s": round(dt, 4), "startup_s": round(max(dt - load - kern - tail, 0.0), 4), "load_s": round(load, 4), "kernels_s": round(kern, 4),
+            "tail_s": round(tail, 4), "device_context_overlapped_s": ph.get("device context (overlapped)", ph.get("device context"))}
+
+
+def e2e_leg(c, n_reads, large_copies=10):
     """BAM -> TSV: the stand-alone `metheor pdr` executable on a config-2 BAM written here (the north_star's end-to-end
-    clause).  Whole-process wall time, file in the page cache, best and median of 5."""
+    clause).  Whole-process wall time, file in the page cache, best and median of 5, the median run split by phase; then the
+    same on a `large_copies` x larger file (the contig's reads on that many contigs) -- the fixed cost of a process (runtime
+    start-up ~0.1 s) is a third of a 10 M-read run and a twentieth of a 100 M-read one."""
     from metheor_amd import hostapi
     d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     bam, tsv = os.path.join(d, "metheor_bench_%d.bam" % os.getpid()), os.path.join(d, "metheor_bench_%d.tsv" % os.getpid())
+    exe = os.path.join(ROOT, "metheor_amd", "metheor")
     try:
         t0 = time.perf_counter()
         hostapi.write_synthetic_bam(bam, c, contig="chr19", seed=7)
         t_write = time.perf_counter() - t0
         size = os.path.getsize(bam)
-        exe = os.path.join(ROOT, "metheor_amd", "metheor")
-        ts = []
-        for _ in range(6):
-            t0 = time.perf_counter()
-            r = subprocess.run([exe, "pdr", "-i", bam, "-o", tsv], capture_output=True, text=True)
-            ts.append(time.perf_counter() - t0)
-            if r.returncode != 0:
-                return {"error": r.stderr[-300:]}
-        ts = sorted(ts[1:])
+        runs, err = _run_cli(exe, bam, tsv, 6)
+        if runs is None:
+            return {"error": err}
+        runs = sorted(runs[1:], key=lambda x: x[0])
         rows = sum(1 for _ in open(tsv))
-        return {"what": "`metheor pdr -i <bam> -o <tsv>` whole-process wall time: BGZF inflate + record walk + XM decode + PDR on the "
-                        "device, fetch, format, write; BAM in the page cache; 5 runs after one warm-up",
-                "reads": n_reads, "bam_bytes": size, "tsv_rows": rows, "best_s": round(ts[0], 4), "median_s": round(ts[len(ts) // 2], 4),
-                "M_reads_per_s_best": round(n_reads / ts[0] / 1e6, 2), "M_reads_per_s_median": round(n_reads / ts[len(ts) // 2] / 1e6, 2),
-                "bam_write_s": round(t_write, 1)}
+        med = runs[len(runs) // 2]
+        out = {"what": "`metheor pdr -i <bam> -o <tsv>` whole-process wall time: BGZF inflate + record walk + XM decode + PDR on the "
+                       "device, fetch, format, write; BAM in the page cache; 5 runs after one warm-up",
+               "reads": n_reads, "bam_bytes": size, "tsv_rows": rows, "best_s": round(runs[0][0], 4), "median_s": round(med[0], 4),
+               "M_reads_per_s_best": round(n_reads / runs[0][0] / 1e6, 2), "M_reads_per_s_median": round(n_reads / med[0] / 1e6, 2),
+               "median_run": _split(*med), "best_run": _split(*runs[0]),
+               "load_phase_M_reads_per_s_median": round(n_reads / max(_split(*med)["load_s"], 1e-9) / 1e6, 1),
+               "bam_write_s": round(t_write, 1)}
+        os.remove(bam)
+        # ---- the larger file ----
+        try:
+            import shutil
+            free = shutil.disk_usage(d).free
+            if large_copies > 1 and free > 3 * large_copies * size:
+                cs = []
+                for k in range(large_copies):
+                    ck = dict(c)
+                    ck["tid"] = k
+                    cs.append(ck)
+                t0 = time.perf_counter()
+                hostapi.write_synthetic_bam_multi(bam, cs, ["chr19_%d" % k for k in range(large_copies)], seed=7)
+                t_w = time.perf_counter() - t0
+                del cs
+                big = os.path.getsize(bam)
+                runs2, err = _run_cli(exe, bam, tsv, 4)
+                if runs2 is None:
+                    out["large"] = {"error": err}
+                else:
+                    runs2 = sorted(runs2[1:], key=lambda x: x[0])
+                    nb = n_reads * large_copies
+                    m2 = runs2[len(runs2) // 2]
+                    out["large"] = {"what": "the same reads on %d contigs in one BAM (%d reads): 3 runs after one warm-up" % (large_copies, nb),
+                                    "reads": nb, "bam_bytes": big, "tsv_rows": sum(1 for _ in open(tsv)), "best_s": round(runs2[0][0], 4),
+                                    "median_s": round(m2[0], 4), "M_reads_per_s_best": round(nb / runs2[0][0] / 1e6, 2),
+                                    "M_reads_per_s_median": round(nb / m2[0] / 1e6, 2), "median_run": _split(*m2), "bam_write_s": round(t_w, 1),
+                                    "marginal_M_reads_per_s": round((nb - n_reads) / max(m2[0] - med[0], 1e-9) / 1e6, 2)}
+            else:
+                out["large"] = {"skipped": "not enough room in %s" % d}
+        except Exception as ex:
+            out["large"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+        return out
     finally:
         for p in (bam, tsv):
             if os.path.exists(p):

@@ -4,6 +4,8 @@
 // compresses like a real BAM.  Records are built and deflated (BGZF, zlib level 6) in parallel.
 // Block layout as htslib writes it (bgzf_flush_try before every record): a block holds whole records, at most
 // 0xff00 inflated bytes -- no record straddles two BGZF blocks.
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstring>
@@ -54,7 +56,7 @@ extern "C" int mth_host_write_synthetic_bam_multi(const char *path, int32_t n_co
     if (!path || !contigs || !contig_lens || n_contigs < 1 || n_reads < 0 || read_len <= 0) return MTH_HOST_ERR_INVALID;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
     if (nthreads <= 0) nthreads = 1;
-    if (nthreads > 128) nthreads = 128;
+    if (nthreads > 256) nthreads = 256;
     std::vector<uint8_t> head;
     std::string text = "@HD\tVN:1.0\tSO:coordinate\n";
     for (int32_t c = 0; c < n_contigs; ++c) text += std::string("@SQ\tSN:") + contigs[c] + "\tLN:" + std::to_string(contig_lens[c]) + "\n";
@@ -98,15 +100,30 @@ extern "C" int mth_host_write_synthetic_bam_multi(const char *path, int32_t n_co
         if (!raw.empty()) bgzf_append(out, raw.data(), raw.size());
     });
     for (auto &x : th) x.join();
-    FILE *f = fopen(path, "wb");
-    if (!f) return MTH_HOST_ERR_OPEN;
+    // header, the threads' parts at their offsets (written in parallel: one fwrite of a 100 M-read file is ten seconds), EOF block
     std::vector<uint8_t> hb;
     bgzf_append(hb, head.data(), head.size());
-    bool ok = fwrite(hb.data(), 1, hb.size(), f) == hb.size();
-    for (auto &p : parts) ok = ok && (p.empty() || fwrite(p.data(), 1, p.size(), f) == p.size());
     static const uint8_t eof_blk[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    ok = ok && fwrite(eof_blk, 1, 28, f) == 28;
-    ok = (fclose(f) == 0) && ok;
+    std::vector<uint64_t> at(parts.size() + 1);
+    at[0] = hb.size();
+    for (size_t t = 0; t < parts.size(); ++t) at[t + 1] = at[t] + parts[t].size();
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return MTH_HOST_ERR_OPEN;
+    auto put = [&](const uint8_t *p, size_t n, uint64_t off) {
+        while (n) {
+            const ssize_t w = pwrite(fd, p, n, (off_t)off);
+            if (w <= 0) return false;
+            p += w; n -= (size_t)w; off += (uint64_t)w;
+        }
+        return true;
+    };
+    std::vector<char> okv(parts.size(), 1);
+    std::vector<std::thread> wr;
+    for (size_t t = 0; t < parts.size(); ++t) wr.emplace_back([&, t] { okv[t] = put(parts[t].data(), parts[t].size(), at[t]) ? 1 : 0; });
+    bool ok = put(hb.data(), hb.size(), 0) && put(eof_blk, 28, at[parts.size()]);
+    for (auto &x : wr) x.join();
+    for (char o : okv) ok = ok && o;
+    ok = (close(fd) == 0) && ok;
     return ok ? MTH_HOST_OK : MTH_HOST_ERR_OPEN;
 }
 
