@@ -582,296 +582,6 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
     return tile_compact<W, B, WIDE>(a, t, P0, Wp, cnt, wave_off, out_base);
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same pass SPLIT BY READ LENGTH IN CALLS (round 3).  The one-pass form above spends ~230 vector instructions per 64 reads
-// whatever they hold: every read pays for 8 call slots -- masks, 28 slot pairs, 8 scatter adds -- while a read of config 2
-// has 2.94 calls and one at WGBS depth 1.35.  Here pass A takes every candidate read with a LEAN form that holds NA slots
-// (2 for sparse batches: one pair, two adds, ~55 instructions; 4 for dense ones: six pairs, ~110) and handles the reads with
-// <= NA calls completely; a read with more calls is left untouched and its index goes to a queue in LDS (one segment per wave:
-// no atomics, position = the wave's count + mbcnt of the ballot).  After one barrier pass B runs the full 8-slot form over
-// the queue -- 16 % of the reads at WGBS depth, 18 % on config 2 -- with whole waves of long reads instead of one long lane
-// per wave of short ones.  The counters live until the tile's end, so the order of the two passes does not matter.  A tile
-// whose queue overflows (a pile of long reads) clears its counters and takes the one-pass form: rare, exact.
-constexpr int SPLIT_QSEG = 112;      // queue entries per wave (16-bit read index relative to lo)
-struct SplitQ {
-    uint16_t ent[4][SPLIT_QSEG];
-    uint32_t n[4];
-    uint32_t over;
-};
-typedef uint16_t u16_a1 __attribute__((aligned(1)));
-typedef uint32_t u32_a1 __attribute__((aligned(1)));
-typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-
-template <int W, int B, int MG, int NA>
-__device__ __forceinline__ uint32_t tile_pass_split(const TileArgs &a, const uint32_t t, const int32_t T0, const int32_t T1,
-                                                    const uint32_t lo, const uint32_t hi, const bool do_lp, uint32_t *cnt_raw,
-                                                    uint32_t (*red)[B / 64], uint32_t *wave_off, SlotTabs &tabs, SplitQ &q) {
-    static_assert(B == 256 && MG > 0 && (NA == 2 || NA == 4), "four queue segments; counter margins; 2 or 4 lean slots");
-    constexpr int NB = 8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t *const cnt = cnt_raw + MG;
-    const int32_t P0 = T0;
-    const uint32_t Wp = (uint32_t)(T1 - T0);
-    const uint8_t *__restrict__ rel = reinterpret_cast<const uint8_t *>(a.cpg_rel);
-    uint32_t lp_c = 0, lp_d = 0, n_read = 0, n_valid = 0, bad = 0;
-    const int32_t maxd = min(a.max_dist, 255);       // 8-bit relpos: no distance beyond 255
-    const int32_t mind = max(a.min_dist, 0);
-    const bool lp_possible = do_lp && maxd >= a.min_dist && maxd >= 0;      // min > max: no pair can qualify
-    const uint32_t KA = (0x8000u - (uint32_t)mind) * 0x10001u, KB = (0x8000u + (uint32_t)maxd) * 0x10001u;
-    const uint32_t base4 = (uint32_t)(P0 - MG) << 2;
-
-    // ---- pass A: lean form, NA slots --------------------------------------------------------------------------------
-    uint32_t qn = 0;                 // entries this wave has queued (wave-uniform)
-    uint32_t over = 0;
-    {
-        uint32_t i = lo + tid;
-        uint32_t o0 = 0, o1 = 0;
-        if (i < hi) { o0 = a.cpg_off[i]; o1 = a.cpg_off[i + 1]; }
-        while (i < hi) {
-            const uint32_t inext = i + B;
-            const uint32_t n = o1 - o0;
-            uint32_t v[NA];
-            uint32_t rr = 0;
-            if constexpr (NA == 4) {
-                const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0);
-                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-                if (do_lp) rr = *reinterpret_cast<const u32_a1 *>(rel + o0);
-            } else {
-                const u32x2_a4 x = *reinterpret_cast<const u32x2_a4 *>(a.cpg_pos + o0);
-                v[0] = x.x; v[1] = x.y;
-                if (do_lp) rr = *reinterpret_cast<const u16_a1 *>(rel + o0);
-            }
-            const int32_t s = a.read_start[i];
-            const uint32_t mq = a.read_mapq[i];
-            uint32_t o0n = 0, o1n = 0;
-            if (inext < hi) { o0n = a.cpg_off[inext]; o1n = a.cpg_off[inext + 1]; }
-
-            const bool owned = (s >= T0) && (s < T1);
-            const bool lp_ok = do_lp && owned && (mq >= a.lpmd_min_qual);                    // lpmd.rs:176-179
-            if (do_lp && owned) { n_read += 1; n_valid += lp_ok ? 1u : 0u; }
-            const bool pdr_ok = a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);   // pdr.rs:147-157
-            const bool work = (lp_ok || pdr_ok) && n != 0;
-            const bool lean = work && n <= (uint32_t)NA;
-            const bool defer = work && n > (uint32_t)NA;
-            const bool any_lp = lp_possible && __any(lean && lp_ok && n > 1);
-            if (lean) {
-                const uint32_t sm1 = (uint32_t)(s - 1);
-                const uint32_t dead_w = ((uint32_t)(P0 - MG + lane) & 0x7fffffffu) | (v[0] & 0x80000000u);
-                const uint32_t n_lp = lp_ok ? n : 0u;
-                uint32_t acc = 0, xmax = (v[0] & 0x7fffffffu) - sm1;
-                uint32_t mk[NA];
-                if constexpr (NA == 4) {
-                    const uint4 ma = reinterpret_cast<const uint4 *>(&tabs.mtab[n][0])[0];
-                    mk[0] = ma.x; mk[1] = ma.y; mk[2] = ma.z; mk[3] = ma.w;
-                } else {
-                    const uint2 ma = reinterpret_cast<const uint2 *>(&tabs.mtab[n][0])[0];
-                    mk[0] = ma.x; mk[1] = ma.y;
-                }
-#pragma unroll
-                for (int k = 1; k < NA; ++k) {
-                    const uint32_t x = __builtin_amdgcn_bitop3_b32(v[k] - sm1, mk[k], 0x7fffffffu, 0x80);       // a & b & c
-                    v[k] = __builtin_amdgcn_bitop3_b32(v[k], dead_w, mk[k], 0xe4);                               // c ? a : b
-                    acc = __builtin_amdgcn_bitop3_b32(acc, v[k], v[0], 0xf6);                                    // a | (b ^ c)
-                    xmax = max(xmax, x);
-                }
-                const uint32_t bad_it = (xmax > (uint32_t)a.max_span) ? 1u : 0u;
-                bad |= bad_it;
-                const uint32_t disc = acc >> 31;
-                if (any_lp) {
-                    // packed 16-bit fields as in the full form (mth_tile_dev.h): Q_e = (slot 2e, 2e+1), O_e = (slot 2e+1, 2e+2), the slot
-                    // after the last one a dummy that is always dead (its relpos field is 0 + the table's dead offset)
-                    uint32_t accIN = 0, accDD = 0;
-                    auto sub = [&](const uint32_t later, const uint32_t earlier, const uint32_t sl, const uint32_t se) -> uint32_t {
-                        const uint32_t D = later - earlier;
-                        const uint32_t Bw = KB - D;
-                        const uint32_t IN = __builtin_amdgcn_bitop3_b32(D + KA, Bw, 0x80008000u, 0x80);   // min <= distance <= max
-                        const uint32_t DD = IN & (sl ^ se);
-                        accIN += __builtin_popcount(IN);
-                        accDD += __builtin_popcount(DD);
-                        return Bw;
-                    };
-                    if constexpr (NA == 4) {
-                        const uint32_t SQ0 = __builtin_amdgcn_perm(v[1], v[0], 0x070c030cu), SQ1 = __builtin_amdgcn_perm(v[3], v[2], 0x070c030cu);
-                        const uint32_t SO0 = __builtin_amdgcn_perm(v[2], v[1], 0x070c030cu), SO1 = __builtin_amdgcn_perm(0u, v[3], 0x070c030cu);
-                        const uint2 da = reinterpret_cast<const uint2 *>(&tabs.dtab[n_lp][0])[0], db = reinterpret_cast<const uint2 *>(&tabs.dtab[n_lp][4])[0];
-                        const uint32_t Q0 = __builtin_amdgcn_perm(0u, rr, 0x0c010c00u) + da.x, Q1 = __builtin_amdgcn_perm(0u, rr, 0x0c030c02u) + da.y;
-                        const uint32_t O0 = __builtin_amdgcn_perm(0u, rr, 0x0c020c01u) + db.x, O1 = __builtin_amdgcn_perm(0u, rr, 0x0c0c0c03u) + db.y;
-                        uint32_t orB = sub(O0, Q0, SO0, SQ0) | sub(O1, Q1, SO1, SQ1);                     // call-index gap 1
-                        if (__any((orB & 0x80008000u) != 0u)) {
-                            orB = sub(Q1, Q0, SQ1, SQ0);                                                  // gap 2
-                            if (__any((orB & 0x80008000u) != 0u)) (void)sub(O1, Q0, SO1, SQ0);            // gap 3
-                        }
-                    } else {
-                        const uint32_t SQ0 = __builtin_amdgcn_perm(v[1], v[0], 0x070c030cu), SO0 = __builtin_amdgcn_perm(0u, v[1], 0x070c030cu);
-                        const uint32_t Q0 = __builtin_amdgcn_perm(0u, rr, 0x0c010c00u) + tabs.dtab[n_lp][0];
-                        const uint32_t O0 = __builtin_amdgcn_perm(0u, rr, 0x0c0c0c01u) + tabs.dtab[n_lp][4];
-                        (void)sub(O0, Q0, SO0, SQ0);
-                    }
-                    lp_c += accIN - accDD;
-                    lp_d += accDD;
-                }
-                // scatter (pdr.rs:180-191), as in the full form with margins: one branch per read, a subtract-and-shift per slot
-                if (pdr_ok && !bad_it && (uint32_t)s - (uint32_t)(P0 - MG + 1) <= (uint32_t)(W + MG - 1)) {
-                    const uint32_t one = disc ? 0x10001u : 1u;
-#pragma unroll
-                    for (int k = 0; k < NA; ++k)
-                        atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt_raw) + ((v[k] << 2) - base4)), one);
-                }
-            }
-            // reads with more than NA calls: this wave's segment of the queue
-            const unsigned long long dm = __ballot(defer);
-            if (dm) {
-                const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-                if (defer) {
-                    if (pos < (uint32_t)SPLIT_QSEG) q.ent[wave][pos] = (uint16_t)(i - lo);
-                    else over = 1;
-                }
-                qn += (uint32_t)__builtin_popcountll(dm);
-            }
-            o0 = o0n; o1 = o1n;
-            i = inext;
-        }
-    }
-    if (lane == 0) q.n[wave] = min(qn, (uint32_t)SPLIT_QSEG);
-    if (over) q.over = 1u;
-    __syncthreads();
-    if (q.over) {
-        // a queue segment overflowed: forget pass A (its counters; its LPMD sums were never committed) and take the one-pass form
-        __syncthreads();                                 // everybody has read the flag
-        for (int k = tid; k < (MG + W + MG) / 4; k += B) reinterpret_cast<uint4 *>(cnt_raw)[k] = make_uint4(0, 0, 0, 0);
-        if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
-        __syncthreads();
-        return tile_pass<W, B, NB, uint8_t, false, false, MG>(a, t, T0, T1, T0, Wp, lo, hi, do_lp, 0u, cnt_raw, red, wave_off, tabs);
-    }
-
-    // ---- pass B: the queued reads, full 8-slot form ---------------------------------------------------------------------
-    {
-        const uint32_t c0 = q.n[0], c1 = c0 + q.n[1], c2 = c1 + q.n[2], nq = c2 + q.n[3];
-        for (uint32_t j = tid; j < nq; j += B) {
-            const uint32_t seg = (j >= c0 ? 1u : 0u) + (j >= c1 ? 1u : 0u) + (j >= c2 ? 1u : 0u);
-            const uint32_t off = j - (seg == 0 ? 0u : (seg == 1 ? c0 : (seg == 2 ? c1 : c2)));
-            const uint32_t i = lo + q.ent[seg][off];
-            const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
-            const int32_t s = a.read_start[i];
-            const uint32_t mq = a.read_mapq[i];
-            const uint32_t n = o1 - o0;
-            uint32_t v[NB];
-            uint32_t rraw0 = 0, rraw1 = 0;
-            {
-                const uint32_t *__restrict__ cp = a.cpg_pos + o0;
-#pragma unroll
-                for (int k4 = 0; k4 < NB / 4; ++k4) {
-                    const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(cp + 4 * k4);
-                    v[4 * k4] = x.x; v[4 * k4 + 1] = x.y; v[4 * k4 + 2] = x.z; v[4 * k4 + 3] = x.w;
-                }
-                if (do_lp) { const u32x2_a1 x = *reinterpret_cast<const u32x2_a1 *>(rel + o0); rraw0 = x.x; rraw1 = x.y; }
-            }
-            const bool owned = (s >= T0) && (s < T1);
-            const bool lp_ok = do_lp && owned && (mq >= a.lpmd_min_qual);          // (the read totals were counted by pass A)
-            const bool pdr_ok = a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual);
-            // (every queued read has work to do and n > NA >= 2)
-            const bool any_lp = lp_possible && __any(lp_ok);
-            const uint32_t sm1 = (uint32_t)(s - 1);
-            const uint32_t dead_w = ((uint32_t)(P0 - MG + lane) & 0x7fffffffu) | (v[0] & 0x80000000u);
-            const uint32_t n_lp = lp_ok ? min(n, (uint32_t)NB) : 0u;
-            uint32_t acc = 0, xmax;
-            {
-                const uint32_t nrow = min(n, 8u);
-                const uint4 ma = reinterpret_cast<const uint4 *>(&tabs.mtab[nrow][0])[0], mb = reinterpret_cast<const uint4 *>(&tabs.mtab[nrow][0])[1];
-                const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
-                uint32_t xs[8];
-                xs[0] = (v[0] & 0x7fffffffu) - sm1;
-#pragma unroll
-                for (int k = 1; k < 8; ++k) {
-                    xs[k] = __builtin_amdgcn_bitop3_b32(v[k] - sm1, mk[k], 0x7fffffffu, 0x80);
-                    v[k] = __builtin_amdgcn_bitop3_b32(v[k], dead_w, mk[k], 0xe4);
-                    acc = __builtin_amdgcn_bitop3_b32(acc, v[k], v[0], 0xf6);
-                }
-                xmax = max(max(max(xs[0], xs[1]), max(xs[2], xs[3])), max(max(xs[4], xs[5]), max(xs[6], xs[7])));
-            }
-            uint32_t bad_it = (xmax > (uint32_t)a.max_span) ? 1u : 0u;
-            uint32_t disc = acc >> 31;
-            const bool any_long = __any(n > (uint32_t)NB);
-            if (any_long && n > (uint32_t)NB) {
-                const uint32_t first = v[0] >> 31;
-                for (uint32_t k = NB; k < n; ++k) {
-                    const uint32_t x = a.cpg_pos[o0 + k];
-                    disc |= (x >> 31) ^ first;
-                    bad_it |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
-                }
-            }
-            bad |= bad_it;
-            if (any_lp) {
-                uint32_t SQ[4], SO[4], Q[4], O[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) SQ[e] = __builtin_amdgcn_perm(v[2 * e + 1], v[2 * e], 0x070c030cu);
-#pragma unroll
-                for (int e = 0; e < 3; ++e) SO[e] = __builtin_amdgcn_perm(v[2 * e + 2], v[2 * e + 1], 0x070c030cu);
-                SO[3] = __builtin_amdgcn_perm(0u, v[7], 0x070c030cu);
-                Q[0] = __builtin_amdgcn_perm(0u, rraw0, 0x0c010c00u); Q[1] = __builtin_amdgcn_perm(0u, rraw0, 0x0c030c02u);
-                Q[2] = __builtin_amdgcn_perm(0u, rraw1, 0x0c010c00u); Q[3] = __builtin_amdgcn_perm(0u, rraw1, 0x0c030c02u);
-                O[0] = __builtin_amdgcn_perm(0u, rraw0, 0x0c020c01u); O[1] = __builtin_amdgcn_perm(rraw1, rraw0, 0x0c040c03u);
-                O[2] = __builtin_amdgcn_perm(0u, rraw1, 0x0c020c01u); O[3] = __builtin_amdgcn_perm(0u, rraw1, 0x0c0c0c03u);
-                {
-                    const uint4 da = reinterpret_cast<const uint4 *>(&tabs.dtab[n_lp][0])[0], db = reinterpret_cast<const uint4 *>(&tabs.dtab[n_lp][0])[1];
-                    Q[0] += da.x; Q[1] += da.y; Q[2] += da.z; Q[3] += da.w; O[0] += db.x; O[1] += db.y; O[2] += db.z; O[3] += db.w;
-                }
-                uint32_t accIN = 0, accDD = 0;
-#pragma unroll
-                for (int g = 1; g < 8; ++g) {
-                    uint32_t orB = 0;
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const int li = (g & 1) ? (g - 1) / 2 + m : g / 2 + m;
-                        if (li > 3) break;
-                        const uint32_t later = (g & 1) ? O[li] : Q[li], sl = (g & 1) ? SO[li] : SQ[li];
-                        const uint32_t D = later - Q[m];
-                        const uint32_t Bw = KB - D;
-                        const uint32_t IN = __builtin_amdgcn_bitop3_b32(D + KA, Bw, 0x80008000u, 0x80);
-                        const uint32_t DD = IN & (sl ^ SQ[m]);
-                        accIN += __builtin_popcount(IN);
-                        accDD += __builtin_popcount(DD);
-                        orB |= Bw;
-                    }
-                    if (!__any((orB & 0x80008000u) != 0u)) break;
-                }
-                lp_c += accIN - accDD;
-                lp_d += accDD;
-            }
-            if (any_long && lp_ok && n > (uint32_t)NB) {
-                for (uint32_t k = NB; k < n; ++k) {
-                    const int32_t rk = (int32_t)rel[o0 + k];
-                    const uint32_t mkk = a.cpg_pos[o0 + k] >> 31;
-                    for (uint32_t jj = k; jj-- > 0;) {
-                        const int32_t dist = rk - (int32_t)rel[o0 + jj];
-                        if (dist > a.max_dist) break;          // readutil.rs:184
-                        if (dist < a.min_dist) continue;       // readutil.rs:196
-                        if ((a.cpg_pos[o0 + jj] >> 31) == mkk) lp_c += 1; else lp_d += 1;
-                    }
-                }
-            }
-            if (pdr_ok && !bad_it && (uint32_t)s - (uint32_t)(P0 - MG + 1) <= (uint32_t)(W + MG - 1)) {
-                const uint32_t one = disc ? 0x10001u : 1u;
-#pragma unroll
-                for (int k = 0; k < NB; ++k)
-                    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt_raw) + ((v[k] << 2) - base4)), one);
-                if (any_long) {
-                    for (uint32_t k = NB; k < n; ++k) {
-                        const uint32_t pk = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)P0;
-                        if (pk < Wp) atomicAdd(cnt + pk, one);
-                    }
-                }
-            }
-        }
-    }
-    if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
-    if (do_lp) tile_lpmd_partials<B, true>(a, t, red, lp_c, lp_d, n_read, n_valid);
-    __syncthreads();
-    if (do_lp) tile_lpmd_commit<B>(a, t, red);
-    if (!a.want_pdr) return 0u;
-    return tile_compact<W, B, false>(a, t, P0, Wp, cnt, wave_off, 0u);
-}
-
 // Tile kernel.  W = reference positions per tile, B = threads per workgroup, NB = CpG calls of a
 // read held in registers (reads with more calls take the memory loop for the tail).
 //
@@ -885,15 +595,13 @@ __device__ __forceinline__ uint32_t tile_pass_split(const TileArgs &a, const uin
 // is called at most once per candidate read, so while the tile has <= 65535 candidates both counts fit 16 bits
 // (packed).  Heavier tiles (deep amplicons) take two passes over their reads with 32-bit counters, each
 // covering half of the tile's positions -- same LDS footprint, no extra launch, exact.
-template <int W, int B, int NB, typename RelT, int MG, int NA = 0>
+template <int W, int B, int NB, typename RelT, int MG>
 __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
     static_assert(MG == 0 || (MG >= 64 && MG % 4 == 0), "the wide passes keep their trash words in the high margin");
     __shared__ __attribute__((aligned(16))) uint32_t cnt[MG ? MG + W + MG : W + 64];   // [margin,] counters, then margin / one trash word per lane
     __shared__ uint32_t red[4][B / 64];
     __shared__ __attribute__((aligned(16))) uint32_t wave_off[B / 64];
     __shared__ __attribute__((aligned(16))) SlotTabs tabs;
-    __shared__ __attribute__((aligned(16))) uint32_t splitq_raw[NA ? (sizeof(SplitQ) + 3) / 4 : 1];      // the split form's queue
-    SplitQ &splitq0 = *reinterpret_cast<SplitQ *>(splitq_raw);
 
     // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
     const uint32_t per_xcd = (ntiles + 7) / 8;
@@ -919,16 +627,12 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
     };
     clear();
     slot_tabs_init(tabs, threadIdx.x);
-    if (NA && threadIdx.x == 0) splitq0.over = 0u;
     __syncthreads();
     const uint32_t lo = min(lo_raw, a.n_reads), hi = min(hi_raw, a.n_reads);
     uint32_t rows;
     if (hi - lo <= 65535u) {
         static_assert(NB == 8, "safe_hi is computed for 8 call slots");
-        if constexpr (NA > 0 && MG > 0 && sizeof(RelT) == 1) {
-            if (hi <= safe_hi) rows = tile_pass_split<W, B, MG, NA>(a, t, T0, T1, lo, hi, a.want_lpmd != 0, cnt, red, wave_off, tabs, splitq0);
-            else rows = tile_pass<W, B, NB, RelT, false, true, MG>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
-        } else if (hi <= safe_hi)
+        if (hi <= safe_hi)
             rows = tile_pass<W, B, NB, RelT, false, false, MG>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
         else
             rows = tile_pass<W, B, NB, RelT, false, true, MG>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
@@ -1017,17 +721,11 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(const SiteRec *__r
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE_MARGIN = 256;   // counter margins on either side of a tile for batches with max_span <= 256
 template <int W, int B, typename RelT>
-static void launch_tile(const TileArgs &a, uint32_t ntiles, hipStream_t s, int na) {
+static void launch_tile(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
     const uint32_t grid = ((ntiles + 7) / 8) * 8;   // whole rows of 8 XCDs (remap in the kernel)
     static const bool no_margin = getenv("MTH_TILE_NO_MARGIN") != nullptr;   // A/B switch
-    if (a.max_span <= TILE_MARGIN && !no_margin) {
-        if constexpr (sizeof(RelT) == 1) {
-            // the split form (lean pass + queue of long reads, tile_pass_split): 2 lean slots for sparse batches, 4 for dense ones
-            if (na == 2) { hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT, TILE_MARGIN, 2>), dim3(grid), dim3(B), 0, s, a, ntiles); return; }
-            if (na == 4) { hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT, TILE_MARGIN, 4>), dim3(grid), dim3(B), 0, s, a, ntiles); return; }
-        }
-        hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT, TILE_MARGIN>), dim3(grid), dim3(B), 0, s, a, ntiles);
-    } else hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT, 0>), dim3(grid), dim3(B), 0, s, a, ntiles);
+    if (a.max_span <= TILE_MARGIN && !no_margin) hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT, TILE_MARGIN>), dim3(grid), dim3(B), 0, s, a, ntiles);
+    else hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT, 0>), dim3(grid), dim3(B), 0, s, a, ntiles);
 }
 
 // the linear read index alone (for kernels that find a tile's candidate reads without running the PDR/LPMD pass):
@@ -1098,11 +796,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     {
         LaunchTimer lt(ctx, K_TILE);
         const bool r8 = b.cpg_rel != nullptr;
-        // lean slots of the split form by the batch's calls per read (MTH_TILE_NA = 0 / 2 / 4 overrides: A/B and tests)
-        const char *na_env = getenv("MTH_TILE_NA");
-        const double cpr = b.n_reads ? (double)b.n_cpgs / (double)b.n_reads : 0.0;
-        const int na = na_env ? atoi(na_env) : (cpr < 2.0 ? 2 : 4);
-        if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s, na); else launch_tile<4096, 256, uint16_t>(a, ntiles, s, 0);
+        if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
     }
     {
         LaunchTimer lt(ctx, K_GATHER);
