@@ -50,6 +50,9 @@ struct TileArgs {
     uint32_t min_cpgs;
     int32_t  min_dist, max_dist;
     uint8_t  pdr_min_qual, lpmd_min_qual, want_pdr, want_lpmd;
+#ifdef MTH_TILE_TRACE
+    unsigned long long *trace;     // experiment build: 8 ticks per tile (tools/tile_trace.py)
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -282,11 +285,20 @@ __device__ __forceinline__ void load_rel(const RelT *__restrict__ rp, int32_t (&
 // (first pass only).  Returns the number of rows the pass appended at scratch[out_base..].
 // MG > 0 (batches with max_span <= MG): the counter array has MG margin words on either side of the tile's W, so every call of a
 // read that can touch the tile has a word of its own and the scatter address needs no clamp (see the scatter below).
+#ifdef MTH_TILE_TRACE
+#define g_tk4 (*mth_tk4p)
+#define g_tk5 (*mth_tk5p)
+__device__ unsigned long long mth_tk_dummy[2];
+#endif
 template <int W, int B, int NB, typename RelT, bool WIDE, bool CLAMP, int MG>
 __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t t, const int32_t T0, const int32_t T1,
                                               const int32_t P0, const uint32_t Wp, const uint32_t lo, const uint32_t hi,
                                               const bool do_lp, const uint32_t out_base, uint32_t *cnt_raw,
-                                              uint32_t (*red)[B / 64], uint32_t *wave_off, SlotTabs &tabs) {
+                                              uint32_t (*red)[B / 64], uint32_t *wave_off, SlotTabs &tabs
+#ifdef MTH_TILE_TRACE
+                                              , unsigned long long *mth_tk4p = &mth_tk_dummy[0], unsigned long long *mth_tk5p = &mth_tk_dummy[1]
+#endif
+                                              ) {
     const int tid = threadIdx.x;
     uint32_t *const cnt = cnt_raw + MG;                         // the tile's first position
     constexpr bool MARGIN = MG > 0 && !WIDE;
@@ -574,9 +586,15 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
         else if (more) { s = a.read_start[inext]; o0 = a.cpg_off[inext]; n = a.cpg_off[inext + 1] - o0; mq = a.read_mapq[inext]; }
         i = inext;
     }
+#ifdef MTH_TILE_TRACE
+    g_tk4 = __builtin_readcyclecounter();
+#endif
     if (bad) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
     if (do_lp) tile_lpmd_partials<B, !WIDE>(a, t, red, lp_c, lp_d, n_read, n_valid);
     __syncthreads();
+#ifdef MTH_TILE_TRACE
+    g_tk5 = __builtin_readcyclecounter();
+#endif
     if (do_lp) tile_lpmd_commit<B>(a, t, red);
     if (!a.want_pdr) return 0u;
     return tile_compact<W, B, WIDE>(a, t, P0, Wp, cnt, wave_off, out_base);
@@ -607,6 +625,13 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= ntiles) return;
+#ifdef MTH_TILE_TRACE
+    unsigned long long tk[8];
+    tk[0] = __builtin_readcyclecounter();
+#define MTH_TK(k) do { tk[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MTH_TK(k) do {} while (0)
+#endif
     const int32_t T0 = a.region_beg + (int32_t)(t * W);
     // (T0 + W can exceed INT32_MAX on a contig of ~2^31 bp: bounds in 64-bit / unsigned arithmetic)
     const int32_t T1 = (int32_t)min((int64_t)T0 + W, (int64_t)a.region_end);
@@ -627,13 +652,20 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
     };
     clear();
     slot_tabs_init(tabs, threadIdx.x);
+    MTH_TK(1);
     __syncthreads();
+    MTH_TK(2);
     const uint32_t lo = min(lo_raw, a.n_reads), hi = min(hi_raw, a.n_reads);
+    MTH_TK(3);
     uint32_t rows;
     if (hi - lo <= 65535u) {
         static_assert(NB == 8, "safe_hi is computed for 8 call slots");
         if (hi <= safe_hi)
-            rows = tile_pass<W, B, NB, RelT, false, false, MG>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
+            rows = tile_pass<W, B, NB, RelT, false, false, MG>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs
+#ifdef MTH_TILE_TRACE
+                                                               , &tk[4], &tk[5]
+#endif
+                                                               );
         else
             rows = tile_pass<W, B, NB, RelT, false, true, MG>(a, t, T0, T1, T0, (uint32_t)(T1 - T0), lo, hi, a.want_lpmd != 0, 0u, cnt, red, wave_off, tabs);
     } else {
@@ -648,6 +680,10 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
         a.tile_cnt[t] = rows;
         if (rows) atomicAdd(a.bucket + (t >> TILE_BUCKET_SHIFT), (unsigned long long)rows);
     }
+#ifdef MTH_TILE_TRACE
+    MTH_TK(7);
+    if (threadIdx.x == 0 && a.trace) { tk[6] = hi - lo; for (int k = 0; k < 8; ++k) a.trace[8 * (size_t)t + k] = tk[k]; }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -793,6 +829,11 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     a.min_dist = p.lpmd_min_distance; a.max_dist = p.lpmd_max_distance;
     a.pdr_min_qual = p.pdr_min_qual; a.lpmd_min_qual = p.lpmd_min_qual;
     a.want_pdr = p.want_pdr; a.want_lpmd = p.want_lpmd;
+#ifdef MTH_TILE_TRACE
+    static unsigned long long *d_ttrace = nullptr;
+    if (!d_ttrace) (void)hipMalloc((void **)&d_ttrace, 8 * 8 * 262144);
+    a.trace = ntiles <= 262144 ? d_ttrace : nullptr;
+#endif
     {
         LaunchTimer lt(ctx, K_TILE);
         const bool r8 = b.cpg_rel != nullptr;
@@ -804,6 +845,15 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
                            ctx->tile_cnt.as<uint32_t>(), ctx->tile_bucket.as<unsigned long long>(), nbk, ntiles,
                            p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, bcnt, (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
     }
+#ifdef MTH_TILE_TRACE
+    if (getenv("MTH_TILE_TRACE_OUT") && ntiles <= 262144) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> tt(8 * (size_t)ntiles);
+        (void)hipMemcpy(tt.data(), d_ttrace, tt.size() * 8, hipMemcpyDeviceToHost);
+        FILE *f = fopen(getenv("MTH_TILE_TRACE_OUT"), "wb");
+        if (f) { fwrite(tt.data(), 8, tt.size(), f); fclose(f); }
+    }
+#endif
     MTH_HIP(ctx, hipGetLastError());
     return MTH_OK;
 }
