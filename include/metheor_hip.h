@@ -289,7 +289,8 @@ int  mth_decoded_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *start, int32_t *en
                        uint64_t *cpg_off, uint32_t *cpg_pos, uint16_t *cpg_rel);
 /* the decoded stream as runs of equal tid, in file order (a coordinate-sorted file has one run per contig): up to `cap`
  * runs are returned, *n_runs is the true number; *flags bit0 = some read has no aligned base (start < 0), bit1 = some
- * record has no contig (tid < 0) -- such records cannot enter a batch as they are */
+ * record has no contig (tid < 0) -- such records cannot enter a batch as they are --, bit2 = some read starts before its
+ * predecessor on the same contig (the input is not coordinate-sorted) */
 int  mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *read_beg, uint64_t *read_end,
                          uint32_t *n_runs, uint32_t *flags);
 /* reads [read_beg, read_end) of the decoded stream -- ONE contig's reads (or a region slice of them) -- as a

@@ -269,6 +269,12 @@ struct Contig {
 struct Input {
     mth_host_t *h = nullptr;
     std::vector<Contig> contigs;
+    // the reads re-ordered by (tid, start) -- order-free measures on an input that is not coordinate-sorted (sort_reads)
+    std::vector<int32_t> s_tid, s_start, s_end;
+    std::vector<uint8_t> s_mapq;
+    std::vector<uint64_t> s_off;
+    std::vector<uint32_t> s_pos;
+    std::vector<uint16_t> s_rel;
     mth_ctx_t *ctx = nullptr;   // set when the records were decoded on the device (the batches live in its HBM)
     bool device = false;
 };
@@ -481,6 +487,25 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
     return true;
 }
 
+// LPMD, ME and PM keep no per-site state that a later read could flush (lpmd.rs:175-200, me.rs:106-125, pm.rs:101-121 iterate the
+// records in file order into hash maps that are only read at the end): their results do not depend on the order of the
+// records, and the reference accepts any BAM.  For those subcommands an input that is not coordinate-sorted / not grouped by
+// contig is sorted here, stably by (tid, start), and then batched like any other.  PDR, MHL, FDRP and qFDRP finalise sites as
+// the stream moves past them (pdr.rs:160-177, mhl.rs:162-173, fdrp.rs:206-218): their output on unsorted input is a function
+// of the record order itself, which batches cut by contig do not carry -- those subcommands keep refusing it, loudly.
+bool g_order_free = false;
+
+bool reads_in_order(const int32_t *tid, const int32_t *st, int64_t n) {
+    // records without a contig (a sorted BAM keeps them at its end) or without an aligned base never enter a batch: not looked at
+    int64_t p = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        if (tid[i] < 0 || st[i] < 0) continue;
+        if (p >= 0 && (tid[i] < tid[p] || (tid[i] == tid[p] && st[i] < st[p]))) return false;
+        p = i;
+    }
+    return true;
+}
+
 Input load(const std::string &path, const char *cpg_set) {
     Phase ph_all("load: open+decode+batch");
     Input in;
@@ -507,6 +532,31 @@ Input load(const std::string &path, const char *cpg_set) {
     const uint64_t *off = mth_host_cpg_off(in.h);
     const uint32_t *pos = mth_host_cpg_pos(in.h);
     const uint16_t *rel = mth_host_cpg_rel(in.h);
+    if (!reads_in_order(tid, st, n)) {
+        if (!g_order_free)
+            die("input BAM is not coordinate-sorted (or not grouped by contig).  pdr, mhl, fdrp and qfdrp finalise a CpG as the reads move "
+                "past it (pdr.rs:160-177, mhl.rs:162-173, fdrp.rs:206-218): on unsorted input their output depends on the record order "
+                "itself, which the MI355X path does not replay -- sort the file (samtools sort).  lpmd, me and pm take any order.");
+        Phase ps("  sort by (tid, start)");
+        std::vector<int64_t> perm((size_t)n);
+        for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = i;
+        std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) { return tid[x] != tid[y] ? tid[x] < tid[y] : st[x] < st[y]; });
+        in.s_tid.resize((size_t)n); in.s_start.resize((size_t)n); in.s_end.resize((size_t)n); in.s_mapq.resize((size_t)n);
+        in.s_off.assign((size_t)n + 1, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t r = perm[(size_t)i];
+            in.s_tid[(size_t)i] = tid[r]; in.s_start[(size_t)i] = st[r]; in.s_end[(size_t)i] = en[r]; in.s_mapq[(size_t)i] = mq[r];
+            in.s_off[(size_t)i + 1] = in.s_off[(size_t)i] + (off[r + 1] - off[r]);
+        }
+        in.s_pos.resize((size_t)in.s_off[(size_t)n]); in.s_rel.resize((size_t)in.s_off[(size_t)n]);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t r = perm[(size_t)i];
+            std::copy(pos + off[r], pos + off[r + 1], in.s_pos.begin() + (ptrdiff_t)in.s_off[(size_t)i]);
+            std::copy(rel + off[r], rel + off[r + 1], in.s_rel.begin() + (ptrdiff_t)in.s_off[(size_t)i]);
+        }
+        tid = in.s_tid.data(); st = in.s_start.data(); en = in.s_end.data(); mq = in.s_mapq.data();
+        off = in.s_off.data(); pos = in.s_pos.data(); rel = in.s_rel.data();
+    }
     for (int64_t i = 0; i < n;) {
         int64_t e = i;
         bool loose = false;
@@ -695,6 +745,7 @@ int run_lpmd(const Args &a) {
     // lpmd.rs:161-164
     fprintf(stderr, "Computing subset-LPMD with parameters input=%s, min_distance=%d, max_distance=%d\n", input.c_str(), mind, maxd);
     g_shard.xm_min_mapq = (int)a.n.at("min-qual");      // lpmd.rs:176-181: the mapq filter comes before BismarkRead::new (the XM panic)
+    g_order_free = true;
     Input in = load(input, a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
     mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_pdr_lpmd_params_t p;
@@ -741,6 +792,7 @@ int run_lpmd(const Args &a) {
 // me.rs:68-88 / pm.rs:63-83: one line per quartet with depth >= min_depth,
 // chrom, pos1..pos4, value (me.rs:57-65).  The reference iterates a HashMap (random order).
 int run_quartet(const Args &a, bool want_me) {
+    g_order_free = true;
     Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
     mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_quartet_params_t p;

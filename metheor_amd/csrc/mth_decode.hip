@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_dec_rebase(const unsigned long long *__
 
 // contig runs of the decoded stream: every i where tid changes opens a run (appended through an atomic counter, sorted by
 // the host -- there are only as many runs as contigs); flags: bit0 a read without aligned base (start < 0), bit1 a record
-// without contig (tid < 0)
+// without contig (tid < 0), bit2 a read that starts before its predecessor on the same contig (input not coordinate-sorted)
 __global__ __launch_bounds__(256) void k_dec_contigs(const int32_t *__restrict__ tid, const int32_t *__restrict__ start, uint64_t n,
                                                      uint32_t cap, uint32_t *__restrict__ count, uint64_t *__restrict__ run_beg,
                                                      int32_t *__restrict__ run_tid, uint32_t *__restrict__ flags) {
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void k_dec_contigs(const int32_t *__restrict__
     if (i >= n) return;
     const int32_t t = tid[i];
     uint32_t f = (start[i] < 0 ? 1u : 0u) | (t < 0 ? 2u : 0u);
+    if (i > 0 && tid[i - 1] == t && start[i] < start[i - 1]) f |= 4u;      // bit2: not coordinate-sorted inside a contig's run
     if (f) atomicOr(flags, f);
     if (i == 0 || tid[i - 1] != t) {
         const uint32_t k = atomicAdd(count, 1u);

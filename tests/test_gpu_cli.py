@@ -525,3 +525,61 @@ def test_sam_text_input_runs_like_bam_input(golden_dir, tmp_path):
     noxm.write_text("".join(l.split("\tXM:Z:")[0] + "\n" if not l.startswith("@") else l for l in open(sam)))
     r = run("pdr", "-i", str(noxm), "-o", str(a))
     assert r.returncode == 101 and "Error reading XM tag in BAM record" in r.stderr
+
+
+# ---- input that is not coordinate-sorted: the order-free measures take it, the others say why not ---------
+def _two_contig_records(seed):
+    from metheor_amd import synth
+    rng = np.random.default_rng(seed)
+    cs = [synth.make_contig(0, 60_000, 9_000, 0.03, rng), synth.make_contig(1, 30_000, 5_000, 0.03, rng)]
+    r0, r1 = util.contig_to_records(cs[0], "chrS1"), util.contig_to_records(cs[1], "chrS2")
+    return bamio.Records([r0.refs[0], r1.refs[0]], np.concatenate([r0.tid, r1.tid + 1]), np.concatenate([r0.pos, r1.pos]),
+                         np.concatenate([r0.flag, r1.flag]), np.concatenate([r0.mapq, r1.mapq]), r0.cigars + r1.cigars, r0.xms + r1.xms)
+
+
+def _permute(rec, perm):
+    return bamio.Records(rec.refs, rec.tid[perm], rec.pos[perm], rec.flag[perm], rec.mapq[perm], [rec.cigars[i] for i in perm], [rec.xms[i] for i in perm])
+
+
+@pytest.mark.parametrize("kind", ["shuffled", "sorted_within_but_contigs_interleaved", "grouped_but_unsorted_within"])
+def test_unsorted_input_order_free_measures(tmp_path, kind):
+    """lpmd.rs:175-200, me.rs:106-125, pm.rs:101-121 iterate the records in whatever order the file has into maps that are only read
+    at the end: LPMD (+ its pairs table), ME and PM of a shuffled BAM equal those of the sorted one -- and the oracle's, which
+    streams the shuffled records as they come.  PDR / MHL / FDRP / qFDRP refuse it and say why."""
+    rec = _two_contig_records(23)
+    n = len(rec.tid)
+    rng = np.random.default_rng(5)
+    if kind == "shuffled":
+        perm = rng.permutation(n)
+    elif kind == "sorted_within_but_contigs_interleaved":
+        perm = np.argsort(rng.integers(0, 40, size=n) * 0 + (np.arange(n) % 7), kind="stable")      # seven interleaved strides: tid runs repeat
+    else:
+        perm = np.concatenate([rng.permutation(9_000), 9_000 + rng.permutation(5_000)])               # one run per contig, unsorted inside
+    sh = _permute(rec, perm)
+    bam = str(tmp_path / "unsorted.bam")
+    bamio.write_bam(bam, sh)
+    reads = pyoracle.Reads.decode(sh)                # the oracle streams the records in FILE order, as the reference does
+    o, pf = tmp_path / "o.tsv", tmp_path / "pairs.tsv"
+    r = run("lpmd", "-i", bam, "-o", str(o), "-p", str(pf))
+    assert r.returncode == 0, r.stderr
+    res = reads.lpmd(min_distance=2, max_distance=16, min_qual=10, pairs=True)
+    assert o.read_text() == "name\tlpmd\n%s\t%s\n" % (bam, pyoracle.format_f32(res["lpmd"]))
+    t = res["pairs"]
+    names = ["chrS1", "chrS2"]
+    want = "chrom\tcpg1\tcpg2\tlpmd\tn_concordant\tn_discordant\n" + "".join(
+        "%s\t%d\t%d\t%s\t%d\t%d\n" % (names[ti], p[0], p[1], pyoracle.format_f32(v), c[0], c[1]) for ti, p, v, c in zip(t.tid, t.pos, t.val, t.cnt))
+    assert pf.read_text() == want and want.count("\n") > 1000
+    r = run("pm", "-i", bam, "-o", str(o), "-d", "5")
+    assert r.returncode == 0, r.stderr
+    wl = _quartet_lines(reads.pm(min_depth=5, min_qual=10), names)
+    assert sorted(o.read_text().splitlines()) == wl and len(wl) > 500
+    r = run("me", "-i", bam, "-o", str(o), "-d", "5")
+    assert r.returncode == 0, r.stderr
+    got, wl = sorted(o.read_text().splitlines()), _quartet_lines(reads.me(min_depth=5, min_qual=10), names)
+    assert len(got) == len(wl)
+    for g, w in zip(got, wl):
+        gf, wf = g.split("\t"), w.split("\t")
+        assert gf[:5] == wf[:5] and abs(float(gf[5]) - float(wf[5])) <= 1e-6
+    for sub in ("pdr", "mhl", "fdrp", "qfdrp"):
+        r = run(sub, "-i", bam, "-o", str(o))
+        assert r.returncode == 101 and "not coordinate-sorted" in r.stderr and "lpmd, me and pm take any order" in r.stderr, (sub, r.stderr)
