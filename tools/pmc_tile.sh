@@ -5,7 +5,7 @@ out=${1:-gpurun_out/pmc}; mkdir -p $out
 export TMPDIR=/tmp
 run() {  # $1 tag, rest counters
   tag=$1; shift 1
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$tag -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --soak-seconds 0 --roofline-steps 2 > $out/$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$tag -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-wgbs --no-traffic --soak-seconds 0 --roofline-steps 2 > $out/$tag.log 2>&1
 }
 run a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 run b SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT

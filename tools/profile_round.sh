@@ -5,7 +5,7 @@
 tag=${1:-rXX}; commit=${2:-unknown}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
-B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --soak-seconds 0"
+B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-wgbs --no-traffic --soak-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- $B > $out/write.log 2>&1
