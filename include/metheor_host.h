@@ -138,6 +138,12 @@ int  mth_host_write_synthetic_bam_multi(const char *path, int32_t n_contigs, con
                                         int64_t n_reads, int32_t read_len, const int32_t *tid, const int32_t *start,
                                         const uint8_t *fwd, const uint8_t *mapq, const uint64_t *cpg_off,
                                         const uint16_t *cpg_rel, const uint32_t *cpg_pos, uint64_t seed, int nthreads);
+/* the same base_reads reads of one contig on n_copies contigs (record i = read i % base_reads on contig i / base_reads): a large
+ * test / bench file without a large SoA */
+int  mth_host_write_synthetic_bam_repeat(const char *path, int32_t n_copies, const char *const *contigs, const int64_t *contig_lens,
+                                         int64_t base_reads, int32_t read_len, const int32_t *start, const uint8_t *fwd,
+                                         const uint8_t *mapq, const uint64_t *cpg_off, const uint16_t *cpg_rel,
+                                         const uint32_t *cpg_pos, uint64_t seed, int nthreads);
 
 /* Rust `{}` of an f32 (shortest round-trip digits, positional, "NaN"/"inf"); buf >= 64 bytes */
 int  mth_host_format_f32(float v, char *buf);

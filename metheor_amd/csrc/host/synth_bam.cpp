@@ -22,19 +22,26 @@ void put16(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)x); v.pus
 
 constexpr size_t BGZF_BLOCK = 0xff00;   // htslib's BGZF_BLOCK_SIZE
 // append `n` uncompressed bytes as BGZF blocks (<= 0xff00 bytes each)
+// (one deflate state per thread, reset per block: deflateInit2 allocates ~270 KB through mmap every time, and 256 threads doing that
+// for every 64-KB block spent their time in the kernel's address-space lock -- a 100 M-read file took 68 s)
+struct Deflater {
+    z_stream zs;
+    bool ok;
+    Deflater() { memset(&zs, 0, sizeof zs); ok = deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK; }
+    ~Deflater() { if (ok) deflateEnd(&zs); }
+};
 void bgzf_append(std::vector<uint8_t> &out, const uint8_t *p, size_t n) {
+    static thread_local Deflater df;
     size_t o = 0;
     do {
         const size_t take = std::min<size_t>(BGZF_BLOCK, n - o);
         uint8_t comp[70000];
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        z_stream &zs = df.zs;
+        deflateReset(&zs);
         zs.next_in = const_cast<uint8_t *>(p + o); zs.avail_in = (uInt)take;
         zs.next_out = comp; zs.avail_out = sizeof comp;
         deflate(&zs, Z_FINISH);
         const size_t clen = sizeof comp - zs.avail_out;
-        deflateEnd(&zs);
         const uint8_t hdr[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
         out.insert(out.end(), hdr, hdr + 12);
         out.push_back('B'); out.push_back('C'); put16(out, 2); put16(out, (uint32_t)(clen + 25));
@@ -49,10 +56,12 @@ inline uint64_t rng_next(uint64_t &s) { s += 0x9e3779b97f4a7c15ULL; uint64_t z =
 
 }  // namespace
 
-extern "C" int mth_host_write_synthetic_bam_multi(const char *path, int32_t n_contigs, const char *const *contigs, const int64_t *contig_lens,
-                                                  int64_t n_reads, int32_t read_len, const int32_t *tid, const int32_t *start,
-                                                  const uint8_t *fwd, const uint8_t *mapq, const uint64_t *cpg_off,
-                                                  const uint16_t *cpg_rel, const uint32_t *cpg_pos, uint64_t seed, int nthreads) {
+// base_n > 0: the arrays describe base_n reads of ONE contig and record i of the file is read i % base_n on contig i / base_n (the same
+// reads on several contigs: a large file without a large SoA; bench.py's 100 M-read end-to-end leg)
+static int write_core(const char *path, int32_t n_contigs, const char *const *contigs, const int64_t *contig_lens,
+                      int64_t n_reads, int32_t read_len, const int32_t *tid, const int32_t *start,
+                      const uint8_t *fwd, const uint8_t *mapq, const uint64_t *cpg_off,
+                      const uint16_t *cpg_rel, const uint32_t *cpg_pos, uint64_t seed, int nthreads, int64_t base_n) {
     if (!path || !contigs || !contig_lens || n_contigs < 1 || n_reads < 0 || read_len <= 0) return MTH_HOST_ERR_INVALID;
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
     if (nthreads <= 0) nthreads = 1;
@@ -76,13 +85,15 @@ extern "C" int mth_host_write_synthetic_bam_multi(const char *path, int32_t n_co
         std::vector<uint8_t> &out = parts[(size_t)t];
         uint64_t rs = seed ^ (0x51ed27ULL * (uint64_t)(t + 1));
         const uint32_t seqb = (uint32_t)(read_len + 1) / 2;
-        for (int64_t i = r0; i < r1; ++i) {
+        out.reserve((size_t)(r1 - r0) * 190 + 65536);
+        for (int64_t fi = r0; fi < r1; ++fi) {
+            const int64_t i = base_n > 0 ? fi % base_n : fi;
             char name[32];
-            const int ln = snprintf(name, sizeof name, "r%lld", (long long)i) + 1;
+            const int ln = snprintf(name, sizeof name, "r%lld", (long long)fi) + 1;
             const uint32_t aux_len = 4 + 3 + (uint32_t)read_len + 1 + 6;
             const uint32_t bs = 32 + (uint32_t)ln + 4 + seqb + (uint32_t)read_len + aux_len;
             if (!raw.empty() && raw.size() + 4 + bs > BGZF_BLOCK) { bgzf_append(out, raw.data(), raw.size()); raw.clear(); }   // bgzf_flush_try
-            put32(raw, bs); put32(raw, tid ? (uint32_t)tid[i] : 0u); put32(raw, (uint32_t)start[i]);
+            put32(raw, bs); put32(raw, base_n > 0 ? (uint32_t)(fi / base_n) : (tid ? (uint32_t)tid[i] : 0u)); put32(raw, (uint32_t)start[i]);
             raw.push_back((uint8_t)ln); raw.push_back(mapq[i]); put16(raw, 4680); put16(raw, 1);
             put16(raw, fwd[i] ? 0 : 16); put32(raw, (uint32_t)read_len); put32(raw, 0xffffffffu); put32(raw, 0xffffffffu); put32(raw, 0);
             raw.insert(raw.end(), name, name + ln);
@@ -125,6 +136,22 @@ extern "C" int mth_host_write_synthetic_bam_multi(const char *path, int32_t n_co
     for (char o : okv) ok = ok && o;
     ok = (close(fd) == 0) && ok;
     return ok ? MTH_HOST_OK : MTH_HOST_ERR_OPEN;
+}
+
+extern "C" int mth_host_write_synthetic_bam_multi(const char *path, int32_t n_contigs, const char *const *contigs, const int64_t *contig_lens,
+                                                  int64_t n_reads, int32_t read_len, const int32_t *tid, const int32_t *start,
+                                                  const uint8_t *fwd, const uint8_t *mapq, const uint64_t *cpg_off,
+                                                  const uint16_t *cpg_rel, const uint32_t *cpg_pos, uint64_t seed, int nthreads) {
+    return write_core(path, n_contigs, contigs, contig_lens, n_reads, read_len, tid, start, fwd, mapq, cpg_off, cpg_rel, cpg_pos, seed, nthreads, 0);
+}
+
+extern "C" int mth_host_write_synthetic_bam_repeat(const char *path, int32_t n_copies, const char *const *contigs, const int64_t *contig_lens,
+                                                   int64_t base_reads, int32_t read_len, const int32_t *start, const uint8_t *fwd,
+                                                   const uint8_t *mapq, const uint64_t *cpg_off, const uint16_t *cpg_rel,
+                                                   const uint32_t *cpg_pos, uint64_t seed, int nthreads) {
+    if (n_copies < 1 || base_reads < 1) return MTH_HOST_ERR_INVALID;
+    return write_core(path, n_copies, contigs, contig_lens, base_reads * n_copies, read_len, nullptr, start, fwd, mapq, cpg_off, cpg_rel, cpg_pos, seed,
+                      nthreads, base_reads);
 }
 
 extern "C" int mth_host_write_synthetic_bam(const char *path, const char *contig, int64_t contig_len, int64_t n_reads,

@@ -12,7 +12,7 @@ SYMBOLS = [
     "mth_host_ref_len", "mth_host_ref_tid", "mth_host_set_xm_min_mapq", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_plan_region", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
     "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
     "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32", "mth_host_write_synthetic_bam",
-    "mth_host_write_synthetic_bam_multi", "mth_host_header_text", "mth_host_path", "mth_host_sam_format", "mth_host_fasta_open", "mth_host_fasta_close",
+    "mth_host_write_synthetic_bam_multi", "mth_host_write_synthetic_bam_repeat", "mth_host_header_text", "mth_host_path", "mth_host_sam_format", "mth_host_fasta_open", "mth_host_fasta_close",
     "mth_host_fasta_last_error", "mth_host_fasta_fetch",
 ]
 
@@ -66,6 +66,7 @@ def lib():
         L.mth_host_format_f32.argtypes = [C.c_float, C.c_char_p]
         L.mth_host_write_synthetic_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int32] + [vp] * 6 + [C.c_uint64, C.c_int]
         L.mth_host_write_synthetic_bam_multi.argtypes = [C.c_char_p, C.c_int32, vp, vp, C.c_int64, C.c_int32] + [vp] * 7 + [C.c_uint64, C.c_int]
+        L.mth_host_write_synthetic_bam_repeat.argtypes = [C.c_char_p, C.c_int32, vp, vp, C.c_int64, C.c_int32] + [vp] * 6 + [C.c_uint64, C.c_int]
         L.mth_host_path.argtypes = [vp]; L.mth_host_path.restype = C.c_char_p
         L.mth_host_header_text.argtypes = [vp, C.POINTER(C.c_uint64)]; L.mth_host_header_text.restype = vp
         L.mth_host_sam_format.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_int64]; L.mth_host_sam_format.restype = C.c_int64
@@ -93,6 +94,21 @@ def write_synthetic_bam(path, c, contig="chr19", seed=0, threads=0):
             np.ascontiguousarray(c["cpg_rel"], np.uint16), np.ascontiguousarray(c["cpg_pos"], np.uint32)]
     rc = lib().mth_host_write_synthetic_bam(os.fsencode(path), contig.encode(), int(c["length"]), n, rl,
                                             *[a.ctypes.data_as(C.c_void_p) for a in arrs], seed, threads)
+    if rc != 0:
+        raise HostError(rc, "cannot write " + path)
+
+
+def write_synthetic_bam_repeat(path, c, names, seed=0, threads=0):
+    """the reads of contig dict c on len(names) contigs (one copy each) -> one BAM file, without concatenating the SoA"""
+    n = len(c["read_start"])
+    rl = int(c["read_end"][0] - c["read_start"][0] + 1) if n else 150
+    nm = (C.c_char_p * len(names))(*[x.encode() for x in names])
+    ln = (C.c_int64 * len(names))(*[int(c["length"])] * len(names))
+    arrs = [np.ascontiguousarray(c["read_start"], np.int32), np.ascontiguousarray(c["read_fwd"], np.uint8),
+            np.ascontiguousarray(c["read_mapq"], np.uint8), np.ascontiguousarray(c["cpg_off"], np.uint64),
+            np.ascontiguousarray(c["cpg_rel"], np.uint16), np.ascontiguousarray(c["cpg_pos"], np.uint32)]
+    rc = lib().mth_host_write_synthetic_bam_repeat(os.fsencode(path), len(names), nm, ln, n, rl,
+                                                   *[a.ctypes.data_as(C.c_void_p) for a in arrs], seed, threads)
     if rc != 0:
         raise HostError(rc, "cannot write " + path)
 
