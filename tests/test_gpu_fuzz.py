@@ -103,8 +103,17 @@ def test_random_scenario_all_measures(eng, seed):
     pk = dict(min_depth=int(rng.choice([0, 1, 3, 10])), min_cpgs=int(rng.choice([0, 1, 2, 4, 9])), min_qual=mq)
     lk = dict(min_distance=int(rng.choice([0, 1, 2, 5])), max_distance=int(rng.choice([1, 4, 16, 60, 300])), min_qual=mq)
     p = PdrLpmdParams(min_distance=lk["min_distance"], max_distance=lk["max_distance"], lpmd_min_qual=mq, **pk)
-    d, l = T_pdr.run_device(eng, cs, p, regions=regions, rel16=bool(rng.integers(0, 2)))
+    rel16 = bool(rng.integers(0, 2))
+    d, l = T_pdr.run_device(eng, cs, p, regions=regions, rel16=rel16)
     T_pdr.check_against_oracle(d, l, reads, pk, lk)
+    # the same through the streaming form of the pass (mth_stream.hip; opt-in): identical rows and counters
+    import os
+    os.environ["MTH_STREAM"] = "1"
+    try:
+        d2, l2 = T_pdr.run_device(eng, cs, p, regions=regions, rel16=rel16)
+    finally:
+        del os.environ["MTH_STREAM"]
+    assert all((d[k].view(np.uint32) == d2[k].view(np.uint32)).all() for k in d) and all(l[k] == l2[k] for k in l if k != "lpmd")
 
     # LPMD per-pair table
     T_pairs.check(T_pairs.run_device(eng, cs, lk, regions=regions), reads, lk)
