@@ -660,9 +660,14 @@ def main():
     collective = "none"
     if use_dist and not shared:
         # the one exchange step of the path: all-reduce(sum) of the 4 LPMD int64 counters, RCCL over xGMI, behind the C ABI
+        preflight(torch, rank, device_index)
         ids = [metheor_amd.Engine.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        eng.rccl_init_rank(ids[0], rank, world)
+        try:
+            eng.rccl_init_rank(ids[0], rank, world)
+        except Exception as ex:
+            sys.stderr.write("bench.py: rank %d: RCCL communicator could not be created (ncclCommInitRank): %s\n" % (rank, ex))
+            return 4
         collective = "RCCL ncclAllReduce(int64 x 4, sum) via mth_allreduce_lpmd_rank, world %d, %s" % (
             world, "after every step" if args.reduce_every_step else "once per job: after the last step, inside the timed region")
     elif use_dist:
