@@ -97,3 +97,21 @@ def test_reference_tinyref_fixture_layout(tmp_path):
     open(p, "w").write(">ref\n" + "CGGGGCGGGGCGCGCGGGGGCGCGCGCGGGGCGCGCGCGCGCGGGGGGGGG" + "\n")
     open(p + ".fai", "w").write("ref\t51\t5\t51\t52\n")
     assert hostapi.Fasta(p).fetch("ref", 51) == b"CGGGGCGGGGCGCGCGGGGGCGCGCGCGGGGCGCGCGCGCGCGGGGGGGGG"
+
+
+def test_sam_line_longer_than_four_characters_per_record_byte(tmp_path):
+    """a B:c / B:s array prints up to 5-7 characters per 1-2 byte element (",-128", ",-32768"): the formatted line
+    outgrows the 4 x record bytes + 256 the callers used to size their buffer by.  mth_host_sam_format returns what it needs;
+    hostapi.BamFile.sam_line (and the CLI's tag writer) ask again with that size."""
+    arr_c = ",".join(["-128"] * 3000)
+    arr_s = ",".join(["-32768"] * 1500)
+    lines = ["@HD\tVN:1.6", "@SQ\tSN:c1\tLN:1000",
+             "r1\t0\tc1\t10\t60\t4M\t*\t0\t0\tACGT\t*\tBA:B:c," + arr_c + "\tBS:B:s," + arr_s]
+    p = tmp_path / "b.sam"
+    p.write_text("\n".join(lines) + "\n")
+    f = hostapi.BamFile(str(p))
+    (raw, off), = f.windows()
+    rec_bytes = int(off[1] - off[0])
+    line = f.sam_line(raw, int(off[0]), int(off[1]), xm=b"....")
+    assert len(line) > 4 * rec_bytes + 256 + 4          # the case the old bound missed
+    assert line.decode() == lines[2] + "\tXM:Z:....\n"
