@@ -878,6 +878,38 @@ def main():
         out["soak"] = {"seconds": round(time.perf_counter() - t0, 2), "steps": n_soak,
                        "ms_per_step": round((time.perf_counter() - t0) / n_soak * 1e3, 4)}
 
+    # ---- the same steps over TWO contexts of the one GPU (secondary; `value` stays the one-context figure) -----------------------------
+    if rank == 0 and world == 1 and not args.no_wgbs:
+        try:
+            import threading
+            st2 = torch.cuda.Stream(device=dev)
+            eng2 = metheor_amd.Engine(device_index, stream=st2.cuda_stream)
+            k2 = 600
+
+            def run_steps(e):
+                for _ in range(k2):
+                    e.reset()
+                    e.pdr_lpmd_accumulate(batch, params)
+                e.sync()
+            run_steps(eng2)
+            best2 = None
+            for _ in range(3):
+                th = [threading.Thread(target=run_steps, args=(e,)) for e in (eng, eng2)]
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                d2 = time.perf_counter() - t0
+                best2 = d2 if best2 is None else min(best2, d2)
+            assert eng2.pdr_count() == n_sites
+            eng2.close()
+            out["two_contexts"] = {"what": "the same steps spread over two contexts (a stream and work buffers each, one host thread each) of the one GPU: the "
+                                           "index -> tile -> gather boundaries of one step's kernels are filled by the other's",
+                                   "steps": 2 * k2, "ms_per_step": round(best2 / (2 * k2) * 1e3, 4), "M_reads_per_s": round(n_reads * 2 * k2 / best2 / 1e6, 1)}
+        except Exception as ex:
+            out["two_contexts"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+
     # ---- WGBS depth (the workload the metric is named after): roofline_wgbs, all seven measures on config 3, config-4 pairs/s --
     if rank == 0 and world == 1 and not args.no_wgbs:
         try:
