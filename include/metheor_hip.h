@@ -293,6 +293,10 @@ int  mth_decoded_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *start, int32_t *en
  * predecessor on the same contig (the input is not coordinate-sorted) */
 int  mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *read_beg, uint64_t *read_end,
                          uint32_t *n_runs, uint32_t *flags);
+/* re-order the decoded stream by (tid, start), stably, on the device -- for the measures whose result does not depend on the
+ * record order (lpmd.rs:175-200, me.rs:106-125, pm.rs:101-121): an input that is not coordinate-sorted or not grouped by contig
+ * can then be batched like a sorted one.  Every record must have a contig and an aligned base (flags bit0 / bit1 clear). */
+int  mth_decoded_sort(mth_ctx_t *ctx);
 /* reads [read_beg, read_end) of the decoded stream -- ONE contig's reads (or a region slice of them) -- as a
  * device-resident batch for the accumulate calls: 32-bit offsets rebased on the device, max_span reduced on
  * the device.  region_end < 0 = up to the last position these reads cover (reduced on the device too): what a

@@ -16,7 +16,7 @@ SYMBOLS = [
     "mth_pdr_fetch", "mth_result_buffer_alloc", "mth_result_buffer_free", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
     "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
-    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_bgzf_stage", "mth_decode_reserve", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
+    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_bgzf_stage", "mth_decode_reserve", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_sort", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -135,6 +135,7 @@ def lib():
         L.mth_tag_records.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(mth_tag_out_t)]
         L.mth_decoded_fetch.argtypes = [vp] * 9
         L.mth_decoded_contigs.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.mth_decoded_sort.argtypes = [vp]
         L.mth_decoded_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(mth_batch_t)]
         L.mth_timing_enable.argtypes = [vp, C.c_int]
         L.mth_timing_reset.argtypes = [vp]
@@ -446,6 +447,10 @@ class Engine:
         self._check(self.L.mth_decoded_contigs(self.h, cap, tids.ctypes.data, beg.ctypes.data, end.ctypes.data, C.byref(n), C.byref(fl)))
         k = min(n.value, cap)
         return tids[:k], beg[:k], end[:k], fl.value
+
+    def decoded_sort(self):
+        """the decoded stream re-ordered by (tid, start) on the device (order-free measures on unsorted input)"""
+        self._check(self.L.mth_decoded_sort(self.h))
 
     def decoded_batch(self, read_beg, read_end, tid, region_beg, region_end):
         """device-resident batch over reads [read_beg, read_end) of the decoded stream (one contig)"""

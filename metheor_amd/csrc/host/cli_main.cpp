@@ -359,6 +359,8 @@ int window_to_device(void *user, const uint8_t *buf, const uint64_t *rec_off, ui
 // Whole load path on the device (mth_bgzf_decode): the file's bytes go to the GPU as they are, BGZF inflate, record
 // boundaries and record decode all happen there.  Needs every BGZF block to hold whole records (what htslib-family
 // writers produce); returns false -- with the context reset -- for a file where that does not hold.
+bool g_order_free = false;     // set by lpmd / me / pm: their result does not depend on the record order (see load())
+
 bool load_bgzf_on_device(Input &in) {
     mth_host_bgzf_t bz;
     if (mth_host_bgzf_blocks(in.h, &bz) != 0) die(mth_host_last_error(in.h));
@@ -468,6 +470,18 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
     std::vector<uint64_t> rb(cap), re(cap);
     uint32_t n_runs = 0, flags = 0;
     check(in.ctx, mth_decoded_contigs(in.ctx, cap, tids.data(), rb.data(), re.data(), &n_runs, &flags));
+    {
+        // not coordinate-sorted / contigs not grouped: the order-free measures sort the decoded stream where it is, on the device
+        // (mth_decoded_sort); the others go on to the host path, which says why it refuses
+        bool regroup = n_runs > cap || (flags & 4u);
+        for (uint32_t k = 0; k < std::min(n_runs, cap) && !regroup; ++k)
+            for (uint32_t j = 0; j < k; ++j) if (tids[j] == tids[k]) regroup = true;
+        if (regroup && g_order_free && !(flags & 3u) && !g_shard.planned()) {
+            Phase ps("  device sort by (tid, start)");
+            check(in.ctx, mth_decoded_sort(in.ctx));
+            check(in.ctx, mth_decoded_contigs(in.ctx, cap, tids.data(), rb.data(), re.data(), &n_runs, &flags));
+        }
+    }
     if (flags || n_runs > cap) return false;                       // unaligned / contig-less records, or contigs not grouped
     for (uint32_t k = 0; k < n_runs; ++k) {
         for (const Contig &c : in.contigs) if (c.tid == tids[k]) return false;   // the host path reports it
@@ -493,8 +507,6 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
 // contig is sorted here, stably by (tid, start), and then batched like any other.  PDR, MHL, FDRP and qFDRP finalise sites as
 // the stream moves past them (pdr.rs:160-177, mhl.rs:162-173, fdrp.rs:206-218): their output on unsorted input is a function
 // of the record order itself, which batches cut by contig do not carry -- those subcommands keep refusing it, loudly.
-bool g_order_free = false;
-
 bool reads_in_order(const int32_t *tid, const int32_t *st, int64_t n) {
     // records without a contig (a sorted BAM keeps them at its end) or without an aligned base never enter a batch: not looked at
     int64_t p = -1;

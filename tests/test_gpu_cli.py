@@ -560,10 +560,16 @@ def test_unsorted_input_order_free_measures(tmp_path, kind):
     bamio.write_bam(bam, sh)
     reads = pyoracle.Reads.decode(sh)                # the oracle streams the records in FILE order, as the reference does
     o, pf = tmp_path / "o.tsv", tmp_path / "pairs.tsv"
-    r = run("lpmd", "-i", bam, "-o", str(o), "-p", str(pf))
+    r = run_env({"METHEOR_TIMING": "1"}, "lpmd", "-i", bam, "-o", str(o), "-p", str(pf))
     assert r.returncode == 0, r.stderr
+    assert "device sort by (tid, start)" in r.stderr          # sorted where it was decoded: on the device (mth_decoded_sort)
     res = reads.lpmd(min_distance=2, max_distance=16, min_qual=10, pairs=True)
     assert o.read_text() == "name\tlpmd\n%s\t%s\n" % (bam, pyoracle.format_f32(res["lpmd"]))
+    # ... and the same through the host decoder's sort (METHEOR_HOST_DECODE=1: the fallback for files the device path does not take)
+    o2 = tmp_path / "o2.tsv"
+    r = run_env({"METHEOR_HOST_DECODE": "1", "METHEOR_TIMING": "1"}, "lpmd", "-i", bam, "-o", str(o2))
+    assert r.returncode == 0 and "sort by (tid, start)" in r.stderr and "device sort" not in r.stderr
+    assert o2.read_text() == o.read_text()
     t = res["pairs"]
     names = ["chrS1", "chrS2"]
     want = "chrom\tcpg1\tcpg2\tlpmd\tn_concordant\tn_discordant\n" + "".join(

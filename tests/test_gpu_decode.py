@@ -206,3 +206,43 @@ def test_hand_worked_cigar_and_strand_rules(eng, tmp_path):
     refs, body, offs = record_stream(p)
     eng.decode_records(body, offs)
     check_hand_worked(eng.decoded_fetch(), expected)
+
+
+def test_device_sort_of_a_shuffled_stream(eng, tmp_path):
+    """mth_decoded_sort: the decoded SoA of a shuffled BAM, re-ordered by (tid, start) on the device, equals the stable numpy sort of the
+    same arrays (reads AND their calls), the run finder then sees one sorted run per contig, and LPMD over the device batches equals the
+    oracle streaming the shuffled file (lpmd.rs:175-200 does not care about the order)"""
+    from metheor_amd import PdrLpmdParams, synth
+    from tests import util
+    rng = np.random.default_rng(92)
+    cs = [synth.make_contig(0, 70_000, 11_000, 0.03, rng), synth.make_contig(1, 40_000, 6_000, 0.03, rng, read_len=100)]
+    r0, r1 = util.contig_to_records(cs[0], "c0"), util.contig_to_records(cs[1], "c1")
+    n = 17_000
+    perm = rng.permutation(n)
+    tid = np.concatenate([r0.tid, r1.tid + 1])[perm]
+    recs = bamio.Records([("c0", 70_000), ("c1", 40_000)], tid, np.concatenate([r0.pos, r1.pos])[perm], np.concatenate([r0.flag, r1.flag])[perm],
+                         np.concatenate([r0.mapq, r1.mapq])[perm], [(r0.cigars + r1.cigars)[i] for i in perm], [(r0.xms + r1.xms)[i] for i in perm])
+    p = str(tmp_path / "shuf.bam")
+    bamio.write_bam(p, recs)
+    reads = pyoracle.Reads.decode(recs)
+    refs, body, offs = record_stream(p)
+    eng.decode_records(body, offs)
+    before = eng.decoded_fetch()
+    t0, _, _, fl = eng.decoded_contigs()
+    assert len(t0) > 100 and (fl & 4 or len(t0) > 2)
+    eng.decoded_sort()
+    got = eng.decoded_fetch()
+    order = np.lexsort((before["start"], before["tid"]))           # stable: ties keep the file order, as the radix sort does
+    for k in ("tid", "start", "end", "mapq", "fwd"):
+        assert (got[k] == before[k][order]).all(), k
+    cnt = np.diff(before["cpg_off"].astype(np.int64))
+    assert (np.diff(got["cpg_off"].astype(np.int64)) == cnt[order]).all()
+    src = np.concatenate([np.arange(before["cpg_off"][i], before["cpg_off"][i + 1]) for i in order]).astype(np.int64)
+    assert (got["cpg_pos"] == before["cpg_pos"][src]).all() and (got["cpg_rel"] == before["cpg_rel"][src]).all()
+    tids, rb, re_, fl = eng.decoded_contigs()
+    assert tids.tolist() == [0, 1] and fl == 0 and int(re_[1]) == n
+    eng.reset()
+    for t, (_, length) in enumerate(refs):
+        eng.pdr_lpmd_accumulate(eng.decoded_batch(int(rb[t]), int(re_[t]), t, 0, length), PdrLpmdParams(want_pdr=False))
+    l, o = eng.lpmd_global(), reads.lpmd()
+    assert all(l[k] == o[k] for k in ("n_concordant", "n_discordant", "n_read", "n_valid_read"))
