@@ -24,6 +24,7 @@
 
 #include "mth_ctx.h"
 #include "mth_scan.h"
+#include "mth_tile_dev.h"
 
 namespace mth {
 
@@ -51,7 +52,10 @@ struct PairArgs {
     int tile_shift;                 // log2 of the tile width the flags were made with
 };
 
-constexpr int PT_S = 2048, PT_B = 256, PT_U = 4, PT_CHUNK = 1024, PT_GRID = 8192;   // tile kernel: LDS slots, threads, reads per thread and round (the tile
+// PT_U / PT_OCC: 2 reads per thread and round at 6 waves per SIMD (80 VGPRs; 26 KiB of LDS allow 6 workgroups per CU) measured best
+// (tools/ab_pairs.sh: 1 / 6 +5 %, 2 / 5 +2 %, 3 / 5 +17 %, 4 / 4 +21 %; profiles/r03_pairs_tile.md)
+constexpr int PT_OCC = 6;
+constexpr int PT_S = 2048, PT_B = 256, PT_U = 2, PT_CHUNK = 1024, PT_GRID = 8192;   // tile kernel: LDS slots, threads, reads per thread and round (the tile
                                                    // width is a template parameter: 8192 / 16384 / 32768, chosen per batch)
 constexpr int P_STATE_WORDS = 8;
 constexpr int PT_NC = 8;                                 // calls of a read parked in LDS for the pair loops
@@ -155,7 +159,7 @@ struct PTileArgs {
     const uint32_t *cpg_off, *cpg_pos, *idx;
     const void     *cpg_rel;
     int32_t region_beg, region_end, idx_base, max_span, min_dist, max_dist;
-    uint32_t n_reads, ntiles;
+    uint32_t n_reads, ntiles, n_cpgs;
     uint8_t min_qual, force_heavy;            // force_heavy: tests send every tile down the global path
     unsigned long long *row_total;            // rows claimed so far (all batches, gaps included)
     unsigned long long row_cap;               // rows the output holds; a range beyond it is claimed but not written ...
@@ -168,7 +172,7 @@ struct PTileArgs {
     DevState *st;
 };
 template <typename RelT, int PT_SHIFT>
-__global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
+__global__ __launch_bounds__(PT_B, PT_OCC) void k_pairs_tile(const PTileArgs a) {
     constexpr int PT_W = 1 << PT_SHIFT;
     constexpr int DBITS = 32 - PT_SHIFT;              // key = (pos1 - tile start) << DBITS | (pos2 - pos1)
     // slot h: tab[2h] = counters (concordant | discordant << 16), tab[2h+1] = key; as a 64-bit word key is the high half
@@ -176,7 +180,6 @@ __global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
     __shared__ uint32_t s_heavy, ws[PT_B / 64 + 1];
     __shared__ uint32_t bcnt[PT_B], bbase[PT_B];        // bucket sort: words per bucket, first rank of the bucket
     __shared__ uint32_t s_cw[PT_NC][PT_B];              // per thread (column): the first calls of the read it is working on
-    __shared__ uint16_t s_cr[PT_NC][PT_B];
     __shared__ unsigned long long s_row0;
     uint32_t *tab = reinterpret_cast<uint32_t *>(tab64);
     const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
@@ -202,69 +205,147 @@ __global__ __launch_bounds__(PT_B) void k_pairs_tile(const PTileArgs a) {
     __syncthreads();
     if (!s_heavy) {
         uint32_t bad = 0;
-        // PT_U reads per thread and round, their fields requested before any of them is used (see mth_quartet.hip)
+        // (distances between live calls are < 2^16; dead slots sit (k + 1) << 24 away, beyond every capped max_distance)
+        const int32_t maxd = min(a.max_dist, 1 << 20), mind = max(a.min_dist, 0);
+        // one pair of a read into the tile's table (lpmd.rs:70-87); the pair belongs to the tile of its first position
+        auto insert = [&](const uint32_t wj, const uint32_t wk) {
+            const int32_t p1 = (int32_t)(wj & 0x7fffffffu);
+            if (p1 < T0 || p1 >= T1) return;
+            const uint32_t delta = (wk & 0x7fffffffu) - (uint32_t)p1;
+            if (delta >= (1u << DBITS) - 1u) { s_heavy = 1u; return; }      // does not fit the 32-bit key (also: calls out of order)
+            const uint32_t key = ((uint32_t)(p1 - T0) << DBITS) | delta;
+            uint32_t h = (key * 0x9E3779B1u) >> (32 - 11), probes = 0;
+            static_assert(PT_S == 1 << 11, "slot hash takes the top 11 bits");
+            bool placed = false;
+            while (probes++ < (uint32_t)PT_S) {
+                const uint32_t cur = atomicCAS(&tab[2 * h + 1], 0xffffffffu, key);
+                if (cur == 0xffffffffu || cur == key) { placed = true; break; }
+                h = (h + 1) & (PT_S - 1);
+            }
+            if (placed) atomicAdd(&tab[2 * h], ((wj ^ wk) >> 31) ? 0x10000u : 1u);    // lpmd.rs:79-86
+            else s_heavy = 1u;                                                          // more distinct pairs than slots
+        };
+        // PT_U reads per thread and round: their offsets, then ALL their calls (the first PT_NC of each: two 16-byte loads of the
+        // call words and one of the relative positions, from a per-read base -- the PDR tile kernel's form) are requested before
+        // any of them is used.  (Round 2's form fetched 2 x PT_NC single words per read behind a first / last look-up -- four times
+        // the PDR kernel's load instructions -- and walked the pairs in two nested loops over an LDS column: a chain of
+        // dependent LDS look-ups with divergent trip counts, 62 % of the wave cycles waiting; profiles/r03_mhl_sparse.md.)
+        // Two round trips per round would be offsets -> calls; the NEXT round's offsets are requested right behind this round's
+        // calls (the PDR tile kernel's PF form), start and mapq travel with the calls, so a round waits once.
+        uint32_t o0s[PT_U], o1s[PT_U];
+#pragma unroll
+        for (int u = 0; u < PT_U; ++u) {
+            const uint32_t ii = min(lo + (uint32_t)u * PT_B + tid, hi - 1);
+            o0s[u] = a.cpg_off[ii]; o1s[u] = a.cpg_off[ii + 1];
+        }
         for (uint32_t b0 = lo; b0 < hi; b0 += PT_B * PT_U) {
-          uint32_t o0s[PT_U], o1s[PT_U], fs[PT_U], ls[PT_U];
           int32_t st[PT_U];
+          uint32_t mq[PT_U], o0n[PT_U], o1n[PT_U];
           bool ok[PT_U];
+          bool inside = true;
+          uint32_t vv[PT_U][PT_NC], rw[PT_U][4];
 #pragma unroll
           for (int u = 0; u < PT_U; ++u) {
-              const uint32_t i = b0 + (uint32_t)u * PT_B + tid, ii = min(i, hi - 1);
-              o0s[u] = a.cpg_off[ii]; o1s[u] = a.cpg_off[ii + 1];
-              ok[u] = i < hi && a.read_mapq[ii] >= a.min_qual;                 // lpmd.rs:177
-              st[u] = a.read_start[ii];
+              const uint32_t i = b0 + (uint32_t)u * PT_B + tid;
+              ok[u] = i < hi && o1s[u] - o0s[u] >= 2;
+              inside = inside && (!ok[u] || (unsigned long long)o0s[u] + PT_NC <= (unsigned long long)a.n_cpgs);
+          }
+          static_assert(PT_NC == 8, "two 16-byte loads per read");
+          if (__all(inside)) {                     // wave-uniform: only the batch's last few reads have a window that leaves the arrays
+#pragma unroll
+              for (int u = 0; u < PT_U; ++u) {
+                  if (!ok[u]) continue;
+                  const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0s[u]), y = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0s[u] + 4);
+                  vv[u][0] = x.x; vv[u][1] = x.y; vv[u][2] = x.z; vv[u][3] = x.w; vv[u][4] = y.x; vv[u][5] = y.y; vv[u][6] = y.z; vv[u][7] = y.w;
+                  if constexpr (sizeof(RelT) == 1) { const u32x2_a1 z = *reinterpret_cast<const u32x2_a1 *>(rel + o0s[u]); rw[u][0] = z.x; rw[u][1] = z.y; }
+                  else { const u32x4_a2 z = *reinterpret_cast<const u32x4_a2 *>(rel + o0s[u]); rw[u][0] = z.x; rw[u][1] = z.y; rw[u][2] = z.z; rw[u][3] = z.w; }
+              }
+          } else {
+#pragma unroll
+              for (int u = 0; u < PT_U; ++u) {
+                  if (!ok[u]) continue;
+                  const uint32_t nc = o1s[u] - o0s[u];
+                  rw[u][0] = rw[u][1] = rw[u][2] = rw[u][3] = 0;
+#pragma unroll
+                  for (int k = 0; k < PT_NC; ++k) {
+                      const uint32_t kk = o0s[u] + min((uint32_t)k, nc - 1);
+                      vv[u][k] = a.cpg_pos[kk];
+                      if constexpr (sizeof(RelT) == 1) rw[u][k >> 2] |= (uint32_t)rel[kk] << (8 * (k & 3));
+                      else rw[u][k >> 1] |= (uint32_t)rel[kk] << (16 * (k & 1));
+                  }
+              }
           }
 #pragma unroll
           for (int u = 0; u < PT_U; ++u) {
-              ok[u] = ok[u] && o1s[u] - o0s[u] >= 2;
-              if (ok[u]) { fs[u] = a.cpg_pos[o0s[u]]; ls[u] = a.cpg_pos[o1s[u] - 1]; }
+              const uint32_t ii = min(b0 + (uint32_t)u * PT_B + tid, hi - 1);
+              st[u] = a.read_start[ii]; mq[u] = a.read_mapq[ii];
+              const uint32_t in = min(b0 + (uint32_t)(PT_U + u) * PT_B + tid, hi - 1);
+              o0n[u] = a.cpg_off[in]; o1n[u] = a.cpg_off[in + 1];
           }
 #pragma unroll
+          for (int u = 0; u < PT_U; ++u) ok[u] = ok[u] && mq[u] >= a.min_qual;                 // lpmd.rs:177
+#pragma unroll
           for (int u = 0; u < PT_U; ++u) {
-            if (!ok[u]) continue;
+            if (!__any(ok[u])) continue;
             const uint32_t o0 = o0s[u], o1 = o1s[u];
+            const uint32_t n_calls = ok[u] ? o1 - o0 : 0u, nl = min(n_calls, (uint32_t)PT_NC);
             // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (rule of the PDR tile kernel)
             const uint32_t sm1 = (uint32_t)st[u] - 1u;
-            bad |= ((fs[u] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
-            bad |= ((ls[u] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
-            // The pair loops below are a chain of dependent look-ups (PMC: 77 % of the wave cycles waiting, VALU 25 % busy).
-            // The read's first PT_NC calls -- all of them for most reads -- are fetched together and parked in the thread's own
-            // LDS column (call word and relative position), so the loops wait on LDS instead of on global memory.
-            const uint32_t n_calls = o1 - o0;
+            int32_t r[PT_NC];
+            uint32_t xmax = 0;
 #pragma unroll
-            for (int t = 0; t < PT_NC; ++t) {
-                const uint32_t kk = o0 + min((uint32_t)t, n_calls - 1);
-                s_cw[t][tid] = a.cpg_pos[kk];
-                s_cr[t][tid] = (uint16_t)rel[kk];
+            for (int k = 0; k < PT_NC; ++k) {
+                const bool live = (uint32_t)k < nl;
+                const uint32_t raw = sizeof(RelT) == 1 ? (rw[u][k >> 2] >> (8 * (k & 3))) & 0xffu : (rw[u][k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                r[k] = live ? (int32_t)raw : (int32_t)((k + 1) << 24);
+                xmax = max(xmax, live ? (vv[u][k] & 0x7fffffffu) - sm1 : 0u);
+                if (ok[u]) s_cw[k][tid] = vv[u][k];                    // the thread's own LDS column: the pairs found below are looked up by slot number
             }
-            auto call_w = [&](uint32_t k) { return k - o0 < (uint32_t)PT_NC ? s_cw[k - o0][tid] : a.cpg_pos[k]; };
-            auto call_r = [&](uint32_t k) { return (int32_t)(k - o0 < (uint32_t)PT_NC ? (uint32_t)s_cr[k - o0][tid] : (uint32_t)rel[k]); };
-            for (uint32_t k = o0 + 1; k < o1; ++k) {
-                const int32_t rk = call_r(k);
-                const uint32_t wk = call_w(k);
-                for (uint32_t j = k; j-- > o0;) {
-                    const int32_t dist = rk - call_r(j);
-                    if (dist > a.max_dist) break;                              // readutil.rs:184
-                    if (dist < a.min_dist) continue;                           // readutil.rs:196
-                    const uint32_t wj = call_w(j);
-                    const int32_t p1 = (int32_t)(wj & 0x7fffffffu);
-                    if (p1 < T0 || p1 >= T1) continue;                         // owned by the tile of pos1
-                    const uint32_t delta = (wk & 0x7fffffffu) - (uint32_t)p1;
-                    if (delta >= (1u << DBITS) - 1u) { s_heavy = 1u; continue; }  // does not fit the 32-bit key (also: calls out of order)
-                    const uint32_t key = ((uint32_t)(p1 - T0) << DBITS) | delta;
-                    uint32_t h = (key * 0x9E3779B1u) >> (32 - 11), probes = 0;
-                    static_assert(PT_S == 1 << 11, "slot hash takes the top 11 bits");
-                    bool placed = false;
-                    while (probes++ < (uint32_t)PT_S) {
-                        const uint32_t cur = atomicCAS(&tab[2 * h + 1], 0xffffffffu, key);
-                        if (cur == 0xffffffffu || cur == key) { placed = true; break; }
-                        h = (h + 1) & (PT_S - 1);
+            bad |= (xmax > (uint32_t)a.max_span) ? 1u : 0u;
+            // Pairs (j, j + g) of the first PT_NC calls with min <= rel[j + g] - rel[j] <= max (readutil.rs:166-224), diagonal by
+            // diagonal: the calls are sorted, so once no lane has a distance <= max on a diagonal the later ones have none either.
+            // One mask byte per diagonal (bit (7 - g) - j for the pair starting at slot j).
+            uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+            for (int g = 1; g < PT_NC; ++g) {
+                uint32_t notin = 0, within = 0;
+#pragma unroll
+                for (int j = 0; j + g < PT_NC; ++j) {
+                    const int32_t dist = r[j + g] - r[j];
+                    const uint32_t below = (uint32_t)(dist - mind), above = (uint32_t)(maxd - dist);     // sign bit: outside
+                    notin = __builtin_amdgcn_alignbit(notin, below | above, 31);
+                    within |= ~above;
+                }
+                const uint32_t dm = ~notin & ((1u << (PT_NC - g)) - 1u);
+                if (g <= 4) mlo |= dm << (8 * (g - 1)); else mhi |= dm << (8 * (g - 5));
+                if (!__any((int32_t)within < 0)) break;
+            }
+            while (__any((mlo | mhi) != 0u)) {
+                if (mlo | mhi) {
+                    uint32_t bit;
+                    if (mlo) { bit = (uint32_t)__builtin_ctz(mlo); mlo &= mlo - 1; }
+                    else { bit = 32u + (uint32_t)__builtin_ctz(mhi); mhi &= mhi - 1; }
+                    const uint32_t g = (bit >> 3) + 1u, j = (7u - g) - (bit & 7u);
+                    insert(s_cw[j][tid], s_cw[j + g][tid]);
+                }
+            }
+            // a read with more than PT_NC calls: the pairs whose LATER call is the (PT_NC + 1)-th or beyond, from memory (rare)
+            if (__any(n_calls > (uint32_t)PT_NC) && n_calls > (uint32_t)PT_NC) {
+                for (uint32_t k = o0 + PT_NC; k < o1; ++k) {
+                    const int32_t rk = (int32_t)rel[k];
+                    const uint32_t wk = a.cpg_pos[k];
+                    bad |= ((wk & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+                    for (uint32_t j = k; j-- > o0;) {
+                        const int32_t dist = rk - (int32_t)rel[j];
+                        if (dist > a.max_dist) break;                              // readutil.rs:184
+                        if (dist < a.min_dist) continue;                           // readutil.rs:196
+                        insert(a.cpg_pos[j], wk);
                     }
-                    if (placed) atomicAdd(&tab[2 * h], ((wj ^ wk) >> 31) ? 0x10000u : 1u);    // lpmd.rs:79-86
-                    else s_heavy = 1u;                                          // more distinct pairs than slots
                 }
             }
           }
+#pragma unroll
+          for (int u = 0; u < PT_U; ++u) { o0s[u] = o0n[u]; o1s[u] = o1n[u]; }
         }
         if (bad) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
     }
@@ -401,7 +482,7 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
         a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
         a.idx = ctx->idx.as<uint32_t>(); a.cpg_rel = r8 ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
         a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
-        a.min_dist = params->min_distance; a.max_dist = params->max_distance; a.n_reads = d.n_reads; a.ntiles = ntiles;
+        a.min_dist = params->min_distance; a.max_dist = params->max_distance; a.n_reads = d.n_reads; a.ntiles = ntiles; a.n_cpgs = (uint32_t)d.n_cpgs;
         a.min_qual = params->min_qual; a.force_heavy = getenv("MTH_PAIRS_FORCE_GLOBAL") ? 1 : 0;
         a.row_total = ps + 1; a.row_cap = ctx->p_cap; a.unfit = ps + 6; a.n_heavy = ps + 5;
         a.tile_flag = ctx->p_tflag.as<uint32_t>();
