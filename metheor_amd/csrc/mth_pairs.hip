@@ -53,7 +53,7 @@ struct PairArgs {
 };
 
 // PT_U / PT_OCC: 2 reads per thread and round at 6 waves per SIMD (80 VGPRs; 26 KiB of LDS allow 6 workgroups per CU) measured best
-// (tools/ab_pairs.sh: 1 / 6 +5 %, 2 / 5 +2 %, 3 / 5 +17 %, 4 / 4 +21 %; profiles/r03_pairs_tile.md)
+// (tools/ab_measure.sh pairs: 1 / 6 +5 %, 2 / 5 +2 %, 3 / 5 +17 %, 4 / 4 +21 %; profiles/r03_pairs_tile.md)
 constexpr int PT_OCC = 6;
 constexpr int PT_S = 2048, PT_B = 256, PT_U = 2, PT_CHUNK = 1024, PT_GRID = 8192;   // tile kernel: LDS slots, threads, reads per thread and round (the tile
                                                    // width is a template parameter: 8192 / 16384 / 32768, chosen per batch)

@@ -23,13 +23,16 @@
 
 #include "mth_ctx.h"
 #include "mth_scan.h"
+#include "mth_tile_dev.h"
 
 namespace mth {
 
 constexpr unsigned long long QKEY_EMPTY = ~0ull;
 // tile kernel: reference positions per tile, LDS table slots, threads.  Measured on S-chr19-10M (profiles/r01_quartet_tile.md):
 // wider tiles re-read fewer halo reads and clear LDS less often, a smaller table lets more tiles share a CU (25 KB each).
-constexpr int QT_S = 512, QT_B = 256, QT_U = 4, QT_CHUNK = 512, QT_GRID = 8192;   // (the tile width is a template parameter: 8192 / 16384 / 32768, chosen per batch)
+constexpr int QT_NC = 8;   // calls of a read held in registers
+constexpr int QT_OCC = 6;  // waves per SIMD (LDS: 23 KiB per workgroup = 6 per CU)
+constexpr int QT_S = 512, QT_B = 256, QT_U = 2, QT_CHUNK = 512, QT_GRID = 8192;   // (the tile width is a template parameter: 8192 / 16384 / 32768, chosen per batch)
 constexpr int Q_STATE_WORDS = 8;
 
 __device__ __forceinline__ unsigned long long qhash(unsigned long long x) {
@@ -248,7 +251,7 @@ struct QTileArgs {
     const uint8_t  *read_mapq;
     const uint32_t *cpg_off, *cpg_pos, *idx;
     int32_t region_beg, region_end, idx_base, max_span;
-    uint32_t n_reads, ntiles;
+    uint32_t n_reads, ntiles, n_cpgs;
     uint8_t min_qual, force_heavy;            // force_heavy: tests send every tile down the global path
     unsigned long long *row_total;            // rows claimed so far (all batches, gaps included)
     unsigned long long row_cap;               // rows the output holds; a range beyond it is claimed but not written ...
@@ -261,7 +264,7 @@ struct QTileArgs {
     DevState *st;
 };
 template <int QT_W>
-__global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
+__global__ __launch_bounds__(QT_B, QT_OCC) void k_quartet_tile(const QTileArgs a) {
     __shared__ unsigned long long keys[QT_S];  // the hash table; later its keys in bucket order
     __shared__ uint16_t sslot[QT_S];           // ... and the slot each of them came from
     __shared__ uint32_t bcnt[QT_B], bbase[QT_B];   // bucket sort on p1: keys per bucket, first rank of the bucket
@@ -292,63 +295,107 @@ __global__ __launch_bounds__(QT_B) void k_quartet_tile(const QTileArgs a) {
     __syncthreads();
     if (!s_heavy) {
         uint32_t bad = 0;
-        // QT_U reads per thread and round, their fields and first calls requested before any of them is used: the chain
-        // idx -> offsets -> calls is paid once per round, not once per read (sparse WGBS: a tile's time is this latency)
+        // one window of four consecutive calls (readutil.rs:105-129) into the tile's table; the quartet belongs to the tile of p1
+        auto window = [&](const uint32_t x, const uint32_t y, const uint32_t z, const uint32_t w) {
+            const int32_t p1 = (int32_t)(x & 0x7fffffffu);
+            if (p1 < T0 || p1 >= T1) return;
+            const uint32_t d2 = (y & 0x7fffffffu) - (x & 0x7fffffffu), d3 = (z & 0x7fffffffu) - (y & 0x7fffffffu),
+                           d4 = (w & 0x7fffffffu) - (z & 0x7fffffffu);
+            const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 33) | ((unsigned long long)d2 << 22) |
+                                           ((unsigned long long)d3 << 11) | (unsigned long long)d4;
+            if (d2 - 1u >= 2047u || d3 - 1u >= 2047u || d4 - 1u >= 2047u || key == QKEY_EMPTY) {
+                s_heavy = 1u;                                        // CpGs >= 2048 bp apart (or out of order): the global path sorts it out
+                return;
+            }
+            const uint32_t pat = ((x >> 31) << 3) | ((y >> 31) << 2) | ((z >> 31) << 1) | (w >> 31);
+            uint32_t h = qslot(key), probes = 0;
+            bool placed = false;
+            while (probes++ < (uint32_t)QT_S) {
+                const unsigned long long cur = atomicCAS(&keys[h], QKEY_EMPTY, key);
+                if (cur == QKEY_EMPTY || cur == key) { placed = true; break; }
+                h = (h + 1) & (QT_S - 1);
+            }
+            if (placed) atomicAdd(&bins[h * 8 + (pat >> 1)], (pat & 1u) ? 0x10000u : 1u);      // me.rs:121-125
+            else s_heavy = 1u;                                   // more distinct quartets than slots
+        };
+        // QT_U reads per thread and round.  A read's first QT_NC calls arrive as two 16-byte loads from a per-read base (the PDR
+        // tile kernel's form; a wave that holds one of the batch's last reads takes clamped single loads instead), together with
+        // its start and mapq and the NEXT round's offsets: one wait per round.  The windows of those calls run from registers;
+        // only a read with more than QT_NC calls goes back to memory, one dependent load per further window (round 2's form paid
+        // that for every window after the first: the chain idx -> offsets -> calls -> next call -> ...).
+        uint32_t o0s[QT_U], o1s[QT_U];
+#pragma unroll
+        for (int u = 0; u < QT_U; ++u) {
+            const uint32_t ii = min(lo + (uint32_t)u * QT_B + tid, hi - 1);
+            o0s[u] = a.cpg_off[ii]; o1s[u] = a.cpg_off[ii + 1];
+        }
         for (uint32_t b0 = lo; b0 < hi; b0 += QT_B * QT_U) {
-            uint32_t o0s[QT_U], o1s[QT_U], xs[QT_U], ys[QT_U], zs[QT_U], ws4[QT_U], ls[QT_U];
             int32_t st[QT_U];
+            uint32_t mq[QT_U], o0n[QT_U], o1n[QT_U], vv[QT_U][QT_NC];
             bool ok[QT_U];
+            bool inside = true;
 #pragma unroll
             for (int u = 0; u < QT_U; ++u) {
-                const uint32_t i = b0 + (uint32_t)u * QT_B + tid, ii = min(i, hi - 1);
-                o0s[u] = a.cpg_off[ii]; o1s[u] = a.cpg_off[ii + 1];
-                ok[u] = i < hi && a.read_mapq[ii] >= a.min_qual;
-                st[u] = a.read_start[ii];
+                const uint32_t i = b0 + (uint32_t)u * QT_B + tid;
+                ok[u] = i < hi && o1s[u] - o0s[u] >= 4;                     // readutil.rs:101, me.rs:115
+                inside = inside && (!ok[u] || (unsigned long long)o0s[u] + QT_NC <= (unsigned long long)a.n_cpgs);
+            }
+            static_assert(QT_NC == 8, "two 16-byte loads per read");
+            if (__all(inside)) {
+#pragma unroll
+                for (int u = 0; u < QT_U; ++u) {
+                    if (!ok[u]) continue;
+                    const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0s[u]), y = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0s[u] + 4);
+                    vv[u][0] = x.x; vv[u][1] = x.y; vv[u][2] = x.z; vv[u][3] = x.w; vv[u][4] = y.x; vv[u][5] = y.y; vv[u][6] = y.z; vv[u][7] = y.w;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < QT_U; ++u) {
+                    if (!ok[u]) continue;
+                    const uint32_t nc = o1s[u] - o0s[u];
+#pragma unroll
+                    for (int k = 0; k < QT_NC; ++k) vv[u][k] = a.cpg_pos[o0s[u] + min((uint32_t)k, nc - 1)];
+                }
             }
 #pragma unroll
             for (int u = 0; u < QT_U; ++u) {
-                ok[u] = ok[u] && o1s[u] - o0s[u] >= 4;                      // readutil.rs:101, me.rs:115
-                if (ok[u]) { xs[u] = a.cpg_pos[o0s[u]]; ys[u] = a.cpg_pos[o0s[u] + 1]; zs[u] = a.cpg_pos[o0s[u] + 2]; ws4[u] = a.cpg_pos[o0s[u] + 3]; ls[u] = a.cpg_pos[o1s[u] - 1]; }
+                const uint32_t ii = min(b0 + (uint32_t)u * QT_B + tid, hi - 1);
+                st[u] = a.read_start[ii]; mq[u] = a.read_mapq[ii];
+                const uint32_t in = min(b0 + (uint32_t)(QT_U + u) * QT_B + tid, hi - 1);
+                o0n[u] = a.cpg_off[in]; o1n[u] = a.cpg_off[in + 1];
             }
 #pragma unroll
+            for (int u = 0; u < QT_U; ++u) ok[u] = ok[u] && mq[u] >= a.min_qual;
+#pragma unroll
             for (int u = 0; u < QT_U; ++u) {
-                if (!ok[u]) continue;
+                if (!__any(ok[u])) continue;
                 const uint32_t o0 = o0s[u], o1 = o1s[u];
-                uint32_t x = xs[u], y = ys[u], z = zs[u];
+                const uint32_t n_calls = ok[u] ? o1 - o0 : 0u;
                 // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (a reverse read's first call
                 // may sit one base before its start, readutil.rs:338; rule of the PDR tile kernel).  Unsigned: a call further
                 // left is caught too; the windows' deltas are checked to be 1..2047 below, so the calls in between are ordered.
                 const uint32_t sm1 = (uint32_t)st[u] - 1u;
-                bad |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
-                bad |= ((ls[u] & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
-                uint32_t w_next = ws4[u];                                       // the window's last call is requested one window ahead
-                for (uint32_t k = o0 + 3; k < o1; ++k) {                        // readutil.rs:105-129
-                    const uint32_t w = w_next;
-                    w_next = a.cpg_pos[min(k + 1, o1 - 1)];
-                    const int32_t p1 = (int32_t)(x & 0x7fffffffu);
-                    if (p1 >= T0 && p1 < T1) {
-                        const uint32_t d2 = (y & 0x7fffffffu) - (x & 0x7fffffffu), d3 = (z & 0x7fffffffu) - (y & 0x7fffffffu),
-                                       d4 = (w & 0x7fffffffu) - (z & 0x7fffffffu);
-                        const unsigned long long key = ((unsigned long long)(uint32_t)p1 << 33) | ((unsigned long long)d2 << 22) |
-                                                       ((unsigned long long)d3 << 11) | (unsigned long long)d4;
-                        if (d2 - 1u >= 2047u || d3 - 1u >= 2047u || d4 - 1u >= 2047u || key == QKEY_EMPTY) {
-                            s_heavy = 1u;                                        // CpGs >= 2048 bp apart (or out of order): the global path sorts it out
-                        } else {
-                            const uint32_t pat = ((x >> 31) << 3) | ((y >> 31) << 2) | ((z >> 31) << 1) | (w >> 31);
-                            uint32_t h = qslot(key), probes = 0;
-                            bool placed = false;
-                            while (probes++ < (uint32_t)QT_S) {
-                                const unsigned long long cur = atomicCAS(&keys[h], QKEY_EMPTY, key);
-                                if (cur == QKEY_EMPTY || cur == key) { placed = true; break; }
-                                h = (h + 1) & (QT_S - 1);
-                            }
-                            if (placed) atomicAdd(&bins[h * 8 + (pat >> 1)], (pat & 1u) ? 0x10000u : 1u);      // me.rs:121-125
-                            else s_heavy = 1u;                                   // more distinct quartets than slots
-                        }
+                uint32_t xmax = 0;
+#pragma unroll
+                for (int k = 0; k < QT_NC; ++k) xmax = max(xmax, (uint32_t)k < n_calls ? (vv[u][k] & 0x7fffffffu) - sm1 : 0u);
+                bad |= (xmax > (uint32_t)a.max_span) ? 1u : 0u;
+#pragma unroll
+                for (int k = 3; k < QT_NC; ++k) {
+                    if (!__any((uint32_t)k < n_calls)) break;               // wave-uniform
+                    if ((uint32_t)k < n_calls) window(vv[u][k - 3], vv[u][k - 2], vv[u][k - 1], vv[u][k]);
+                }
+                if (__any(n_calls > (uint32_t)QT_NC) && n_calls > (uint32_t)QT_NC) {
+                    uint32_t x = vv[u][QT_NC - 3], y = vv[u][QT_NC - 2], z = vv[u][QT_NC - 1];
+                    for (uint32_t k = o0 + QT_NC; k < o1; ++k) {
+                        const uint32_t w = a.cpg_pos[k];
+                        bad |= ((w & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+                        window(x, y, z, w);
+                        x = y; y = z; z = w;
                     }
-                    x = y; y = z; z = w;
                 }
             }
+#pragma unroll
+            for (int u = 0; u < QT_U; ++u) { o0s[u] = o0n[u]; o1s[u] = o1n[u]; }
         }
         if (bad) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
     }
@@ -513,7 +560,7 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
         a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
         a.idx = ctx->idx.as<uint32_t>();
         a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
-        a.n_reads = d.n_reads; a.ntiles = ntiles; a.min_qual = params->min_qual;
+        a.n_reads = d.n_reads; a.ntiles = ntiles; a.n_cpgs = (uint32_t)d.n_cpgs; a.min_qual = params->min_qual;
         a.force_heavy = getenv("MTH_QUARTET_FORCE_GLOBAL") ? 1 : 0;
         a.row_total = qs + 1; a.row_cap = ctx->q_cap; a.unfit = qs + 6; a.n_heavy = qs + 5;
         a.tile_flag = ctx->q_tflag.as<uint32_t>();
