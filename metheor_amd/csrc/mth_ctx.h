@@ -178,6 +178,8 @@ struct TileSink {
     uint32_t *batch_cnt;
 };
 int build_read_index(mth_ctx *ctx, const mth_batch_t &dev_batch, int tile_w, int32_t &idx_base, uint32_t &ntiles);
+// MHL as one tile pass (mth_mhl_tile.hip): candidate-site arrays filled with finished rows and the sites left to the exact walk
+int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_mhl_params_t &p, uint64_t &bound);
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p,
                     const TileSink *sink = nullptr);
 // mth_stream.hip: the same pass as one stream over the sorted reads (batches with 8-bit relpos and max_span <= 256)

@@ -1,0 +1,510 @@
+// mth_mhl_tile.hip -- MHL (mhl.rs:135-208, 43-73; readutil.rs:147-164) as ONE tile pass over the reads (gfx950).
+//
+// compute_mhl (mhl.rs:43-73) only needs, per site, two small histograms over the reads that cover it:
+//   hn[n]  = covering reads with n CpGs                       ->  D[l] = sum_n hn[n] * max(0, n - l + 1)    (mhl.rs:53-58)
+//   hm[m]  = maximal methylated runs of length m in them       ->  S[l] = sum_m hm[m] * max(0, m - l + 1)    (mhl.rs:36-41)
+// (D is the reference's f32 running sum of integers: exact and order-free below 2^24, which 65535 reads x 16 stay under.)
+// Both are sums over reads, so a site whose covering reads form ONE segment of the reference's stream (mhl.rs:162-173: a read
+// whose first CpG lies beyond c flushes c; a later contribution re-opens it) needs no walk at all: every read adds 1 to
+// hn[n] and its run lengths to hm[] at each of its calls -- the PDR tile kernel with three LDS atomics per call instead of one.
+// The tile keeps its sites in an LDS hash table (key = position; 16 + 16 sixteen-bit bins per slot), so there is no site
+// discovery pass either: one pass over the reads replaces the PDR-style discovery, the per-site walk and its staging.
+//
+// Exactness.  Site c can have more than one segment only if some read k with >= 1 CpG has start_k - 1 <= c < first_cpg(k)
+// while a LATER read still calls c (a later contributor j has start_j <= c + 1, a flusher between two contributors starts at or
+// before that too).  Two cases:
+//   c >= start_k:      the tile marks [start_k, first_cpg(k)) in a position bitmap F; a site under a mark is handed on.  Reads
+//                      that call every CpG they overlap (the usual case) mark stretches without sites.
+//   c == start_k - 1:  forward reads starting one base past a CpG do this all the time, but only a reverse read with the SAME
+//                      start can call c after them.  Each slot keeps the largest index of a contributor that calls its own
+//                      start - 1; at the end the few reads with that start and a smaller index are looked at.
+// Sites handed on (flag 4), sites covered by a read with more than 16 CpGs and the sites of tiles with more than 8191 candidate
+// reads (the 16-bit bins) take k_mhl_walk_big's exact per-site walk (mth_sites.hip) -- conservative hand-ons cost time only.
+// A sub-range of a tile with more distinct sites than slots (CpG islands) is redone in halves (down to 256 positions = 256 slots).
+//
+// Output: per tile, rows sorted by position in a scratch slice (site, mhl, coverage, flag); k_mhl_tile_gather packs the slices
+// into the candidate-site arrays the rest of the MHL pipeline (k_mhl_walk_big / _huge, k_mhl_emit) already works on.
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#include "mth_ctx.h"
+#include "mth_scan.h"
+#include "mth_tile_dev.h"
+
+namespace mth {
+
+struct MhlRec { int32_t pos; float val; uint32_t cov, flags; };
+static_assert(sizeof(MhlRec) == sizeof(SiteRec), "the PDR scratch buffer is reused");
+
+struct MhlTileArgs {
+    const int32_t  *read_start;
+    const uint8_t  *read_mapq;
+    const uint32_t *cpg_off, *cpg_pos, *idx;
+    int32_t region_beg, region_end, idx_base, max_span;
+    uint32_t n_reads, ntiles, n_cpgs, min_depth, min_cpgs;
+    uint8_t min_qual;
+    uint8_t force_sub;            // tests: start every tile with 256-position sub-ranges
+    uint8_t force_hand_on;        // tests: every site goes to the exact walk
+    uint8_t dbg;                  // timing experiments (MTH_MHL_DBG): 1 = no flusher marks, 2 = no contributions, 4 = no row values
+    MhlRec *scratch;              // W rows per tile (the PDR pipeline's 16 bytes per position)
+    uint32_t *tile_cnt;           // rows of the tile
+    unsigned long long *bucket;   // rows per 256 tiles
+    DevState *st;
+};
+
+constexpr int MT_S = 256, MT_B = 256, MT_U = 2, MT_NC = 8, MT_LCAP = 16;
+// slot h: tkey[h] = position; taux[h] bit 31 = "a read with > 16 CpGs calls it", low bits = largest (index - lo + 1) of a contributor
+// calling its own start - 1; thist[17 h ..]: words 0..7 hn, 8..15 hm (bin b in half (b - 1) & 1 of word (b - 1) >> 1); the 17th word
+// is padding: with 16 the slots' words fall on 4 of the 64 LDS banks (measured: contributions 0.17 -> 0.22 ms)
+constexpr int MT_HW = 17;
+constexpr int MT_Q = 1024;         // contributing reads a sub-range may queue (more: the sub-range is halved)
+constexpr uint32_t MT_EMPTY = 0xffffffffu;
+constexpr uint32_t MT_HEAVY = 8191;   // candidate reads a sub-range may have with 16-bit bins (a read adds up to 8 to one hm bin)
+
+// A contributing read of a `heavy` stretch: a slot per called position, a 32-bit count in the slot's first histogram word.  Out of
+// line: the stretch is rare and its registers would otherwise be live across the whole kernel (21 spilled VGPRs when it was inline).
+__device__ __noinline__ bool mhl_count_only(const uint32_t *__restrict__ cpg_pos, const uint32_t o0, const uint32_t o1, const uint32_t sm1,
+                                            const uint32_t max_span, const uint32_t P0, const uint32_t Wp, uint32_t *tkey, uint32_t *thist,
+                                            uint32_t &bad) {
+    bool over = false;
+    for (uint32_t k = o0; k < o1; ++k) {
+        const uint32_t pw = cpg_pos[k] & 0x7fffffffu, d = pw - P0;
+        bad |= (pw - sm1 > max_span) ? 1u : 0u;
+        if (d >= Wp) continue;
+        uint32_t h = (d >> 1) & (MT_S - 1), probes = 0;
+        bool placed = false;
+        while (probes++ < (uint32_t)MT_S) {
+            const uint32_t cur = atomicCAS(&tkey[h], MT_EMPTY, pw);
+            if (cur == MT_EMPTY || cur == pw) { atomicAdd(&thist[h * MT_HW], 1u); placed = true; break; }
+            h = (h + 1) & (MT_S - 1);
+        }
+        over = over || !placed;
+    }
+    return over;
+}
+
+template <int MT_SHIFT>
+#ifndef MTH_MT_OCC
+#define MTH_MT_OCC 6
+#endif
+__global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs a) {
+    constexpr int W = 1 << MT_SHIFT;
+    __shared__ uint32_t tkey[MT_S], taux[MT_S];
+    __shared__ uint32_t thist[MT_S * MT_HW];
+    __shared__ uint32_t F[W / 32];
+    // the contributor queue (phases 1 and 2) and the sort arrays of the row phase share their LDS
+    __shared__ uint32_t q_or_sort[MT_Q > 2 * MT_B ? MT_Q : 2 * MT_B];
+    __shared__ uint32_t bcnt[MT_B];
+    uint32_t *const rq = q_or_sort, *const bbase = q_or_sort;
+    int32_t *const skey = reinterpret_cast<int32_t *>(q_or_sort + MT_B);
+    __shared__ uint32_t ws[MT_B / 64 + 1];
+    __shared__ uint32_t s_over, s_qn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
+    const uint32_t per_xcd = (a.ntiles + 7) / 8;
+    const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= a.ntiles) return;
+    const int32_t T0 = a.region_beg + (int32_t)(t * W);
+    const int32_t T1 = (int32_t)min((int64_t)T0 + W, (int64_t)a.region_end);
+    MhlRec *__restrict__ out = a.scratch + (size_t)t * W;
+    uint32_t rows_out = 0;
+    int sub_shift = a.force_sub ? 8 : MT_SHIFT;            // log2 of the sub-range width (block-uniform)
+    uint32_t bad = 0;
+    bool heavy_redo = false;                               // block-uniform
+    for (int64_t P0l = T0; P0l < T1;) {
+        const int32_t P0 = (int32_t)P0l;
+        const int32_t P1 = (int32_t)min(P0l + (1ll << sub_shift), (int64_t)T1);
+        const uint32_t Wp = (uint32_t)(P1 - P0);
+        // candidate reads: start in [P0 - max_span + 1, P1]  (a call sits in [start - 1, start - 1 + max_span])
+        const uint32_t lo = min(a.idx[((uint32_t)P0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
+        const uint32_t hi = min(a.idx[(((uint32_t)P1 - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        // more candidate reads than the 16-bit bins can count: halve the stretch; at 256 positions (thousands-fold depth) the sites
+        // are only counted and all handed on (`heavy`); the same when the contributor queue overflows at 256 positions
+        if (hi - lo > MT_HEAVY && sub_shift > 8) { --sub_shift; continue; }
+        const bool heavy = hi - lo > MT_HEAVY || heavy_redo;
+        const uint32_t o_lo = lo < hi ? a.cpg_off[lo] : 0u;      // queue entries carry call offsets relative to the sub-range's first
+        static_assert(MT_S == MT_B, "one slot per thread");
+        tkey[tid] = MT_EMPTY; taux[tid] = 0u;
+        for (int i = tid; i < MT_S * MT_HW; i += MT_B) thist[i] = 0u;
+        for (int i = tid; i < W / 32; i += MT_B) F[i] = 0u;
+        bcnt[tid] = 0u;
+        if (tid == 0) { s_over = 0u; s_qn = 0u; }
+        __syncthreads();
+        if (lo < hi) {
+            // Phase 1, every candidate read (offsets one round ahead, then start, mapq and the FIRST call in one wait): the flusher's
+            // mark, and the read's index into the queue if it contributes.  Contributors are a minority (reads with >= min_cpgs CpGs:
+            // a third of config 2's reads, a twentieth at WGBS density) while the contribution code below is the expensive part of
+            // the kernel: run over all candidates it executed with 5-30 % of the lanes live (0.17 of 0.25 ms on config 2).
+            uint32_t o0s[MT_U], o1s[MT_U];
+#pragma unroll
+            for (int u = 0; u < MT_U; ++u) {
+                const uint32_t ii = min(lo + (uint32_t)u * MT_B + tid, hi - 1);
+                o0s[u] = a.cpg_off[ii]; o1s[u] = a.cpg_off[ii + 1];
+            }
+            for (uint32_t b0 = lo; b0 < hi; b0 += MT_B * MT_U) {
+                int32_t st[MT_U];
+                uint32_t mq[MT_U], o0n[MT_U], o1n[MT_U], fw[MT_U];
+#pragma unroll
+                for (int u = 0; u < MT_U; ++u) {
+                    const uint32_t i = b0 + (uint32_t)u * MT_B + tid, ii = min(i, hi - 1);
+                    const bool has = i < hi && o1s[u] != o0s[u];                 // a read without a CpG neither flushes nor contributes (mhl.rs:162)
+                    fw[u] = has ? a.cpg_pos[o0s[u]] : 0u;
+                    st[u] = a.read_start[ii]; mq[u] = a.read_mapq[ii];
+                    const uint32_t in = min(i + (uint32_t)MT_U * MT_B, hi - 1);
+                    o0n[u] = a.cpg_off[in]; o1n[u] = a.cpg_off[in + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < MT_U; ++u) {
+                    const uint32_t i = b0 + (uint32_t)u * MT_B + tid;
+                    const uint32_t n = i < hi ? o1s[u] - o0s[u] : 0u;
+                    if (n && !(a.dbg & 1)) {
+                        // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (rule of the PDR tile kernel):
+                        // the first call here, a contributor's other calls in phase 2
+                        const uint32_t first = fw[u] & 0x7fffffffu;
+                        bad |= (first - ((uint32_t)st[u] - 1u) > (uint32_t)a.max_span) ? 1u : 0u;
+                        // a flusher: the stretch [start, first CpG) of the sub-range is marked
+                        const int64_t f0 = max((int64_t)st[u], (int64_t)P0) - P0, f1 = min((int64_t)first, (int64_t)P1) - P0;
+                        if (f0 < f1) {
+                            const uint32_t b_lo = (uint32_t)f0, b_hi = (uint32_t)f1 - 1u;       // inclusive bit range
+                            for (uint32_t w = b_lo >> 5; w <= (b_hi >> 5); ++w) {
+                                uint32_t m = 0xffffffffu;
+                                if (w == (b_lo >> 5)) m &= 0xffffffffu << (b_lo & 31u);
+                                if (w == (b_hi >> 5)) m &= 0xffffffffu >> (31u - (b_hi & 31u));
+                                atomicOr(&F[w], m);
+                            }
+                        }
+                    }
+                    const bool contrib = n != 0 && mq[u] >= a.min_qual && n >= a.min_cpgs && !(a.dbg & 2);      // mhl.rs:176, 181
+                    if (heavy) {                                                   // (rare: slots made and counted straight from memory)
+                        if (contrib && mhl_count_only(a.cpg_pos, o0s[u], o1s[u], (uint32_t)st[u] - 1u, (uint32_t)a.max_span, (uint32_t)P0, Wp, tkey, thist, bad))
+                            s_over = 1u;
+                        continue;
+                    }
+                    const unsigned long long bal = __ballot(contrib);
+                    if (bal) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&s_qn, (uint32_t)__builtin_popcountll(bal));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const uint32_t at = base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                        // entry: read (13 bits: <= 8191 candidates) and call offset (19 bits; more -- long reads -- goes the heavy way)
+                        if (contrib) {
+                            const uint32_t dr = i - lo, doff = o0s[u] - o_lo;
+                            if (at < (uint32_t)MT_Q && doff < (1u << 19)) rq[at] = dr | (doff << 13);
+                            else s_over = 1u;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < MT_U; ++u) { o0s[u] = o0n[u]; o1s[u] = o1n[u]; }
+            }
+        }
+        __syncthreads();
+        // Phase 2, the queued contributors with every lane live: the read's calls (two 16-byte loads; its first MT_NC), its runs,
+        // then per call the slot (found or made) and the histogram increments.
+        const uint32_t qn = heavy ? 0u : min(s_qn, (uint32_t)MT_Q);
+        if (!s_over) {
+            // `runs`: the read's maximal methylated runs, length - 1 in four bits each, n_runs of them (readutil.rs:147-164)
+            auto contribute = [&](const uint32_t word, const uint32_t n, const uint32_t runs, const uint32_t n_runs, const uint32_t max_runs,
+                                  const uint32_t sm1, const uint32_t rel_idx) {
+                const uint32_t p = word & 0x7fffffffu, d = p - (uint32_t)P0;
+                if (d >= Wp) return;
+                // CpG sites lie at least two positions apart: (d >> 1) spreads a dense stretch over consecutive slots (a multiplicative
+                // hash costs a quarter-rate multiply per call)
+                uint32_t h = (d >> 1) & (MT_S - 1), probes = 0;
+                bool placed = false;
+                while (probes++ < (uint32_t)MT_S) {
+                    const uint32_t cur = atomicCAS(&tkey[h], MT_EMPTY, p);
+                    if (cur == MT_EMPTY || cur == p) { placed = true; break; }
+                    h = (h + 1) & (MT_S - 1);
+                }
+                if (!placed) { s_over = 1u; return; }
+                uint32_t *hist = &thist[h * MT_HW];
+                if (n > (uint32_t)MT_LCAP) { atomicOr(&taux[h], 0x80000000u); atomicAdd(&hist[0], 1u); return; }   // (counted for the min_depth test)
+                if (p == sm1) atomicMax(&taux[h], rel_idx);
+                atomicAdd(&hist[(n - 1u) >> 1], ((n - 1u) & 1u) ? 0x10000u : 1u);
+                for (uint32_t r = 0; r < max_runs; ++r) {                          // max_runs: the wave's largest n_runs
+                    const uint32_t m1 = (runs >> (4u * r)) & 15u;
+                    if (r < n_runs) atomicAdd(&hist[8u + (m1 >> 1)], (m1 & 1u) ? 0x10000u : 1u);
+                }
+            };
+            for (uint32_t j0 = 0; j0 < qn; j0 += MT_B) {
+                const uint32_t j = j0 + tid;
+                const bool act = j < qn;
+                const uint32_t e = act ? rq[j] : 0u;
+                const uint32_t i = lo + (e & 8191u);
+                const uint32_t o0 = o_lo + (e >> 13), o1 = a.cpg_off[i + 1];      // (the calls are requested at once)
+                const uint32_t n = act ? o1 - o0 : 0u, nl = min(n, (uint32_t)MT_NC);
+                uint32_t vv[MT_NC];
+                static_assert(MT_NC == 8, "two 16-byte loads per read");
+                if (__all(!act || (unsigned long long)o0 + MT_NC <= (unsigned long long)a.n_cpgs)) {
+                    if (act) {
+                        const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0), y = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0 + 4);
+                        vv[0] = x.x; vv[1] = x.y; vv[2] = x.z; vv[3] = x.w; vv[4] = y.x; vv[5] = y.y; vv[6] = y.z; vv[7] = y.w;
+                    }
+                } else if (act) {
+#pragma unroll
+                    for (int k = 0; k < MT_NC; ++k) vv[k] = a.cpg_pos[o0 + min((uint32_t)k, n - 1)];
+                }
+                const uint32_t sm1 = (uint32_t)a.read_start[i] - 1u;
+                uint32_t xmax = 0;
+#pragma unroll
+                for (int k = 0; k < MT_NC; ++k) xmax = max(xmax, (uint32_t)k < nl ? (vv[k] & 0x7fffffffu) - sm1 : 0u);
+                bad |= (xmax > (uint32_t)a.max_span) ? 1u : 0u;
+                uint32_t runs = 0, n_runs = 0;
+                const bool longer = n > (uint32_t)MT_NC;
+                if (act && n <= (uint32_t)MT_LCAP) {
+                    // methylation states of the read's calls, then its maximal runs
+                    uint32_t mb = 0;
+#pragma unroll
+                    for (int k = 0; k < MT_NC; ++k) mb |= ((uint32_t)k < nl ? vv[k] >> 31 : 0u) << k;
+                    if (longer)
+                        for (uint32_t k = MT_NC; k < n; ++k) mb |= (a.cpg_pos[o0 + k] >> 31) << k;
+                    uint32_t x = mb;
+                    while (x) {                                                     // at most 8 runs in 16 calls
+                        x >>= __builtin_ctz(x);
+                        const uint32_t m = (uint32_t)__builtin_ctz(~x);           // 1..16 (x < 2^16)
+                        x >>= m;
+                        runs |= (m - 1u) << (4u * n_runs);
+                        ++n_runs;
+                    }
+                }
+                uint32_t max_runs = n_runs;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) max_runs = max(max_runs, (uint32_t)__shfl_xor((int)max_runs, o, 64));
+                max_runs = __builtin_amdgcn_readfirstlane(max_runs);
+                const uint32_t rel_idx = i - lo + 1u;
+#pragma unroll
+                for (int k = 0; k < MT_NC; ++k) {
+                    if (!__any((uint32_t)k < nl)) break;                            // wave-uniform
+                    if ((uint32_t)k < nl) contribute(vv[k], n, runs, n_runs, max_runs, sm1, rel_idx);
+                }
+                if (__any(longer) && longer)
+                    for (uint32_t k = o0 + MT_NC; k < o1; ++k) {
+                        const uint32_t w = a.cpg_pos[k];
+                        bad |= ((w & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+                        contribute(w, n, runs, n_runs, max_runs, sm1, rel_idx);
+                    }
+            }
+        }
+        __syncthreads();
+        const uint32_t over = s_over;
+        __syncthreads();                                    // (s_over is cleared at the top of the next trip; the queue is done with)
+        if (over && sub_shift > 8) { --sub_shift; continue; }      // too many distinct sites or contributors: the same stretch again in halves
+        if (over && !heavy) { heavy_redo = true; continue; }       // 256 positions and still more contributors than the queue holds
+        if (over) bad |= 2u;                                // cannot happen: 256 positions, 256 slots
+        heavy_redo = false;
+        // rows: the slots whose coverage reaches min_depth (no segment holds more reads than that), sorted by position.
+        // Bucket sort: thread = slot = bucket; a bucket is Wsub / 256 positions.
+        const uint32_t key = tkey[tid];
+        uint32_t cov = 0;
+        uint32_t hn[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) hn[w] = 0;
+        if (key != MT_EMPTY) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) hn[w] = thist[tid * MT_HW + w];
+            const bool counted = heavy || (taux[tid] >> 31);
+            if (counted) cov = 0xffffffffu;                 // decided below
+            else {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) cov += (hn[w] & 0xffffu) + (hn[w] >> 16);
+            }
+        }
+        const uint32_t aux = key != MT_EMPTY ? taux[tid] : 0u;
+        bool hand_on = key != MT_EMPTY && (heavy || (aux >> 31) || a.force_hand_on);
+        if (key != MT_EMPTY && cov == 0xffffffffu) {
+            // heavy: hist word 0 is a 32-bit count of all contributors; "> 16 CpGs": word 0 holds hn[1] | hn[2] << 16 plus one per long read --
+            // an upper bound of the coverage is all the row test needs (the walk decides)
+            cov = 0;
+            if (heavy) cov = hn[0];
+            else {
+#pragma unroll
+                for (int w = 1; w < 8; ++w) cov += (hn[w] & 0xffffu) + (hn[w] >> 16);
+                cov += hn[0];                               // >= hn[1] + hn[2] + long reads
+            }
+        }
+        const bool row = key != MT_EMPTY && cov >= a.min_depth;
+        const uint32_t bk = row ? (key - (uint32_t)P0) >> (sub_shift - 8) : 0u;
+        uint32_t pib = 0;
+        if (row) pib = atomicAdd(&bcnt[bk], 1u);
+        __syncthreads();
+        const uint32_t m_b = bcnt[tid];
+        const uint32_t incl = wave_scan_incl(m_b);
+        if (lane == 63) ws[wave + 1] = incl;
+        __syncthreads();
+        if (tid == 0) { ws[0] = 0; for (int w = 1; w <= MT_B / 64; ++w) ws[w] += ws[w - 1]; }
+        __syncthreads();
+        const uint32_t n_rows = ws[MT_B / 64];
+        bbase[tid] = ws[wave] + incl - m_b;
+        __syncthreads();
+        if (row) skey[bbase[bk] + pib] = (int32_t)key;
+        __syncthreads();
+        if (row) {
+            const uint32_t b0 = bbase[bk], b1 = b0 + bcnt[bk];
+            uint32_t r = b0;
+            for (uint32_t i = b0; i < b1; ++i) r += skey[i] < (int32_t)key ? 1u : 0u;
+            const int32_t c = (int32_t)key;
+            // handed on: under a flusher's mark, or a reverse read with start == c + 1 calls c after a read of that start whose
+            // first CpG lies beyond c
+            if (!hand_on) hand_on = (F[(key - (uint32_t)P0) >> 5] >> ((key - (uint32_t)P0) & 31u)) & 1u;
+            const uint32_t self = aux & 0x7fffffffu;
+            if (!hand_on && self) {
+                const uint32_t K = lo + self - 1u;          // the last contributor that calls its own start - 1 here
+                uint32_t r2 = min(a.idx[((uint32_t)c + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
+                for (; r2 < K; ++r2) {
+                    const int32_t s = a.read_start[r2];
+                    if (s > c + 1) break;
+                    if (s != c + 1) continue;
+                    const uint32_t q0 = a.cpg_off[r2], q1 = a.cpg_off[r2 + 1];
+                    if (q1 != q0 && (int32_t)(a.cpg_pos[q0] & 0x7fffffffu) > c) { hand_on = true; break; }
+                }
+            }
+            MhlRec rec;
+            rec.pos = c; rec.cov = cov; rec.val = 0.0f; rec.flags = 4u;
+            if (!hand_on && !(a.dbg & 4)) {
+                // compute_mhl (mhl.rs:43-73) from the histograms: suffix sums twice give S[l], D[l]; same operations and order as
+                // mhl_walk_site's finalize()
+                uint32_t hm[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) hm[w] = thist[tid * MT_HW + 8 + w];
+                uint32_t S[MT_LCAP], D[MT_LCAP];
+                uint32_t maxn = 0;
+#pragma unroll
+                for (int l = 0; l < MT_LCAP; ++l) {
+                    S[l] = (l & 1) ? hm[l >> 1] >> 16 : hm[l >> 1] & 0xffffu;
+                    D[l] = (l & 1) ? hn[l >> 1] >> 16 : hn[l >> 1] & 0xffffu;
+                    if (D[l]) maxn = (uint32_t)l + 1u;
+                }
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+                    for (int l = MT_LCAP - 2; l >= 0; --l) { S[l] += S[l + 1]; D[l] += D[l + 1]; }
+                float l_sum = 0.0f;
+                for (uint32_t l = 1; l < maxn + 1; ++l) l_sum = l_sum + (float)l;
+                float mhl = 0.0f;
+#pragma unroll
+                for (int l = 1; l <= MT_LCAP; ++l)
+                    if (S[l - 1] > 0) { const float tq = ((float)l * (float)S[l - 1]) / (float)D[l - 1]; mhl = mhl + tq; }
+                rec.val = mhl / l_sum;
+                rec.flags = 1u;
+            }
+            out[rows_out + r] = rec;
+        }
+        rows_out += n_rows;
+        P0l = P1;
+        __syncthreads();                                    // the table is cleared by the next trip
+    }
+    if (bad & 1u) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
+    if (bad & 2u) atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);
+    if (tid == 0) {
+        a.tile_cnt[t] = rows_out;
+        if (rows_out) atomicAdd(a.bucket + (t >> TILE_BUCKET_SHIFT), (unsigned long long)rows_out);
+    }
+}
+
+// One wave per tile: the tile's first row = rows of the buckets before its bucket + rows of the bucket's earlier tiles; its rows
+// go to the candidate-site arrays.  The wave of the last tile leaves the total in sites_st->n_sites.
+constexpr int MG_WAVES = 4;
+__global__ __launch_bounds__(64 * MG_WAVES) void k_mhl_tile_gather(const MhlRec *__restrict__ scratch, const uint32_t *__restrict__ tile_cnt,
+                                                                   const unsigned long long *__restrict__ bucket, const uint32_t ntiles,
+                                                                   const uint32_t rows_per_tile, DevState *__restrict__ sites_st,
+                                                                   int32_t *__restrict__ site_pos, float *__restrict__ val,
+                                                                   uint32_t *__restrict__ cov, uint32_t *__restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * MG_WAVES + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const uint32_t bk = t >> TILE_BUCKET_SHIFT, t_first = bk << TILE_BUCKET_SHIFT;
+    unsigned long long before = 0;
+    for (uint32_t b = lane; b < bk; b += 64) before += bucket[b];
+    uint32_t in_bucket = 0;
+    for (uint32_t q = t_first + lane; q < t; q += 64) in_bucket += tile_cnt[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        before += __shfl_xor(before, o, 64);
+        in_bucket += __shfl_xor(in_bucket, o, 64);
+    }
+    const unsigned long long base = before + in_bucket;
+    const uint32_t n = tile_cnt[t];
+    const MhlRec *__restrict__ src = scratch + (size_t)t * rows_per_tile;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const MhlRec r = src[i];
+        site_pos[base + i] = r.pos; val[base + i] = r.val; cov[base + i] = r.cov; flags[base + i] = r.flags;
+    }
+    if (t == ntiles - 1 && lane == 0) sites_st->n_sites = base + n;
+}
+
+// The tile pass of one batch: candidate-site arrays (ctx->s_pos, w_val, w_cov, w_flags; count in d_state2->n_sites) filled with
+// the finished rows (flag 1) and the sites left to k_mhl_walk_big (flag 4); the read index is left for that walk.
+int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &p, uint64_t &bound) {
+    hipStream_t s = ctx->stream;
+    const int64_t region_len = (int64_t)d.region_end - d.region_beg;
+    bound = (uint64_t)std::min<int64_t>((int64_t)d.n_cpgs, std::max<int64_t>(region_len, 0));
+    if (!ctx->d_state2) MTH_HIP(ctx, hipMalloc((void **)&ctx->d_state2, sizeof(DevState)));
+    MTH_HIP(ctx, hipMemsetAsync(ctx->d_state2, 0, sizeof(DevState), s));
+    MTH_HIP(ctx, ctx->s_pos.reserve((bound + 1) * 4, s));
+    MTH_HIP(ctx, ctx->w_val.reserve((bound + 1) * 4, s));
+    MTH_HIP(ctx, ctx->w_cov.reserve((bound + 1) * 4, s));
+    MTH_HIP(ctx, ctx->w_flags.reserve((bound + 1) * 4, s));
+    if (d.n_reads == 0 || region_len <= 0) return MTH_OK;
+    // Tile width: up to 0.65 x 256 slots' worth of sites per tile at the batch's call density (a denser stretch is redone in halves)
+    // and few enough candidate reads for the 16-bit bins.  A tile is a chain of ~6 dependent round trips and ~10 barriers whatever it
+    // holds, so the widest tile that fits wins: config-3 density 0.319 / 0.220 / 0.144 ms at 4096 / 8192 / 16384 bp, config 2 0.209 /
+    // 0.204 at 4096 / 8192 (16384 overflows the slots there: 1.27 ms)
+    int shift = 12;
+    {
+        const double sites_per_bp = (double)d.n_cpgs / (double)d.n_reads / (double)std::max(d.max_span, 1);
+        const double reads_per_bp = (double)d.n_reads / (double)region_len;
+        while (shift < 14 && sites_per_bp * (double)(2 << shift) <= 0.65 * MT_S &&
+               reads_per_bp * (double)((2 << shift) + d.max_span + 2 * IDX_Q) <= 0.75 * MT_HEAVY)
+            ++shift;
+    }
+    if (const char *e = getenv("MTH_MHL_TILE_SHIFT")) shift = std::min(14, std::max(12, atoi(e)));   // tests / tuning
+    const int W = 1 << shift;
+    int32_t idx_base = 0;
+    uint32_t ntiles = 0;
+    int rc = build_read_index(ctx, d, W, idx_base, ntiles);
+    if (rc) return rc;
+    const uint32_t nbk = (ntiles + (1u << TILE_BUCKET_SHIFT) - 1) >> TILE_BUCKET_SHIFT;
+    MTH_HIP(ctx, ctx->tile_cnt.reserve((size_t)ntiles * 4, s));
+    MTH_HIP(ctx, ctx->tile_bucket.reserve((size_t)nbk * 5 * sizeof(unsigned long long), s));
+    MTH_HIP(ctx, hipMemsetAsync(ctx->tile_bucket.p, 0, (size_t)nbk * sizeof(unsigned long long), s));
+    MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * W * sizeof(MhlRec), s));
+    MhlTileArgs a;
+    a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos; a.idx = ctx->idx.as<uint32_t>();
+    a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
+    a.n_reads = d.n_reads; a.ntiles = ntiles; a.n_cpgs = (uint32_t)d.n_cpgs; a.min_depth = p.min_depth; a.min_cpgs = p.min_cpgs;
+    a.min_qual = p.min_qual;
+    a.force_sub = getenv("MTH_MHL_FORCE_SUB") ? 1 : 0; a.force_hand_on = getenv("MTH_MHL_FORCE_HAND_ON") ? 1 : 0;
+    a.dbg = getenv("MTH_MHL_DBG") ? (uint8_t)atoi(getenv("MTH_MHL_DBG")) : 0;
+    a.scratch = reinterpret_cast<MhlRec *>(ctx->scratch.p); a.tile_cnt = ctx->tile_cnt.as<uint32_t>();
+    a.bucket = ctx->tile_bucket.as<unsigned long long>(); a.st = ctx->d_state;
+    const uint32_t grid = ((ntiles + 7) / 8) * 8;
+    {
+        LaunchTimer lt(ctx, K_MHLTILE);
+        if (shift == 12) hipLaunchKernelGGL((k_mhl_tile<12>), dim3(grid), dim3(MT_B), 0, s, a);
+        else if (shift == 13) hipLaunchKernelGGL((k_mhl_tile<13>), dim3(grid), dim3(MT_B), 0, s, a);
+        else hipLaunchKernelGGL((k_mhl_tile<14>), dim3(grid), dim3(MT_B), 0, s, a);
+    }
+    {
+        LaunchTimer lt(ctx, K_GATHER);
+        hipLaunchKernelGGL(k_mhl_tile_gather, dim3((ntiles + MG_WAVES - 1) / MG_WAVES), dim3(64 * MG_WAVES), 0, s,
+                           reinterpret_cast<const MhlRec *>(ctx->scratch.p), ctx->tile_cnt.as<uint32_t>(),
+                           ctx->tile_bucket.as<unsigned long long>(), ntiles, (uint32_t)W, ctx->d_state2, ctx->s_pos.as<int32_t>(),
+                           ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->w_flags.as<uint32_t>());
+    }
+    MTH_HIP(ctx, hipGetLastError());
+    if (getenv("MTH_MHL_DEBUG")) {       // how many sites the tile pass finished / handed on (tuning aid; synchronises)
+        DevState st;
+        MTH_HIP(ctx, hipStreamSynchronize(s));
+        MTH_HIP(ctx, hipMemcpy(&st, ctx->d_state2, sizeof st, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> f((size_t)st.n_sites);
+        if (!f.empty()) MTH_HIP(ctx, hipMemcpy(f.data(), ctx->w_flags.p, f.size() * 4, hipMemcpyDeviceToHost));
+        size_t n4 = 0;
+        for (uint32_t x : f) n4 += x == 4u;
+        fprintf(stderr, "[mhl tile] W=%d tiles=%u rows=%llu handed_on=%zu\n", W, ntiles, (unsigned long long)st.n_sites, n4);
+    }
+    return MTH_OK;
+}
+
+}  // namespace mth

@@ -703,8 +703,14 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
     if (rc) return rc;
     hipStream_t s = ctx->stream;
     uint64_t bound = 0;
+    // Default: one tile pass computes every site whose covering reads form a single segment and leaves the others to
+    // k_mhl_walk_big (mth_mhl_tile.hip).  MTH_MHL_WALK=1: round 2's form -- PDR-style site discovery, then the per-site walk
+    // out of LDS (k_mhl_walk_lds) -- kept for A/B and as the tests' second implementation.
+    const bool walk_form = getenv("MTH_MHL_WALK") != nullptr;
+    if (walk_form) {
         // (the site list is NOT filtered by min_depth here: the walk skips such sites itself and keeps its staging dense)
-    if ((rc = discover_sites(ctx, d, params->min_cpgs, params->min_qual, bound))) return rc;
+        if ((rc = discover_sites(ctx, d, params->min_cpgs, params->min_qual, bound))) return rc;
+    } else if ((rc = launch_mhl_tile(ctx, d, *params, bound))) return rc;
     if (bound == 0) { ctx->m_batches.push_back(BatchMeta{batch->tid}); bound = 1; }
     else ctx->m_batches.push_back(BatchMeta{batch->tid});
     // per-candidate-site work arrays
@@ -743,7 +749,7 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
     // (d_state2 was cleared as a whole by discover_sites a moment ago and nothing of the tile pipeline writes this word: no
     // second fill kernel for it)
     a.huge_any = &ctx->d_state2->pad_;
-    {
+    if (walk_form) {
         LaunchTimer lt(ctx, K_MHLWALK);
         hipLaunchKernelGGL(k_mhl_walk_lds, dim3(grid), dim3(256), 0, s, a);
     }

@@ -16,6 +16,22 @@ f32 = np.float32
 TOL = 1e-6
 
 
+@pytest.fixture(autouse=True, params=["tile", "walk", "tile-sub", "tile-hand-on"])
+def mhl_form(request, monkeypatch):
+    """every case runs through the one-pass tile form (mth_mhl_tile.hip, the default), through round 2's discovery + per-site walk
+    (MTH_MHL_WALK=1), through the tile form started with 256-position sub-ranges (the path a tile with more sites than slots
+    takes) and through the tile form with every site handed on to the exact walk (the path of sites with several segments)"""
+    for k in ("MTH_MHL_WALK", "MTH_MHL_FORCE_SUB", "MTH_MHL_FORCE_HAND_ON"):
+        monkeypatch.delenv(k, raising=False)
+    if request.param == "walk":
+        monkeypatch.setenv("MTH_MHL_WALK", "1")
+    elif request.param == "tile-sub":
+        monkeypatch.setenv("MTH_MHL_FORCE_SUB", "1")
+    elif request.param == "tile-hand-on":
+        monkeypatch.setenv("MTH_MHL_FORCE_HAND_ON", "1")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def eng():
     import metheor_amd
@@ -193,3 +209,20 @@ def test_long_reads_beyond_512_cpgs(eng):
         d = run_device(eng, [long_c], kw)
         nd, nrows = check(d, reads, kw)
         assert nrows > 1000
+
+
+def test_deep_stretch_queue_overflow_and_heavy(eng):
+    """thousands-fold depth on a few hundred bp (amplicon data): the tile form's contributor queue (1024 reads per stretch)
+    overflows, the stretch is halved down to 256 positions and then only counted and handed on to the exact walk; with more than
+    8191 candidate reads the 16-bit bins are not used at all.  Same rows as the oracle either way."""
+    from metheor_amd import synth
+    rng = np.random.default_rng(47)
+    for n_reads in (3000, 12000):
+        # all the reads start within 300 bp in the middle of the contig
+        st = np.sort(rng.integers(10_000, 10_300, n_reads)).astype(np.int32)
+        deep = synth.make_contig(0, 20_000, n_reads, 0.04, rng, starts=st)
+        reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(deep))
+        kw = dict(min_depth=10, min_cpgs=4, min_qual=10)
+        d = run_device(eng, [deep], kw)
+        ne, n = check(d, reads, kw)
+        assert n > 5
