@@ -410,7 +410,8 @@ __global__ __launch_bounds__(64 * MG_WAVES) void k_mhl_tile_gather(const MhlRec 
                                                                    const unsigned long long *__restrict__ bucket, const uint32_t ntiles,
                                                                    const uint32_t rows_per_tile, DevState *__restrict__ sites_st,
                                                                    int32_t *__restrict__ site_pos, float *__restrict__ val,
-                                                                   uint32_t *__restrict__ cov, uint32_t *__restrict__ flags) {
+                                                                   uint32_t *__restrict__ cov, uint32_t *__restrict__ flags,
+                                                                   uint32_t *__restrict__ hand_list) {
     const int lane = threadIdx.x & 63;
     const uint32_t t = blockIdx.x * MG_WAVES + (threadIdx.x >> 6);
     if (t >= ntiles) return;
@@ -430,8 +431,150 @@ __global__ __launch_bounds__(64 * MG_WAVES) void k_mhl_tile_gather(const MhlRec 
     for (uint32_t i = lane; i < n; i += 64) {
         const MhlRec r = src[i];
         site_pos[base + i] = r.pos; val[base + i] = r.val; cov[base + i] = r.cov; flags[base + i] = r.flags;
+        // the handed-on sites, listed for k_mhl_walk_wave (any order; the count lives in the sink state's first spare counter)
+        if (r.flags == 4u) hand_list[atomicAdd(reinterpret_cast<unsigned long long *>(&sites_st->lpmd[0]), 1ull)] = (uint32_t)(base + i);
     }
     if (t == ntiles - 1 && lane == 0) sites_st->n_sites = base + n;
+}
+
+
+// ---- the handed-on sites: one WAVE per site --------------------------------------------------------------------------------
+// k_mhl_walk_big gives a site to one lane, which walks its ~40 candidate reads through a chain of dependent loads: ~75 us for the
+// longest chain however few sites there are (config 2: 1 750 of 726 028 rows).  Here lane = candidate read: the reads' fields and calls
+// arrive in two round trips for the whole site, every lane decides alone what its read is -- a flusher (>= 1 CpG, the first one
+// beyond c: mhl.rs:162-173), a contributor (mapq, n_cpgs, calls c: mhl.rs:176-192) or neither -- and the reference's sequential loop
+// becomes bit arithmetic on two ballots: the contributors between two flushers are one segment; the LAST segment with >=
+// min_depth reads is the site's row (mhl.rs:163-171, 201-205).  Per-lane byte histograms (CpG count, run lengths) of the open
+// segment are summed over the wave when a segment with enough reads closes.  Sites with more than 512 candidates, or with a
+// covering read of more than 16 CpGs, keep flag 4 and take k_mhl_walk_big as before.
+struct MhlWaveArgs {
+    const uint8_t  *read_mapq;
+    const uint32_t *cpg_off, *cpg_pos, *idx;
+    const DevState *sites_st;
+    const uint32_t *hand_list;
+    const int32_t  *site_pos;
+    float *val; uint32_t *cov, *flags;
+    int32_t idx_base, max_span;
+    uint32_t n_reads, n_cpgs, min_depth, min_cpgs;
+    uint8_t min_qual;
+};
+constexpr uint32_t MWV_MAX_CAND = 512;
+
+__global__ __launch_bounds__(256) void k_mhl_walk_wave(const MhlWaveArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = (blockIdx.x * 256u + threadIdx.x) >> 6, nwv = (gridDim.x * 256u) >> 6;
+    const uint32_t n_hand = (uint32_t)a.sites_st->lpmd[0];
+    for (uint32_t e = wv; e < n_hand; e += nwv) {
+        const uint32_t j = a.hand_list[e];
+        const int32_t c = a.site_pos[j];
+        const uint32_t lo = min(a.idx[(uint32_t)(c - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
+        const uint32_t hi = min(a.idx[((uint32_t)(c + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        if (hi - lo > MWV_MAX_CAND) continue;                                   // wave-uniform: left to k_mhl_walk_big
+        // the open segment: per-lane byte histograms (bins 1..16 of the CpG count / of the run lengths), reads in it
+        unsigned long long hn_lo = 0, hn_hi = 0, hm_lo = 0, hm_hi = 0;
+        uint32_t open_cov = 0;
+        bool have = false, defer = false;
+        float res = 0.0f;
+        uint32_t res_cov = 0;
+        auto close_segment = [&]() {                                            // wave-uniform call; compute_mhl (mhl.rs:43-73)
+            uint32_t hn[8], hm[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const unsigned long long sn = w < 4 ? hn_lo >> (16 * w) : hn_hi >> (16 * (w - 4));
+                const unsigned long long sm = w < 4 ? hm_lo >> (16 * w) : hm_hi >> (16 * (w - 4));
+                hn[w] = wave_sum(((uint32_t)sn & 0xffu) | (((uint32_t)sn & 0xff00u) << 8));
+                hm[w] = wave_sum(((uint32_t)sm & 0xffu) | (((uint32_t)sm & 0xff00u) << 8));
+            }
+            uint32_t S[MT_LCAP], D[MT_LCAP], maxn = 0;
+#pragma unroll
+            for (int l = 0; l < MT_LCAP; ++l) {
+                S[l] = (l & 1) ? hm[l >> 1] >> 16 : hm[l >> 1] & 0xffffu;
+                D[l] = (l & 1) ? hn[l >> 1] >> 16 : hn[l >> 1] & 0xffffu;
+                if (D[l]) maxn = (uint32_t)l + 1u;
+            }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+                for (int l = MT_LCAP - 2; l >= 0; --l) { S[l] += S[l + 1]; D[l] += D[l + 1]; }
+            float l_sum = 0.0f;
+            for (uint32_t l = 1; l < maxn + 1; ++l) l_sum = l_sum + (float)l;
+            float mhl = 0.0f;
+#pragma unroll
+            for (int l = 1; l <= MT_LCAP; ++l)
+                if (S[l - 1] > 0) { const float tq = ((float)l * (float)S[l - 1]) / (float)D[l - 1]; mhl = mhl + tq; }
+            res = mhl / l_sum; res_cov = open_cov; have = true;
+        };
+        for (uint32_t b0 = lo; b0 < hi; b0 += 64) {
+            const uint32_t i = b0 + (uint32_t)lane;
+            const bool in = i < hi;
+            const uint32_t ii = in ? i : hi - 1;
+            const uint32_t o0 = a.cpg_off[ii], o1 = a.cpg_off[ii + 1], mq = a.read_mapq[ii];
+            const uint32_t n = in ? o1 - o0 : 0u, nl = min(n, (uint32_t)MT_NC);
+            uint32_t vv[MT_NC];
+            if (__all(n == 0 || (unsigned long long)o0 + MT_NC <= (unsigned long long)a.n_cpgs)) {
+                if (n) {
+                    const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0), y = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0 + 4);
+                    vv[0] = x.x; vv[1] = x.y; vv[2] = x.z; vv[3] = x.w; vv[4] = y.x; vv[5] = y.y; vv[6] = y.z; vv[7] = y.w;
+                }
+            } else if (n) {
+#pragma unroll
+                for (int k = 0; k < MT_NC; ++k) vv[k] = a.cpg_pos[o0 + min((uint32_t)k, n - 1)];
+            }
+            const bool flusher = n != 0 && c < (int32_t)(vv[0] & 0x7fffffffu);                  // mhl.rs:163 (strict '<', before the filters)
+            bool contrib = false;
+            uint32_t mb = 0;
+            if (n != 0 && !flusher && mq >= a.min_qual && n >= a.min_cpgs) {                    // mhl.rs:176, 181
+#pragma unroll
+                for (int k = 0; k < MT_NC; ++k) {
+                    const bool live = (uint32_t)k < nl;
+                    contrib = contrib || (live && (int32_t)(vv[k] & 0x7fffffffu) == c);
+                    mb |= (live ? vv[k] >> 31 : 0u) << k;
+                }
+                if (n > (uint32_t)MT_NC && n <= (uint32_t)MT_LCAP)
+                    for (uint32_t k = MT_NC; k < n; ++k) {
+                        const uint32_t w = a.cpg_pos[o0 + k];
+                        contrib = contrib || (int32_t)(w & 0x7fffffffu) == c;
+                        mb |= (w >> 31) << k;
+                    }
+                if (n > (uint32_t)MT_LCAP) {                                                    // does it call c at all ?
+                    for (uint32_t k = MT_NC; k < n && !contrib; ++k) contrib = (int32_t)(a.cpg_pos[o0 + k] & 0x7fffffffu) == c;
+                    if (contrib) defer = true;
+                }
+            }
+            if (__any(defer)) { defer = true; break; }
+            // this read's own histogram entries
+            unsigned long long my_n_lo = 0, my_n_hi = 0, my_m_lo = 0, my_m_hi = 0;
+            if (contrib) {
+                if (n <= 8u) my_n_lo = 1ull << (8u * (n - 1u)); else my_n_hi = 1ull << (8u * (n - 9u));
+                uint32_t x = mb;
+                while (x) {                                                                     // readutil.rs:147-164
+                    x >>= __builtin_ctz(x);
+                    const uint32_t m = (uint32_t)__builtin_ctz(~x);
+                    x >>= m;
+                    if (m <= 8u) my_m_lo += 1ull << (8u * (m - 1u)); else my_m_hi += 1ull << (8u * (m - 9u));
+                }
+            }
+            unsigned long long Fm = __ballot(flusher), Cm = __ballot(contrib);
+            // segments of this chunk, in lane order: the contributors below each flusher join the open segment, which then closes
+            unsigned long long done = 0;                                                        // lanes already accounted for
+            while (true) {
+                const unsigned long long upto = Fm ? ((Fm & (~Fm + 1ull)) - 1ull) : ~0ull;      // lanes below the next flusher (all, if none)
+                const unsigned long long grp = Cm & upto & ~done;
+                if ((grp >> lane) & 1ull) { hn_lo += my_n_lo; hn_hi += my_n_hi; hm_lo += my_m_lo; hm_hi += my_m_hi; }
+                open_cov += (uint32_t)__builtin_popcountll(grp);
+                if (!Fm) break;
+                if (open_cov > 0) {                                                             // the flush (mhl.rs:163-171)
+                    if (open_cov >= a.min_depth) close_segment();
+                    hn_lo = hn_hi = hm_lo = hm_hi = 0; open_cov = 0;
+                }
+                done = upto | (Fm & (~Fm + 1ull));
+                Fm &= Fm - 1ull;
+            }
+        }
+        if (defer) continue;                                                                    // a read with > 16 CpGs covers c: k_mhl_walk_big
+        if (open_cov > 0 && open_cov >= a.min_depth) close_segment();                          // mhl.rs:201-205
+        if (lane == 0) { a.val[j] = res; a.cov[j] = res_cov; a.flags[j] = have ? 1u : 0u; }
+    }
 }
 
 // The tile pass of one batch: candidate-site arrays (ctx->s_pos, w_val, w_cov, w_flags; count in d_state2->n_sites) filled with
@@ -446,6 +589,7 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     MTH_HIP(ctx, ctx->w_val.reserve((bound + 1) * 4, s));
     MTH_HIP(ctx, ctx->w_cov.reserve((bound + 1) * 4, s));
     MTH_HIP(ctx, ctx->w_flags.reserve((bound + 1) * 4, s));
+    MTH_HIP(ctx, ctx->w_aux.reserve((bound + 1) * 4, s));
     if (d.n_reads == 0 || region_len <= 0) return MTH_OK;
     // Tile width: up to 0.65 x 256 slots' worth of sites per tile at the batch's call density (a denser stretch is redone in halves)
     // and few enough candidate reads for the 16-bit bins.  A tile is a chain of ~6 dependent round trips and ~10 barriers whatever it
@@ -491,7 +635,17 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
         hipLaunchKernelGGL(k_mhl_tile_gather, dim3((ntiles + MG_WAVES - 1) / MG_WAVES), dim3(64 * MG_WAVES), 0, s,
                            reinterpret_cast<const MhlRec *>(ctx->scratch.p), ctx->tile_cnt.as<uint32_t>(),
                            ctx->tile_bucket.as<unsigned long long>(), ntiles, (uint32_t)W, ctx->d_state2, ctx->s_pos.as<int32_t>(),
-                           ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->w_flags.as<uint32_t>());
+                           ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->w_flags.as<uint32_t>(), ctx->w_aux.as<uint32_t>());
+    }
+    if (!getenv("MTH_MHL_NO_WAVE_WALK")) {
+        LaunchTimer lt(ctx, K_MHLWALK);
+        MhlWaveArgs w;
+        w.read_mapq = d.read_mapq; w.cpg_off = d.cpg_off; w.cpg_pos = d.cpg_pos; w.idx = ctx->idx.as<uint32_t>();
+        w.sites_st = ctx->d_state2; w.hand_list = ctx->w_aux.as<uint32_t>(); w.site_pos = ctx->s_pos.as<int32_t>();
+        w.val = ctx->w_val.as<float>(); w.cov = ctx->w_cov.as<uint32_t>(); w.flags = ctx->w_flags.as<uint32_t>();
+        w.idx_base = idx_base; w.max_span = d.max_span; w.n_reads = d.n_reads; w.n_cpgs = (uint32_t)d.n_cpgs;
+        w.min_depth = p.min_depth; w.min_cpgs = p.min_cpgs; w.min_qual = p.min_qual;
+        hipLaunchKernelGGL(k_mhl_walk_wave, dim3(1024), dim3(256), 0, s, w);
     }
     MTH_HIP(ctx, hipGetLastError());
     if (getenv("MTH_MHL_DEBUG")) {       // how many sites the tile pass finished / handed on (tuning aid; synchronises)

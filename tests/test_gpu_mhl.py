@@ -16,12 +16,13 @@ f32 = np.float32
 TOL = 1e-6
 
 
-@pytest.fixture(autouse=True, params=["tile", "walk", "tile-sub", "tile-hand-on"])
+@pytest.fixture(autouse=True, params=["tile", "walk", "tile-sub", "tile-hand-on", "tile-hand-on-big"])
 def mhl_form(request, monkeypatch):
     """every case runs through the one-pass tile form (mth_mhl_tile.hip, the default), through round 2's discovery + per-site walk
     (MTH_MHL_WALK=1), through the tile form started with 256-position sub-ranges (the path a tile with more sites than slots
-    takes) and through the tile form with every site handed on to the exact walk (the path of sites with several segments)"""
-    for k in ("MTH_MHL_WALK", "MTH_MHL_FORCE_SUB", "MTH_MHL_FORCE_HAND_ON"):
+    takes) and through the tile form with every site handed on to the exact walks (the path of sites with several segments): the
+    wave-per-site walk (k_mhl_walk_wave), or -- "big" -- the lane-per-site walk that takes what the wave walk leaves"""
+    for k in ("MTH_MHL_WALK", "MTH_MHL_FORCE_SUB", "MTH_MHL_FORCE_HAND_ON", "MTH_MHL_NO_WAVE_WALK"):
         monkeypatch.delenv(k, raising=False)
     if request.param == "walk":
         monkeypatch.setenv("MTH_MHL_WALK", "1")
@@ -29,6 +30,9 @@ def mhl_form(request, monkeypatch):
         monkeypatch.setenv("MTH_MHL_FORCE_SUB", "1")
     elif request.param == "tile-hand-on":
         monkeypatch.setenv("MTH_MHL_FORCE_HAND_ON", "1")
+    elif request.param == "tile-hand-on-big":
+        monkeypatch.setenv("MTH_MHL_FORCE_HAND_ON", "1")
+        monkeypatch.setenv("MTH_MHL_NO_WAVE_WALK", "1")
     return request.param
 
 
