@@ -51,6 +51,7 @@ struct MhlTileArgs {
     uint32_t *tile_cnt;           // rows of the tile
     unsigned long long *bucket;   // rows per 256 tiles
     DevState *st;
+    unsigned long long *trace;    // -DMTH_MT_TRACE builds: cycles per phase, summed over the sub-ranges (thread 0 of each workgroup)
 };
 
 constexpr int MT_S = 256, MT_B = 256, MT_U = 2, MT_NC = 8, MT_LCAP = 16;
@@ -110,6 +111,12 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
     MhlRec *__restrict__ out = a.scratch + (size_t)t * W;
     uint32_t rows_out = 0;
     int sub_shift = a.force_sub ? 8 : MT_SHIFT;            // log2 of the sub-range width (block-uniform)
+#ifdef MTH_MT_TRACE
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MT_TK(k) do { tk[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MT_TK(k) do {} while (0)
+#endif
     uint32_t bad = 0;
     bool heavy_redo = false;                               // block-uniform
     for (int64_t P0l = T0; P0l < T1;) {
@@ -122,6 +129,7 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
         // more candidate reads than the 16-bit bins can count: halve the stretch; at 256 positions (thousands-fold depth) the sites
         // are only counted and all handed on (`heavy`); the same when the contributor queue overflows at 256 positions
         if (hi - lo > MT_HEAVY && sub_shift > 8) { --sub_shift; continue; }
+        MT_TK(0);
         const bool heavy = hi - lo > MT_HEAVY || heavy_redo;
         const uint32_t o_lo = lo < hi ? a.cpg_off[lo] : 0u;      // queue entries carry call offsets relative to the sub-range's first
         static_assert(MT_S == MT_B, "one slot per thread");
@@ -131,6 +139,7 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
         bcnt[tid] = 0u;
         if (tid == 0) { s_over = 0u; s_qn = 0u; }
         __syncthreads();
+        MT_TK(1);
         if (lo < hi) {
             // Phase 1, every candidate read (offsets one round ahead, then start, mapq and the FIRST call in one wait): the flusher's
             // mark, and the read's index into the queue if it contributes.  Contributors are a minority (reads with >= min_cpgs CpGs:
@@ -199,7 +208,9 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                 for (int u = 0; u < MT_U; ++u) { o0s[u] = o0n[u]; o1s[u] = o1n[u]; }
             }
         }
+        MT_TK(2);
         __syncthreads();
+        MT_TK(3);
         // Phase 2, the queued contributors with every lane live: the read's calls (two 16-byte loads; its first MT_NC), its runs,
         // then per call the slot (found or made) and the histogram increments.
         const uint32_t qn = heavy ? 0u : min(s_qn, (uint32_t)MT_Q);
@@ -228,6 +239,10 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                     if (r < n_runs) atomicAdd(&hist[8u + (m1 >> 1)], (m1 & 1u) ? 0x10000u : 1u);
                 }
             };
+            // (NEGATIVE, twice: giving the lanes of an instruction entries a hundred bp or more apart -- 64 stretches of the queue, one per
+            // lane -- so that their LDS atomics do not meet on one address changed nothing, here (0.211 against 0.212 ms) or in the
+            // one-phase form.  The cycle trace (-DMTH_MT_TRACE) puts a config-2 tile at 37 % phase 1, 32 % phase 2, 19 % rows, the rest
+            // barriers: every phase is a couple of dependent round trips with four waves to hide them.)
             for (uint32_t j0 = 0; j0 < qn; j0 += MT_B) {
                 const uint32_t j = j0 + tid;
                 const bool act = j < qn;
@@ -287,7 +302,9 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                     }
             }
         }
+        MT_TK(4);
         __syncthreads();
+        MT_TK(5);
         const uint32_t over = s_over;
         __syncthreads();                                    // (s_over is cleared at the top of the next trip; the queue is done with)
         if (over && sub_shift > 8) { --sub_shift; continue; }      // too many distinct sites or contributors: the same stretch again in halves
@@ -393,7 +410,12 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
         }
         rows_out += n_rows;
         P0l = P1;
+        MT_TK(6);
         __syncthreads();                                    // the table is cleared by the next trip
+        MT_TK(7);
+#ifdef MTH_MT_TRACE
+        if (tid == 0 && a.trace) { for (int k = 1; k < 8; ++k) atomicAdd(a.trace + k, tk[k] - tk[k - 1]); atomicAdd(a.trace, 1ull); }
+#endif
     }
     if (bad & 1u) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
     if (bad & 2u) atomicOr(&a.st->err, (uint32_t)ERRB_CAPACITY);
@@ -623,6 +645,13 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     a.dbg = getenv("MTH_MHL_DBG") ? (uint8_t)atoi(getenv("MTH_MHL_DBG")) : 0;
     a.scratch = reinterpret_cast<MhlRec *>(ctx->scratch.p); a.tile_cnt = ctx->tile_cnt.as<uint32_t>();
     a.bucket = ctx->tile_bucket.as<unsigned long long>(); a.st = ctx->d_state;
+    a.trace = nullptr;
+#ifdef MTH_MT_TRACE
+    static unsigned long long *d_trace = nullptr;
+    if (!d_trace) MTH_HIP(ctx, hipMalloc((void **)&d_trace, 64));
+    MTH_HIP(ctx, hipMemsetAsync(d_trace, 0, 64, s));
+    a.trace = d_trace;
+#endif
     const uint32_t grid = ((ntiles + 7) / 8) * 8;
     {
         LaunchTimer lt(ctx, K_MHLTILE);
@@ -647,6 +676,15 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
         w.min_depth = p.min_depth; w.min_cpgs = p.min_cpgs; w.min_qual = p.min_qual;
         hipLaunchKernelGGL(k_mhl_walk_wave, dim3(1024), dim3(256), 0, s, w);
     }
+#ifdef MTH_MT_TRACE
+    {
+        unsigned long long h[8];
+        MTH_HIP(ctx, hipStreamSynchronize(s));
+        MTH_HIP(ctx, hipMemcpy(h, a.trace, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[mhl tile trace] sub-ranges %llu; cycles per sub-range: clear %.0f  phase1 %.0f  barrier %.0f  phase2 %.0f  barrier %.0f  rows %.0f  barrier %.0f\n", h[0],
+                (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[7] / h[0]);
+    }
+#endif
     MTH_HIP(ctx, hipGetLastError());
     if (getenv("MTH_MHL_DEBUG")) {       // how many sites the tile pass finished / handed on (tuning aid; synchronises)
         DevState st;
