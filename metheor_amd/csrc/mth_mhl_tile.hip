@@ -46,7 +46,7 @@ struct MhlTileArgs {
     uint8_t min_qual;
     uint8_t force_sub;            // tests: start every tile with 256-position sub-ranges
     uint8_t force_hand_on;        // tests: every site goes to the exact walk
-    uint8_t dbg;                  // timing experiments (MTH_MHL_DBG): 1 = no flusher marks, 2 = no contributions, 4 = no row values
+    uint8_t dbg;                  // timing experiments (MTH_MHL_DBG): 1 = no flusher marks, 2 = no contributions, 4 = no row values, 8 = no same-start check
     MhlRec *scratch;              // W rows per tile (the PDR pipeline's 16 bytes per position)
     uint32_t *tile_cnt;           // rows of the tile
     unsigned long long *bucket;   // rows per 256 tiles
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
             // first CpG lies beyond c
             if (!hand_on) hand_on = (F[(key - (uint32_t)P0) >> 5] >> ((key - (uint32_t)P0) & 31u)) & 1u;
             const uint32_t self = aux & 0x7fffffffu;
-            if (!hand_on && self) {
+            if (!hand_on && self && !(a.dbg & 8)) {
                 const uint32_t K = lo + self - 1u;          // the last contributor that calls its own start - 1 here
                 uint32_t r2 = min(a.idx[((uint32_t)c + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
                 for (; r2 < K; ++r2) {
