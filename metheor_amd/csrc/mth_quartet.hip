@@ -31,6 +31,7 @@ constexpr unsigned long long QKEY_EMPTY = ~0ull;
 // tile kernel: reference positions per tile, LDS table slots, threads.  Measured on S-chr19-10M (profiles/r01_quartet_tile.md):
 // wider tiles re-read fewer halo reads and clear LDS less often, a smaller table lets more tiles share a CU (25 KB each).
 constexpr int QT_NC = 8;   // calls of a read held in registers
+constexpr int QT_QCAP = 2048;   // candidate reads per fill of the contributor queue
 constexpr int QT_OCC = 6;  // waves per SIMD (LDS: 23 KiB per workgroup = 6 per CU)
 constexpr int QT_S = 512, QT_B = 256, QT_U = 2, QT_CHUNK = 512, QT_GRID = 8192;   // (the tile width is a template parameter: 8192 / 16384 / 32768, chosen per batch)
 constexpr int Q_STATE_WORDS = 8;
@@ -266,8 +267,15 @@ struct QTileArgs {
 template <int QT_W>
 __global__ __launch_bounds__(QT_B, QT_OCC) void k_quartet_tile(const QTileArgs a) {
     __shared__ unsigned long long keys[QT_S];  // the hash table; later its keys in bucket order
-    __shared__ uint16_t sslot[QT_S];           // ... and the slot each of them came from
-    __shared__ uint32_t bcnt[QT_B], bbase[QT_B];   // bucket sort on p1: keys per bucket, first rank of the bucket
+    __shared__ uint32_t bcnt[QT_B];            // bucket sort on p1: keys per bucket
+    // the contributor queue of the read phases (16-bit read numbers) shares its LDS with two arrays of the row phase: the first
+    // rank of each bucket, and the slot each sorted key came from
+    __shared__ uint32_t q_or_sort[QT_QCAP / 2];
+    static_assert(QT_QCAP / 2 >= QT_B + QT_S / 2, "bbase and sslot fit under the queue");
+    uint16_t *const rq = reinterpret_cast<uint16_t *>(q_or_sort);
+    uint32_t *const bbase = q_or_sort;
+    uint16_t *const sslot = reinterpret_cast<uint16_t *>(q_or_sort + QT_B);
+    __shared__ uint32_t s_qn;
     __shared__ uint32_t bins[QT_S * 8];        // bin 2w in the low half of word w, bin 2w+1 in the high half
     __shared__ uint32_t s_heavy, ws[QT_B / 64 + 1];
     __shared__ unsigned long long s_row0;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(QT_B, QT_OCC) void k_quartet_tile(const QTileArgs a
     for (int i = tid; i < QT_S; i += QT_B) keys[i] = QKEY_EMPTY;
     bcnt[tid] = 0;
     for (int i = tid; i < QT_S * 8; i += QT_B) bins[i] = 0;
-    if (tid == 0) s_heavy = (hi - lo > 65535u || a.force_heavy) ? 1u : 0u;      // a bin counts at most one update per candidate read
+    if (tid == 0) { s_heavy = (hi - lo > 65535u || a.force_heavy) ? 1u : 0u; s_qn = 0u; }      // a bin counts at most one update per candidate read
     __syncthreads();
     if (!s_heavy) {
         uint32_t bad = 0;
@@ -318,74 +326,84 @@ __global__ __launch_bounds__(QT_B, QT_OCC) void k_quartet_tile(const QTileArgs a
             if (placed) atomicAdd(&bins[h * 8 + (pat >> 1)], (pat & 1u) ? 0x10000u : 1u);      // me.rs:121-125
             else s_heavy = 1u;                                   // more distinct quartets than slots
         };
-        // QT_U reads per thread and round.  A read's first QT_NC calls arrive as two 16-byte loads from a per-read base (the PDR
-        // tile kernel's form; a wave that holds one of the batch's last reads takes clamped single loads instead), together with
-        // its start and mapq and the NEXT round's offsets: one wait per round.  The windows of those calls run from registers;
-        // only a read with more than QT_NC calls goes back to memory, one dependent load per further window (round 2's form paid
-        // that for every window after the first: the chain idx -> offsets -> calls -> next call -> ...).
-        uint32_t o0s[QT_U], o1s[QT_U];
-#pragma unroll
-        for (int u = 0; u < QT_U; ++u) {
-            const uint32_t ii = min(lo + (uint32_t)u * QT_B + tid, hi - 1);
-            o0s[u] = a.cpg_off[ii]; o1s[u] = a.cpg_off[ii + 1];
-        }
-        for (uint32_t b0 = lo; b0 < hi; b0 += QT_B * QT_U) {
-            int32_t st[QT_U];
-            uint32_t mq[QT_U], o0n[QT_U], o1n[QT_U], vv[QT_U][QT_NC];
-            bool ok[QT_U];
-            bool inside = true;
+        // Two phases per stretch of QT_QCAP candidate reads.  Phase 1, every candidate (offsets one round ahead, mapq): the reads with
+        // >= 4 CpGs that pass mapq (readutil.rs:101, me.rs:115) -- a third of config 2's reads, a twentieth at WGBS density -- are
+        // queued.  Phase 2, the queue with every lane live: the read's first QT_NC calls as two 16-byte loads from a per-read base
+        // (the PDR tile kernel's form; a wave that holds one of the batch's last reads takes clamped single loads instead), its
+        // windows from registers; only a read with more than QT_NC calls goes back to memory, one dependent load per further window.
+        // (One phase over all candidates ran the window code with 5-30 % of the lanes live; measured gain of the split: config 2
+        // 0.124 -> 0.121 ms, config-3 density 0.160 -> 0.158 -- the tile's fixed chain, not the windows, is what this kernel waits for.)
+        for (uint32_t c0 = lo; c0 < hi; c0 += QT_QCAP) {
+            const uint32_t c1 = min(c0 + (uint32_t)QT_QCAP, hi);
+            if (c0 != lo) {
+                __syncthreads();                            // the previous stretch's queue is done with
+                if (tid == 0) s_qn = 0u;
+                __syncthreads();
+            }
+            uint32_t o0s[QT_U], o1s[QT_U];
 #pragma unroll
             for (int u = 0; u < QT_U; ++u) {
-                const uint32_t i = b0 + (uint32_t)u * QT_B + tid;
-                ok[u] = i < hi && o1s[u] - o0s[u] >= 4;                     // readutil.rs:101, me.rs:115
-                inside = inside && (!ok[u] || (unsigned long long)o0s[u] + QT_NC <= (unsigned long long)a.n_cpgs);
+                const uint32_t ii = min(c0 + (uint32_t)u * QT_B + tid, c1 - 1);
+                o0s[u] = a.cpg_off[ii]; o1s[u] = a.cpg_off[ii + 1];
             }
-            static_assert(QT_NC == 8, "two 16-byte loads per read");
-            if (__all(inside)) {
+            for (uint32_t b0 = c0; b0 < c1; b0 += QT_B * QT_U) {
+                uint32_t mq[QT_U], o0n[QT_U], o1n[QT_U];
 #pragma unroll
                 for (int u = 0; u < QT_U; ++u) {
-                    if (!ok[u]) continue;
-                    const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0s[u]), y = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0s[u] + 4);
-                    vv[u][0] = x.x; vv[u][1] = x.y; vv[u][2] = x.z; vv[u][3] = x.w; vv[u][4] = y.x; vv[u][5] = y.y; vv[u][6] = y.z; vv[u][7] = y.w;
+                    const uint32_t i = b0 + (uint32_t)u * QT_B + tid;
+                    mq[u] = a.read_mapq[min(i, c1 - 1)];
+                    const uint32_t in = min(i + (uint32_t)QT_U * QT_B, c1 - 1);
+                    o0n[u] = a.cpg_off[in]; o1n[u] = a.cpg_off[in + 1];
                 }
-            } else {
 #pragma unroll
                 for (int u = 0; u < QT_U; ++u) {
-                    if (!ok[u]) continue;
-                    const uint32_t nc = o1s[u] - o0s[u];
-#pragma unroll
-                    for (int k = 0; k < QT_NC; ++k) vv[u][k] = a.cpg_pos[o0s[u] + min((uint32_t)k, nc - 1)];
+                    const uint32_t i = b0 + (uint32_t)u * QT_B + tid;
+                    const bool contrib = i < c1 && o1s[u] - o0s[u] >= 4 && mq[u] >= a.min_qual;
+                    const unsigned long long bal = __ballot(contrib);
+                    if (bal) {
+                        uint32_t base = 0;
+                        if ((tid & 63) == 0) base = atomicAdd(&s_qn, (uint32_t)__builtin_popcountll(bal));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (contrib) rq[base + (uint32_t)__builtin_popcountll(bal & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)(i - c0);
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < QT_U; ++u) { o0s[u] = o0n[u]; o1s[u] = o1n[u]; }
             }
+            __syncthreads();
+            const uint32_t qn = s_qn;
+            for (uint32_t j0 = 0; j0 < qn; j0 += QT_B) {
+                const uint32_t j = j0 + tid;
+                const bool act = j < qn;
+                const uint32_t i = c0 + (act ? (uint32_t)rq[j] : 0u);
+                const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+                const uint32_t n_calls = act ? o1 - o0 : 0u;
+                uint32_t vv[QT_NC];
+                static_assert(QT_NC == 8, "two 16-byte loads per read");
+                if (__all(!act || (unsigned long long)o0 + QT_NC <= (unsigned long long)a.n_cpgs)) {
+                    if (act) {
+                        const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0), y = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0 + 4);
+                        vv[0] = x.x; vv[1] = x.y; vv[2] = x.z; vv[3] = x.w; vv[4] = y.x; vv[5] = y.y; vv[6] = y.z; vv[7] = y.w;
+                    }
+                } else if (act) {
 #pragma unroll
-            for (int u = 0; u < QT_U; ++u) {
-                const uint32_t ii = min(b0 + (uint32_t)u * QT_B + tid, hi - 1);
-                st[u] = a.read_start[ii]; mq[u] = a.read_mapq[ii];
-                const uint32_t in = min(b0 + (uint32_t)(QT_U + u) * QT_B + tid, hi - 1);
-                o0n[u] = a.cpg_off[in]; o1n[u] = a.cpg_off[in + 1];
-            }
-#pragma unroll
-            for (int u = 0; u < QT_U; ++u) ok[u] = ok[u] && mq[u] >= a.min_qual;
-#pragma unroll
-            for (int u = 0; u < QT_U; ++u) {
-                if (!__any(ok[u])) continue;
-                const uint32_t o0 = o0s[u], o1 = o1s[u];
-                const uint32_t n_calls = ok[u] ? o1 - o0 : 0u;
+                    for (int k = 0; k < QT_NC; ++k) vv[k] = a.cpg_pos[o0 + min((uint32_t)k, n_calls - 1)];
+                }
                 // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (a reverse read's first call
                 // may sit one base before its start, readutil.rs:338; rule of the PDR tile kernel).  Unsigned: a call further
                 // left is caught too; the windows' deltas are checked to be 1..2047 below, so the calls in between are ordered.
-                const uint32_t sm1 = (uint32_t)st[u] - 1u;
+                const uint32_t sm1 = (uint32_t)a.read_start[i] - 1u;
                 uint32_t xmax = 0;
 #pragma unroll
-                for (int k = 0; k < QT_NC; ++k) xmax = max(xmax, (uint32_t)k < n_calls ? (vv[u][k] & 0x7fffffffu) - sm1 : 0u);
+                for (int k = 0; k < QT_NC; ++k) xmax = max(xmax, (uint32_t)k < n_calls ? (vv[k] & 0x7fffffffu) - sm1 : 0u);
                 bad |= (xmax > (uint32_t)a.max_span) ? 1u : 0u;
 #pragma unroll
                 for (int k = 3; k < QT_NC; ++k) {
                     if (!__any((uint32_t)k < n_calls)) break;               // wave-uniform
-                    if ((uint32_t)k < n_calls) window(vv[u][k - 3], vv[u][k - 2], vv[u][k - 1], vv[u][k]);
+                    if ((uint32_t)k < n_calls) window(vv[k - 3], vv[k - 2], vv[k - 1], vv[k]);
                 }
                 if (__any(n_calls > (uint32_t)QT_NC) && n_calls > (uint32_t)QT_NC) {
-                    uint32_t x = vv[u][QT_NC - 3], y = vv[u][QT_NC - 2], z = vv[u][QT_NC - 1];
+                    uint32_t x = vv[QT_NC - 3], y = vv[QT_NC - 2], z = vv[QT_NC - 1];
                     for (uint32_t k = o0 + QT_NC; k < o1; ++k) {
                         const uint32_t w = a.cpg_pos[k];
                         bad |= ((w & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
@@ -394,8 +412,6 @@ __global__ __launch_bounds__(QT_B, QT_OCC) void k_quartet_tile(const QTileArgs a
                     }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < QT_U; ++u) { o0s[u] = o0n[u]; o1s[u] = o1n[u]; }
         }
         if (bad) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
     }
