@@ -32,28 +32,6 @@
 
 namespace mth {
 
-struct TileArgs {
-    const int32_t  *read_start;
-    const uint8_t  *read_mapq;
-    const uint32_t *cpg_off;
-    const uint32_t *cpg_pos;
-    const void     *cpg_rel;
-    const uint32_t *idx;
-    const DevState *st;
-    uint32_t *tile_cnt;
-    unsigned long long *bucket;   // per 256-tile bucket: [nbk] rows, then [nbk][4] LPMD partial sums
-    uint32_t nbk;
-    SiteRec  *scratch;     // TILE_W rows per tile
-    int32_t region_beg, region_end, idx_base, max_span;
-    uint32_t n_reads, n_cpgs;
-    uint32_t min_cov;      // max(pdr_min_depth, 1)
-    uint32_t min_cpgs;
-    int32_t  min_dist, max_dist;
-    uint8_t  pdr_min_qual, lpmd_min_qual, want_pdr, want_lpmd;
-#ifdef MTH_TILE_TRACE
-    unsigned long long *trace;     // experiment build: 8 ticks per tile (tools/tile_trace.py)
-#endif
-};
 
 // ---------------------------------------------------------------------------------------------
 // idx[q] = first read i with read_start[i] >= idx_base + q*IDX_Q   (q = 0..nq)
@@ -793,8 +771,33 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     float *o_pdr = sink ? sink->pdr : ctx->out_pdr.as<float>();
     uint32_t *o_nc = sink ? sink->nc : ctx->out_nc.as<uint32_t>();
     uint32_t *o_nd = sink ? sink->nd : ctx->out_nd.as<uint32_t>();
-    constexpr int tile_w = 4096;   // (8192-bp tiles, 4 workgroups per CU: config 3 0.1655 -> 0.1956 ms, config 2 0.0858 -> 0.1069; profiles/r03_stream_kernel.md)
     const int64_t region_len = (int64_t)b.region_end - b.region_beg;
+    // Two forms of the tile kernel.  Dense batches: one LDS counter per position, 4096-bp tiles (8192-bp tiles, 4 workgroups per CU:
+    // config 3 0.1655 -> 0.1956 ms, config 2 0.0858 -> 0.1069; profiles/r03_stream_kernel.md).  Sparse batches (WGBS depth: few calls
+    // per read and few reads per 4096 bp, so that a tile's fixed chain of round trips is what the kernel waits for): hashed sites,
+    // 16384- to 65536-bp tiles (mth_pdr_wide.hip).  MTH_PDR_WIDE=0 / 14 / 15 / 16 overrides the choice (tests, A/B).
+    int wide_shift = 0;
+    if (b.n_reads && region_len > 0) {
+        const double sites_per_bp = (double)b.n_cpgs / (double)b.n_reads / (double)std::max(b.max_span, 1);
+        const double reads_per_bp = (double)b.n_reads / (double)region_len;
+        // (1024 slots: up to ~0.6 of them for the sites a tile can expect; a denser stretch is redone in halves)
+        // A hashed insert (compare-and-swap + adds) costs more than the dense form's one LDS add: the wide form only pays while few
+        // calls are inserted.  Expected insertions per read = E[n; n >= min_cpgs] = lambda P(N >= min_cpgs - 1) for Poisson calls per
+        // read: 0.22 under the CLI defaults at config-3 density (0.117 against 0.170 ms), 1.37 for FDRP's site discovery (min_cpgs 1:
+        // 0.202 against 0.153 ms -- that pass keeps the dense form).
+        double ins_per_read = 0.0;
+        if (p.want_pdr) {
+            const double lam = (double)b.n_cpgs / (double)b.n_reads;
+            const int kmin = (int)std::min<uint32_t>(std::max<uint32_t>(p.pdr_min_cpgs, 1u), 64u) - 1;     // P(N >= kmin)
+            double term = std::exp(-lam), cdf = 0.0;
+            for (int k = 0; k < kmin; ++k) { cdf += term; term *= lam / (double)(k + 1); }
+            ins_per_read = lam * std::max(0.0, 1.0 - cdf);
+        }
+        if (sites_per_bp <= 0.012 && reads_per_bp * 4096.0 <= 400.0 && ins_per_read <= 0.6)
+            wide_shift = sites_per_bp * 65536.0 <= 0.6 * 1024 ? 16 : sites_per_bp * 32768.0 <= 0.6 * 1024 ? 15 : 14;
+    }
+    if (const char *e = getenv("MTH_PDR_WIDE")) { const int k = atoi(e); wide_shift = k >= 14 && k <= 16 ? k : 0; }
+    const int tile_w = wide_shift ? 1 << wide_shift : 4096;
     const uint32_t ntiles = (uint32_t)((region_len + tile_w - 1) / tile_w);
     if (ntiles == 0) return MTH_OK;
     // index origin: a whole number of quanta below the region so that halo reads are indexed
@@ -806,7 +809,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     MTH_HIP(ctx, ctx->tile_cnt.reserve((size_t)ntiles * 4, s));
     const uint32_t nbk = (ntiles + (1u << TILE_BUCKET_SHIFT) - 1) >> TILE_BUCKET_SHIFT;
     MTH_HIP(ctx, ctx->tile_bucket.reserve((size_t)nbk * 5 * sizeof(unsigned long long), s));
-    if (p.want_pdr) MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * tile_w * sizeof(SiteRec), s));
+    if (p.want_pdr) MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * (size_t)tile_w * sizeof(SiteRec), s));
 
     {
         LaunchTimer lt(ctx, K_INDEX);
@@ -837,7 +840,8 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     {
         LaunchTimer lt(ctx, K_TILE);
         const bool r8 = b.cpg_rel != nullptr;
-        if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
+        if (wide_shift) launch_tile_wide(a, ntiles, wide_shift, r8, s);
+        else if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
     }
     {
         LaunchTimer lt(ctx, K_GATHER);

@@ -27,6 +27,30 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 
 constexpr int TILE_BUCKET_SHIFT = 8;   // 256 tiles per bucket
 
+// arguments of the PDR + LPMD tile kernels (mth_pdr_lpmd.hip: dense counters, 4096-bp tiles; mth_pdr_wide.hip: hashed sites, wide tiles)
+struct TileArgs {
+    const int32_t  *read_start;
+    const uint8_t  *read_mapq;
+    const uint32_t *cpg_off;
+    const uint32_t *cpg_pos;
+    const void     *cpg_rel;
+    const uint32_t *idx;
+    const DevState *st;
+    uint32_t *tile_cnt;
+    unsigned long long *bucket;   // per 256-tile bucket: [nbk] rows, then [nbk][4] LPMD partial sums
+    uint32_t nbk;
+    SiteRec  *scratch;     // TILE_W rows per tile
+    int32_t region_beg, region_end, idx_base, max_span;
+    uint32_t n_reads, n_cpgs;
+    uint32_t min_cov;      // max(pdr_min_depth, 1)
+    uint32_t min_cpgs;
+    int32_t  min_dist, max_dist;
+    uint8_t  pdr_min_qual, lpmd_min_qual, want_pdr, want_lpmd;
+#ifdef MTH_TILE_TRACE
+    unsigned long long *trace;     // experiment build: 8 ticks per tile (tools/tile_trace.py)
+#endif
+};
+
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
 typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
@@ -44,6 +68,9 @@ typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
 // ascends with the slot, dead offsets ascend faster).  With A = D + (0x8000 - min) and B = (0x8000 + max) - D per
 // field, bit 15 of A & B says "min <= distance <= max"; the call states sit in bit 15 of a second set of packed words,
 // so one xor + and gives "in the window and discordant".  Only full-rate VALU ops (add / sub / and / xor / or / shift).
+// hashed-site form for sparse batches (mth_pdr_wide.hip): shift = log2 of the tile width (14 or 15)
+void launch_tile_wide(const TileArgs &a, uint32_t ntiles, int shift, bool rel8, hipStream_t s);
+
 struct SlotTabs {
     uint32_t mtab[9][8];
     uint32_t dtab[9][8];

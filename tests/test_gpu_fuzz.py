@@ -107,13 +107,15 @@ def test_random_scenario_all_measures(eng, seed):
     d, l = T_pdr.run_device(eng, cs, p, regions=regions, rel16=rel16)
     T_pdr.check_against_oracle(d, l, reads, pk, lk)
     # the same through the streaming form of the pass (mth_stream.hip; opt-in): identical rows and counters
+    # ... and through the hashed-site form for sparse batches (mth_pdr_wide.hip) whatever the batch's density
     import os
-    os.environ["MTH_STREAM"] = "1"
-    try:
-        d2, l2 = T_pdr.run_device(eng, cs, p, regions=regions, rel16=rel16)
-    finally:
-        del os.environ["MTH_STREAM"]
-    assert all((d[k].view(np.uint32) == d2[k].view(np.uint32)).all() for k in d) and all(l[k] == l2[k] for k in l if k != "lpmd")
+    for env, val in (("MTH_STREAM", "1"), ("MTH_PDR_WIDE", str(14 + seed % 3)), ("MTH_PDR_WIDE", "0")):
+        os.environ[env] = val
+        try:
+            d2, l2 = T_pdr.run_device(eng, cs, p, regions=regions, rel16=rel16)
+        finally:
+            del os.environ[env]
+        assert all((d[k].view(np.uint32) == d2[k].view(np.uint32)).all() for k in d) and all(l[k] == l2[k] for k in l if k != "lpmd"), (env, val)
 
     # LPMD per-pair table
     T_pairs.check(T_pairs.run_device(eng, cs, lk, regions=regions), reads, lk)
