@@ -12,7 +12,7 @@ namespace mth {
 static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_gather",
                                           "k_quartet_bound", "k_quartet_tile", "k_quartet_insert", "k_quartet_emit",
                                           "k_mhl_walk", "k_mhl_walk_big", "k_mhl_emit", "k_pdr_walk",
-                                          "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_pairs_tile", "k_decode", "k_inflate", "k_crc32", "k_pdr_lpmd_stream", "k_mhl_tile"};
+                                          "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_pairs_tile", "k_decode", "k_inflate", "k_crc32", "k_pdr_lpmd_stream", "k_mhl_tile", "k_pdr_lpmd_wide"};
 
 int fail(mth_ctx *ctx, int status, const char *what, hipError_t e) {
     if (ctx) {

@@ -838,7 +838,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     a.trace = ntiles <= 262144 ? d_ttrace : nullptr;
 #endif
     {
-        LaunchTimer lt(ctx, K_TILE);
+        LaunchTimer lt(ctx, wide_shift ? K_WIDE : K_TILE);
         const bool r8 = b.cpg_rel != nullptr;
         if (wide_shift) launch_tile_wide(a, ntiles, wide_shift, r8, s);
         else if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
