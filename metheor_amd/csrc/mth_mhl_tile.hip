@@ -625,7 +625,7 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
                reads_per_bp * (double)((2 << shift) + d.max_span + 2 * IDX_Q) <= 0.75 * MT_HEAVY)
             ++shift;
     }
-    if (const char *e = getenv("MTH_MHL_TILE_SHIFT")) shift = std::min(14, std::max(12, atoi(e)));   // tests / tuning
+    if (const char *e = getenv("MTH_MHL_TILE_SHIFT")) shift = std::min(16, std::max(12, atoi(e)));   // tests / tuning
     const int W = 1 << shift;
     int32_t idx_base = 0;
     uint32_t ntiles = 0;
@@ -657,7 +657,9 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
         LaunchTimer lt(ctx, K_MHLTILE);
         if (shift == 12) hipLaunchKernelGGL((k_mhl_tile<12>), dim3(grid), dim3(MT_B), 0, s, a);
         else if (shift == 13) hipLaunchKernelGGL((k_mhl_tile<13>), dim3(grid), dim3(MT_B), 0, s, a);
-        else hipLaunchKernelGGL((k_mhl_tile<14>), dim3(grid), dim3(MT_B), 0, s, a);
+        else if (shift == 14) hipLaunchKernelGGL((k_mhl_tile<14>), dim3(grid), dim3(MT_B), 0, s, a);
+        else if (shift == 15) hipLaunchKernelGGL((k_mhl_tile<15>), dim3(grid), dim3(MT_B), 0, s, a);
+        else hipLaunchKernelGGL((k_mhl_tile<16>), dim3(grid), dim3(MT_B), 0, s, a);
     }
     {
         LaunchTimer lt(ctx, K_GATHER);
