@@ -794,7 +794,13 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
             ins_per_read = lam * std::max(0.0, 1.0 - cdf);
         }
         if (sites_per_bp <= 0.012 && reads_per_bp * 4096.0 <= 400.0 && ins_per_read <= 0.6)
+        {
             wide_shift = sites_per_bp * 65536.0 <= 0.6 * 1024 ? 16 : sites_per_bp * 32768.0 <= 0.6 * 1024 ? 15 : 14;
+            // ... and enough tiles to fill the chip twice over (7 workgroups on each of 256 CUs): a short contig takes narrower tiles
+            // (config 3's 24 contigs: 2.33 -> 2.20 ms; the same rule made the quartet / pairs kernels slower -- 2.36 -> 2.62, 2.72 -> 2.95 ms --
+            // whose persistent workgroups gain more from the wider tile than they lose to a half-filled last round)
+            while (wide_shift > 14 && (region_len >> wide_shift) < 2 * 7 * 256) --wide_shift;
+        }
     }
     if (const char *e = getenv("MTH_PDR_WIDE")) { const int k = atoi(e); wide_shift = k >= 14 && k <= 16 ? k : 0; }
     const int tile_w = wide_shift ? 1 << wide_shift : 4096;
