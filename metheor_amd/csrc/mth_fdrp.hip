@@ -920,7 +920,7 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         hipLaunchKernelGGL(k_flags_blockcount, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
                            (const unsigned long long *)&ctx->d_state2->n_sites, ctx->w_blk.as<uint32_t>());
         hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk, fs, fs + 1,
-                           ctx->f_batch_rows.as<uint32_t>(), (uint32_t)nb);
+                           ctx->f_batch_rows.as<uint32_t>(), (uint32_t)nb, (const unsigned long long *)&ctx->d_state2->n_sites);
         hipLaunchKernelGGL(k_fdrp_emit, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
                            ctx->w_val.as<float>(), reinterpret_cast<const float *>(ctx->w_aux.p), ctx->w_cov.as<uint32_t>(),
                            ctx->d_state2, ctx->w_blk.as<uint32_t>(), fs + 1, ctx->f_pos.as<int32_t>(), ctx->f_val.as<float>(),

@@ -23,7 +23,11 @@ __global__ __launch_bounds__(256) void k_flags_blockcount(const uint32_t *__rest
 __global__ __launch_bounds__(1024) void k_block_scan(uint32_t *__restrict__ blk, uint32_t nblk,
                                                        unsigned long long *__restrict__ total,
                                                        unsigned long long *__restrict__ base,
-                                                       uint32_t *__restrict__ batch_rows, uint32_t batch_idx) {
+                                                       uint32_t *__restrict__ batch_rows, uint32_t batch_idx,
+                                                       const unsigned long long *__restrict__ n_ptr) {
+    // n_ptr: the number of flagged entries the counts were taken over (device side); blocks beyond it counted nothing, and the
+    // host's nblk comes from an upper bound that can be hundreds of times larger (every call of a contig against its rows)
+    if (n_ptr) nblk = (uint32_t)min((unsigned long long)nblk, (*n_ptr + 256ull * SCAN_PER - 1ull) / (256ull * SCAN_PER));
     __shared__ uint32_t wsum[17];
     __shared__ uint32_t running;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -679,7 +679,7 @@ int launch_pdr_exact(mth_ctx *ctx, const mth_batch_t &d, const mth_pdr_lpmd_para
         // totals live in the main DevState: n_sites is the running total, cur_base the batch's base
         hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk,
                            (unsigned long long *)&ctx->d_state->n_sites, (unsigned long long *)&ctx->d_state->cur_base,
-                           ctx->batch_cnt.as<uint32_t>(), (uint32_t)ctx->batches.size());
+                           ctx->batch_cnt.as<uint32_t>(), (uint32_t)ctx->batches.size(), (const unsigned long long *)&ctx->d_state2->n_sites);
         hipLaunchKernelGGL(k_pdr_walk_emit, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
                            ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->w_aux.as<uint32_t>(), ctx->d_state2,
                            ctx->w_blk.as<uint32_t>(), ctx->d_state, ctx->out_pos.as<int32_t>(), ctx->out_pdr.as<float>(),
@@ -769,7 +769,7 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
         hipLaunchKernelGGL(k_flags_blockcount, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
                            (const unsigned long long *)&ctx->d_state2->n_sites, ctx->w_blk.as<uint32_t>());
         hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk, ms, ms + 1,
-                           ctx->m_batch_rows.as<uint32_t>(), (uint32_t)nb);
+                           ctx->m_batch_rows.as<uint32_t>(), (uint32_t)nb, (const unsigned long long *)&ctx->d_state2->n_sites);
         hipLaunchKernelGGL(k_mhl_emit, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
                            ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->d_state2, ctx->w_blk.as<uint32_t>(),
                            ms + 1, ctx->m_pos.as<int32_t>(), ctx->m_val.as<float>(), ctx->m_cov.as<uint32_t>());
