@@ -183,7 +183,8 @@ def _split(dt, ph):
     runtime start-up -- overlapped with opening the file --, exit)"""
     load = ph.get("device inflate + walk + decode", ph.get("inflate + device record decode", ph.get("host decode (BGZF+BAM+XM)", 0.0)))
     kern = ph.get("H2D + kernels (sync)", 0.0)
-    tail = ph.get("fetch", 0.0) + ph.get("format + write", 0.0) + ph.get("fetch + TSV write", 0.0)
+    # ("fetch + TSV write" is the CLI's outer phase around "fetch" and "format + write": one or the other, never their sum)
+    tail = ph["fetch + TSV write"] if "fetch + TSV write" in ph else ph.get("fetch", 0.0) + ph.get("format + write", 0.0)
     return {"wall_s": round(dt, 4), "startup_s": round(max(dt - load - kern - tail, 0.0), 4), "load_s": round(load, 4), "kernels_s": round(kern, 4),
             "tail_s": round(tail, 4), "device_context_overlapped_s": ph.get("device context (overlapped)", ph.get("device context"))}
 
