@@ -298,8 +298,8 @@ int finish(mth_ctx_t *ctx, mth_host_t *h) {
     if (g_shard.world > 1) return 0;      // a shard's thread: main() writes the files and leaves
     if (getenv("METHEOR_TEARDOWN")) {
         Phase ph("teardown");
-        mth_ctx_destroy(ctx);
-        mth_host_close(h);
+        { Phase p1("  device context destroy"); mth_ctx_destroy(ctx); }
+        { Phase p2("  input close (munmap)"); mth_host_close(h); }
         return 0;
     }
     fflush(nullptr);
