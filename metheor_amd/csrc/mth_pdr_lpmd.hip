@@ -793,9 +793,11 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
             for (int k = 0; k < kmin; ++k) { cdf += term; term *= lam / (double)(k + 1); }
             ins_per_read = lam * std::max(0.0, 1.0 - cdf);
         }
-        if (sites_per_bp <= 0.012 && reads_per_bp * 4096.0 <= 400.0 && ins_per_read <= 0.6)
+        // Depth: measured on a chr1-sized contig at density 0.0091 -- 16 M reads (10x) dense 0.170 / wide 0.113 ms, 24 M 0.201 / 0.160,
+        // 32 M 0.238 / 0.196, 48 M (29x) 0.295 / 0.277, each with a gather of 0.027 / 0.008 on top; 65536-bp tiles only lead at 10x.
+        if (sites_per_bp <= 0.012 && reads_per_bp * 4096.0 <= 900.0 && ins_per_read <= 0.6)
         {
-            wide_shift = sites_per_bp * 65536.0 <= 0.6 * 1024 ? 16 : sites_per_bp * 32768.0 <= 0.6 * 1024 ? 15 : 14;
+            wide_shift = sites_per_bp * 65536.0 <= 0.6 * 1024 && reads_per_bp * 65536.0 <= 4500.0 ? 16 : sites_per_bp * 32768.0 <= 0.6 * 1024 ? 15 : 14;
             // ... and enough tiles to fill the chip twice over (7 workgroups on each of 256 CUs): a short contig takes narrower tiles
             // (config 3's 24 contigs: 2.33 -> 2.20 ms; the same rule made the quartet / pairs kernels slower -- 2.36 -> 2.62, 2.72 -> 2.95 ms --
             // whose persistent workgroups gain more from the wider tile than they lose to a half-filled last round)
