@@ -236,7 +236,8 @@ def e2e_leg(c, n_reads, large_copies=10):
                     out["large"] = {"what": "the same reads on %d contigs in one BAM (%d reads): 3 runs after one warm-up" % (large_copies, nb),
                                     "reads": nb, "bam_bytes": big, "tsv_rows": sum(1 for _ in open(tsv)), "best_s": round(runs2[0][0], 4),
                                     "median_s": round(m2[0], 4), "M_reads_per_s_best": round(nb / runs2[0][0] / 1e6, 2),
-                                    "M_reads_per_s_median": round(nb / m2[0] / 1e6, 2), "median_run": _split(*m2), "bam_write_s": round(t_w, 1),
+                                    "M_reads_per_s_median": round(nb / m2[0] / 1e6, 2), "median_run": _split(*m2),
+                                    "load_phase_M_reads_per_s_median": round(nb / max(_split(*m2)["load_s"], 1e-9) / 1e6, 1), "bam_write_s": round(t_w, 1),
                                     "marginal_M_reads_per_s": round((nb - n_reads) / max(m2[0] - med[0], 1e-9) / 1e6, 2)}
             else:
                 out["large"] = {"skipped": "not enough room in %s" % d}
