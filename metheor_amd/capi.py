@@ -13,7 +13,7 @@ MTH_MEM_HOST, MTH_MEM_DEVICE = 0, 1
 SYMBOLS = [
     "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
     "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
-    "mth_pdr_fetch", "mth_result_buffer_alloc", "mth_result_buffer_free", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_from_counts",
+    "mth_pdr_fetch", "mth_result_buffer_alloc", "mth_result_buffer_free", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_add_unbatched", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
     "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
     "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_bgzf_stage", "mth_decode_reserve", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_sort", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
@@ -108,6 +108,7 @@ def lib():
         L.mth_result_buffer_free.argtypes = [vp, vp]
         L.mth_pdr_device_view.argtypes = [vp, C.POINTER(C.c_uint64)] + [C.POINTER(vp)] * 4
         L.mth_lpmd_global.argtypes = [vp, C.POINTER(C.c_int64 * 4), C.POINTER(C.c_float)]
+        L.mth_lpmd_add_unbatched.argtypes = [vp, C.c_uint64, C.c_uint64]
         L.mth_lpmd_from_counts.restype = C.c_float
         L.mth_lpmd_from_counts.argtypes = [C.c_int64, C.c_int64]
         L.mth_lpmd_export_device.argtypes = [vp, vp]
@@ -275,6 +276,10 @@ class Engine:
         self._check(self.L.mth_lpmd_global(self.h, C.byref(g), C.byref(v)))
         return dict(n_concordant=g[0], n_discordant=g[1], n_read=g[2], n_valid_read=g[3],
                     lpmd=np.float32(v.value))
+
+    def lpmd_add_unbatched(self, n_read, n_valid_read):
+        """records left out of the batches (no contig / no aligned base): lpmd.rs:176-179 still counts them"""
+        self._check(self.L.mth_lpmd_add_unbatched(self.h, int(n_read), int(n_valid_read)))
 
     def lpmd_export_device(self, dst_ptr):
         """dst_ptr: device address of 4 x int64 (e.g. torch_tensor.data_ptr())"""

@@ -277,6 +277,7 @@ struct Input {
     std::vector<uint16_t> s_rel;
     mth_ctx_t *ctx = nullptr;   // set when the records were decoded on the device (the batches live in its HBM)
     bool device = false;
+    std::vector<uint8_t> unbatched_mapq;   // mapq of the records that entered no batch (no contig / no aligned base): lpmd.rs:176-179 counts them
 };
 
 // METHEOR_TIMING=1: phase wall times on stderr (never stdout)
@@ -573,7 +574,7 @@ Input load(const std::string &path, const char *cpg_set) {
         int64_t e = i;
         bool loose = false;
         while (e < n && tid[e] == tid[i]) { loose |= st[e] < 0; ++e; }
-        if (tid[i] < 0) { i = e; continue; }                       // records without a contig never enter a batch
+        if (tid[i] < 0) { in.unbatched_mapq.insert(in.unbatched_mapq.end(), mq + i, mq + e); i = e; continue; }   // records without a contig never enter a batch
         for (const Contig &c : in.contigs)
             if (c.tid == tid[i]) die("input BAM is not grouped by contig (coordinate-sorted input is required on the MI355X path)");
         in.contigs.emplace_back();
@@ -591,7 +592,7 @@ Input load(const std::string &path, const char *cpg_set) {
         } else {
             c.off.push_back(0);
             for (int64_t r = i; r < e; ++r) {
-                if (st[r] < 0) continue;                           // no aligned base: no CpG, no position
+                if (st[r] < 0) { in.unbatched_mapq.push_back(mq[r]); continue; }   // no aligned base: no CpG, no position
                 c.o_start.push_back(st[r]); c.o_end.push_back(en[r]); c.o_mapq.push_back(mq[r]);
                 for (uint64_t k = off[r]; k < off[r + 1]; ++k) { c.o_pos.push_back(pos[k]); c.o_rel.push_back(rel[k]); }
                 if (c.o_pos.size() >= (1ull << 32)) die("metheor (MI355X path): a contig with 2^32 or more CpG calls does not fit one batch on the host-decode path");
@@ -766,10 +767,16 @@ int run_lpmd(const Args &a) {
     p.lpmd_min_distance = mind; p.lpmd_max_distance = maxd;
     p.want_lpmd = 1;
     submit(ctx, in, p);
+    if (!in.unbatched_mapq.empty()) {                            // lpmd.rs:176-179: every record counts, also those without a position
+        uint64_t nv = 0;
+        for (uint8_t q : in.unbatched_mapq) nv += q >= p.lpmd_min_qual ? 1u : 0u;
+        check(ctx, mth_lpmd_add_unbatched(ctx, in.unbatched_mapq.size(), nv));
+    }
     if (g_shard.world > 1) gang_allreduce_lpmd(ctx);             // every shard now holds the genome-wide counters
     int64_t g[4] = {0, 0, 0, 0};
     float lp = 0.f;
     check(ctx, mth_lpmd_global(ctx, g, &lp));
+    if (getenv("METHEOR_DEBUG_COUNTS")) fprintf(stderr, "[metheor counts] n_concordant=%lld n_discordant=%lld n_read=%lld n_valid_read=%lld\n", (long long)g[0], (long long)g[1], (long long)g[2], (long long)g[3]);
     // records that never enter a batch only move n_read / n_valid_read (not part of the TSV)
     FILE *f = open_output(a.s.at("output"));
     char fb[64];

@@ -14,6 +14,8 @@ static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k
                                           "k_mhl_walk", "k_mhl_walk_big", "k_mhl_emit", "k_pdr_walk",
                                           "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_pairs_tile", "k_decode", "k_inflate", "k_crc32", "k_pdr_lpmd_stream", "k_mhl_tile", "k_pdr_lpmd_wide"};
 
+__global__ void k_lpmd_add2(DevState *st, long long n_read, long long n_valid) { st->lpmd[2] += n_read; st->lpmd[3] += n_valid; }
+
 int fail(mth_ctx *ctx, int status, const char *what, hipError_t e) {
     if (ctx) {
         ctx->last_error = what ? what : "";
@@ -397,6 +399,17 @@ int mth_lpmd_global(mth_ctx_t *ctx, int64_t out[4], float *lpmd) {
     }
     if (out) for (int k = 0; k < 4; ++k) out[k] = v[k];
     if (lpmd) *lpmd = mth_lpmd_from_counts(v[0], v[1]);
+    return MTH_OK;
+}
+
+// lpmd.rs:176-179 counts EVERY record of the file in n_read, and in n_valid_read when its mapq passes -- also the records that never
+// enter a batch (no contig, no aligned base: they have no CpG and no position).  The caller that dropped them hands their counts over.
+int mth_lpmd_add_unbatched(mth_ctx_t *ctx, uint64_t n_read, uint64_t n_valid_read) {
+    if (!ctx || n_valid_read > n_read) return MTH_ERR_INVALID;
+    if (n_read == 0) return MTH_OK;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_lpmd_add2, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state, (long long)n_read, (long long)n_valid_read);
+    MTH_HIP(ctx, hipGetLastError());
     return MTH_OK;
 }
 

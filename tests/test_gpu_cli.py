@@ -589,3 +589,30 @@ def test_unsorted_input_order_free_measures(tmp_path, kind):
     for sub in ("pdr", "mhl", "fdrp", "qfdrp"):
         r = run(sub, "-i", bam, "-o", str(o))
         assert r.returncode == 101 and "not coordinate-sorted" in r.stderr and "lpmd, me and pm take any order" in r.stderr, (sub, r.stderr)
+
+
+def test_lpmd_counts_records_that_enter_no_batch(tmp_path):
+    """lpmd.rs:176-179 counts EVERY record in n_read, and in n_valid_read when its mapq passes -- also a pure soft-clip record (no
+    reference position) and records without a contig, which the batches cannot hold.  The CLI hands their counts to the engine
+    (mth_lpmd_add_unbatched); the totals equal the record count / the count of records with mapq >= min_qual, and the oracle's."""
+    from tests.test_host_decode import _weird_records
+    rec = _weird_records()
+    n0 = len(rec)
+    # ten records without a contig at the end of the file (where a coordinate-sorted BAM keeps them), half of them with a passing mapq
+    tid = np.concatenate([rec.tid, np.full(10, -1, np.int32)])
+    pos = np.concatenate([rec.pos, np.full(10, -1, np.int32)])
+    flag = np.concatenate([rec.flag, np.full(10, 4, np.uint16)])
+    mapq = np.concatenate([rec.mapq, np.array([0, 40] * 5, np.uint8)])
+    rec2 = bamio.Records(rec.refs, tid, pos, flag, mapq, list(rec.cigars) + [[(50 << 4) | 4]] * 10, list(rec.xms) + [b"." * 50] * 10)
+    bam = str(tmp_path / "loose.bam")
+    bamio.write_bam(bam, rec2)
+    for q in (10, 0, 41):
+        r = run_env({"METHEOR_DEBUG_COUNTS": "1"}, "lpmd", "-i", bam, "-o", str(tmp_path / "l.tsv"), "-q", str(q))
+        assert r.returncode == 0, r.stderr
+        line = [l for l in r.stderr.splitlines() if l.startswith("[metheor counts]")][0]
+        got = dict(kv.split("=") for kv in line.split()[2:])
+        assert int(got["n_read"]) == n0 + 10, line
+        assert int(got["n_valid_read"]) == int((mapq >= q).sum()), line
+        o = pyoracle.lpmd_bam(bam, min_qual=q) if hasattr(pyoracle, "lpmd_bam") else None
+        if o is not None:
+            assert int(got["n_read"]) == int(o["n_read"]) and int(got["n_valid_read"]) == int(o["n_valid_read"])
