@@ -448,11 +448,11 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
         const double sites_per_bp = (double)d.n_cpgs / (double)d.n_reads / (double)std::max(d.max_span, 1);
         const double reads_per_bp = (double)d.n_reads / (double)region_len;
         const double window = std::max(1.0, (double)std::min<int64_t>((int64_t)params->max_distance - std::max(params->min_distance, 0) + 1, d.max_span));
-        while (tile_shift < 15 && sites_per_bp * (double)(2 << tile_shift) * std::max(1.0, sites_per_bp * window) <= 0.3 * PT_S &&
+        while (tile_shift < 16 && sites_per_bp * (double)(2 << tile_shift) * std::max(1.0, sites_per_bp * window) <= 0.3 * PT_S &&
                reads_per_bp * (double)((2 << tile_shift) + d.max_span + 2 * IDX_Q) <= 30000.0)
             ++tile_shift;
     }
-    if (const char *e = getenv("MTH_PAIRS_TILE_SHIFT")) tile_shift = std::min(15, std::max(13, atoi(e)));   // tests / tuning
+    if (const char *e = getenv("MTH_PAIRS_TILE_SHIFT")) tile_shift = std::min(16, std::max(13, atoi(e)));   // tests / tuning
     const int PT_W = 1 << tile_shift;
     const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + PT_W - 1) / PT_W) : 0u;
     const uint64_t tiles_before = ctx->p_meta.empty() ? 0 : ctx->p_meta.back().tile_end;
@@ -497,9 +497,12 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
             } else if (tile_shift == 14) {
                 if (r8) hipLaunchKernelGGL((k_pairs_tile<uint8_t, 14>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
                 else hipLaunchKernelGGL((k_pairs_tile<uint16_t, 14>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
-            } else {
+            } else if (tile_shift == 15) {
                 if (r8) hipLaunchKernelGGL((k_pairs_tile<uint8_t, 15>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
                 else hipLaunchKernelGGL((k_pairs_tile<uint16_t, 15>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
+            } else {
+                if (r8) hipLaunchKernelGGL((k_pairs_tile<uint8_t, 16>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
+                else hipLaunchKernelGGL((k_pairs_tile<uint16_t, 16>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
             }
         }
         MTH_HIP(ctx, hipMemcpyAsync(st, ps, P_STATE_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -542,11 +542,11 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
         // 0.112 ms at 32768 -- a tile's fixed chain of round trips and barriers is what these kernels wait for.)
         const double lam = sites_per_bp * (double)std::max(d.max_span, 1);
         const double p3 = std::max(0.05, 1.0 - std::exp(-lam) * (1.0 + lam + 0.5 * lam * lam));
-        while (tile_shift < 15 && sites_per_bp * p3 * (double)(2 << tile_shift) <= 0.4 * QT_S &&
+        while (tile_shift < 16 && sites_per_bp * p3 * (double)(2 << tile_shift) <= 0.4 * QT_S &&
                reads_per_bp * (double)((2 << tile_shift) + d.max_span + 2 * IDX_Q) <= 30000.0)
             ++tile_shift;
     }
-    if (const char *e = getenv("MTH_QUARTET_TILE_SHIFT")) tile_shift = std::min(15, std::max(13, atoi(e)));   // tests / tuning
+    if (const char *e = getenv("MTH_QUARTET_TILE_SHIFT")) tile_shift = std::min(16, std::max(13, atoi(e)));   // tests / tuning
     const int QT_W = 1 << tile_shift;
     const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + QT_W - 1) / QT_W) : 0u;
     const uint64_t tiles_before = ctx->q_meta.empty() ? 0 : ctx->q_meta.back().tile_end;
@@ -594,7 +594,8 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
             LaunchTimer lt(ctx, K_QTILE);
             if (tile_shift == 13) hipLaunchKernelGGL(k_quartet_tile<8192>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
             else if (tile_shift == 14) hipLaunchKernelGGL(k_quartet_tile<16384>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
-            else hipLaunchKernelGGL(k_quartet_tile<32768>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
+            else if (tile_shift == 15) hipLaunchKernelGGL(k_quartet_tile<32768>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
+            else hipLaunchKernelGGL(k_quartet_tile<65536>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
         }
         MTH_HIP(ctx, hipMemcpyAsync(st, qs, Q_STATE_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         MTH_HIP(ctx, hipStreamSynchronize(s));            // one sync per batch: rows, flagged tiles, fit
