@@ -12,7 +12,7 @@ namespace mth {
 static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k_gather",
                                           "k_quartet_bound", "k_quartet_tile", "k_quartet_insert", "k_quartet_emit",
                                           "k_mhl_walk", "k_mhl_walk_big", "k_mhl_emit", "k_pdr_walk",
-                                          "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_pairs_tile", "k_decode", "k_inflate", "k_crc32", "k_pdr_lpmd_stream", "k_mhl_tile", "k_pdr_lpmd_wide"};
+                                          "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_pairs_tile", "k_decode", "k_inflate", "k_crc32", "k_mhl_tile", "k_pdr_lpmd_wide"};
 
 __global__ void k_lpmd_add2(DevState *st, long long n_read, long long n_valid) { st->lpmd[2] += n_read; st->lpmd[3] += n_valid; }
 
@@ -202,7 +202,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rccl_release(ctx);
     for (DevBuf *b : {&ctx->st_start, &ctx->st_end, &ctx->st_mapq, &ctx->st_fwd, &ctx->st_off, &ctx->st_pos,
-                      &ctx->st_rel, &ctx->idx, &ctx->slice_base, &ctx->sbucket, &ctx->tile_cnt, &ctx->tile_bucket, &ctx->scratch, &ctx->dec_raw, &ctx->dec_recoff, &ctx->dec_tid, &ctx->dec_start, &ctx->dec_end,
+                      &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_bucket, &ctx->scratch, &ctx->dec_raw, &ctx->dec_recoff, &ctx->dec_tid, &ctx->dec_start, &ctx->dec_end,
                       &ctx->dec_mapq, &ctx->dec_fwd, &ctx->dec_n, &ctx->dec_off, &ctx->dec_pos, &ctx->dec_rel, &ctx->dec_blk, &ctx->dec_off32, &ctx->dec_runs, &ctx->dec_xm, &ctx->dec_filter,
                       &ctx->inf_file, &ctx->inf_file2, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff, &ctx->crc_mat,
                       &ctx->tag_genome, &ctx->tag_goff, &ctx->tag_ncol, &ctx->tag_coloff, &ctx->tag_xmlen, &ctx->tag_cols, &ctx->tag_xm,

@@ -44,10 +44,6 @@ struct mth_ctx {
     mth::DevBuf st_start, st_end, st_mapq, st_fwd, st_off, st_pos, st_rel;
     // per-batch work buffers
     mth::DevBuf idx, tile_cnt, tile_bucket, scratch, batch_cnt;
-    // streaming PDR + LPMD kernel (mth_stream.hip): per-wave scratch bases; two alternating sets of bucket sums
-    mth::DevBuf slice_base, sbucket;
-    size_t sbucket_words = 0;
-    int sbucket_set = 0;
     // device-side BAM record decode (mth_decode.hip): staged input, decoded SoA, scan scratch, one batch's 32-bit offsets
     mth::DevBuf dec_raw, dec_recoff, dec_tid, dec_start, dec_end, dec_mapq, dec_fwd, dec_n, dec_off, dec_pos, dec_rel, dec_blk, dec_off32, dec_runs, dec_xm, dec_filter;
     bool dec_filter_on = false;
@@ -182,8 +178,5 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &dev_batch, int tile_w, int
 int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_mhl_params_t &p, uint64_t &bound);
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p,
                     const TileSink *sink = nullptr);
-// mth_stream.hip: the same pass as one stream over the sorted reads (batches with 8-bit relpos and max_span <= 256)
-bool stream_eligible(const mth_batch_t &dev_batch);
-int launch_pdr_lpmd_stream(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p, const TileSink *sink);
 
 }  // namespace mth

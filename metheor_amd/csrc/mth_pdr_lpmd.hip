@@ -761,7 +761,6 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &id
 }
 
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_params_t &p, const TileSink *sink) {
-    if (stream_eligible(b)) return launch_pdr_lpmd_stream(ctx, b, p, sink);
     hipStream_t s = ctx->stream;
     // where the compacted rows and their counters go: the PDR result columns by default, or a
     // caller-supplied sink (site discovery for the site-walk measures)

@@ -1,4 +1,4 @@
-// mth_tile_dev.h -- device helpers shared by the PDR + LPMD kernels (mth_pdr_lpmd.hip: tile kernel, mth_stream.hip: streaming kernel).
+// mth_tile_dev.h -- device helpers shared by the PDR + LPMD kernels (mth_pdr_lpmd.hip: dense tile kernel, mth_pdr_wide.hip: hashed-site form).
 #pragma once
 #include "mth_common.h"
 

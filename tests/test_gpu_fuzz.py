@@ -106,10 +106,10 @@ def test_random_scenario_all_measures(eng, seed):
     rel16 = bool(rng.integers(0, 2))
     d, l = T_pdr.run_device(eng, cs, p, regions=regions, rel16=rel16)
     T_pdr.check_against_oracle(d, l, reads, pk, lk)
-    # the same through the streaming form of the pass (mth_stream.hip; opt-in): identical rows and counters
-    # ... and through the hashed-site form for sparse batches (mth_pdr_wide.hip) whatever the batch's density
+    # the same through the hashed-site form for sparse batches (mth_pdr_wide.hip) whatever the batch's density, and through the dense
+    # form forced: identical rows and counters
     import os
-    for env, val in (("MTH_STREAM", "1"), ("MTH_PDR_WIDE", str(14 + seed % 3)), ("MTH_PDR_WIDE", "0")):
+    for env, val in (("MTH_PDR_WIDE", str(14 + seed % 3)), ("MTH_PDR_WIDE", "0")):
         os.environ[env] = val
         try:
             d2, l2 = T_pdr.run_device(eng, cs, p, regions=regions, rel16=rel16)

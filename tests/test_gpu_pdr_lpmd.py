@@ -16,19 +16,16 @@ pytestmark = pytest.mark.gpu
 f32 = np.float32
 
 
-@pytest.fixture(autouse=True, params=["tile", "stream", "wide14", "wide16"])
+@pytest.fixture(autouse=True, params=["auto", "tile", "wide14", "wide15", "wide16"])
 def kernel_form(request, monkeypatch):
-    """every case runs through the dense tile kernel (forced: MTH_PDR_WIDE=0), through the streaming kernel (mth_stream.hip,
-    MTH_STREAM=1; batches it does not take -- 16-bit relpos, spans > 256 -- fall back to the tile pipeline by themselves) and
-    through the hashed-site form for sparse batches (mth_pdr_wide.hip) with 16384- and 65536-bp tiles forced"""
-    monkeypatch.delenv("MTH_STREAM", raising=False)
-    monkeypatch.setenv("MTH_PDR_WIDE", "0")
-    if request.param == "stream":
-        monkeypatch.setenv("MTH_STREAM", "1")
-    elif request.param == "wide14":
-        monkeypatch.setenv("MTH_PDR_WIDE", "14")
-    elif request.param == "wide16":
-        monkeypatch.setenv("MTH_PDR_WIDE", "16")
+    """every case runs with the engine's own choice of kernel form (MTH_PDR_WIDE unset: the density chooser of
+    launch_pdr_lpmd, the path production takes), through the dense tile kernel (forced: MTH_PDR_WIDE=0) and through the
+    hashed-site form for sparse batches (mth_pdr_wide.hip) with 16384-, 32768- and 65536-bp tiles forced"""
+    monkeypatch.delenv("MTH_PDR_WIDE", raising=False)
+    if request.param == "tile":
+        monkeypatch.setenv("MTH_PDR_WIDE", "0")
+    elif request.param.startswith("wide"):
+        monkeypatch.setenv("MTH_PDR_WIDE", request.param[4:])
     return request.param
 
 
