@@ -67,8 +67,32 @@ LaunchTimer::~LaunchTimer() {
     ctx->timed.push_back(TimedLaunch{kernel, beg, end});
 }
 
+// a mth_reset that arrived inside a pipelined run and has not been folded into a gather: do it now, on ctx->stream
+static int flush_reset(mth_ctx *ctx) {
+    if (!ctx->reset_pending) return MTH_OK;
+    ctx->reset_pending = false;
+    MTH_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream));
+    return MTH_OK;
+}
+
+int pipe_join(mth_ctx *ctx) {
+    if (ctx->pipe_active) {
+        for (PdrLane &l : ctx->lane)
+            if (l.used) { MTH_HIP(ctx, hipStreamWaitEvent(ctx->stream, l.done, 0)); l.used = false; }
+        ctx->pipe_active = false;
+        ctx->pipe_tail = -1;
+    }
+    ctx->pdr_streak = 0;
+    return flush_reset(ctx);
+}
+
+int enter(mth_ctx *ctx) {
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    return pipe_join(ctx);
+}
+
 int sync_and_check(mth_ctx *ctx) {
-    MTH_HIP(ctx, hipSetDevice(ctx->device));   // every entry point passes through here or stage_batch: the calling thread may be new
+    MTH_ENTER(ctx);   // every entry point passes through here or stage_batch: the calling thread may be new
     MTH_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
     MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t e = ctx->h_state->err;
@@ -93,13 +117,14 @@ static int stage(mth_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, const
     return MTH_OK;
 }
 
-int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &d) {
+int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &d, bool join) {
     if (b.region_end < b.region_beg || b.max_span < 0) return fail(ctx, MTH_ERR_INVALID, "bad region / max_span");
     if (b.n_reads && (!b.read_start || !b.read_end || !b.read_mapq || !b.cpg_off))
         return fail(ctx, MTH_ERR_INVALID, "batch arrays missing");
     if (b.n_cpgs && (!b.cpg_pos || (!b.cpg_rel == !b.cpg_rel16)))
         return fail(ctx, MTH_ERR_INVALID, "exactly one of cpg_rel / cpg_rel16 must be given");
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    if (join || b.mem == MTH_MEM_HOST) MTH_ENTER(ctx);      // (host batches: the single set of staging buffers is reused -> always joined)
+    else MTH_HIP(ctx, hipSetDevice(ctx->device));
     d = b;
     if (b.mem == MTH_MEM_HOST) {
         int rc;
@@ -199,8 +224,16 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stage_thread.joinable()) ctx->stage_thread.join();
+    for (PdrLane &l : ctx->lane) if (l.stream) (void)hipStreamSynchronize(l.stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     rccl_release(ctx);
+    for (PdrLane &l : ctx->lane) {
+        for (DevBuf *b : {&l.idx, &l.tile_cnt, &l.tile_bucket, &l.scratch}) b->release();
+        if (l.st) (void)hipFree(l.st);
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
+    if (ctx->pipe_in) (void)hipEventDestroy(ctx->pipe_in);
     for (DevBuf *b : {&ctx->st_start, &ctx->st_end, &ctx->st_mapq, &ctx->st_fwd, &ctx->st_off, &ctx->st_pos,
                       &ctx->st_rel, &ctx->idx, &ctx->tile_cnt, &ctx->tile_bucket, &ctx->scratch, &ctx->dec_raw, &ctx->dec_recoff, &ctx->dec_tid, &ctx->dec_start, &ctx->dec_end,
                       &ctx->dec_mapq, &ctx->dec_fwd, &ctx->dec_n, &ctx->dec_off, &ctx->dec_pos, &ctx->dec_rel, &ctx->dec_blk, &ctx->dec_off32, &ctx->dec_runs, &ctx->dec_xm, &ctx->dec_filter,
@@ -228,7 +261,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
 
 int mth_ctx_set_stream(mth_ctx_t *ctx, void *hip_stream) {
     if (!ctx) return MTH_ERR_INVALID;
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return MTH_OK;
@@ -242,7 +275,11 @@ int mth_ctx_sync(mth_ctx_t *ctx) {
 int mth_reset(mth_ctx_t *ctx) {
     if (!ctx) return MTH_ERR_INVALID;
     MTH_HIP(ctx, hipSetDevice(ctx->device));
-    MTH_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream));
+    // Inside a pipelined run of PDR + LPMD batches the job state (DevState: row count, batch counts, LPMD totals, error bits) is
+    // owned by the chain of gathers: the reset is folded into the next batch's gather (or done on ctx->stream by the next join)
+    // instead of draining the lanes here.  The other measures' states are only ever touched from ctx->stream.
+    if (ctx->pipe_active) ctx->reset_pending = true;
+    else MTH_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, sizeof(DevState), ctx->stream));
     ctx->batches.clear();
     ctx->out_bound = 0;
     ctx->lpmd_reduced = false;
@@ -271,9 +308,13 @@ int mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_
     // tile kernel).  Longer spans take the exact site walk (mth_sites.hip) for the PDR half.
     const bool pdr_exact = params->want_pdr && b.max_span > PDR_FLUSH_MARGIN;
     if (params->want_lpmd) ctx->lpmd_reduced = false;
+    // Pipelined batches (mth_pdr_lpmd.hip): device-resident batches that take the fused tile pass, from the second of a run of such
+    // calls on (mth_reset does not break a run; any other entry point does).  Not while kernels are being timed one by one.
+    if (ctx->pipe_mode < 0) { const char *e = getenv("MTH_PIPELINE"); ctx->pipe_mode = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool eligible = ctx->pipe_mode == 1 && b.mem == MTH_MEM_DEVICE && !pdr_exact && !ctx->timing;
     mth_batch_t d;
     {
-        const int rcs = stage_batch(ctx, b, d);
+        const int rcs = stage_batch(ctx, b, d, !eligible);
         if (rcs) return rcs;
     }
     // an empty region owns no site and no read: nothing is launched, so nothing may be recorded either (the per-batch
@@ -300,15 +341,19 @@ int mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_
         }
         ctx->out_bound += add;
     }
-    MTH_HIP(ctx, ctx->batch_cnt.reserve((ctx->batches.size() + 1) * 4, ctx->stream, true, ctx->batches.size() * 4));
+    if ((ctx->batches.size() + 2) * 4 > ctx->batch_cnt.cap) {
+        MTH_ENTER(ctx);       // the gathers in flight write this array: drain them before it moves
+        MTH_HIP(ctx, ctx->batch_cnt.reserve((ctx->batches.size() + 2) * 4 + 4096, ctx->stream, true, ctx->batches.size() * 4));
+    }
     int rc;
     if (!pdr_exact) {
-        if ((rc = launch_pdr_lpmd(ctx, d, *params))) return rc;
+        const bool pipelined = eligible && ctx->pdr_streak >= 1;       // (a join above -- growth -- restarts the run)
+        if ((rc = launch_pdr_lpmd(ctx, d, *params, nullptr, pipelined))) return rc;
         ctx->batches.push_back(BatchMeta{b.tid});
+        if (eligible) ctx->pdr_streak += 1;
         return MTH_OK;
     }
-    // every pass appends one (possibly empty) entry to the per-batch row counts: keep host and device in step
-    MTH_HIP(ctx, ctx->batch_cnt.reserve((ctx->batches.size() + 2) * 4, ctx->stream, true, ctx->batches.size() * 4));
+    // (every pass appends one (possibly empty) entry to the per-batch row counts: two entries were reserved above)
     if (params->want_lpmd) {
         mth_pdr_lpmd_params_t lp = *params;
         lp.want_pdr = 0;
@@ -355,7 +400,7 @@ int mth_pdr_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *pos, float *pdr, uint32
 int mth_result_buffer_alloc(mth_ctx_t *ctx, size_t bytes, void **out) {
     if (!ctx || !out) return MTH_ERR_INVALID;
     *out = nullptr;
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     const hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
     if (e != hipSuccess) { *out = nullptr; return fail(ctx, MTH_ERR_HIP, "hipHostMalloc (result buffer)", e); }
     return MTH_OK;
@@ -407,7 +452,7 @@ int mth_lpmd_global(mth_ctx_t *ctx, int64_t out[4], float *lpmd) {
 int mth_lpmd_add_unbatched(mth_ctx_t *ctx, uint64_t n_read, uint64_t n_valid_read) {
     if (!ctx || n_valid_read > n_read) return MTH_ERR_INVALID;
     if (n_read == 0) return MTH_OK;
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     hipLaunchKernelGGL(k_lpmd_add2, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state, (long long)n_read, (long long)n_valid_read);
     MTH_HIP(ctx, hipGetLastError());
     return MTH_OK;
@@ -415,7 +460,7 @@ int mth_lpmd_add_unbatched(mth_ctx_t *ctx, uint64_t n_read, uint64_t n_valid_rea
 
 int mth_lpmd_export_device(mth_ctx_t *ctx, int64_t *dst) {
     if (!ctx || !dst) return MTH_ERR_INVALID;
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     MTH_HIP(ctx, hipMemcpyAsync(dst, ctx->d_state->lpmd, 4 * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
     return MTH_OK;
 }

@@ -28,6 +28,17 @@ struct BatchMeta {
     int32_t tid;
 };
 
+// One lane of the PDR + LPMD batch pipeline (mth_pdr_lpmd.hip, "Pipelined batches"): a stream of its own, the per-batch work
+// buffers (lane 0 borrows the context's own idx / tile_cnt / tile_bucket / scratch, lane 1 has a second set) and a small
+// device block for what belongs to the batch in flight on the lane rather than to the job: error bits, safe_hi, the row base.
+struct PdrLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;          // recorded behind the lane's latest k_gather
+    DevBuf idx, tile_cnt, tile_bucket, scratch;      // lane 1 only
+    DevState *st = nullptr;
+    bool used = false;                  // has work that ctx->stream has not been made to wait for
+};
+
 }  // namespace mth
 
 struct mth_ctx {
@@ -44,6 +55,18 @@ struct mth_ctx {
     mth::DevBuf st_start, st_end, st_mapq, st_fwd, st_off, st_pos, st_rel;
     // per-batch work buffers
     mth::DevBuf idx, tile_cnt, tile_bucket, scratch, batch_cnt;
+    // PDR + LPMD batch pipeline: consecutive device-resident batches alternate between two lanes so that batch k+1's index build
+    // and the head of its tile kernel run beside batch k's tail and gather; only the gathers form a chain (each waits for the one
+    // before it: row bases, batch counts and the LPMD totals live in DevState).  Any other entry point joins the lanes back into
+    // ctx->stream first (mth::enter).
+    mth::PdrLane lane[2];
+    hipEvent_t pipe_in = nullptr;       // recorded on ctx->stream at each pipelined call: the lane waits for the caller's producers
+    int pipe_mode = -1;                 // -1: not decided (MTH_PIPELINE env), 0: off, 1: on
+    int pipe_next = 0;                  // lane of the next pipelined batch
+    int pipe_tail = -1;                 // lane that holds the latest gather (-1: none since the last join)
+    bool pipe_active = false;           // lanes hold work ctx->stream has not been ordered behind
+    unsigned pdr_streak = 0;            // consecutive eligible mth_pdr_lpmd_accumulate calls (mth_reset does not break the run)
+    bool reset_pending = false;         // mth_reset inside a pipelined run: folded into the next batch's gather
     // device-side BAM record decode (mth_decode.hip): staged input, decoded SoA, scan scratch, one batch's 32-bit offsets
     mth::DevBuf dec_raw, dec_recoff, dec_tid, dec_start, dec_end, dec_mapq, dec_fwd, dec_n, dec_off, dec_pos, dec_rel, dec_blk, dec_off32, dec_runs, dec_xm, dec_filter;
     bool dec_filter_on = false;
@@ -135,6 +158,15 @@ struct mth_ctx {
 namespace mth {
 
 int  fail(mth_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
+// first thing every entry point does: make the context's device current for the calling thread (it may be new) and order
+// ctx->stream behind whatever the PDR + LPMD pipeline lanes still hold
+int  enter(mth_ctx *ctx);
+int  pipe_join(mth_ctx *ctx);
+#define MTH_ENTER(ctx)                                                  \
+    do {                                                                \
+        const int rc__ = mth::enter(ctx);                               \
+        if (rc__) return rc__;                                          \
+    } while (0)
 #define MTH_HIP(ctx, call)                                              \
     do {                                                                \
         hipError_t e__ = (call);                                        \
@@ -153,7 +185,7 @@ struct LaunchTimer {
 void rccl_release(mth_ctx *ctx);    // mth_rccl.hip: destroy the context's communicator, if any
 int sync_and_check(mth_ctx *ctx);   // stream sync + read DevState + map error bits
 // validate a caller batch and make it device-resident (MTH_MEM_HOST arrays go through the staging buffers)
-int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &dev);
+int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &dev, bool join = true);
 // mth_decode.hip: 64-bit exclusive scan of a u32 array (synchronises), and the record decode over device-resident input
 int scan_u32_to_u64(mth_ctx *ctx, const uint32_t *n, uint32_t count, unsigned long long base, unsigned long long *off,
                     unsigned long long *total_host);
@@ -177,6 +209,6 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &dev_batch, int tile_w, int
 // MHL as one tile pass (mth_mhl_tile.hip): candidate-site arrays filled with finished rows and the sites left to the exact walk
 int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_mhl_params_t &p, uint64_t &bound);
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p,
-                    const TileSink *sink = nullptr);
+                    const TileSink *sink = nullptr, bool pipelined = false);
 
 }  // namespace mth

@@ -415,7 +415,7 @@ int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const 
                        int append, mth_decoded_t *out) {
     if (!ctx || !out || (n_rec && (!raw || !rec_off))) return MTH_ERR_INVALID;
     if (n_rec >= (1ull << 32) - 16) return fail(ctx, MTH_ERR_CAPACITY, "more than 2^32 records in one decode call: split the stream");
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const uint8_t *d_raw = (const uint8_t *)raw;
     const uint64_t *d_off = rec_off;
@@ -436,7 +436,7 @@ int mth_decode_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const 
 
 int mth_decode_set_cpg_filter(mth_ctx_t *ctx, const uint64_t *keys_sorted, uint64_t n_keys, int enabled) {
     if (!ctx || (enabled && n_keys && !keys_sorted)) return MTH_ERR_INVALID;
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     ctx->dec_filter_on = enabled != 0;
     ctx->dec_filter_n = enabled ? n_keys : 0;
     if (enabled && n_keys) {
@@ -451,7 +451,7 @@ int mth_decode_set_cpg_filter(mth_ctx_t *ctx, const uint64_t *keys_sorted, uint6
 
 int mth_decode_reserve(mth_ctx_t *ctx, uint64_t n_reads, uint64_t n_cpgs) {
     if (!ctx) return MTH_ERR_INVALID;
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const size_t R0 = (size_t)ctx->dec_reads, C0 = (size_t)ctx->dec_cpgs, R = (size_t)n_reads, C = (size_t)n_cpgs;
     MTH_HIP(ctx, ctx->dec_tid.reserve(R * 4 + 4, s, R0 > 0, R0 * 4));
@@ -474,7 +474,7 @@ int mth_decode_set_xm_min_mapq(mth_ctx_t *ctx, uint32_t min_mapq) {
 int mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *read_beg, uint64_t *read_end, uint32_t *n_runs,
                         uint32_t *flags) {
     if (!ctx || !n_runs || !flags || (cap && (!tids || !read_beg || !read_end))) return MTH_ERR_INVALID;
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const uint64_t n = ctx->dec_reads;
     *n_runs = 0; *flags = 0;
@@ -530,7 +530,7 @@ int mth_decoded_batch(mth_ctx_t *ctx, uint64_t read_beg, uint64_t read_end, int3
     if (!ctx || !batch || read_end < read_beg || read_end > ctx->dec_reads) return MTH_ERR_INVALID;
     const uint64_t n = read_end - read_beg;
     if (n >= (1ull << 32) - 1) return fail(ctx, MTH_ERR_CAPACITY, "batch of more than 2^32 reads");
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     hipStream_t s = ctx->stream;
     MTH_HIP(ctx, ctx->dec_off32.reserve((size_t)(n + 1) * 4 + 16, s));
     uint32_t *d_span = ctx->dec_off32.as<uint32_t>() + n + 1;

@@ -495,7 +495,7 @@ static void crc_zero_operators(uint32_t (*mat)[32]) {
 static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, const uint64_t *coff, const uint32_t *csize,
                           const uint32_t *isize, uint64_t n_blocks, uint64_t &total, uint64_t *&d_uoff, uint32_t *&d_isize) {
     if (n_blocks >= (1ull << 31)) return fail(ctx, MTH_ERR_CAPACITY, "too many BGZF blocks in one call: split the file");
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const size_t nb = (size_t)n_blocks;
     // output offsets of the blocks + validation of the table against the byte range given

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
     // first kernel of a batch: its rows go after everything emitted so far, and the bucket sums start at zero
     // (nothing else runs between the previous batch's last kernel and this one on the stream)
     const uint32_t gtid = blockIdx.x * BLOCK + threadIdx.x;
-    if (gtid == 0) cst->cur_base = cst->n_sites;
+    if (gtid == 0 && cst) cst->cur_base = cst->n_sites;      // (pipelined batches: the base travels along the chain of gathers instead)
     for (uint32_t w = gtid; w < n_bucket_words; w += gridDim.x * BLOCK) bucket_sums[w] = 0ull;
     // safe_hi: the largest read index r with cpg_off[r] + 8 <= n_cpgs, searched among the batch's last 256 indices by the
     // first wave (0 if it is not there: every tile then takes the clamped loads).  The tile kernel used to load
@@ -677,7 +677,9 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(const SiteRec *__r
                                                const uint32_t *__restrict__ tile_cnt,
                                                const unsigned long long *__restrict__ bucket, uint32_t nbk,
                                                uint32_t ntiles, int fin_only, int want_lpmd,
-                                               DevState *__restrict__ st, uint32_t *__restrict__ batch_cnt,
+                                               DevState *__restrict__ st, const DevState *__restrict__ base_st,
+                                               DevState *__restrict__ next_st, DevState *__restrict__ lane_st, int reset_first,
+                                               uint32_t *__restrict__ batch_cnt,
                                                uint32_t tile_w,
                                                int32_t *__restrict__ out_pos, float *__restrict__ out_pdr,
                                                uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(const SiteRec *__r
     SiteRec r0; r0.pos = 0; r0.n_conc = 0; r0.n_disc = 0; r0.pad = 0;
     if (!fin_only) r0 = src[lane];
     const uint32_t n = tile_cnt[t];
-    const uint64_t cur = st->cur_base;
+    const uint64_t cur = reset_first ? 0ull : base_st->cur_base;
     const uint32_t u0 = (bk << TILE_BUCKET_SHIFT) + lane;
     uint32_t x[4];
 #pragma unroll
@@ -715,21 +717,37 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(const SiteRec *__r
     }
     if (t != ntiles - 1) return;
     const uint32_t total = before + n;
+    // Pipelined batches (base_st = lane_st = the lane's block, next_st = the other lane's): this gather runs strictly after the one
+    // before it, so it may read and write the job state; the next batch's gather finds its row base in ITS lane's block (other
+    // waves of this launch may still be reading base_st->cur_base: nobody in a launch reads what the launch writes).  The batch's
+    // own error bits (index: unsorted, tile: span) were collected in the lane's block, because the job's may be cleared by a
+    // mth_reset that sits in the chain between two batches; reset_first: this batch is the first after such a reset.
     if (lane == 0) {
+        const uint32_t nb = reset_first ? 0u : st->n_batches;
         st->n_sites = cur + total;
-        batch_cnt[st->n_batches] = total;
-        st->n_batches += 1;
+        batch_cnt[nb] = total;
+        st->n_batches = nb + 1;
+        if (next_st) next_st->cur_base = cur + total;
+        uint32_t e = reset_first ? 0u : st->err;
+        if (lane_st) { e |= lane_st->err; lane_st->err = 0; }
+        if (lane_st || reset_first) st->err = e;
     }
-    if (want_lpmd) {
+    if (want_lpmd || reset_first) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             unsigned long long x = 0;
-            for (uint32_t b = lane; b < nbk; b += 64) x += bucket[nbk + (size_t)b * 4 + k];
+            if (want_lpmd) for (uint32_t b = lane; b < nbk; b += 64) x += bucket[nbk + (size_t)b * 4 + k];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-            if (lane == 0) st->lpmd[k] += (long long)x;
+            if (lane == 0) st->lpmd[k] = (reset_first ? 0ll : st->lpmd[k]) + (long long)x;
         }
     }
+}
+
+// first pipelined batch since ctx->stream was last joined: its lane's row base is the job's row count as that stream leaves it
+__global__ void k_pipe_seed(const DevState *__restrict__ st, DevState *__restrict__ lane_st) {
+    lane_st->cur_base = st->n_sites;
+    lane_st->err = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -760,8 +778,52 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &id
     return MTH_OK;
 }
 
-int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_params_t &p, const TileSink *sink) {
-    hipStream_t s = ctx->stream;
+// ---------------------------------------------------------------------------------------------
+// Pipelined batches.  A job is a sequence of batches (contigs, regions).  Within one batch the three kernels depend on each
+// other, but batch k+1's index build and tile kernel need nothing of batch k: only the gathers form a chain (row bases, per-batch
+// counts and the LPMD totals are job state).  Consecutive device-resident batches therefore alternate between two LANES -- a
+// stream, a set of work buffers (index, per-tile counts, bucket sums, scratch rows) and a 64-byte block for the batch's own
+// error bits / safe_hi / row base each -- and each gather waits for the event behind the previous one:
+//     lane 0:  index 0 | tile 0 ........ | gather 0 | index 2 | tile 2 ........ |        gather 2
+//     lane 1:            index 1 | tile 1 ........ |  gather 1 | index 3 | tile 3 ...
+// so a tile kernel's drain (a third of a 10 M-read launch is filling and draining the chip) is covered by the
+// next batch's fill, and the small index / gather kernels run beside a tile kernel instead of between two.  ctx->stream is
+// ordered behind the lanes by mth::enter() at every other entry point; the lanes wait for ctx->stream's work as of the call
+// (the caller's producers of the batch arrays).
+static int pipe_begin(mth_ctx *ctx, int &li) {
+    if (!ctx->pipe_in) {
+        MTH_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_in, hipEventDisableTiming));
+        for (PdrLane &l : ctx->lane) {
+            MTH_HIP(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+            MTH_HIP(ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+            MTH_HIP(ctx, hipMalloc((void **)&l.st, sizeof(DevState)));
+            MTH_HIP(ctx, hipMemsetAsync(l.st, 0, sizeof(DevState), l.stream));
+        }
+    }
+    li = ctx->pipe_next;
+    ctx->pipe_next ^= 1;
+    PdrLane &L = ctx->lane[li];
+    MTH_HIP(ctx, hipEventRecord(ctx->pipe_in, ctx->stream));
+    MTH_HIP(ctx, hipStreamWaitEvent(L.stream, ctx->pipe_in, 0));
+    if (!ctx->pipe_active) {
+        hipLaunchKernelGGL(k_pipe_seed, dim3(1), dim3(1), 0, L.stream, ctx->d_state, L.st);
+        ctx->pipe_active = true;
+        ctx->pipe_tail = -1;
+    }
+    L.used = true;
+    return MTH_OK;
+}
+
+int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_params_t &p, const TileSink *sink, bool pipelined) {
+    if (sink) pipelined = false;
+    int li = 0;
+    if (pipelined) { const int rc = pipe_begin(ctx, li); if (rc) return rc; }
+    PdrLane *L = pipelined ? &ctx->lane[li] : nullptr;
+    hipStream_t s = L ? L->stream : ctx->stream;
+    // lane 0 (and every unpipelined batch) works in the context's own buffers, lane 1 in its second set
+    DevBuf &b_idx = li ? L->idx : ctx->idx, &b_tile_cnt = li ? L->tile_cnt : ctx->tile_cnt;
+    DevBuf &b_bucket = li ? L->tile_bucket : ctx->tile_bucket, &b_scratch = li ? L->scratch : ctx->scratch;
+    DevState *lane_st = L ? L->st : ctx->d_state;        // error bits, safe_hi of the batch in flight
     // where the compacted rows and their counters go: the PDR result columns by default, or a
     // caller-supplied sink (site discovery for the site-walk measures)
     DevState *cst = sink ? sink->st : ctx->d_state;
@@ -812,26 +874,26 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     const int32_t idx_base = b.region_beg - ext;
     const uint32_t nq = (uint32_t)(((int64_t)ntiles * tile_w + ext) >> IDX_QSHIFT) + 2;
 
-    MTH_HIP(ctx, ctx->idx.reserve((size_t)(nq + 1) * 4, s));
-    MTH_HIP(ctx, ctx->tile_cnt.reserve((size_t)ntiles * 4, s));
+    MTH_HIP(ctx, b_idx.reserve((size_t)(nq + 1) * 4, s));
+    MTH_HIP(ctx, b_tile_cnt.reserve((size_t)ntiles * 4, s));
     const uint32_t nbk = (ntiles + (1u << TILE_BUCKET_SHIFT) - 1) >> TILE_BUCKET_SHIFT;
-    MTH_HIP(ctx, ctx->tile_bucket.reserve((size_t)nbk * 5 * sizeof(unsigned long long), s));
-    if (p.want_pdr) MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * (size_t)tile_w * sizeof(SiteRec), s));
+    MTH_HIP(ctx, b_bucket.reserve((size_t)nbk * 5 * sizeof(unsigned long long), s));
+    if (p.want_pdr) MTH_HIP(ctx, b_scratch.reserve((size_t)ntiles * (size_t)tile_w * sizeof(SiteRec), s));
 
     {
         LaunchTimer lt(ctx, K_INDEX);
         const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK * IDX_GROUPS - 1) / (BLOCK * IDX_GROUPS);
         hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start,
                            b.n_reads, idx_base, nq, (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0),
-                           ctx->idx.as<uint32_t>(), ctx->d_state, cst, ctx->tile_bucket.as<unsigned long long>(), nbk * 5u,
+                           b_idx.as<uint32_t>(), lane_st, L ? (DevState *)nullptr : cst, b_bucket.as<unsigned long long>(), nbk * 5u,
                            b.cpg_off, b.n_cpgs);
     }
     TileArgs a;
     a.read_start = b.read_start; a.read_mapq = b.read_mapq; a.cpg_off = b.cpg_off; a.cpg_pos = b.cpg_pos;
     a.cpg_rel = b.cpg_rel ? (const void *)b.cpg_rel : (const void *)b.cpg_rel16;
-    a.idx = ctx->idx.as<uint32_t>(); a.st = ctx->d_state;
-    a.tile_cnt = ctx->tile_cnt.as<uint32_t>(); a.bucket = ctx->tile_bucket.as<unsigned long long>(); a.nbk = nbk;
-    a.scratch = ctx->scratch.as<SiteRec>();
+    a.idx = b_idx.as<uint32_t>(); a.st = lane_st;
+    a.tile_cnt = b_tile_cnt.as<uint32_t>(); a.bucket = b_bucket.as<unsigned long long>(); a.nbk = nbk;
+    a.scratch = b_scratch.as<SiteRec>();
     a.region_beg = b.region_beg; a.region_end = b.region_end; a.idx_base = idx_base; a.max_span = b.max_span;
     a.n_reads = b.n_reads; a.n_cpgs = b.n_cpgs;
     a.min_cov = p.pdr_min_depth > 1 ? p.pdr_min_depth : 1;
@@ -852,9 +914,19 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     }
     {
         LaunchTimer lt(ctx, K_GATHER);
-        hipLaunchKernelGGL(k_gather, dim3(p.want_pdr ? (ntiles + GATHER_WAVES - 1) / GATHER_WAVES : 1u), dim3(p.want_pdr ? 64 * GATHER_WAVES : 64), 0, s, ctx->scratch.as<SiteRec>(),
-                           ctx->tile_cnt.as<uint32_t>(), ctx->tile_bucket.as<unsigned long long>(), nbk, ntiles,
-                           p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, bcnt, (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
+        int reset_first = 0;
+        if (L) {
+            // the chain: behind the previous batch's gather (the other lane's; this lane's own earlier work precedes in stream order)
+            if (ctx->pipe_tail >= 0 && ctx->pipe_tail != li) MTH_HIP(ctx, hipStreamWaitEvent(s, ctx->lane[ctx->pipe_tail].done, 0));
+            reset_first = ctx->reset_pending ? 1 : 0;
+            ctx->reset_pending = false;
+        }
+        hipLaunchKernelGGL(k_gather, dim3(p.want_pdr ? (ntiles + GATHER_WAVES - 1) / GATHER_WAVES : 1u), dim3(p.want_pdr ? 64 * GATHER_WAVES : 64), 0, s, b_scratch.as<SiteRec>(),
+                           b_tile_cnt.as<uint32_t>(), b_bucket.as<unsigned long long>(), nbk, ntiles,
+                           p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, L ? (const DevState *)L->st : (const DevState *)cst,
+                           L ? ctx->lane[li ^ 1].st : (DevState *)nullptr, L ? L->st : (DevState *)nullptr, reset_first,
+                           bcnt, (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
+        if (L) { MTH_HIP(ctx, hipEventRecord(L->done, s)); ctx->pipe_tail = li; }
     }
 #ifdef MTH_TILE_TRACE
     if (getenv("MTH_TILE_TRACE_OUT") && ntiles <= 262144) {

@@ -97,7 +97,7 @@ int mth_rccl_init_rank(mth_ctx_t *ctx, const void *id128, int rank, int world) {
     Rccl *r = rccl();
     if (!r) return rccl_fail(ctx, "RCCL is not available", ncclSuccess);
     if (ctx->rccl_comm) return fail(ctx, MTH_ERR_STATE, "this context already has a communicator");
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     ncclComm_t c = nullptr;
@@ -116,7 +116,7 @@ int mth_allreduce_lpmd_rank(mth_ctx_t *ctx) {
     if (!ctx->rccl_comm) return fail(ctx, MTH_ERR_STATE, "mth_rccl_init_rank first");
     if (ctx->lpmd_reduced) return fail(ctx, MTH_ERR_STATE, "the LPMD counters of this context are already all-reduced");
     Rccl *r = rccl();
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     if (!ctx->red_stream) {
         MTH_HIP(ctx, hipStreamCreateWithFlags(&ctx->red_stream, hipStreamNonBlocking));
         MTH_HIP(ctx, hipMalloc((void **)&ctx->red_buf, mth_ctx::RED_RING * 4 * sizeof(long long)));
@@ -146,6 +146,7 @@ int mth_allreduce_lpmd(mth_ctx_t **ctxs, int n) {
         for (int j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return fail(ctxs[i], MTH_ERR_INVALID, "a context appears twice");
         if (ctxs[i]->lpmd_reduced) return fail(ctxs[i], MTH_ERR_STATE, "the LPMD counters of this context are already all-reduced");
     }
+    for (int i = 0; i < n; ++i) { const int rc = enter(ctxs[i]); if (rc) return rc; }     // joins each context's PDR + LPMD pipeline
     if (n == 1) { ctxs[0]->lpmd_reduced = true; ctxs[0]->red_slot = -1; return MTH_OK; }
     // contexts that share a GPU (several shards per device) are summed on that GPU into the first of them; RCCL
     // then runs between one context per distinct GPU (it refuses two ranks on one device); the result is copied back

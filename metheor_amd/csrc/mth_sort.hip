@@ -51,7 +51,7 @@ using namespace mth;
 
 extern "C" int mth_decoded_sort(mth_ctx_t *ctx) {
     if (!ctx) return MTH_ERR_INVALID;
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const uint64_t R = ctx->dec_reads, Cn = ctx->dec_cpgs;
     if (R < 2) return MTH_OK;

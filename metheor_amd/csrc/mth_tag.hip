@@ -250,7 +250,7 @@ extern "C" {
 
 int mth_tag_set_genome(mth_ctx_t *ctx, int32_t n_refs, const int64_t *ref_len, const uint8_t *const *seq, const int64_t *seq_len) {
     if (!ctx || n_refs < 0 || (n_refs && (!ref_len || !seq || !seq_len))) return MTH_ERR_INVALID;
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     hipStream_t s = ctx->stream;
     std::vector<uint64_t> off((size_t)n_refs + 1, 0);
     for (int32_t t = 0; t < n_refs; ++t) {
@@ -273,7 +273,7 @@ int mth_tag_records(mth_ctx_t *ctx, const void *raw, uint64_t n_bytes, const uin
     if (!ctx || !out || (n_rec && (!raw || !rec_off))) return MTH_ERR_INVALID;
     if (n_rec >= (1ull << 32) - 16) return fail(ctx, MTH_ERR_CAPACITY, "more than 2^32 records in one tag call: split the stream");
     if (ctx->tag_n_refs < 0) return fail(ctx, MTH_ERR_STATE, "mth_tag_set_genome has not been called");
-    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    MTH_ENTER(ctx);
     hipStream_t s = ctx->stream;
     *out = mth_tag_out_t{};
     ctx->tag_h_off.assign(1, 0);
