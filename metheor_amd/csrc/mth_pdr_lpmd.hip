@@ -38,10 +38,17 @@ namespace mth {
 // One thread handles 4 consecutive reads (one 16-byte load + the element before them); the thread
 // whose group contains index n_reads also plays the sentinel that closes the index.
 constexpr int IDX_GROUPS = 1;   // groups of 4 reads per thread; 4 (all loads hoisted) measured slower: 0.0177 against 0.0157 ms on config 2
+// NIDX = 1: the fine index (QSHIFT = IDX_QSHIFT, 32-bp quanta) every tile / site kernel can look any position up in.
+// NIDX = 2 (the dense PDR + LPMD tile kernel's own, round 4): that kernel asks two questions per 4096-bp tile only -- the first
+// read starting at or after T0 - max_span + 1 and the first one starting after T0 + W -- so two indices with ONE entry per tile
+// (quantum = tile width, origins region_beg - max_span + 1 and region_beg + 1) answer them exactly: 2 x 14 312 entries instead of
+// 1.83 M on config 2, no store loop for four reads in five, and the tile's candidate range loses the up to 2 x 31 bp of reads the
+// 32-bp rounding handed it.
+template <int NIDX>
 __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict__ read_start,
-                                                       uint32_t n_reads, int32_t idx_base,
+                                                       uint32_t n_reads, int32_t idx_base, int32_t idx_base2, int qshift,
                                                        uint32_t nq, int aligned16,
-                                                       uint32_t *__restrict__ idx,
+                                                       uint32_t *__restrict__ idx, uint32_t *__restrict__ idx2,
                                                        DevState *__restrict__ st, DevState *__restrict__ cst,
                                                        unsigned long long *__restrict__ bucket_sums, uint32_t n_bucket_words,
                                                        const uint32_t *__restrict__ cpg_off, uint32_t n_cpgs) {
@@ -67,9 +74,9 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
         for (int o = 32; o > 0; o >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 64));
         if (gtid == 0) st->safe_hi = best;
     }
-    auto bucket = [&](int32_t s) -> int32_t {  // min(floor((s-base)/Q), nq), -1 below the base
-        const int64_t d = (int64_t)s - idx_base;
-        return d < 0 ? -1 : (int32_t)min(d >> IDX_QSHIFT, (int64_t)nq);
+    auto bucket = [&](int32_t s, int32_t base) -> int32_t {  // min(floor((s-base)/Q), nq), -1 below the base
+        const int64_t d = (int64_t)s - base;
+        return d < 0 ? -1 : (int32_t)min(d >> qshift, (int64_t)nq);
     };
     // IDX_GROUPS groups of 4 reads per thread, BLOCK groups apart (coalesced); all their loads are requested before the
     // first is used
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
         // slower: 0.0171 against 0.0163 ms; the load hits the line its neighbour fetches and waits for nothing extra)
         if (i0 > 0 && i0 <= n_reads) sp[u] = read_start[i0 - 1];
     }
-    // The quantum is 32 bp (it was 256: the candidates of a tile or a site then carried up to 362 bp of reads that cannot
+    // The fine quantum is 32 bp (it was 256: the candidates of a tile or a site then carried up to 362 bp of reads that cannot
     // touch it, 8 % of a 4096-bp tile's loop iterations), so a read usually opens an entry or two; a stretch without reads
     // (assembly gaps: megabases) is filled by the whole wave, 64 entries per step, not by the one lane that found it.
     const int lane = threadIdx.x & 63;
@@ -104,35 +111,59 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
     for (int u = 0; u < IDX_GROUPS; ++u) {
         const uint32_t i0 = gi[u];
         const bool gact = i0 <= n_reads;
-        int32_t g_prev = -1, s_prev = 0;
-        bool have_prev = false;
-        if (gact && i0 > 0) { s_prev = sp[u]; g_prev = bucket(s_prev); have_prev = true; }
+        if (NIDX == 2) {
+            // sortedness once, on the values alone (the per-family loops below only run where a boundary is crossed)
+            int32_t sprev = sp[u];
+            bool hp = gact && i0 > 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t i = i0 + k;
-            const bool act = gact && i <= n_reads;
-            int32_t g_cur = g_prev;
-            if (act) {
-                if (i < n_reads) {
-                    const int32_t s = sv[u][k];
-                    g_cur = bucket(s);
-                    if (have_prev && s < s_prev) err |= ERRB_UNSORTED;
-                    s_prev = s; have_prev = true;
-                } else {
-                    g_cur = (int32_t)nq;   // sentinel closes the index
+            for (int k = 0; k < 4; ++k) {
+                if (gact && i0 + k < n_reads) { if (hp && sv[u][k] < sprev) err |= ERRB_UNSORTED; sprev = sv[u][k]; hp = true; }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < NIDX; ++w) {
+            uint32_t *__restrict__ out = w ? idx2 : idx;
+            const int32_t base = w ? idx_base2 : idx_base;
+            int32_t g_prev = -1, s_prev = 0;
+            bool have_prev = false;
+            if (gact && i0 > 0) { s_prev = sp[u]; g_prev = bucket(s_prev, base); have_prev = true; }
+            if (NIDX == 2) {
+                // tile-granular families: the reads of a wave (256 consecutive ones) cross a boundary of the family in about one
+                // wave out of three on config 2 -- the others are done after two bucket computations per lane
+                int32_t g_last = g_prev;
+                if (gact) {
+                    const uint32_t last = min(i0 + 3u, n_reads);            // the group's last index (n_reads: the sentinel)
+                    g_last = last == n_reads ? (int32_t)nq : bucket(sv[u][last - i0], base);
                 }
+                if (!__any(g_last > g_prev)) continue;
             }
-            const bool big = act && g_cur - g_prev > 32;
-            if (act && !big) for (int32_t q = g_prev + 1; q <= g_cur; ++q) idx[q] = i;
-            unsigned long long m = __ballot(big);
-            while (m) {
-                const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
-                m &= m - 1;
-                const int32_t gp = __builtin_amdgcn_readlane(g_prev, l), gc = __builtin_amdgcn_readlane(g_cur, l);
-                const uint32_t ii = (uint32_t)__builtin_amdgcn_readlane((int)i, l);
-                for (int32_t q = gp + 1 + lane; q <= gc; q += 64) idx[q] = ii;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = i0 + k;
+                const bool act = gact && i <= n_reads;
+                int32_t g_cur = g_prev;
+                if (act) {
+                    if (i < n_reads) {
+                        const int32_t s = sv[u][k];
+                        g_cur = bucket(s, base);
+                        if (NIDX == 1 && have_prev && s < s_prev) err |= ERRB_UNSORTED;
+                        s_prev = s; have_prev = true;
+                    } else {
+                        g_cur = (int32_t)nq;   // sentinel closes the index
+                    }
+                }
+                const bool big = act && g_cur - g_prev > 32;
+                if (act && !big) for (int32_t q = g_prev + 1; q <= g_cur; ++q) out[q] = i;
+                unsigned long long m = __ballot(big);
+                while (m) {
+                    const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                    m &= m - 1;
+                    const int32_t gp = __builtin_amdgcn_readlane(g_prev, l), gc = __builtin_amdgcn_readlane(g_cur, l);
+                    const uint32_t ii = (uint32_t)__builtin_amdgcn_readlane((int)i, l);
+                    for (int32_t q = gp + 1 + lane; q <= gc; q += 64) out[q] = ii;
+                }
+                if (g_cur > g_prev) g_prev = g_cur;
             }
-            if (g_cur > g_prev) g_prev = g_cur;
         }
     }
     if (err) atomicOr(&st->err, err);
@@ -620,8 +651,9 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
     // getters report the error.  (An explicit load of the error flag here cost every tile a dependent
     // round trip before its first useful load.)
     // The three words the tile needs first are requested together; the counters are cleared while they travel.
-    const uint32_t lo_raw = a.idx[((uint32_t)T0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT];
-    const uint32_t hi_raw = a.idx[(((uint32_t)T0 + (uint32_t)W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1];
+    // (idx2: the kernel's own tile-granular index, exact bounds; otherwise the fine index every kernel can use)
+    const uint32_t lo_raw = a.idx2 ? a.idx[t] : a.idx[((uint32_t)T0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT];
+    const uint32_t hi_raw = a.idx2 ? a.idx2[t + 1] : a.idx[(((uint32_t)T0 + (uint32_t)W - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1];
     // only a tile that holds the batch's last reads can have a read whose NB-slot window runs past the call arrays:
     // k_build_index left the last read index that is safe for every tile ending at or before it
     const uint32_t safe_hi = a.st->safe_hi;
@@ -751,6 +783,7 @@ __global__ void k_pipe_seed(const DevState *__restrict__ st, DevState *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+constexpr int DENSE_TILE_SHIFT = 12;   // the dense kernel's 4096-bp tiles
 constexpr int TILE_MARGIN = 256;   // counter margins on either side of a tile for batches with max_span <= 256
 template <int W, int B, typename RelT>
 static void launch_tile(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
@@ -772,8 +805,8 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &id
     MTH_HIP(ctx, ctx->idx.reserve((size_t)(nq + 1) * 4, s));
     LaunchTimer lt(ctx, K_INDEX);
     const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK * IDX_GROUPS - 1) / (BLOCK * IDX_GROUPS);
-    hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, idx_base, nq,
-                       (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0), ctx->idx.as<uint32_t>(), ctx->d_state,
+    hipLaunchKernelGGL(k_build_index<1>, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, idx_base, 0, (int)IDX_QSHIFT, nq,
+                       (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0), ctx->idx.as<uint32_t>(), (uint32_t *)nullptr, ctx->d_state,
                        ctx->d_state, (unsigned long long *)nullptr, 0u, (const uint32_t *)nullptr, 0u);   // cur_base is rewritten by the next PDR batch's own index build
     return MTH_OK;
 }
@@ -803,8 +836,12 @@ static int pipe_begin(mth_ctx *ctx, int &li) {
     li = ctx->pipe_next;
     ctx->pipe_next ^= 1;
     PdrLane &L = ctx->lane[li];
-    MTH_HIP(ctx, hipEventRecord(ctx->pipe_in, ctx->stream));
-    MTH_HIP(ctx, hipStreamWaitEvent(L.stream, ctx->pipe_in, 0));
+    // the caller's producers of the batch arrays, and whatever a join put on ctx->stream: the lane waits for them -- unless that
+    // stream is idle, which one query tells (a cross-stream wait costs the lane's queue a barrier packet)
+    if (!ctx->pipe_active || hipStreamQuery(ctx->stream) != hipSuccess) {
+        MTH_HIP(ctx, hipEventRecord(ctx->pipe_in, ctx->stream));
+        MTH_HIP(ctx, hipStreamWaitEvent(L.stream, ctx->pipe_in, 0));
+    }
     if (!ctx->pipe_active) {
         hipLaunchKernelGGL(k_pipe_seed, dim3(1), dim3(1), 0, L.stream, ctx->d_state, L.st);
         ctx->pipe_active = true;
@@ -874,7 +911,12 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     const int32_t idx_base = b.region_beg - ext;
     const uint32_t nq = (uint32_t)(((int64_t)ntiles * tile_w + ext) >> IDX_QSHIFT) + 2;
 
-    MTH_HIP(ctx, b_idx.reserve((size_t)(nq + 1) * 4, s));
+    // The dense tile kernel's own index: one entry per tile in each of two families (k_build_index<2>).  Site discovery for the walk
+    // measures (sink) leaves the fine index behind for them; the wide form looks up arbitrary stretch bounds.  MTH_COARSE_INDEX=0: A/B.
+    static const bool coarse_off = getenv("MTH_COARSE_INDEX") && atoi(getenv("MTH_COARSE_INDEX")) == 0;
+    const bool coarse = !sink && wide_shift == 0 && !coarse_off;
+    const uint32_t coarse_stride = (ntiles + 2u + 3u) & ~3u;
+    MTH_HIP(ctx, b_idx.reserve(coarse ? (size_t)coarse_stride * 2 * 4 : (size_t)(nq + 1) * 4, s));
     MTH_HIP(ctx, b_tile_cnt.reserve((size_t)ntiles * 4, s));
     const uint32_t nbk = (ntiles + (1u << TILE_BUCKET_SHIFT) - 1) >> TILE_BUCKET_SHIFT;
     MTH_HIP(ctx, b_bucket.reserve((size_t)nbk * 5 * sizeof(unsigned long long), s));
@@ -883,15 +925,20 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     {
         LaunchTimer lt(ctx, K_INDEX);
         const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK * IDX_GROUPS - 1) / (BLOCK * IDX_GROUPS);
-        hipLaunchKernelGGL(k_build_index, dim3(nb), dim3(BLOCK), 0, s, b.read_start,
-                           b.n_reads, idx_base, nq, (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0),
-                           b_idx.as<uint32_t>(), lane_st, L ? (DevState *)nullptr : cst, b_bucket.as<unsigned long long>(), nbk * 5u,
-                           b.cpg_off, b.n_cpgs);
+        const int al16 = (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0);
+        if (coarse)
+            hipLaunchKernelGGL(k_build_index<2>, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, b.region_beg - b.max_span + 1, b.region_beg + 1,
+                               DENSE_TILE_SHIFT, ntiles + 1u, al16, b_idx.as<uint32_t>(), b_idx.as<uint32_t>() + coarse_stride, lane_st,
+                               L ? (DevState *)nullptr : cst, b_bucket.as<unsigned long long>(), nbk * 5u, b.cpg_off, b.n_cpgs);
+        else
+            hipLaunchKernelGGL(k_build_index<1>, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, idx_base, 0, (int)IDX_QSHIFT, nq, al16,
+                               b_idx.as<uint32_t>(), (uint32_t *)nullptr, lane_st, L ? (DevState *)nullptr : cst,
+                               b_bucket.as<unsigned long long>(), nbk * 5u, b.cpg_off, b.n_cpgs);
     }
     TileArgs a;
     a.read_start = b.read_start; a.read_mapq = b.read_mapq; a.cpg_off = b.cpg_off; a.cpg_pos = b.cpg_pos;
     a.cpg_rel = b.cpg_rel ? (const void *)b.cpg_rel : (const void *)b.cpg_rel16;
-    a.idx = b_idx.as<uint32_t>(); a.st = lane_st;
+    a.idx = b_idx.as<uint32_t>(); a.idx2 = coarse ? b_idx.as<uint32_t>() + coarse_stride : nullptr; a.st = lane_st;
     a.tile_cnt = b_tile_cnt.as<uint32_t>(); a.bucket = b_bucket.as<unsigned long long>(); a.nbk = nbk;
     a.scratch = b_scratch.as<SiteRec>();
     a.region_beg = b.region_beg; a.region_end = b.region_end; a.idx_base = idx_base; a.max_span = b.max_span;
@@ -910,7 +957,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
         LaunchTimer lt(ctx, wide_shift ? K_WIDE : K_TILE);
         const bool r8 = b.cpg_rel != nullptr;
         if (wide_shift) launch_tile_wide(a, ntiles, wide_shift, r8, s);
-        else if (r8) launch_tile<4096, 256, uint8_t>(a, ntiles, s); else launch_tile<4096, 256, uint16_t>(a, ntiles, s);
+        else if (r8) launch_tile<(1 << DENSE_TILE_SHIFT), 256, uint8_t>(a, ntiles, s); else launch_tile<(1 << DENSE_TILE_SHIFT), 256, uint16_t>(a, ntiles, s);
     }
     {
         LaunchTimer lt(ctx, K_GATHER);

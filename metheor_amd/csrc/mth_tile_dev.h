@@ -35,6 +35,7 @@ struct TileArgs {
     const uint32_t *cpg_pos;
     const void     *cpg_rel;
     const uint32_t *idx;
+    const uint32_t *idx2;         // dense kernel only: second family of its tile-granular index (nullptr: idx is the fine index)
     const DevState *st;
     uint32_t *tile_cnt;
     unsigned long long *bucket;   // per 256-tile bucket: [nbk] rows, then [nbk][4] LPMD partial sums
