@@ -126,7 +126,7 @@ struct mth_ctx {
     std::vector<mth::BatchMeta> m_batches;
 
     // FDRP / qFDRP result rows (mth_fdrp.hip)
-    mth::DevBuf f_state, f_pos, f_val, f_qval, f_n, f_batch_rows, f_rows, f_pairtab, f_redo;
+    mth::DevBuf f_state, f_pos, f_val, f_qval, f_n, f_batch_rows, f_rows, f_pairtab, f_redo, f_terms, f_soff, f_snz, f_sdisc;
     uint64_t f_cap = 0, f_rows_bound = 0;
     std::vector<mth::BatchMeta> f_batches;
 

@@ -65,7 +65,14 @@ struct FdrpArgs {
     const uint16_t *pair_tab;         // SLOTS = 64: (i | j << 8) of the k-th pair of n reads at [n (n-1) (n-2) / 6 + k], n <= 64
     uint32_t slots_cap;
     uint32_t only_flag;               // SLOTS = 64: 0 = every site, else only the sites k_fdrp_walk4 handed back
-    unsigned long long *redo_mask;    // per block of 64 consecutive sites: the sites k_fdrp_walk4 handed back (written for every block)
+    unsigned long long *redo_mask;    // per block of 64 consecutive sites: the sites k_fdrp_walk4 / k_fdrp_tile handed back (written for every block)
+    // k_fdrp_tile / k_fdrp_chain: the non-zero qFDRP terms of a site as byte codes, in the reference's (i, j) order
+    uint8_t  *terms;                  // term lists (budget bytes), claimed per tile through *cursor
+    unsigned long long *cursor;
+    unsigned long long budget;
+    unsigned long long *site_off;     // per site: first byte of its list
+    uint32_t *site_nz, *site_disc;    // per site: listed terms, discordant pairs
+    uint32_t *redo_list, *redo_cnt;   // the sites k_fdrp_tile handed back, one after the other (k_fdrp_walk takes them wave by wave)
 };
 
 // the oracle's orc_sample_j: splitmix64 over (seed, tid, pos, total) -> 1..=total
@@ -115,9 +122,11 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
     // requested one site ahead, so a run of skipped sites is not a run of exposed round trips.
     // (after k_fdrp_walk4 -- only_flag set -- the pass walks the set bits of that kernel's per-block hand-back masks instead: one
     // word per 64 sites to look at, not one per site)
-    const bool listed = SLOTS == 64 && a.only_flag != 0u;
+    const bool from_list = SLOTS == 64 && a.only_flag != 0u && a.redo_list != nullptr;
+    const bool listed = SLOTS == 64 && a.only_flag != 0u && !from_list;
+    const uint32_t n_list = from_list ? sgpr(*a.redo_cnt) : 0u;
     uint32_t cov_j = 0;
-    if (SLOTS == 64 && !listed && wave_id < n_sites) cov_j = a.site_nc[wave_id] + a.site_nd[wave_id];
+    if (SLOTS == 64 && !listed && !from_list && wave_id < n_sites) cov_j = a.site_nc[wave_id] + a.site_nd[wave_id];
     uint32_t l_blk = wave_id, l_cur = 0;
     unsigned long long l_m = 0;
     // (A site pipeline -- the wave holding this site's position and index entries and the next site's position as scalars,
@@ -137,11 +146,16 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
             if (end) break;
             j = l_cur * 64u + (uint32_t)__builtin_ctzll(l_m);
             l_m &= l_m - 1ull;
+        } else if (from_list) {
+            // (k_fdrp_tile's hand-backs come in runs -- a whole tile of a dense stretch -- and cost up to 100 us each on the
+            // call-by-call path: taken from a list, a run is spread over as many waves as it has sites)
+            if (it >= n_list) break;
+            j = sgpr(a.redo_list[it]);
         } else {
             j = it;
             if (j >= n_sites) break;
         }
-        if (SLOTS == 64 && !listed) {
+        if (SLOTS == 64 && !listed && !from_list) {
             const uint32_t cov = sgpr(cov_j);
             const uint32_t jn = j + n_waves;
             if (jn < n_sites) cov_j = a.site_nc[jn] + a.site_nd[jn];
@@ -777,6 +791,381 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 4: the read x read form.  What the wave-per-site walk repeats at every site -- inspecting the ~60-120
+// candidate reads, turning the stored ones into three 64-bit masks -- depends on the READ, not on the site: in the reference a
+// stored read is never cut by the +-201 window, it is kept whole or dropped (fdrp.rs:51-63), so overlap bases, shared calls and
+// Hamming count of a read pair are the same at every site the two share.  And the ordered f32 sum (qfdrp.rs:152) is a chain
+// of dependent adds that uses one lane of 64 when a wave owns one site.  On config 4 (50x hotspots, -D 64) the old kernel's 6.55 ms
+// were walk + set-up 2.6, pair rounds 1.4, chain 2.5 (ablation, profiles/r04_fdrp_tile.md).
+//   k_fdrp_tile   one workgroup per TILE of FT_CORE consecutive sites.  Phase 1, once per tile: every candidate read (one per
+//                 thread) is loaded, filtered (mapq, >= 1 call: fdrp.rs:205-210) and turned into {start, end, first call, calls,
+//                 covered calls, methylated covered calls} over the tile's window of <= 64 sites (the core plus the sites within
+//                 max_span on either side: all a core site's readers can call), kept in LDS.  Phase 2, per core site (a wave
+//                 each, in turn): the stored reads are the passing reads whose call mask has the site's bit, in file order --
+//                 ballots over the LDS table, with the flush rule (a passing read whose first call lies past the site, strict:
+//                 fdrp.rs:212) checked on the same ballots; their rows go to the wave's slot array and the pair rounds run as in
+//                 the walk's compact finalize (lane k = k-th pair of the (i, j) order), except that a round does not chain its
+//                 terms: it appends the non-zero ones, as one byte each (ncpg (ncpg + 1) / 2 + ham, ncpg <= 21), to the site's
+//                 list in HBM -- claimed per tile with one atomic from a buffer whose size bounds them exactly.
+//   k_fdrp_chain  one THREAD per site: the chain over the site's list (byte -> quotient from a 253-entry LDS table filled by the
+//                 same f32 divisions), 64 sites per wave instead of one; then fdrp.rs:143 / qfdrp.rs:155.
+// Only the common shape: spans <= 200 bp (host side), a window of <= 64 sites within FT_SPAN bp, <= FT_RMAX candidates, every
+// call of a stored read on a window site, one segment per site (no hit after a flusher), <= min(max_depth, 64) stored reads,
+// <= 21 shared calls per pair.  Anything else is handed back through redo_mask to k_fdrp_walk (only_flag), bit-identical either way.
+constexpr int FT_CORE = 32, FT_RMAX = 384, FT_SPAN = 2048, FT_LIST = 128;
+constexpr uint32_t FD_CHAIN = 8u;                 // flags: the site's terms are listed, k_fdrp_chain finishes it
+constexpr uint32_t FT_NCPG_MAX = 21u;             // 21 * 22 / 2 + 21 = 252: the codes fit a byte
+
+template <int FD_NB>
+__global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    // the tile's table, one row per candidate read: start; span | first call - (start - 1) | window bit of an uncovered first call;
+    // calls; methylated calls (both over the tile's window of <= 64 sites)
+    __shared__ uint8_t s_bit[FT_SPAN];
+    __shared__ int32_t s_start[FT_RMAX];
+    __shared__ uint32_t s_pack[FT_RMAX];
+    __shared__ unsigned long long s_mC[FT_RMAX], s_mM[FT_RMAX];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[4][64 * 8];     // per wave: the stored reads of the site in hand
+    __shared__ uint16_t s_list[4][FT_LIST];                                    // per wave: the site's readers in arrival order
+    __shared__ uint8_t s_draw[4][FT_LIST];                                     // per wave: reservoir draws of the arrivals past max_depth
+    __shared__ uint32_t s_cnt[FT_CORE];
+    __shared__ unsigned long long s_off[FT_CORE];
+    __shared__ uint32_t s_hdr[8];                 // 0: window first site, 1: window sites, 2: fallback, 3: lo, 4: hi
+    __shared__ uint32_t s_redo[4];
+    uint32_t *const rows = s_rows[wave];
+    uint16_t *const list = s_list[wave];
+    uint8_t *const draw = s_draw[wave];
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    const uint32_t n_tiles = (n_sites + FT_CORE - 1) / FT_CORE;
+    const uint32_t dcap = min(a.max_depth, 64u);  // stored reads a site of this kernel can hold (fdrp.rs:81-85)
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t ja = tile * FT_CORE, jb = min(ja + (uint32_t)FT_CORE, n_sites);       // core sites [ja, jb)
+        const uint32_t ncore = jb - ja;
+        __syncthreads();                          // the previous tile's LDS is no longer read
+        // ---- the window: the core and the sites within max_span of it (sorted positions: a count on either side) ----
+        if (wave == 0) {
+            const int32_t p_first = a.site_pos[ja], p_last = a.site_pos[jb - 1];
+            const bool lower = lane < 32;
+            const int64_t js = lower ? (int64_t)ja - 1 - lane : (int64_t)jb + (lane - 32);
+            const bool in = js >= 0 && js < (int64_t)n_sites;
+            const int32_t p = in ? a.site_pos[in ? js : 0] : 0;
+            const bool q = in && (lower ? (int64_t)p >= (int64_t)p_first - a.max_span : (int64_t)p <= (int64_t)p_last + a.max_span);
+            const unsigned long long m = __ballot(q);
+            const uint32_t L = (uint32_t)__builtin_popcount((uint32_t)m), U = (uint32_t)__builtin_popcount((uint32_t)(m >> 32));
+            const uint32_t W = L + ncore + U;
+            const int32_t w_first = a.site_pos[ja - L], w_last = a.site_pos[jb - 1 + U];
+            // (32 qualifying sites on a side: there may be more -- not a window this kernel holds)
+            bool fb = W > 64u || L >= 32u || U >= 32u || (int64_t)w_last - w_first >= FT_SPAN;
+            // (halo reads of a region slice call positions outside the region, which are not in the site list: phase 1 notices)
+            const uint32_t lo = min(a.idx[(uint32_t)(p_first - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
+            const uint32_t hi = min(a.idx[((uint32_t)(p_last + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+            fb = fb || hi - lo > (uint32_t)FT_RMAX || a.n_cpgs < 4u;
+            if (lane == 0) { s_hdr[0] = ja - L; s_hdr[1] = W; s_hdr[2] = fb ? 1u : 0u; s_hdr[3] = lo; s_hdr[4] = hi; }
+        }
+        if (tid < FT_CORE) s_cnt[tid] = 0u;
+        __syncthreads();
+        // (workgroup-uniform values are made scalar explicitly: loaded from LDS they count as divergent, and every loop they bound
+        // would be compiled with exec-mask bookkeeping per trip)
+        const uint32_t jw = sgpr(s_hdr[0]), W = sgpr(s_hdr[1]), lo = sgpr(s_hdr[3]), hi = sgpr(s_hdr[4]);
+        const uint32_t R = hi - lo;
+        bool fallback = sgpr(s_hdr[2]) != 0u;     // workgroup-uniform
+        const uint32_t cbit = ja - jw;            // window bit of the first core site
+        const int32_t w_base = sgpr(a.site_pos[jw]);
+        if (!fallback) {
+            const int32_t w_span = sgpr(a.site_pos[jw + W - 1]) - w_base + 1;
+            for (int p = tid; p < ((w_span + 3) & ~3); p += 256) s_bit[p] = 0xffu;
+            __syncthreads();
+            if (tid < (int)W) s_bit[a.site_pos[jw + tid] - w_base] = (uint8_t)tid;
+            __syncthreads();
+            // ---- phase 1: one candidate read per thread -> its row of the tile's table ----
+            bool bad = false;                     // a read that stores itself at a core site has a call without a window bit
+            for (uint32_t r = tid; r < ((R + 63u) & ~63u); r += 256) {
+                const bool valid = r < R;
+                const uint32_t i = lo + (valid ? r : 0u);
+                const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+                const int32_t rs = a.read_start[i], re = a.read_end[i];
+                const uint32_t mq = a.read_mapq[i];
+                const uint32_t n = o1 - o0;
+                const bool pass = valid & (mq >= (uint32_t)a.min_qual) & (n > 0u);            // fdrp.rs:205, 208
+                unsigned long long mC = 0, mM = 0;
+                uint32_t miss = 0, w0 = 0;
+                auto bit_at = [&](const uint32_t pos) {
+                    const uint32_t rel = pos - (uint32_t)w_base;
+                    return rel < (uint32_t)w_span ? (uint32_t)s_bit[rel] : 0xffu;
+                };
+                auto add_call = [&](const uint32_t w, const bool live) {
+                    const uint32_t b = bit_at(w & 0x7fffffffu);
+                    miss |= live ? b >> 7 : 0u;                                                // 0xff: not a site of the window
+                    const unsigned long long bb = live ? 1ull << (b & 63u) : 0ull;
+                    mC |= bb;
+                    mM |= bb & (unsigned long long)((long long)(int32_t)w >> 31);
+                };
+                // the calls four per load, a quad at a time (the address is clamped so that the quad lies inside the array; the few
+                // reads at the batch's end whose quad would cross it are re-read word by word)
+#pragma unroll
+                for (int q = 0; q < FD_NB / 4; ++q) {
+                    if (q != 0 && !__any(pass && n > (uint32_t)(4 * q))) break;                 // wave-uniform
+                    const uint32_t oq = o0 + (uint32_t)(4 * q);
+                    const uint32_t oq_safe = min(oq, a.n_cpgs - 4u);
+                    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + oq_safe);
+                    uint32_t cw[4] = {v.x, v.y, v.z, v.w};
+                    if (__builtin_expect(__any(oq != oq_safe), 0)) {
+                        if (oq != oq_safe) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) cw[k] = (oq + (uint32_t)k < a.n_cpgs) ? a.cpg_pos[oq + k] : 0u;
+                        }
+                    }
+                    if (q == 0) w0 = cw[0];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) add_call(cw[k], pass && (uint32_t)(4 * q + k) < n);
+                }
+                if (pass) for (uint32_t t = FD_NB; t < n; ++t) add_call(a.cpg_pos[o0 + t], true);
+                const uint32_t p0 = w0 & 0x7fffffffu;
+                // the one call that can lie outside the covered bases is the first, at start - 1 (a reverse read's)
+                const uint32_t abit = (pass && (int32_t)p0 < rs) ? bit_at(p0) & 63u : 0xffu;
+                if (abit != 0xffu) mM &= ~(1ull << abit);
+                // does the read store itself at a core site?  (those are the reads whose masks must be complete)
+                const unsigned long long core = miss ? 0ull : (mC >> cbit) & (ncore == 64u ? ~0ull : (1ull << ncore) - 1ull);
+                if (pass && miss) {
+                    // it calls a position outside the window: harmless if none of its calls is a core site -- decided on the calls
+                    bool hits_core = false;
+                    for (uint32_t t = 0; t < n; ++t) { const uint32_t b = bit_at(a.cpg_pos[o0 + t] & 0x7fffffffu); hits_core |= b != 0xffu && b >= cbit && b < cbit + ncore; }
+                    bad |= hits_core;
+                    mC = 0; mM = 0;
+                }
+                if (valid) {
+                    s_start[r] = rs;
+                    // first call - (start - 1) in 0 .. span; 0xff: not a flusher (the read does not pass)
+                    s_pack[r] = (uint32_t)(re - rs) | ((pass ? (uint32_t)((int32_t)p0 - (rs - 1)) : 0xffu) << 8) | (abit << 16);
+                    s_mC[r] = mC; s_mM[r] = mM;
+                    unsigned long long cm = core;
+                    while (cm) { const int b = __builtin_ctzll(cm); cm &= cm - 1ull; atomicAdd(&s_cnt[b], 1u); }
+                }
+            }
+            if (__syncthreads_or(bad ? 1 : 0)) fallback = true;
+        }
+        // ---- list space: C(n, 2) bytes (a multiple of 64) per core site that will be evaluated, one claim per tile ----
+        if (!fallback) {
+            if (wave == 0) {
+                const uint32_t n = lane < (int)ncore ? s_cnt[lane] : 0u;
+                const bool ev = lane < (int)ncore && n >= max(a.min_depth, 1u) && n <= (uint32_t)FT_LIST;
+                const uint32_t ns = min(n, dcap);
+                const uint32_t cap = ev ? ((ns * (ns - 1u) / 2u + 63u) & ~63u) : 0u;      // a round writes 64 bytes
+                uint32_t incl = cap;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+                const uint32_t total = __shfl(incl, 63, 64);
+                unsigned long long base = 0;
+                if (lane == 0 && total) base = atomicAdd(a.cursor, (unsigned long long)total);
+                base = __shfl(base, 0, 64);
+                if (lane < (int)ncore) s_off[lane] = base + incl - cap;
+                if (lane == 0) s_hdr[2] = (base + total > a.budget) ? 1u : 0u;
+            }
+            __syncthreads();
+            if (sgpr(s_hdr[2])) fallback = true;
+        }
+        if (fallback) {
+            if (tid < (int)ncore) a.flags[ja + tid] = FD_REDO;
+            if (wave == 0) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.redo_cnt, ncore);
+                base = __shfl(base, 0, 64);
+                if (lane < (int)ncore) a.redo_list[base + lane] = ja + lane;
+            }
+            continue;
+        }
+        // ---- phase 2: a wave per core site ----
+        uint32_t redo_bits = 0;
+        // a site's readers start in [c - max_span + 1, c + 1]: a sub-range of the tile's candidates, from the same index; the
+        // next site's two entries are requested a site ahead
+        auto range_of = [&](const uint32_t kk, uint32_t &r_lo, uint32_t &r_hi) {
+            const int32_t cc = a.site_pos[ja + min(kk, ncore - 1u)];
+            r_lo = a.idx[(uint32_t)(cc - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT];
+            r_hi = a.idx[((uint32_t)(cc + 1 - a.idx_base) >> IDX_QSHIFT) + 1];
+        };
+        uint32_t nx_lo, nx_hi;
+        range_of((uint32_t)wave, nx_lo, nx_hi);
+        for (uint32_t k = (uint32_t)wave; k < ncore; k += 4u) {
+            const uint32_t j = ja + k;
+            const uint32_t c_lo = max(sgpr(min(nx_lo, a.n_reads)), lo) - lo, c_hi = min(sgpr(min(nx_hi, a.n_reads)), hi) - lo;   // rows of the tile's table
+            range_of(k + 4u, nx_lo, nx_hi);
+            const int32_t c = sgpr(a.site_pos[j]);
+            const uint32_t b = cbit + k;
+            const uint32_t n_all = sgpr(s_cnt[k]);
+            __builtin_amdgcn_wave_barrier();      // the previous site's LDS reads are done
+            if (n_all < max(a.min_depth, 1u)) {                                                // fdrp.rs:239-243: no row
+                if (lane == 0) { a.fdrp[j] = 0.0f; a.qfdrp[j] = 0.0f; a.nreads[j] = 0u; a.flags[j] = 0u; }
+                continue;
+            }
+            bool redo = n_all > (uint32_t)FT_LIST;
+            // the site's readers in file order (its arrivals, fdrp.rs:226-231), and the flush rule on the same ballots
+            uint32_t n_arr = 0;
+            bool seen = false, closed = false;
+            for (uint32_t r0 = c_lo; r0 < c_hi && !redo; r0 += 64u) {
+                const uint32_t r = r0 + (uint32_t)lane;
+                const bool v = r < c_hi;
+                const unsigned long long mc = v ? s_mC[r] : 0ull;
+                const uint32_t pk = v ? s_pack[r] : 0xff00u;
+                const bool hit = (mc >> b) & 1ull;
+                const uint32_t fo = (pk >> 8) & 0xffu;
+                const bool fl = fo != 0xffu && s_start[v ? r : 0u] - 1 + (int32_t)fo > c;       // c < first call, fdrp.rs:212
+                const unsigned long long mh = __ballot(hit), mf = __ballot(fl);
+                if (mh) {
+                    if (closed) { redo = true; break; }                                         // a hit after a flusher: a second segment
+                    // flushers above the first hit of the segment close it: no hit may follow
+                    const unsigned long long above_first = seen ? ~0ull : ~((1ull << __builtin_ctzll(mh)) - 1ull);
+                    const unsigned long long f2 = mf & above_first;
+                    if (f2) {
+                        const int ff = __builtin_ctzll(f2);
+                        if (ff < 63 && (mh >> (ff + 1)) != 0ull) { redo = true; break; }
+                        closed = true;
+                    }
+                    seen = true;
+                    if (hit) list[n_arr + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u))] = (uint16_t)r;
+                    n_arr += (uint32_t)__popcll(mh);
+                } else if (seen && mf) closed = true;
+            }
+            // fdrp.rs:81-94: the first max_depth arrivals fill the slots; arrival t beyond (total = t + 1) replaces slot j - 1 when
+            // its draw j is <= max_depth.  Slot s ends up with the LAST such arrival, or with arrival s.
+            const uint32_t nS = min(n_arr, dcap);
+            if (!redo && a.max_depth > 64u && n_arr > 64u) redo = true;                         // more than this kernel's 64 slots are in use
+            if (!redo && n_arr > nS) {
+                for (uint32_t t = nS + (uint32_t)lane; t < n_arr; t += 64u) {
+                    const int32_t jr = sample_j(a.seed, a.tid, c, (int32_t)t + 1);
+                    draw[t] = (uint8_t)(jr <= (int32_t)nS ? jr : 0);                            // (max_depth <= 64 here: nS = max_depth)
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!redo && (uint32_t)lane < nS) {
+                uint32_t src = (uint32_t)lane;
+                for (uint32_t t = nS; t < n_arr; ++t) src = draw[t] == (uint8_t)(lane + 1) ? t : src;
+                const uint32_t r = list[src];
+                const uint32_t pk = s_pack[r];
+                const int32_t rs = s_start[r];
+                const unsigned long long mc = s_mC[r], mm = s_mM[r];
+                const uint32_t ab = pk >> 16;
+                const unsigned long long ma = ab == 0xffu ? mc : mc & ~(1ull << ab);
+                uint32_t *rw = rows + (uint32_t)lane * 8u;
+                rw[0] = (uint32_t)rs; rw[1] = (uint32_t)(rs + (int32_t)(pk & 0xffu));
+                rw[2] = (uint32_t)mc; rw[3] = (uint32_t)(mc >> 32); rw[4] = (uint32_t)ma; rw[5] = (uint32_t)(ma >> 32);
+                rw[6] = (uint32_t)mm; rw[7] = (uint32_t)(mm >> 32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t disc = 0;
+            const unsigned long long off_v = s_off[k];
+            const unsigned long long off = ((unsigned long long)sgpr((uint32_t)(off_v >> 32)) << 32) | sgpr((uint32_t)off_v);
+            if (!redo) {
+                const int P = (int)(nS * (nS - 1u)) >> 1;
+                const uint16_t *const tab = a.pair_tab + (nS * (nS - 1u) * (nS - 2u)) / 6u;
+                uint8_t *const tp = a.terms + off;
+                uint32_t ent_next = tab[P ? min(lane, P - 1) : 0];
+                uint32_t over = 0;
+                for (int k0 = 0; k0 < P; k0 += 64) {
+                    const uint32_t ent = ent_next;
+                    if (k0 + 64 < P) ent_next = tab[min(k0 + 64 + lane, P - 1)];
+                    const int pi = (int)(ent & 0xffu), pj = (int)(ent >> 8);
+                    const uint32_t *ri = rows + pi * 8, *rj = rows + pj * 8;
+                    const int32_t si = (int32_t)ri[0], ei = (int32_t)ri[1], sj = (int32_t)rj[0], ej = (int32_t)rj[1];
+                    const int32_t ov = min(ei, ej) - max(si, sj) + 1;                           // get_num_overlap_bases, fdrp.rs:97-107
+                    const bool pair_ok = (k0 + lane < P) & (max(ov, 0) >= a.min_overlap);        // fdrp.rs:134
+                    const uint32_t ncpg = __builtin_popcount(ri[2] & rj[2]) + __builtin_popcount(ri[3] & rj[3]);   // qfdrp.rs:109-119
+                    const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) +
+                                         __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));                      // fdrp.rs:114-115
+                    disc += (pair_ok && ham != 0u) ? 1u : 0u;                                   // fdrp.rs:138-140
+                    over = max(over, pair_ok ? ncpg : 0u);                                                // (more than 21 shared calls: looked at once, after the rounds)
+                    // Every pair's term goes to the site's list at the pair's own index, as one byte: ncpg (ncpg + 1) / 2 + ham (the
+                    // chain kernel's table gives ham / ncpg: +0.0 when ham is 0 -- x + 0.0 == x -- and NaN for 0 / 0); a skipped
+                    // pair is code 1 = 0 / 1.  Four codes per dword (two DPP ORs inside each quad of lanes), 16 lanes store 64 bytes.
+                    const uint32_t code = pair_ok ? __umul24(ncpg, ncpg + 1u) / 2u + ham : 1u;
+                    uint32_t pk = code << (8 * (lane & 3));
+                    pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, true);
+                    pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x4e /*quad_perm [2,3,0,1]*/, 0xf, 0xf, true);
+                    if ((lane & 3) == 0) *reinterpret_cast<uint32_t *>(tp + k0 + lane) = pk;
+                }
+                if (__any(over > FT_NCPG_MAX)) redo = true;                                     // a code did not fit its byte: the list is void
+            }
+            if (redo) {
+                redo_bits |= 1u << k;
+                if (lane == 0) a.flags[j] = FD_REDO;
+            } else {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) disc += __shfl_xor(disc, o, 64);
+                if (lane == 0) { a.site_off[j] = off; a.site_nz[j] = (nS * (nS - 1u)) >> 1; a.site_disc[j] = disc; a.nreads[j] = nS; a.flags[j] = FD_CHAIN; }
+            }
+        }
+        // the tile's handed-back sites, appended to the list k_fdrp_walk takes them from
+        if (lane == 0) s_redo[wave] = redo_bits;
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t m = s_redo[0] | s_redo[1] | s_redo[2] | s_redo[3];
+            if (m) {                                                            // workgroup-uniform
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.redo_cnt, (uint32_t)__builtin_popcount(m));
+                base = __shfl(base, 0, 64);
+                if (lane < 32 && ((m >> lane) & 1u)) a.redo_list[base + (uint32_t)__builtin_popcount(m & ((1u << lane) - 1u))] = ja + (uint32_t)lane;
+            }
+        }
+    }
+}
+
+// one thread per site: the ordered f32 sum over the site's listed terms (qfdrp.rs:152), then fdrp.rs:143 / qfdrp.rs:155
+__global__ __launch_bounds__(256) void k_fdrp_chain(const FdrpArgs a) {
+    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    if (blockIdx.x * 256u >= n_sites) return;              // (the grid comes from the host's upper bound of the site count)
+    __shared__ float s_q[256];
+    {   // code = ncpg (ncpg + 1) / 2 + ham, ham <= ncpg <= 21: the quotient by the division the pair loop would do (0 / 0 = NaN at code 0)
+        uint32_t ncpg = 0;
+        while ((ncpg + 1u) * (ncpg + 2u) / 2u <= (uint32_t)threadIdx.x) ++ncpg;
+        s_q[threadIdx.x] = (float)((uint32_t)threadIdx.x - ncpg * (ncpg + 1u) / 2u) / (float)ncpg;
+    }
+    __syncthreads();
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n_sites || a.flags[j] != FD_CHAIN) return;
+    const uint8_t *__restrict__ t = a.terms + a.site_off[j];
+    const uint32_t nz = a.site_nz[j];
+    float q = 0.0f;
+    // A list starts on a 64-byte boundary and owns a multiple of 64 bytes: a lane takes a whole cache line per trip (four 16-byte
+    // loads; 16 bytes per trip had every line fetched four times over, the L1 does not hold 64 lanes' lines), the next line is
+    // requested before this one is used.  The codes past the list's end inside its last line are what the tile kernel's last
+    // round wrote for the lanes without a pair: code 1 = 0 / 1 = +0.0, and x + 0.0 == x -- whole lines are added.
+    const uint4 *__restrict__ t4 = reinterpret_cast<const uint4 *>(t);
+    uint4 v[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    if (nz) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = t4[u];
+    }
+    for (uint32_t i = 0; i < nz; i += 64u) {
+        uint32_t w[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { w[4 * u] = v[u].x; w[4 * u + 1] = v[u].y; w[4 * u + 2] = v[u].z; w[4 * u + 3] = v[u].w; }
+        if (i + 64u < nz) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = t4[(i >> 4) + 4u + (uint32_t)u];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float f[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) f[k] = s_q[(w[4 * g + (k >> 2)] >> (8 * (k & 3))) & 0xffu];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) q += f[k];
+        }
+    }
+    const uint32_t nS = a.nreads[j];
+    // (num_reads * (num_reads - 1)) as f32 / 2.0 in usize arithmetic (fdrp.rs:143)
+    const unsigned long long prod = (unsigned long long)(long long)nS * (unsigned long long)((long long)nS - 1);
+    const float den = (float)prod / 2.0f;
+    a.fdrp[j] = (float)a.site_disc[j] / den;
+    a.qfdrp[j] = q / den;
+    a.flags[j] = 1u;
+}
+
 __global__ __launch_bounds__(256) void k_fdrp_emit(const uint32_t *__restrict__ flags, const int32_t *__restrict__ site_pos,
                                                    const float *__restrict__ f, const float *__restrict__ q,
                                                    const uint32_t *__restrict__ nr, const DevState *__restrict__ sites_st,
@@ -831,7 +1220,7 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     MTH_HIP(ctx, ctx->w_aux.reserve(bound * 4, s));
     MTH_HIP(ctx, ctx->w_flags.reserve(bound * 4, s));
     if (!ctx->f_state.p) {
-        MTH_HIP(ctx, ctx->f_state.reserve(4 * sizeof(unsigned long long), s));
+        MTH_HIP(ctx, ctx->f_state.reserve(4 * sizeof(unsigned long long), s));      // rows, base, the tile form's list cursor
         MTH_HIP(ctx, hipMemsetAsync(ctx->f_state.p, 0, 4 * sizeof(unsigned long long), s));
     }
     const uint64_t need = ctx->f_rows_bound + bound;
@@ -859,6 +1248,8 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     a.min_depth = (uint32_t)std::min<uint64_t>(params->min_depth, 0xffffffffull); a.max_depth = params->max_depth;
     a.min_qual = params->min_qual;
     a.rows_scratch = nullptr; a.slots_cap = 0;
+    a.redo_list = nullptr; a.redo_cnt = nullptr;
+    a.terms = nullptr; a.cursor = nullptr; a.budget = 0; a.site_off = nullptr; a.site_nz = nullptr; a.site_disc = nullptr;
     if (!ctx->f_pairtab.p) {
         // the pairs of n stored reads in the reference's (i, j) loop order (fdrp.rs:129-141), n = 2..64, one after the other
         std::vector<uint16_t> t;
@@ -889,6 +1280,40 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         int walk4 = (!dense && d.max_span <= 200 && cand <= 16.0) ? 16 : 0;                                 // lanes per site
         if (const char *e = getenv("METHEOR_FDRP_WALK4")) { const int k = atoi(e); walk4 = d.max_span <= 200 ? (k == 1 ? 16 : (k == 16 || k == 32 ? k : 0)) : 0; }
         a.only_flag = 0u; a.redo_mask = nullptr;
+        // The read x read form (k_fdrp_tile + k_fdrp_chain) for everything the four-sites-per-wave kernel does not take:
+        // METHEOR_FDRP_TILE=0 / 1 forces the choice (A/B, tests).
+        bool tile = d.max_span <= 200 && !walk4;
+        if (const char *e = getenv("METHEOR_FDRP_TILE")) { tile = d.max_span <= 200 && atoi(e) != 0; if (tile) walk4 = 0; }
+        if (tile) {
+            const uint64_t dcap = std::min<uint64_t>(std::max<uint32_t>(params->max_depth, 1u), 64u);
+            // sum over sites of C(n, 2) <= (dcap - 1) / 2 x the sum of n <= (dcap - 1) / 2 x the batch's calls; + the 64-byte rounding
+            const uint64_t budget = (uint64_t)d.n_cpgs * (dcap - 1) / 2 + 64 * bound + 64;
+            MTH_HIP(ctx, ctx->f_terms.reserve(budget, s));
+            MTH_HIP(ctx, ctx->f_soff.reserve(bound * 8, s));
+            MTH_HIP(ctx, ctx->f_snz.reserve(bound * 4, s));
+            MTH_HIP(ctx, ctx->f_sdisc.reserve(bound * 4, s));
+            MTH_HIP(ctx, ctx->f_redo.reserve((bound + 2) * 4, s));
+            unsigned long long *cur = ctx->f_state.as<unsigned long long>() + 2;
+            MTH_HIP(ctx, hipMemsetAsync(cur, 0, 16, s));
+            a.redo_list = ctx->f_redo.as<uint32_t>(); a.redo_cnt = reinterpret_cast<uint32_t *>(cur + 1);
+            a.terms = ctx->f_terms.as<uint8_t>(); a.cursor = cur; a.budget = budget;
+            a.site_off = ctx->f_soff.as<unsigned long long>(); a.site_nz = ctx->f_snz.as<uint32_t>(); a.site_disc = ctx->f_sdisc.as<uint32_t>();
+            const uint32_t gridt = (uint32_t)std::min<uint64_t>((bound + FT_CORE - 1) / FT_CORE, 8192);
+            if (dense) hipLaunchKernelGGL(k_fdrp_tile<16>, dim3(gridt), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(k_fdrp_tile<8>, dim3(gridt), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_fdrp_chain, dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, s, a);
+            a.only_flag = FD_REDO;
+            if (getenv("METHEOR_FDRP_DEBUG")) {          // how much the tile form handed back (synchronises: debugging only)
+                DevState st;
+                unsigned long long cursor = 0;
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(&st, ctx->d_state2, sizeof st, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&cursor, cur, 8, hipMemcpyDeviceToHost);
+                unsigned long long redo = 0;
+                { uint32_t rc = 0; (void)hipMemcpy(&rc, a.redo_cnt, 4, hipMemcpyDeviceToHost); redo = rc; }
+                fprintf(stderr, "[fdrp tile] sites %llu handed back %llu, list bytes claimed %llu of %llu\n", (unsigned long long)st.n_sites, redo, cursor, (unsigned long long)budget);
+            }
+        }
         if (walk4) {
             MTH_HIP(ctx, ctx->f_redo.reserve((bound / 64 + 2) * 8, s));
             a.redo_mask = ctx->f_redo.as<unsigned long long>();

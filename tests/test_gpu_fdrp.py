@@ -17,14 +17,21 @@ f32 = np.float32
 TOL = 1e-6
 
 
-@pytest.fixture(autouse=True, params=["auto", "walk16", "walk32"])
+@pytest.fixture(autouse=True, params=["auto", "walk16", "walk32", "tile", "walk"])
 def walk_choice(request, monkeypatch):
-    """every case three times: with the host's own choice between the wave-per-site walk and k_fdrp_walk4 (16 or 32 lanes per
-    site, the rest handed back to the general walk), and with either width forced -- on dense data mostly the hand-back path"""
-    if request.param != "auto":
+    """every case five times: with the host's own choice of kernel form; with k_fdrp_walk4 forced (16 or 32 lanes per site, the
+    rest handed back to the general walk -- on dense data mostly the hand-back path); with the read x read form forced
+    (k_fdrp_tile + k_fdrp_chain, round 4); and with the wave-per-site walk alone"""
+    monkeypatch.delenv("METHEOR_FDRP_WALK4", raising=False)
+    monkeypatch.delenv("METHEOR_FDRP_TILE", raising=False)
+    if request.param.startswith("walk") and len(request.param) > 4:
         monkeypatch.setenv("METHEOR_FDRP_WALK4", request.param[4:])
-    else:
-        monkeypatch.delenv("METHEOR_FDRP_WALK4", raising=False)
+        monkeypatch.setenv("METHEOR_FDRP_TILE", "0")
+    elif request.param == "tile":
+        monkeypatch.setenv("METHEOR_FDRP_TILE", "1")
+    elif request.param == "walk":
+        monkeypatch.setenv("METHEOR_FDRP_TILE", "0")
+        monkeypatch.setenv("METHEOR_FDRP_WALK4", "0")
     return request.param
 
 

@@ -75,21 +75,24 @@ def scenario(seed):
 
 
 def fdrp_checked(eng, cs, fk, regions, reads):
-    """FDRP / qFDRP against the oracle, then once more with k_fdrp_walk4 (four sites per wave, hand-back to the general walk) forced
-    on: the same rows bit for bit"""
+    """FDRP / qFDRP against the oracle with the engine's own choice of kernel form, then once more with each form forced --
+    k_fdrp_walk4 (four sites per wave, hand-back to the general walk), the read x read form (k_fdrp_tile + k_fdrp_chain), the
+    wave-per-site walk alone: the same rows bit for bit"""
     import os
     d0 = T_fdrp.run_device(eng, cs, fk, regions=regions)
     T_fdrp.check(d0, reads, fk)
-    os.environ["METHEOR_FDRP_WALK4"] = "16"
-    try:
-        d1 = T_fdrp.run_device(eng, cs, fk, regions=regions)
-    finally:
-        del os.environ["METHEOR_FDRP_WALK4"]
-    assert len(d0["pos"]) == len(d1["pos"])
-    for k in ("tid", "pos", "n_reads"):
-        assert (d0[k] == d1[k]).all(), k
-    for k in ("fdrp", "qfdrp"):
-        assert (d0[k].view(np.uint32) == d1[k].view(np.uint32)).all(), k
+    for env in (dict(METHEOR_FDRP_WALK4="16", METHEOR_FDRP_TILE="0"), dict(METHEOR_FDRP_TILE="1"), dict(METHEOR_FDRP_WALK4="0", METHEOR_FDRP_TILE="0")):
+        os.environ.update(env)
+        try:
+            d1 = T_fdrp.run_device(eng, cs, fk, regions=regions)
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert len(d0["pos"]) == len(d1["pos"]), env
+        for k in ("tid", "pos", "n_reads"):
+            assert (d0[k] == d1[k]).all(), (k, env)
+        for k in ("fdrp", "qfdrp"):
+            assert (d0[k].view(np.uint32) == d1[k].view(np.uint32)).all(), (k, env)
 
 
 @pytest.mark.parametrize("seed", range(96))
