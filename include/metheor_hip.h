@@ -138,7 +138,9 @@ int  mth_pdr_device_view(mth_ctx_t *ctx, uint64_t *n_sites, const int32_t **pos,
  * *lpmd = compute_lpmd() with the reference's wrapping i32 counters (lpmd.rs:11-12,51-55) */
 int  mth_lpmd_global(mth_ctx_t *ctx, int64_t out[4], float *lpmd);
 /* lpmd.rs:176-179: records that never enter a batch (no contig, no aligned base) still count in n_read, and in n_valid_read when
- * their mapq passes; the caller that left them out of its batches adds their counts here (queued on the context's stream) */
+ * their mapq passes; the caller that left them out of its batches adds their counts here (queued on the context's stream).
+ * lpmd.rs:181 builds a BismarkRead for every record whose mapq passes, placed or not: a passing record without XM:Z is the
+ * reference's panic -- both decoders refuse such a record before it can be counted here (mth_decode_set_xm_min_mapq) */
 int  mth_lpmd_add_unbatched(mth_ctx_t *ctx, uint64_t n_read, uint64_t n_valid_read);
 /* multi-GPU: enqueue (on the ctx stream) a copy of the 4 exact int64 counters into a DEVICE buffer
  * the caller owns, ready for an RCCL all-reduce(sum) over ranks; no host synchronisation */

@@ -231,6 +231,7 @@ struct Shard {
     bool region = false;
     std::string region_name, bai;
     int32_t r_beg = 0, r_end = INT32_MAX;          // 0-based [r_beg, r_end); INT32_MAX = to the end of the contig's data
+    bool order_free = false;                       // set by lpmd / me / pm: their result does not depend on the record order (see load())
     bool planned() const { return world > 1 || region; }
 };
 thread_local Shard g_shard;
@@ -360,7 +361,6 @@ int window_to_device(void *user, const uint8_t *buf, const uint64_t *rec_off, ui
 // Whole load path on the device (mth_bgzf_decode): the file's bytes go to the GPU as they are, BGZF inflate, record
 // boundaries and record decode all happen there.  Needs every BGZF block to hold whole records (what htslib-family
 // writers produce); returns false -- with the context reset -- for a file where that does not hold.
-bool g_order_free = false;     // set by lpmd / me / pm: their result does not depend on the record order (see load())
 
 bool load_bgzf_on_device(Input &in) {
     mth_host_bgzf_t bz;
@@ -477,7 +477,7 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
         bool regroup = n_runs > cap || (flags & 4u);
         for (uint32_t k = 0; k < std::min(n_runs, cap) && !regroup; ++k)
             for (uint32_t j = 0; j < k; ++j) if (tids[j] == tids[k]) regroup = true;
-        if (regroup && g_order_free && !(flags & 3u) && !g_shard.planned()) {
+        if (regroup && g_shard.order_free && !(flags & 3u) && !g_shard.planned()) {
             Phase ps("  device sort by (tid, start)");
             check(in.ctx, mth_decoded_sort(in.ctx));
             check(in.ctx, mth_decoded_contigs(in.ctx, cap, tids.data(), rb.data(), re.data(), &n_runs, &flags));
@@ -509,10 +509,17 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
 // the stream moves past them (pdr.rs:160-177, mhl.rs:162-173, fdrp.rs:206-218): their output on unsorted input is a function
 // of the record order itself, which batches cut by contig do not carry -- those subcommands keep refusing it, loudly.
 bool reads_in_order(const int32_t *tid, const int32_t *st, int64_t n) {
-    // records without a contig (a sorted BAM keeps them at its end) or without an aligned base never enter a batch: not looked at
+    // Records without an aligned base never enter a batch: not looked at.  Records without a contig (a sorted BAM keeps them at
+    // its end) do not either, but the batching loop below cuts the contigs' runs at them: one BETWEEN two placed records -- tids
+    // 0, -1, 0 re-open contig 0's run; 0, -1, 1 is harmless but not what a sort gives -- counts as out of order, so that the
+    // order-free measures sort the file (the stable sort puts such records first, where they are skipped and counted) instead of
+    // dying on "not grouped by contig".
     int64_t p = -1;
+    bool loose_seen = false;
     for (int64_t i = 0; i < n; ++i) {
-        if (tid[i] < 0 || st[i] < 0) continue;
+        if (tid[i] < 0) { loose_seen = p >= 0; continue; }
+        if (loose_seen) return false;
+        if (st[i] < 0) continue;
         if (p >= 0 && (tid[i] < tid[p] || (tid[i] == tid[p] && st[i] < st[p]))) return false;
         p = i;
     }
@@ -546,7 +553,7 @@ Input load(const std::string &path, const char *cpg_set) {
     const uint32_t *pos = mth_host_cpg_pos(in.h);
     const uint16_t *rel = mth_host_cpg_rel(in.h);
     if (!reads_in_order(tid, st, n)) {
-        if (!g_order_free)
+        if (!g_shard.order_free)
             die("input BAM is not coordinate-sorted (or not grouped by contig).  pdr, mhl, fdrp and qfdrp finalise a CpG as the reads move "
                 "past it (pdr.rs:160-177, mhl.rs:162-173, fdrp.rs:206-218): on unsorted input their output depends on the record order "
                 "itself, which the MI355X path does not replay -- sort the file (samtools sort).  lpmd, me and pm take any order.");
@@ -758,7 +765,7 @@ int run_lpmd(const Args &a) {
     // lpmd.rs:161-164
     fprintf(stderr, "Computing subset-LPMD with parameters input=%s, min_distance=%d, max_distance=%d\n", input.c_str(), mind, maxd);
     g_shard.xm_min_mapq = (int)a.n.at("min-qual");      // lpmd.rs:176-181: the mapq filter comes before BismarkRead::new (the XM panic)
-    g_order_free = true;
+    g_shard.order_free = true;
     Input in = load(input, a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
     mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_pdr_lpmd_params_t p;
@@ -811,7 +818,7 @@ int run_lpmd(const Args &a) {
 // me.rs:68-88 / pm.rs:63-83: one line per quartet with depth >= min_depth,
 // chrom, pos1..pos4, value (me.rs:57-65).  The reference iterates a HashMap (random order).
 int run_quartet(const Args &a, bool want_me) {
-    g_order_free = true;
+    g_shard.order_free = true;
     Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
     mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
     mth_quartet_params_t p;

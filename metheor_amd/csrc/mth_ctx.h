@@ -73,6 +73,7 @@ struct mth_ctx {
     uint32_t dec_xm_min_mapq = 0;       // records without XM:Z are an error from this mapq up (0: always)
     uint64_t dec_filter_n = 0;
     uint64_t dec_reads = 0, dec_cpgs = 0;
+    uint32_t dec_contig_flags = 0;      // flags of the latest mth_decoded_contigs over the decoded stream (bit0 / bit1: records a batch cannot hold)
     // device-side BGZF inflate + per-block record walk (mth_inflate.hip)
     mth::DevBuf inf_file, inf_tab, inf_raw, inf_cnt, inf_base, inf_recoff, crc_mat;
     // mth_bgzf_stage: the NEXT chunk's file bytes, copied on a side stream while the current chunk is being inflated

@@ -491,6 +491,7 @@ int mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *r
     MTH_HIP(ctx, hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, s));
     MTH_HIP(ctx, hipStreamSynchronize(s));
     *n_runs = hc[0]; *flags = hc[1];
+    ctx->dec_contig_flags = hc[1];
     const uint32_t k = std::min(hc[0], cap);
     if (k) {
         std::vector<uint64_t> hb(k);

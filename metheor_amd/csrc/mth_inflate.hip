@@ -18,10 +18,12 @@
 
 namespace mth {
 
-// Reads of a CORRUPT last block can run past the staged file bytes: garbage keeps decoding as literals until the output bound
-// (isize <= 64 KiB) stops it, <= 10 bits each -- 80 KiB of input at most.  The staging buffers carry that much padding, so the
-// scalar loads of the bit reader always stay inside the allocation (the CRC / ISIZE checks then flag the block).
-constexpr size_t INF_FILE_PAD = 96 * 1024;
+// Reads of a CORRUPT last block can run past the staged file bytes: garbage keeps decoding until the output bound (isize <= 64 KiB)
+// stops it.  A literal costs at most 15 bits (the direct-lookup width LROOT is not the code length limit: DEFLATE codes go up to 15
+// bits) = 120 KiB of input for 64 Ki literals; a match costs at most 15 + 5 + 15 + 13 bits and yields >= 3 bytes: less per output
+// byte.  The staging buffers carry 160 KiB of zeroed padding, so the bit reader's scalar loads always stay inside the allocation
+// and read defined bytes (the CRC / ISIZE checks then flag the block).
+constexpr size_t INF_FILE_PAD = 160 * 1024;
 
 constexpr int LROOT = 10, DROOT = 9;          // direct-lookup bits of the literal/length and distance tables
 struct InflArgs {
@@ -533,7 +535,7 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
         // (copying through own page-locked pieces from 2-8 worker threads was measured: no faster than the runtime's pageable path,
         // profiles/r02_e2e.md -- the page-cache reads bound both)
         if (n_bytes) MTH_HIP(ctx, hipMemcpyAsync(ctx->inf_file.p, file, (size_t)n_bytes, hipMemcpyHostToDevice, s));
-        MTH_HIP(ctx, hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file.p) + n_bytes, 0, 64, s));
+        MTH_HIP(ctx, hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file.p) + n_bytes, 0, INF_FILE_PAD, s));
     }
     // (before the inflate is launched: allocating it afterwards synchronised with the inflate and delayed the first CRC launch by ~7 ms)
     if (!ctx->crc_mat.p) {
@@ -559,7 +561,7 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
             if (!ok(hipSetDevice(ctx->device))) return;
             if (!ok(ctx->inf_file2.reserve((size_t)nbytes + INF_FILE_PAD, ctx->copy_stream))) return;
             if (!ok(hipMemcpyAsync(ctx->inf_file2.p, src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->copy_stream))) return;
-            if (!ok(hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file2.p) + nbytes, 0, 64, ctx->copy_stream))) return;
+            if (!ok(hipMemsetAsync(static_cast<uint8_t *>(ctx->inf_file2.p) + nbytes, 0, INF_FILE_PAD, ctx->copy_stream))) return;
             if (!ok(hipEventRecord(ctx->staged_ev, ctx->copy_stream))) return;
             ctx->staged_src = src; ctx->staged_bytes = nbytes;
         });
@@ -609,7 +611,7 @@ static int inflate_blocks(mth_ctx *ctx, const void *file, uint64_t n_bytes, cons
                 MTH_HIP(ctx, hipMemcpyAsync(dst + off, src + off, len, hipMemcpyHostToDevice, ctx->piece_stream));
                 off += len;
                 const bool last = off == (size_t)n_bytes;
-                if (last) MTH_HIP(ctx, hipMemsetAsync(dst + n_bytes, 0, 64, ctx->piece_stream));
+                if (last) MTH_HIP(ctx, hipMemsetAsync(dst + n_bytes, 0, INF_FILE_PAD, ctx->piece_stream));
                 MTH_HIP(ctx, event(k));
                 MTH_HIP(ctx, hipEventRecord(ctx->piece_ev[k], ctx->piece_stream));
                 MTH_HIP(ctx, hipStreamWaitEvent(s, ctx->piece_ev[k], 0));

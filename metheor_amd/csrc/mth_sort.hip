@@ -54,6 +54,10 @@ extern "C" int mth_decoded_sort(mth_ctx_t *ctx) {
     MTH_ENTER(ctx);
     hipStream_t s = ctx->stream;
     const uint64_t R = ctx->dec_reads, Cn = ctx->dec_cpgs;
+    // keys are tid << 32 | start as unsigned numbers: a record without a contig (tid < 0) or without an aligned base (start < 0) would
+    // sort last, silently, into batches the tile kernels do not expect -- the caller must have looked (mth_decoded_contigs) and
+    // take the host path for such files
+    if (ctx->dec_contig_flags & 3u) return fail(ctx, MTH_ERR_STATE, "mth_decoded_sort: the decoded stream holds records without a contig or without an aligned base (mth_decoded_contigs flags bit 0 / 1)");
     if (R < 2) return MTH_OK;
     if (R >= (1ull << 31)) return fail(ctx, MTH_ERR_CAPACITY, "more than 2^31 records in one sort");
     const uint32_t n = (uint32_t)R;

@@ -616,3 +616,36 @@ def test_lpmd_counts_records_that_enter_no_batch(tmp_path):
         o = pyoracle.lpmd_bam(bam, min_qual=q) if hasattr(pyoracle, "lpmd_bam") else None
         if o is not None:
             assert int(got["n_read"]) == int(o["n_read"]) and int(got["n_valid_read"]) == int(o["n_valid_read"])
+
+
+def test_contigless_record_between_two_runs_of_a_contig(tmp_path):
+    """tids 0, -1, 0 -- a record without a contig between two runs of one contig.  The order-free measures accept it
+    (sorted like any other out-of-order file: the unplaced record goes first, where it is skipped and counted), and give what the
+    oracle gives for the file as it is; the flush-based measures refuse it with the usual reason instead of "not grouped"."""
+    rec = _two_contig_records(29)
+    n = len(rec.tid)
+    cut = 4_000
+    tid = np.concatenate([rec.tid[:cut], np.array([-1], np.int32), rec.tid[cut:]])
+    pos = np.concatenate([rec.pos[:cut], np.array([-1], np.int32), rec.pos[cut:]])
+    flag = np.concatenate([rec.flag[:cut], np.array([4], np.uint16), rec.flag[cut:]])
+    mapq = np.concatenate([rec.mapq[:cut], np.array([40], np.uint8), rec.mapq[cut:]])
+    cig = list(rec.cigars[:cut]) + [[(50 << 4) | 4]] + list(rec.cigars[cut:])
+    xms = list(rec.xms[:cut]) + [b"." * 50] + list(rec.xms[cut:])
+    rec2 = bamio.Records(rec.refs, tid, pos, flag, mapq, cig, xms)
+    bam = str(tmp_path / "loose_mid.bam")
+    bamio.write_bam(bam, rec2)
+    reads = pyoracle.Reads.decode(rec2)
+    o = tmp_path / "o.tsv"
+    for env in ({}, {"METHEOR_HOST_DECODE": "1"}):
+        r = run_env(dict(env, METHEOR_DEBUG_COUNTS="1"), "lpmd", "-i", bam, "-o", str(o))
+        assert r.returncode == 0, r.stderr
+        res = reads.lpmd(min_distance=2, max_distance=16, min_qual=10)
+        assert o.read_text() == "name\tlpmd\n%s\t%s\n" % (bam, pyoracle.format_f32(res["lpmd"]))
+        line = [l for l in r.stderr.splitlines() if l.startswith("[metheor counts]")][0]
+        got = dict(kv.split("=") for kv in line.split()[2:])
+        assert int(got["n_read"]) == n + 1 == res["n_read"] and int(got["n_valid_read"]) == res["n_valid_read"]
+        r = run_env(env, "pm", "-i", bam, "-o", str(o), "-d", "5")
+        assert r.returncode == 0, r.stderr
+        assert sorted(o.read_text().splitlines()) == _quartet_lines(reads.pm(min_depth=5, min_qual=10), ["chrS1", "chrS2"])
+    r = run("pdr", "-i", bam, "-o", str(o))
+    assert r.returncode == 101 and "not coordinate-sorted" in r.stderr, r.stderr

@@ -386,3 +386,26 @@ def test_long_reads_lpmd_only(eng):
         for k in ("n_concordant", "n_discordant", "n_read", "n_valid_read"):
             assert l[k] == o[k], (k, l[k], o[k])
         assert f32(l["lpmd"]).view(np.uint32) == f32(o["lpmd"]).view(np.uint32)
+
+
+def test_density_chooser_takes_the_wide_form_on_sparse_batches(eng, kernel_form):
+    """the per-batch choice between the dense tile kernel and the hashed-site form (launch_pdr_lpmd) is what production
+    runs; with MTH_PDR_WIDE unset a WGBS-density batch must take k_pdr_lpmd_wide and a config-2-density batch the dense kernel
+    (seen through the engine's per-kernel timers), both equal to the oracle"""
+    if kernel_form != "auto":
+        pytest.skip("the chooser only runs when MTH_PDR_WIDE is unset")
+    from metheor_amd import PdrLpmdParams, synth
+    rng = np.random.default_rng(91)
+    kw = dict(min_depth=3, min_cpgs=2, min_qual=10)
+    for dens, n_reads, want in ((0.0091, 200_000, "k_pdr_lpmd_wide"), (0.02, 500_000, "k_pdr_lpmd_tile")):
+        c = synth.make_contig(0, 3_000_000, n_reads, dens, rng)
+        reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+        eng.timing_enable(True)
+        eng.timing_reset()
+        p, l = run_device(eng, [c], PdrLpmdParams(**kw), device="cuda:0")
+        t = eng.timing()
+        eng.timing_enable(False)
+        eng.timing_reset()
+        ran = {k for k, v in t.items() if v[1] > 0 and k.startswith("k_pdr_lpmd")}
+        assert ran == {want}, (dens, t)
+        check_against_oracle(p, l, reads, kw, dict())
