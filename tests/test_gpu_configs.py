@@ -217,3 +217,93 @@ def test_config5_sharded_8_vs_oracle_text(wgbs24, tmp_path):
         assert len(want) > (20 if sub == "lpmd" else 10_000), sub
         if sub == "lpmd":
             assert pf.read_text() == want_pairs and want_pairs.count("\n") > 10_000
+
+
+def test_config3_full_size_200M_reads_properties():
+    """BASELINE config 3 AT FULL SIZE under pytest: S-WGBS-200M -- 200 M x 150-bp reads over the 24 hg38-sized contigs,
+    generated on the device (metheor_amd/synth_device.py) -- every measure over every contig, checked through size-independent
+    properties computed from the SoA with torch on the device, per contig: PDR's per-strand mass (sum of n_concordant / n_discordant
+    = calls of the concordant / discordant passing reads) and its site list (= the distinct positions those reads call); LPMD's four
+    counters in closed form (the pair count of the default window by shifted comparisons); the quartet histograms' mass and the
+    pairs table's column sums; MHL / FDRP / qFDRP: the rows are exactly the sites with >= min_depth contributing reads, minus the
+    few whose contributors fall into several segments (bounded below by 0.98 of them), coverage <= contributors, values in [0, 1]."""
+    import torch
+    import metheor_amd
+    from metheor_amd import PdrLpmdParams, synth_device
+    dev = torch.device("cuda", 0)
+    eng = metheor_amd.Engine(0)
+    kw = dict(min_depth=10, min_cpgs=4, min_qual=10)
+    tot_reads = 0
+    exp = dict(nc=0, nd=0, n_read=0, n_valid=0, lc=0, ld=0, quart=0)
+    sites_pdr, rows = [], dict(mhl=0, fdrp=0, mhl_max=0, fdrp_max=0)
+    eng.reset()
+    for bt, info in synth_device.wgbs(n_reads=200_000_000, device=dev):
+        rs, mq, off, pos, rel = bt.keep[0], bt.keep[2], bt.keep[3].to(torch.int64) & 0xffffffff, bt.keep[4], bt.keep[5]
+        n = int(rs.shape[0])
+        tot_reads += n
+        ncpg = off[1:] - off[:-1]
+        total = int(off[-1].item())
+        read_of = torch.repeat_interleave(torch.arange(n, device=dev), ncpg, output_size=total)
+        meth = ((pos.to(torch.int64) >> 31) & 1)
+        p31 = pos.to(torch.int64) & 0x7fffffff
+        msum = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, read_of, meth)
+        disc = (msum > 0) & (msum < ncpg)
+        okq = mq >= 10
+        ok_pdr = okq & (ncpg >= kw["min_cpgs"])
+        # PDR (pdr.rs:147-191): every call of a passing read adds one to its site
+        cov = torch.zeros(info["length"] + 2, dtype=torch.int32, device=dev)
+        cov.index_add_(0, p31[ok_pdr[read_of]], torch.ones(int(ok_pdr[read_of].sum().item()), dtype=torch.int32, device=dev))
+        keep_site = cov >= kw["min_depth"]
+        dsc = torch.zeros(info["length"] + 2, dtype=torch.int32, device=dev)
+        sel = (ok_pdr & disc)[read_of]
+        dsc.index_add_(0, p31[sel], torch.ones(int(sel.sum().item()), dtype=torch.int32, device=dev))
+        exp["nd"] += int(dsc[keep_site].sum().item())
+        exp["nc"] += int((cov - dsc)[keep_site].sum().item())
+        sites_pdr.append(torch.nonzero(keep_site).flatten().to(torch.int32).cpu().numpy())
+        # LPMD (lpmd.rs:176-190)
+        exp["n_read"] += n
+        exp["n_valid"] += int(okq.sum().item())
+        lp_ok = okq[read_of]
+        r64 = rel.to(torch.int64)
+        for g in range(1, 9):                           # CpGs are >= 2 bp apart: at most 8 gaps inside 16 bp
+            same = (read_of[g:] == read_of[:-g]) & lp_ok[g:]
+            dist = r64[g:] - r64[:-g]
+            inw = same & (dist >= 2) & (dist <= 16)
+            dd = inw & (meth[g:] != meth[:-g])
+            d = int(dd.sum().item())
+            exp["ld"] += d
+            exp["lc"] += int(inw.sum().item()) - d
+        exp["quart"] += int(torch.clamp(ncpg[okq] - 3, min=0).sum().item())
+        # MHL: contributors = passing reads with >= min_cpgs calls (mhl.rs:176-190); FDRP: passing reads with >= 1 call (fdrp.rs:205-231)
+        rows["mhl_max"] += int((cov >= kw["min_depth"]).sum().item())
+        covf = torch.zeros(info["length"] + 2, dtype=torch.int32, device=dev)
+        covf.index_add_(0, p31[lp_ok], torch.ones(int(lp_ok.sum().item()), dtype=torch.int32, device=dev))
+        rows["fdrp_max"] += int((covf >= 10).sum().item())
+        del cov, dsc, covf, read_of, meth, p31, msum, r64
+        eng.pdr_lpmd_accumulate(bt, PdrLpmdParams(**kw))
+        eng.quartet_accumulate(bt, 10)
+        eng.lpmd_pairs_accumulate(bt, 2, 16, 10)
+        eng.mhl_accumulate(bt, **kw)
+        eng.fdrp_accumulate(bt, min_qual=10, min_depth=10, max_depth=40, min_overlap=35)
+        eng.sync()                                      # the batch's tensors go away with the loop variable
+    assert tot_reads == 200_000_000 or abs(tot_reads - 200_000_000) < 24
+    p, l = eng.pdr_fetch(), eng.lpmd_global()
+    want_pos = np.concatenate(sites_pdr)
+    assert len(p["pos"]) == len(want_pos) and (p["pos"] == want_pos).all()
+    assert (np.diff(p["tid"]) >= 0).all() and p["tid"][0] == 0 and p["tid"][-1] == 23
+    assert int(p["n_concordant"].astype(np.int64).sum()) == exp["nc"] and int(p["n_discordant"].astype(np.int64).sum()) == exp["nd"]
+    assert ((p["n_concordant"] + p["n_discordant"]) >= kw["min_depth"]).all()
+    assert (l["n_read"], l["n_valid_read"], l["n_concordant"], l["n_discordant"]) == (exp["n_read"], exp["n_valid"], exp["lc"], exp["ld"])
+    q = eng.quartet_fetch(0)
+    assert int(q["cnt"].astype(np.int64).sum()) == exp["quart"]
+    pr = eng.lpmd_pairs_fetch()
+    assert int(pr["n_concordant"].astype(np.int64).sum()) == exp["lc"] and int(pr["n_discordant"].astype(np.int64).sum()) == exp["ld"]
+    dm, df = eng.mhl_fetch(), eng.fdrp_fetch()
+    assert 0.98 * rows["mhl_max"] <= len(dm["pos"]) <= rows["mhl_max"], (len(dm["pos"]), rows)
+    assert 0.98 * rows["fdrp_max"] <= len(df["pos"]) <= rows["fdrp_max"], (len(df["pos"]), rows)
+    assert (dm["cov"] >= 10).all() and np.nanmin(dm["mhl"]) >= 0.0 and np.nanmax(dm["mhl"]) <= 1.0
+    assert (df["n_reads"] >= 10).all() and (df["n_reads"] <= 40).all()
+    for k in ("fdrp", "qfdrp"):
+        assert np.nanmin(df[k]) >= 0.0 and np.nanmax(df[k]) <= 1.0
+    assert len(dm["pos"]) > 300_000 and len(df["pos"]) > 10_000_000
+    eng.close()

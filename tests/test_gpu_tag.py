@@ -45,14 +45,14 @@ def device_xm(eng, sam_path, contigs, paired=False):
     return out
 
 
-def test_device_reproduces_the_reference_output_for_all_1000_reads(eng, chr19):
+def test_device_reproduces_the_golden_xm_8864_letters_md_derived_680_via_29_fitted_flank_bases(eng, chr19):
     got = device_xm(eng, chr19["noxm"], [(chr19["ln"], chr19["contig"])])
     assert len(got) == 1000
     bad = [(k, r.xm, g) for k, (r, g) in enumerate(zip(chr19["reads"], got)) if g.decode() != r.xm]
     assert not bad, bad[:3]
 
 
-def test_cli_tag_golden_bytes(chr19, tmp_path):
+def test_cli_tag_golden_bytes_genome_rebuilt_from_md_tags_29_flank_bases_fitted(chr19, tmp_path):
     # tests/tag-cli.rs:60-80: metheor tag -i test.chr19.noXM.sam -o out.sam -g <genome>; out.sam == test.chr19.XM.sam
     out = tmp_path / "test.chr19.metheor_tag_out.sam"
     r = subprocess.run([EXE, "tag", "-i", chr19["noxm"], "-o", str(out), "-g", chr19["fa"]], capture_output=True, text=True, cwd=ROOT, timeout=600)

@@ -29,7 +29,11 @@ def test_fixture_is_what_the_reference_ships(chr19):
     assert (chr19["n_interior"], chr19["n_letters"], chr19["n_inferred"]) == (8864, 9544, 29)
 
 
-def test_oracle_reproduces_the_reference_output_for_all_1000_reads(chr19):
+def test_oracle_reproduces_the_golden_xm_8864_letters_md_derived_680_via_29_fitted_flank_bases(chr19):
+    """What this pins and what it does not: hg38.chr19.fa is not shipped, the contig is rebuilt from the reads' MD:Z
+    tags.  8864 of the golden's 9544 context letters look only at MD-derived bases: those are an independent check.  The other 680
+    sit in a read's last two columns and look at one of 29 flank bases no read covers, which tests/tag_util.py CHOSE so that the
+    golden letter comes out: for them the test is circular and only shows that one consistent choice exists."""
     contig = bytes(chr19["contig"])
     bad = []
     for k, r in enumerate(chr19["reads"]):
