@@ -950,8 +950,8 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
         if (!fallback) {
             if (wave == 0) {
                 const uint32_t n = lane < (int)ncore ? s_cnt[lane] : 0u;
-                const bool ev = lane < (int)ncore && n >= max(a.min_depth, 1u) && n <= (uint32_t)FT_LIST;
                 const uint32_t ns = min(n, dcap);
+                const bool ev = lane < (int)ncore && ns >= max(a.min_depth, 1u) && n <= (uint32_t)FT_LIST;
                 const uint32_t cap = ev ? ((ns * (ns - 1u) / 2u + 63u) & ~63u) : 0u;      // a round writes 64 bytes
                 uint32_t incl = cap;
 #pragma unroll
@@ -995,7 +995,8 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
             const uint32_t b = cbit + k;
             const uint32_t n_all = sgpr(s_cnt[k]);
             __builtin_amdgcn_wave_barrier();      // the previous site's LDS reads are done
-            if (n_all < max(a.min_depth, 1u)) {                                                // fdrp.rs:239-243: no row
+            // fdrp.rs:239-243: a row needs get_num_reads() = the STORED reads (at most max_depth of the arrivals) >= min_depth
+            if (min(n_all, a.max_depth) < max(a.min_depth, 1u)) {
                 if (lane == 0) { a.fdrp[j] = 0.0f; a.qfdrp[j] = 0.0f; a.nreads[j] = 0u; a.flags[j] = 0u; }
                 continue;
             }

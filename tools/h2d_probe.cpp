@@ -4,6 +4,7 @@
 //   1  N threads pread() into page-locked pieces (ring of 2 per thread), hipMemcpyAsync per piece on a stream per thread
 //   2  as 1, the threads memcpy() from the mmap instead of pread()
 //   3  mmap with MAP_POPULATE, then as 0
+//   4  N threads, each ONE pageable hipMemcpyAsync of its share of the mmap'ed file on its own stream (round 4)
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -38,7 +39,23 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&dev, n + 4096));
     const double t1 = now();
     double t_setup = 0;
-    if (variant == 0 || variant == 3) {
+    if (variant == 4) {
+        const uint8_t *m = (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        std::vector<hipStream_t> st((size_t)nthr);
+        for (auto &s : st) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        t_setup = now() - t1;
+        std::vector<std::thread> th;
+        const size_t share = ((n + (size_t)nthr - 1) / (size_t)nthr + 4095) & ~(size_t)4095;
+        for (int k = 0; k < nthr; ++k) th.emplace_back([&, k] {
+            (void)hipSetDevice(0);
+            const size_t off = (size_t)k * share;
+            if (off >= n) return;
+            const size_t len = std::min(share, n - off);
+            (void)hipMemcpyAsync((uint8_t *)dev + off, m + off, len, hipMemcpyHostToDevice, st[(size_t)k]);
+            (void)hipStreamSynchronize(st[(size_t)k]);
+        });
+        for (auto &t : th) t.join();
+    } else if (variant == 0 || variant == 3) {
         void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | (variant == 3 ? MAP_POPULATE : 0), fd, 0);
         t_setup = now() - t1;
         CK(hipMemcpy(dev, m, n, hipMemcpyHostToDevice));
