@@ -116,7 +116,14 @@ int  mth_reset(mth_ctx_t *ctx);
 
 /* ---- PDR + LPMD, fused single pass (pdr.rs:119-212, lpmd.rs:154-202) --------------------
  * Asynchronous: kernels are enqueued on the ctx stream; data errors (UNSORTED/SPAN/REOPEN/
- * RANGE) are detected on the device and reported by the next synchronising call below. */
+ * RANGE) are detected on the device and reported by the next synchronising call below.
+ * Pipelining (round 4): from the second of a run of consecutive calls with device-resident batches on (mth_reset does not break a
+ * run), the engine runs the batches on two internal streams, ordered behind the work already enqueued on the ctx stream at the time
+ * of the call; the ctx stream is ordered behind them again by every other entry point of this header (getters, mth_ctx_sync, the
+ * other measures, mth_ctx_set_stream, mth_ctx_destroy).  Consequence for a caller that enqueues its OWN work on the stream it gave
+ * to mth_ctx_set_stream: the arrays of a device-resident batch must not be overwritten or freed in stream order right behind the
+ * call -- only after the next entry point that joins (as they always had to outlive the asynchronous kernels).  MTH_PIPELINE=0 in
+ * the environment keeps everything on the ctx stream. */
 int  mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch,
                              const mth_pdr_lpmd_params_t *params);
 /* number of emitted sites so far (synchronises) */
