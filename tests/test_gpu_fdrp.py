@@ -251,12 +251,14 @@ def test_capacity_and_empty(eng):
     eng.reset()
 
 
-def test_max_depth_above_64(eng):
+def test_max_depth_above_64(eng, walk_choice):
     """the main pass stores at most 64 reads per site (one lane each); with max_depth > 64 deeper sites are redone by a
     256-slot pass (pair-parallel merge of the call lists) -- exact, including the reservoir branch beyond max_depth;
     sites beyond 256 stored reads by a third pass with rows in HBM scratch (round 2: the reference has no such limit;
     output_validation.rs runs --max-depth 100); only max_depth > 16384 is refused"""
     from metheor_amd import MthError, synth
+    if walk_choice in ("walk16", "walk32"):
+        pytest.skip("40 s a form: the deep passes sit behind the first pass whatever its form -- host's choice, tile and walk cover them")
     c = synth.make_contig(0, 300_000, 50_000, 0.03, np.random.default_rng(91))           # ~25x: every site below 64 reads
     reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
     kw = dict(min_qual=10, min_depth=5, max_depth=100, min_overlap=20)

@@ -396,7 +396,7 @@ def test_density_chooser_takes_the_wide_form_on_sparse_batches(eng, kernel_form)
         pytest.skip("the chooser only runs when MTH_PDR_WIDE is unset")
     from metheor_amd import PdrLpmdParams, synth
     rng = np.random.default_rng(91)
-    kw = dict(min_depth=3, min_cpgs=2, min_qual=10)
+    kw = dict(min_depth=3, min_cpgs=4, min_qual=10)        # (the CLI's min_cpgs: the chooser weighs the expected insertions per read)
     for dens, n_reads, want in ((0.0091, 200_000, "k_pdr_lpmd_wide"), (0.02, 500_000, "k_pdr_lpmd_tile")):
         c = synth.make_contig(0, 3_000_000, n_reads, dens, rng)
         reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
