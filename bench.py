@@ -185,8 +185,43 @@ def _split(dt, ph):
     kern = ph.get("H2D + kernels (sync)", 0.0)
     # ("fetch + TSV write" is the CLI's outer phase around "fetch" and "format + write": one or the other, never their sum)
     tail = ph["fetch + TSV write"] if "fetch + TSV write" in ph else ph.get("fetch", 0.0) + ph.get("format + write", 0.0)
+    # what the start-up remainder is made of, as far as the process itself can tell: the HIP runtime coming up
+    # (hipGetDeviceCount is where it initialises; properties, first stream, first allocations behind it) -- a box effect shows here
+    hip = {k[4:]: v for k, v in ph.items() if k.startswith("ctx/")}
     return {"wall_s": round(dt, 4), "startup_s": round(max(dt - load - kern - tail, 0.0), 4), "load_s": round(load, 4), "kernels_s": round(kern, 4),
-            "tail_s": round(tail, 4), "device_context_overlapped_s": ph.get("device context (overlapped)", ph.get("device context"))}
+            "tail_s": round(tail, 4), "device_context_overlapped_s": ph.get("device context (overlapped)", ph.get("device context")),
+            "hip_init_s": round(hip.get("hipGetDeviceCount", 0.0), 4), "hip_context_rest_s": round(sum(v for k, v in hip.items() if k != "hipGetDeviceCount"), 4),
+            "load_plus_tail_s": round(load + tail, 4)}
+
+
+def _resident_fraction(path):
+    """fraction of the file's pages in the page cache (mincore over a read-only mapping); None when it cannot be told"""
+    try:
+        import ctypes
+        import mmap
+        size = os.path.getsize(path)
+        if size == 0:
+            return None
+        libc = ctypes.CDLL(None, use_errno=True)
+        ps = mmap.PAGESIZE
+        n = (size + ps - 1) // ps
+        vec = (ctypes.c_ubyte * n)()
+        fd = os.open(path, os.O_RDONLY)
+        libc.mmap.restype = ctypes.c_void_p
+        libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+        p = libc.mmap(None, size, 1, 2, fd, 0)                                     # PROT_READ, MAP_PRIVATE
+        os.close(fd)
+        if p in (None, ctypes.c_void_p(-1).value):
+            return None
+        libc.mincore.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_ubyte)]
+        rc = libc.mincore(ctypes.c_void_p(p), size, vec)
+        libc.munmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        libc.munmap(ctypes.c_void_p(p), size)
+        if rc != 0:
+            return None
+        return round(sum(1 for b in bytes(vec) if b & 1) / n, 4)
+    except Exception:
+        return None
 
 
 def e2e_leg(c, n_reads, large_copies=10):
@@ -215,7 +250,7 @@ def e2e_leg(c, n_reads, large_copies=10):
                "M_reads_per_s_best": round(n_reads / runs[0][0] / 1e6, 2), "M_reads_per_s_median": round(n_reads / med[0] / 1e6, 2),
                "median_run": _split(*med), "best_run": _split(*runs[0]),
                "load_phase_M_reads_per_s_median": round(n_reads / max(_split(*med)["load_s"], 1e-9) / 1e6, 1),
-               "bam_write_s": round(t_write, 1)}
+               "input_in_page_cache_frac": _resident_fraction(bam), "bam_write_s": round(t_write, 1)}
         os.remove(bam)
         # ---- the larger file ----
         try:
