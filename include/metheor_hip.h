@@ -309,6 +309,28 @@ int  mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *
  * record order (lpmd.rs:175-200, me.rs:106-125, pm.rs:101-121): an input that is not coordinate-sorted or not grouped by contig
  * can then be batched like a sorted one.  Every record must have a contig and an aligned base (flags bit0 / bit1 clear). */
 int  mth_decoded_sort(mth_ctx_t *ctx);
+
+/* ---- PDR, MHL, FDRP and qFDRP of a decoded stream that is NOT coordinate-sorted (mth_fileorder.hip) ----------------------------
+ * The reference iterates the records in file order and never checks it (pdr.rs:139, mhl.rs:155, fdrp.rs:197, qfdrp.rs:209); these
+ * four measures finalise a site when a later record's first CpG lies beyond it (pdr.rs:160-177 margin 150, passing records;
+ * mhl.rs:162-173 any record with a CpG; fdrp.rs:212-223 passing records) and a site that is called again starts over, the last
+ * segment with enough reads winning.  On a sorted file the per-contig batches compute that; for any other order this call replays
+ * the stream itself, over the WHOLE decoded stream (mth_decode_records / mth_bgzf_decode, --cpg-set filter included) in the order
+ * it was decoded: rows sorted by (tid, pos) as the reference's BTreeMap gives them.
+ *   MTH_FO_PDR  v0 = pdr, c0 = n_concordant, c1 = n_discordant        (min_depth, min_cpgs, min_qual)
+ *   MTH_FO_MHL  v0 = mhl, c0 = coverage                                (min_depth, min_cpgs, min_qual)
+ *   MTH_FO_FDRP v0 = fdrp, v1 = qfdrp, c0 = stored reads               (min_depth, min_qual, max_depth <= 256, min_overlap, seed)
+ * Synchronous.  MTH_ERR_CAPACITY beyond 2^31 records / calls, MHL reads with > 1024 CpGs, --max-depth > 256. */
+enum { MTH_FO_PDR = 0, MTH_FO_MHL = 1, MTH_FO_FDRP = 2 };
+typedef struct {
+    int32_t  measure;
+    uint32_t min_depth, min_cpgs, max_depth;
+    int32_t  min_overlap;
+    uint8_t  min_qual;
+    uint64_t seed;
+} mth_fileorder_params_t;
+int  mth_fileorder_run(mth_ctx_t *ctx, const mth_fileorder_params_t *params);
+int  mth_fileorder_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos, float *v0, float *v1, uint32_t *c0, uint32_t *c1);
 /* reads [read_beg, read_end) of the decoded stream -- ONE contig's reads (or a region slice of them) -- as a
  * device-resident batch for the accumulate calls: 32-bit offsets rebased on the device, max_span reduced on
  * the device.  region_end < 0 = up to the last position these reads cover (reduced on the device too): what a

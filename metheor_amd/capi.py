@@ -16,7 +16,7 @@ SYMBOLS = [
     "mth_pdr_fetch", "mth_result_buffer_alloc", "mth_result_buffer_free", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_add_unbatched", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
     "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
-    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_bgzf_stage", "mth_decode_reserve", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_sort", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
+    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_bgzf_stage", "mth_decode_reserve", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_sort", "mth_fileorder_run", "mth_fileorder_fetch", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -61,6 +61,11 @@ class mth_mhl_params_t(C.Structure):
 class mth_fdrp_params_t(C.Structure):
     _fields_ = [("min_depth", C.c_uint64), ("seed", C.c_uint64), ("max_depth", C.c_uint32),
                 ("min_overlap", C.c_int32), ("min_qual", C.c_uint8)]
+
+
+class mth_fileorder_params_t(C.Structure):
+    _fields_ = [("measure", C.c_int32), ("min_depth", C.c_uint32), ("min_cpgs", C.c_uint32), ("max_depth", C.c_uint32),
+                ("min_overlap", C.c_int32), ("min_qual", C.c_uint8), ("seed", C.c_uint64)]
 
 
 class mth_lpmd_pairs_params_t(C.Structure):
@@ -137,6 +142,8 @@ def lib():
         L.mth_decoded_fetch.argtypes = [vp] * 9
         L.mth_decoded_contigs.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.mth_decoded_sort.argtypes = [vp]
+        L.mth_fileorder_run.argtypes = [vp, C.POINTER(mth_fileorder_params_t)]
+        L.mth_fileorder_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 6
         L.mth_decoded_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(mth_batch_t)]
         L.mth_timing_enable.argtypes = [vp, C.c_int]
         L.mth_timing_reset.argtypes = [vp]
@@ -456,6 +463,19 @@ class Engine:
     def decoded_sort(self):
         """the decoded stream re-ordered by (tid, start) on the device (order-free measures on unsorted input)"""
         self._check(self.L.mth_decoded_sort(self.h))
+
+    def fileorder(self, measure, min_depth=10, min_cpgs=4, min_qual=10, max_depth=40, min_overlap=35, seed=0):
+        """PDR (0) / MHL (1) / FDRP + qFDRP (2) of the decoded stream in FILE order: the reference's stream semantics on input that is
+        not coordinate-sorted (mth_fileorder.hip); rows sorted by (tid, pos)"""
+        p = mth_fileorder_params_t(int(measure), int(min_depth), int(min_cpgs), int(max_depth), int(min_overlap), int(min_qual), int(seed))
+        self._check(self.L.mth_fileorder_run(self.h, C.byref(p)))
+        n = C.c_uint64(0)
+        self._check(self.L.mth_fileorder_fetch(self.h, C.byref(n), None, None, None, None, None, None))
+        k = n.value
+        out = dict(tid=np.zeros(k, np.int32), pos=np.zeros(k, np.int32), v0=np.zeros(k, np.float32), v1=np.zeros(k, np.float32),
+                   c0=np.zeros(k, np.uint32), c1=np.zeros(k, np.uint32))
+        self._check(self.L.mth_fileorder_fetch(self.h, C.byref(n), *[out[x].ctypes.data_as(C.c_void_p) for x in ("tid", "pos", "v0", "v1", "c0", "c1")]))
+        return out
 
     def decoded_batch(self, read_beg, read_end, tid, region_beg, region_end):
         """device-resident batch over reads [read_beg, read_end) of the decoded stream (one contig)"""

@@ -278,6 +278,7 @@ struct Input {
     std::vector<uint16_t> s_rel;
     mth_ctx_t *ctx = nullptr;   // set when the records were decoded on the device (the batches live in its HBM)
     bool device = false;
+    bool file_order = false;               // pdr / mhl / fdrp / qfdrp on input that is not coordinate-sorted: no batches, the decoded stream itself (mth_fileorder_run)
     std::vector<uint8_t> unbatched_mapq;   // mapq of the records that entered no batch (no contig / no aligned base): lpmd.rs:176-179 counts them
 };
 
@@ -481,6 +482,13 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
             Phase ps("  device sort by (tid, start)");
             check(in.ctx, mth_decoded_sort(in.ctx));
             check(in.ctx, mth_decoded_contigs(in.ctx, cap, tids.data(), rb.data(), re.data(), &n_runs, &flags));
+        } else if (regroup && !g_shard.order_free && !g_shard.planned()) {
+            // pdr / mhl / fdrp / qfdrp finalise sites as the stream moves past them: on such input their result is a function of the
+            // record order itself (pdr.rs:139-178, mhl.rs:155-173, fdrp.rs:197-223), which the decoded stream still has -- replayed as
+            // it is (mth_fileorder.hip), no batches
+            in.file_order = true;
+            in.device = true;
+            return true;
         }
     }
     if (flags || n_runs > cap) return false;                       // unaligned / contig-less records, or contigs not grouped
@@ -554,9 +562,10 @@ Input load(const std::string &path, const char *cpg_set) {
     const uint16_t *rel = mth_host_cpg_rel(in.h);
     if (!reads_in_order(tid, st, n)) {
         if (!g_shard.order_free)
-            die("input BAM is not coordinate-sorted (or not grouped by contig).  pdr, mhl, fdrp and qfdrp finalise a CpG as the reads move "
-                "past it (pdr.rs:160-177, mhl.rs:162-173, fdrp.rs:206-218): on unsorted input their output depends on the record order "
-                "itself, which the MI355X path does not replay -- sort the file (samtools sort).  lpmd, me and pm take any order.");
+            die("input BAM is not coordinate-sorted (or not grouped by contig), and it had to be decoded on the host (records that straddle "
+                "BGZF blocks, or METHEOR_HOST_DECODE): pdr, mhl, fdrp and qfdrp finalise a CpG as the reads move past it (pdr.rs:160-177, "
+                "mhl.rs:162-173, fdrp.rs:206-218), so their output on such input depends on the record order itself, which only the device "
+                "decode path replays (mth_fileorder_run) -- sort the file (samtools sort).  lpmd, me and pm take any order.");
         Phase ps("  sort by (tid, start)");
         std::vector<int64_t> perm((size_t)n);
         for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = i;
@@ -723,6 +732,31 @@ void gang_allreduce_lpmd(mth_ctx_t *ctx) {
     if (g_gang.rc != MTH_OK) check(g_gang.ctxs[0], g_gang.rc);
 }
 
+// pdr / mhl / fdrp / qfdrp of an input that is not coordinate-sorted: the stream replayed in file order on the device
+// (mth_fileorder.hip); which: 0 = the PDR line (pdr.rs:102-116), 1 = value v0 (mhl.rs:114-132, fdrp.rs:162-173), 2 = value v1 (qfdrp.rs:174-185)
+int run_file_order(const Args &a, Input &in, mth_ctx_t *ctx, const mth_fileorder_params_t &fp, int which) {
+    uint64_t n = 0;
+    {
+        Phase ph("file-order replay (kernels, sync)");
+        check(ctx, mth_fileorder_run(ctx, &fp));
+        check(ctx, mth_fileorder_fetch(ctx, &n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+    }
+    Phase ph3("fetch + TSV write");
+    std::vector<int32_t> tid(n), pos(n);
+    std::vector<float> v0(n), v1(n);
+    std::vector<uint32_t> c0(n), c1(n);
+    check(ctx, mth_fileorder_fetch(ctx, &n, tid.data(), pos.data(), v0.data(), v1.data(), c0.data(), c1.data()));
+    FILE *f = open_output(a.s.at("output"));
+    write_rows(f, n, [&](LineWriter &w, uint64_t i) {
+        w.str(mth_host_ref_name(in.h, tid[i])); w.ch('\t'); w.i32(pos[i]); w.ch('\t'); w.i32(pos[i] + 2); w.ch('\t');
+        if (which == 0) { w.f32(v0[i]); w.ch('\t'); w.u32(c0[i]); w.ch('\t'); w.u32(c1[i]); }
+        else w.f32(which == 2 ? v1[i] : v0[i]);
+        w.eol();
+    });
+    if (fclose(f) != 0) die("Error writing to output file.");
+    return finish(ctx, in.h);
+}
+
 int run_pdr(const Args &a) {
     Input in = load(a.s.at("input"), a.has("cpg-set") ? a.s.at("cpg-set").c_str() : nullptr);
     mth_ctx_t *ctx = in.ctx ? in.ctx : make_ctx();
@@ -732,6 +766,12 @@ int run_pdr(const Args &a) {
     p.pdr_min_cpgs = (uint32_t)std::min<int64_t>(a.n.at("min-cpgs"), UINT32_MAX);
     p.pdr_min_qual = (uint8_t)a.n.at("min-qual");
     p.want_pdr = 1;
+    if (in.file_order) {
+        mth_fileorder_params_t fp;
+        memset(&fp, 0, sizeof fp);
+        fp.measure = MTH_FO_PDR; fp.min_depth = p.pdr_min_depth; fp.min_cpgs = p.pdr_min_cpgs; fp.min_qual = p.pdr_min_qual;
+        return run_file_order(a, in, ctx, fp, 0);
+    }
     uint64_t n = 0;
     {
         Phase ph("H2D + kernels (sync)");
@@ -858,6 +898,12 @@ int run_mhl(const Args &a) {
     p.min_depth = (uint32_t)a.n.at("min-depth");
     p.min_cpgs = (uint32_t)std::min<int64_t>(a.n.at("min-cpgs"), UINT32_MAX);
     p.min_qual = (uint8_t)a.n.at("min-qual");
+    if (in.file_order) {
+        mth_fileorder_params_t fp;
+        memset(&fp, 0, sizeof fp);
+        fp.measure = MTH_FO_MHL; fp.min_depth = p.min_depth; fp.min_cpgs = p.min_cpgs; fp.min_qual = p.min_qual;
+        return run_file_order(a, in, ctx, fp, 1);
+    }
     for (const Contig &c : in.contigs) {
         const mth_batch_t b = make_batch(in, c);
         check(ctx, mth_mhl_accumulate(ctx, &b, &p));
@@ -887,6 +933,13 @@ int run_fdrp(const Args &a, bool quantitative) {
     p.min_overlap = (int32_t)a.n.at("min-overlap");
     const char *seed = getenv("METHEOR_SEED");       // reservoir draws (the reference's are OS-seeded)
     p.seed = seed ? strtoull(seed, nullptr, 10) : 0;
+    if (in.file_order) {
+        mth_fileorder_params_t fp;
+        memset(&fp, 0, sizeof fp);
+        fp.measure = MTH_FO_FDRP; fp.min_depth = (uint32_t)std::min<uint64_t>(p.min_depth, UINT32_MAX); fp.max_depth = p.max_depth;
+        fp.min_overlap = p.min_overlap; fp.min_qual = p.min_qual; fp.seed = p.seed;
+        return run_file_order(a, in, ctx, fp, quantitative ? 2 : 1);
+    }
     for (const Contig &c : in.contigs) {
         const mth_batch_t b = make_batch(in, c);
         check(ctx, mth_fdrp_accumulate(ctx, &b, &p));

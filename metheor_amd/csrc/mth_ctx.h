@@ -131,6 +131,10 @@ struct mth_ctx {
     uint64_t f_cap = 0, f_rows_bound = 0;
     std::vector<mth::BatchMeta> f_batches;
 
+    // the flush-based measures of a stream that is not coordinate-sorted (mth_fileorder.hip): work arrays, result rows
+    mth::DevBuf fo_sel, fo_flag, fo_tmp, fo_out;
+    uint64_t fo_rows = 0;
+
     // LPMD per-pair table (mth_pairs.hip)
     mth::DevBuf p_state, p_keys, p_cnt, p_out_key, p_out_cnt, p_batch_rows, p_tflag, p_tile_row0, p_tile_rows;
     uint64_t p_cap = 0, p_rows = 0;        // row capacity of p_out_*, rows in use (known exactly: one sync per batch)

@@ -545,7 +545,7 @@ def _permute(rec, perm):
 def test_unsorted_input_order_free_measures(tmp_path, kind):
     """lpmd.rs:175-200, me.rs:106-125, pm.rs:101-121 iterate the records in whatever order the file has into maps that are only read
     at the end: LPMD (+ its pairs table), ME and PM of a shuffled BAM equal those of the sorted one -- and the oracle's, which
-    streams the shuffled records as they come.  PDR / MHL / FDRP / qFDRP refuse it and say why."""
+    streams the shuffled records as they come.  PDR / MHL / FDRP / qFDRP depend on the order: replayed in file order on the device."""
     rec = _two_contig_records(23)
     n = len(rec.tid)
     rng = np.random.default_rng(5)
@@ -586,9 +586,26 @@ def test_unsorted_input_order_free_measures(tmp_path, kind):
     for g, w in zip(got, wl):
         gf, wf = g.split("\t"), w.split("\t")
         assert gf[:5] == wf[:5] and abs(float(gf[5]) - float(wf[5])) <= 1e-6
-    for sub in ("pdr", "mhl", "fdrp", "qfdrp"):
-        r = run(sub, "-i", bam, "-o", str(o))
-        assert r.returncode == 101 and "not coordinate-sorted" in r.stderr and "lpmd, me and pm take any order" in r.stderr, (sub, r.stderr)
+    # PDR / MHL / FDRP / qFDRP finalise sites as the stream moves past them (pdr.rs:160-177, mhl.rs:162-173, fdrp.rs:212-223): their
+    # output on such a file is a function of the record order, replayed on the device (mth_fileorder.hip) -- byte for byte what the
+    # oracle gives streaming the same file
+    names = ["chrS1", "chrS2"]
+    for dmin in (0, 2):
+        r = run("pdr", "-i", bam, "-o", str(o), "-d", str(dmin), "-p", "2")
+        assert r.returncode == 0, r.stderr
+        assert o.read_text() == util.oracle_tsv_pdr(reads, names, min_depth=dmin, min_cpgs=2, min_qual=10)
+        r = run("mhl", "-i", bam, "-o", str(o), "-d", str(dmin), "-p", "2")
+        assert r.returncode == 0, r.stderr
+        t = reads.mhl(min_depth=dmin, min_cpgs=2, min_qual=10)
+        assert o.read_text() == "".join("%s\t%d\t%d\t%s\n" % (names[ti], p, p + 2, pyoracle.format_f32(v)) for ti, p, v in zip(t.tid, t.pos[:, 0], t.val))
+        for sub, tab in (("fdrp", reads.fdrp(min_qual=10, min_depth=dmin, max_depth=40, min_overlap=35)),
+                         ("qfdrp", reads.qfdrp(min_qual=10, min_depth=dmin, max_depth=40, min_overlap=35))):
+            r = run(sub, "-i", bam, "-o", str(o), "-d", str(dmin))
+            assert r.returncode == 0, (sub, r.stderr)
+            assert o.read_text() == "".join("%s\t%d\t%d\t%s\n" % (names[ti], p, p + 2, pyoracle.format_f32(v)) for ti, p, v in zip(tab.tid, tab.pos[:, 0], tab.val)), sub
+    # the host-decode fallback does not replay the order: loud
+    r = run_env({"METHEOR_HOST_DECODE": "1"}, "pdr", "-i", bam, "-o", str(o))
+    assert r.returncode == 101 and "not coordinate-sorted" in r.stderr and "lpmd, me and pm take any order" in r.stderr, r.stderr
 
 
 def test_lpmd_counts_records_that_enter_no_batch(tmp_path):
@@ -647,5 +664,6 @@ def test_contigless_record_between_two_runs_of_a_contig(tmp_path):
         r = run_env(env, "pm", "-i", bam, "-o", str(o), "-d", "5")
         assert r.returncode == 0, r.stderr
         assert sorted(o.read_text().splitlines()) == _quartet_lines(reads.pm(min_depth=5, min_qual=10), ["chrS1", "chrS2"])
-    r = run("pdr", "-i", bam, "-o", str(o))
-    assert r.returncode == 101 and "not coordinate-sorted" in r.stderr, r.stderr
+    r = run("pdr", "-i", bam, "-o", str(o), "-d", "2")          # the flush-based measures replay the file's order (mth_fileorder.hip)
+    assert r.returncode == 0, r.stderr
+    assert o.read_text() == util.oracle_tsv_pdr(reads, ["chrS1", "chrS2"], min_depth=2, min_cpgs=4, min_qual=10)
