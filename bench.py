@@ -639,6 +639,11 @@ def strong_main(args, rank, world, local_rank, in_rank):
     sites = gather_scalar(int(eng.pdr_count()), torch.int64)
     if rccl or world == 1:
         assert lg["n_read"] == total_reads, (lg, total_reads)
+    elif use_dist:
+        # TEST MODE (--share-devices: the ranks share devices, RCCL refuses that): the ranks' counters summed with gloo on host copies --
+        # the job's n_read must still be the genome's
+        per_rank_n_read = gather_scalar(int(lg["n_read"]), torch.int64)
+        assert sum(per_rank_n_read) == total_reads, (per_rank_n_read, total_reads)
     coll = None
     if rccl:
         fence()
@@ -672,6 +677,9 @@ def strong_main(args, rank, world, local_rank, in_rank):
                "imbalance": round(max(per_rank_own) / (sum(per_rank_own) / world), 4),
                "imbalance_reads": round(max(per_rank_reads) / (sum(per_rank_reads) / world), 4),
                "sites_emitted_total": int(sum(sites)), "collective_ms": coll, "generate_s": round(t_gen, 2), "timed_region_s": round(dt, 4)}
+        if use_dist and not rccl:
+            out["valid"] = False
+            out["collective"] = "gloo on host copies (TEST MODE: ranks share devices)"
         print(json.dumps(out), flush=True)
     eng.close()
     if use_dist:
