@@ -841,9 +841,14 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
     const uint32_t n_tiles = (n_sites + FT_CORE - 1) / FT_CORE;
     const uint32_t dcap = min(a.max_depth, 64u);  // stored reads a site of this kernel can hold (fdrp.rs:81-85)
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint32_t ja = tile * FT_CORE, jb = min(ja + (uint32_t)FT_CORE, n_sites);       // core sites [ja, jb)
+      const uint32_t t_beg = tile * FT_CORE, t_end = min(t_beg + (uint32_t)FT_CORE, n_sites);
+      // a tile is taken as ONE core of 32 sites -- or, where the window of such a core does not fit (a CpG-dense stretch), as cores of
+      // 16 / 8 sites: handing a dense stretch to the wave-per-site walk costs up to a millisecond PER SITE there (call-by-call path)
+      uint32_t cs = FT_CORE;
+      for (uint32_t ja = t_beg, jb = 0; ja < t_end; ja = jb) {
+        jb = min(ja + cs, t_end);                 // core sites [ja, jb)
         const uint32_t ncore = jb - ja;
-        __syncthreads();                          // the previous tile's LDS is no longer read
+        __syncthreads();                          // the previous core's LDS is no longer read
         // ---- the window: the core and the sites within max_span of it (sorted positions: a count on either side) ----
         if (wave == 0) {
             const int32_t p_first = a.site_pos[ja], p_last = a.site_pos[jb - 1];
@@ -857,12 +862,14 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
             const uint32_t W = L + ncore + U;
             const int32_t w_first = a.site_pos[ja - L], w_last = a.site_pos[jb - 1 + U];
             // (32 qualifying sites on a side: there may be more -- not a window this kernel holds)
-            bool fb = W > 64u || L >= 32u || U >= 32u || (int64_t)w_last - w_first >= FT_SPAN;
+            bool fb = L >= 32u || U >= 32u;
+            bool too_wide = W > 64u || (int64_t)w_last - w_first >= FT_SPAN;
             // (halo reads of a region slice call positions outside the region, which are not in the site list: phase 1 notices)
             const uint32_t lo = min(a.idx[(uint32_t)(p_first - a.max_span + 1 - a.idx_base) >> IDX_QSHIFT], a.n_reads);
             const uint32_t hi = min(a.idx[((uint32_t)(p_last + 1 - a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
-            fb = fb || hi - lo > (uint32_t)FT_RMAX || a.n_cpgs < 4u;
-            if (lane == 0) { s_hdr[0] = ja - L; s_hdr[1] = W; s_hdr[2] = fb ? 1u : 0u; s_hdr[3] = lo; s_hdr[4] = hi; }
+            too_wide = too_wide || hi - lo > (uint32_t)FT_RMAX;
+            fb = fb || a.n_cpgs < 4u || (too_wide && ncore <= 8u);
+            if (lane == 0) { s_hdr[0] = ja - L; s_hdr[1] = W; s_hdr[2] = fb ? 1u : (too_wide ? 2u : 0u); s_hdr[3] = lo; s_hdr[4] = hi; }
         }
         if (tid < FT_CORE) s_cnt[tid] = 0u;
         __syncthreads();
@@ -870,6 +877,7 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
         // would be compiled with exec-mask bookkeeping per trip)
         const uint32_t jw = sgpr(s_hdr[0]), W = sgpr(s_hdr[1]), lo = sgpr(s_hdr[3]), hi = sgpr(s_hdr[4]);
         const uint32_t R = hi - lo;
+        if (sgpr(s_hdr[2]) == 2u) { cs = cs > 16u ? 16u : 8u; jb = ja; continue; }            // the same sites again, as smaller cores
         bool fallback = sgpr(s_hdr[2]) != 0u;     // workgroup-uniform
         const uint32_t cbit = ja - jw;            // window bit of the first core site
         const int32_t w_base = sgpr(a.site_pos[jw]);
@@ -952,7 +960,7 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
                 const uint32_t n = lane < (int)ncore ? s_cnt[lane] : 0u;
                 const uint32_t ns = min(n, dcap);
                 const bool ev = lane < (int)ncore && ns >= max(a.min_depth, 1u) && n <= (uint32_t)FT_LIST;
-                const uint32_t cap = ev ? ((ns * (ns - 1u) / 2u + 63u) & ~63u) : 0u;      // a round writes 64 bytes
+                const uint32_t cap = ev ? ((ns * (ns - 1u) + 127u) & ~127u) : 0u;          // two bytes per pair (the wide form's), a round writes 64 / 128 bytes
                 uint32_t incl = cap;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
@@ -1001,9 +1009,15 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
                 continue;
             }
             bool redo = n_all > (uint32_t)FT_LIST;
-            // the site's readers in file order (its arrivals, fdrp.rs:226-231), and the flush rule on the same ballots
-            uint32_t n_arr = 0;
-            bool seen = false, closed = false;
+            // The site's readers in file order (its arrivals, fdrp.rs:226-231) and the flush rule on the same ballots: a passing read
+            // whose first call lies past the site closes the open segment (fdrp.rs:212-223), a reader behind it opens a new one; the
+            // LAST segment whose stored reads reach min_depth is the site's result (BTreeMap::insert overwrites, fdrp.rs:216 / 241).
+            uint32_t n_arr = 0, seg0 = 0, best0 = 0, best1 = 0;
+            bool open = false;
+            auto close_seg = [&]() {
+                if (min(n_arr - seg0, a.max_depth) >= max(a.min_depth, 1u)) { best0 = seg0; best1 = n_arr; }
+                open = false;
+            };
             for (uint32_t r0 = c_lo; r0 < c_hi && !redo; r0 += 64u) {
                 const uint32_t r = r0 + (uint32_t)lane;
                 const bool v = r < c_hi;
@@ -1013,27 +1027,42 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
                 const uint32_t fo = (pk >> 8) & 0xffu;
                 const bool fl = fo != 0xffu && s_start[v ? r : 0u] - 1 + (int32_t)fo > c;       // c < first call, fdrp.rs:212
                 const unsigned long long mh = __ballot(hit), mf = __ballot(fl);
-                if (mh) {
-                    if (closed) { redo = true; break; }                                         // a hit after a flusher: a second segment
-                    // flushers above the first hit of the segment close it: no hit may follow
-                    const unsigned long long above_first = seen ? ~0ull : ~((1ull << __builtin_ctzll(mh)) - 1ull);
-                    const unsigned long long f2 = mf & above_first;
-                    if (f2) {
-                        const int ff = __builtin_ctzll(f2);
-                        if (ff < 63 && (mh >> (ff + 1)) != 0ull) { redo = true; break; }
-                        closed = true;
-                    }
-                    seen = true;
+                if (!mh) { if (open && mf) close_seg(); continue; }
+                // the flushers that can matter: all of them while a segment is open, else those above the chunk's first reader
+                const unsigned long long f2 = mf & (open ? ~0ull : ~((1ull << __builtin_ctzll(mh)) - 1ull));
+                const int ff = f2 ? __builtin_ctzll(f2) : 64;
+                if (ff == 64 || ff == 63 || (mh >> (ff + 1)) == 0ull) {
+                    // the chunk's readers join ONE segment; a flusher behind the last of them closes it
+                    if (!open) { seg0 = n_arr; open = true; }
                     if (hit) list[n_arr + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u))] = (uint16_t)r;
                     n_arr += (uint32_t)__popcll(mh);
-                } else if (seen && mf) closed = true;
+                    if (f2) close_seg();
+                } else {
+                    // readers on both sides of a flusher: the chunk's events one by one, in file order (wave-uniform loop)
+                    unsigned long long ev = mh | mf;
+                    while (ev) {
+                        const int l = __builtin_ctzll(ev);
+                        ev &= ev - 1ull;
+                        if ((mf >> l) & 1ull) { if (open) close_seg(); continue; }
+                        if (!open) { seg0 = n_arr; open = true; }
+                        if (lane == l) list[n_arr] = (uint16_t)r;
+                        n_arr += 1u;
+                    }
+                }
+            }
+            if (open) close_seg();                                                              // the final flush, fdrp.rs:239-243
+            const uint16_t *const lst = list + best0;
+            const uint32_t n_sel = best1 - best0;                                               // arrivals of the chosen segment (0: no row)
+            if (!redo && n_sel == 0u) {
+                if (lane == 0) { a.fdrp[j] = 0.0f; a.qfdrp[j] = 0.0f; a.nreads[j] = 0u; a.flags[j] = 0u; }
+                continue;
             }
             // fdrp.rs:81-94: the first max_depth arrivals fill the slots; arrival t beyond (total = t + 1) replaces slot j - 1 when
             // its draw j is <= max_depth.  Slot s ends up with the LAST such arrival, or with arrival s.
-            const uint32_t nS = min(n_arr, dcap);
-            if (!redo && a.max_depth > 64u && n_arr > 64u) redo = true;                         // more than this kernel's 64 slots are in use
-            if (!redo && n_arr > nS) {
-                for (uint32_t t = nS + (uint32_t)lane; t < n_arr; t += 64u) {
+            const uint32_t nS = min(n_sel, dcap);
+            if (!redo && a.max_depth > 64u && n_sel > 64u) redo = true;                         // more than this kernel's 64 slots are in use
+            if (!redo && n_sel > nS) {
+                for (uint32_t t = nS + (uint32_t)lane; t < n_sel; t += 64u) {
                     const int32_t jr = sample_j(a.seed, a.tid, c, (int32_t)t + 1);
                     draw[t] = (uint8_t)(jr <= (int32_t)nS ? jr : 0);                            // (max_depth <= 64 here: nS = max_depth)
                 }
@@ -1043,8 +1072,8 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (!redo && (uint32_t)lane < nS) {
                 uint32_t src = (uint32_t)lane;
-                for (uint32_t t = nS; t < n_arr; ++t) src = draw[t] == (uint8_t)(lane + 1) ? t : src;
-                const uint32_t r = list[src];
+                for (uint32_t t = nS; t < n_sel; ++t) src = draw[t] == (uint8_t)(lane + 1) ? t : src;
+                const uint32_t r = lst[src];
                 const uint32_t pk = s_pack[r];
                 const int32_t rs = s_start[r];
                 const unsigned long long mc = s_mC[r], mm = s_mM[r];
@@ -1059,6 +1088,7 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             uint32_t disc = 0;
+            bool wide = false;
             const unsigned long long off_v = s_off[k];
             const unsigned long long off = ((unsigned long long)sgpr((uint32_t)(off_v >> 32)) << 32) | sgpr((uint32_t)off_v);
             if (!redo) {
@@ -1089,7 +1119,29 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
                     pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x4e /*quad_perm [2,3,0,1]*/, 0xf, 0xf, true);
                     if ((lane & 3) == 0) *reinterpret_cast<uint32_t *>(tp + k0 + lane) = pk;
                 }
-                if (__any(over > FT_NCPG_MAX)) redo = true;                                     // a code did not fit its byte: the list is void
+                // A pair that shares more than 21 calls: its code did not fit a byte and the list is void.  The site is CpG-dense -- handed to
+                // the wave-per-site walk it takes the call-by-call path with calls beyond the registers, up to a millisecond for ONE site --
+                // so its rounds are run again in the WIDE form: ncpg << 8 | ham in 16 bits per pair (0x0100 = 0 / 1 for a skipped pair),
+                // which the chain kernel divides out itself.
+                wide = __any(over > FT_NCPG_MAX);
+                if (wide) {
+                    if (__any(over > 255u)) redo = true;
+                    disc = 0;
+                    ent_next = tab[P ? min(lane, P - 1) : 0];
+                    for (int k0 = 0; k0 < P && !redo; k0 += 64) {
+                        const uint32_t ent = ent_next;
+                        if (k0 + 64 < P) ent_next = tab[min(k0 + 64 + lane, P - 1)];
+                        const int pi = (int)(ent & 0xffu), pj = (int)(ent >> 8);
+                        const uint32_t *ri = rows + pi * 8, *rj = rows + pj * 8;
+                        const int32_t si = (int32_t)ri[0], ei = (int32_t)ri[1], sj = (int32_t)rj[0], ej = (int32_t)rj[1];
+                        const int32_t ov = min(ei, ej) - max(si, sj) + 1;
+                        const bool pair_ok = (k0 + lane < P) & (max(ov, 0) >= a.min_overlap);
+                        const uint32_t ncpg = __builtin_popcount(ri[2] & rj[2]) + __builtin_popcount(ri[3] & rj[3]);
+                        const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) + __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));
+                        disc += (pair_ok && ham != 0u) ? 1u : 0u;
+                        reinterpret_cast<uint16_t *>(tp)[k0 + lane] = (uint16_t)(pair_ok ? (ncpg << 8) | ham : 0x0100u);
+                    }
+                }
             }
             if (redo) {
                 redo_bits |= 1u << k;
@@ -1097,7 +1149,7 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
             } else {
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) disc += __shfl_xor(disc, o, 64);
-                if (lane == 0) { a.site_off[j] = off; a.site_nz[j] = (nS * (nS - 1u)) >> 1; a.site_disc[j] = disc; a.nreads[j] = nS; a.flags[j] = FD_CHAIN; }
+                if (lane == 0) { a.site_off[j] = off; a.site_nz[j] = ((nS * (nS - 1u)) >> 1) | (wide ? 0x80000000u : 0u); a.site_disc[j] = disc; a.nreads[j] = nS; a.flags[j] = FD_CHAIN; }
             }
         }
         // the tile's handed-back sites, appended to the list k_fdrp_walk takes them from
@@ -1112,6 +1164,7 @@ __global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
                 if (lane < 32 && ((m >> lane) & 1u)) a.redo_list[base + (uint32_t)__builtin_popcount(m & ((1u << lane) - 1u))] = ja + (uint32_t)lane;
             }
         }
+      }
     }
 }
 
@@ -1129,8 +1182,24 @@ __global__ __launch_bounds__(256) void k_fdrp_chain(const FdrpArgs a) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= n_sites || a.flags[j] != FD_CHAIN) return;
     const uint8_t *__restrict__ t = a.terms + a.site_off[j];
-    const uint32_t nz = a.site_nz[j];
+    const uint32_t nzw = a.site_nz[j];
+    const uint32_t nz = nzw & 0x7fffffffu;
     float q = 0.0f;
+    if (nzw >> 31) {                                       // the wide form (a pair sharing more than 21 calls): ncpg << 8 | ham per pair, divided here
+        // (eight codes per load, the next load requested before these are used; the codes past the list's end inside its last
+        // 128 bytes are 0x0100 = +0.0, as in the one-byte form)
+        const uint4 *__restrict__ t4 = reinterpret_cast<const uint4 *>(t);
+        uint4 v = t4[0];
+        for (uint32_t i = 0; i < nz; i += 8u) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            if (i + 8u < nz) v = t4[(i >> 3) + 1u];
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const uint32_t c = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu; f[k] = (float)(c & 0xffu) / (float)(c >> 8); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q += f[k];
+        }
+    } else {
     // A list starts on a 64-byte boundary and owns a multiple of 64 bytes: a lane takes a whole cache line per trip (four 16-byte
     // loads; 16 bytes per trip had every line fetched four times over, the L1 does not hold 64 lanes' lines), the next line is
     // requested before this one is used.  The codes past the list's end inside its last line are what the tile kernel's last
@@ -1157,6 +1226,7 @@ __global__ __launch_bounds__(256) void k_fdrp_chain(const FdrpArgs a) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) q += f[k];
         }
+    }
     }
     const uint32_t nS = a.nreads[j];
     // (num_reads * (num_reads - 1)) as f32 / 2.0 in usize arithmetic (fdrp.rs:143)
@@ -1287,8 +1357,9 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         if (const char *e = getenv("METHEOR_FDRP_TILE")) { tile = d.max_span <= 200 && atoi(e) != 0; if (tile) walk4 = 0; }
         if (tile) {
             const uint64_t dcap = std::min<uint64_t>(std::max<uint32_t>(params->max_depth, 1u), 64u);
-            // sum over sites of C(n, 2) <= (dcap - 1) / 2 x the sum of n <= (dcap - 1) / 2 x the batch's calls; + the 64-byte rounding
-            const uint64_t budget = (uint64_t)d.n_cpgs * (dcap - 1) / 2 + 64 * bound + 64;
+            // sum over sites of C(n, 2) <= (dcap - 1) / 2 x the sum of n <= (dcap - 1) / 2 x the batch's calls; two bytes per pair (the wide
+            // form of a site with a pair that shares more than 21 calls; the usual one-byte form touches half of it) + the rounding
+            const uint64_t budget = (uint64_t)d.n_cpgs * (dcap - 1) + 128 * bound + 128;
             MTH_HIP(ctx, ctx->f_terms.reserve(budget, s));
             MTH_HIP(ctx, ctx->f_soff.reserve(bound * 8, s));
             MTH_HIP(ctx, ctx->f_snz.reserve(bound * 4, s));
