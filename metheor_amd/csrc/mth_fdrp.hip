@@ -818,7 +818,7 @@ constexpr uint32_t FD_CHAIN = 8u;                 // flags: the site's terms are
 constexpr uint32_t FT_NCPG_MAX = 21u;             // 21 * 22 / 2 + 21 = 252: the codes fit a byte
 
 template <int FD_NB>
-__global__ __launch_bounds__(256, 6) void k_fdrp_tile(const FdrpArgs a) {
+__global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
     // the tile's table, one row per candidate read: start; span | first call - (start - 1) | window bit of an uncovered first call;
