@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                 const uint32_t n = lane < (int)ncore ? s_cnt[lane] : 0u;
                 const uint32_t ns = min(n, dcap);
                 const bool ev = lane < (int)ncore && ns >= max(a.min_depth, 1u) && n <= (uint32_t)FT_LIST;
-                const uint32_t cap = ev ? ((ns * (ns - 1u) + 127u) & ~127u) : 0u;          // two bytes per pair (the wide form's), a round writes 64 / 128 bytes
+                const uint32_t cap = ev ? ((ns * (ns - 1u) / 2u + 63u) & ~63u) : 0u;      // a round writes 64 bytes
                 uint32_t incl = cap;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
@@ -1089,6 +1089,7 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             uint32_t disc = 0;
             bool wide = false;
+            float q_wide = 0.0f;
             const unsigned long long off_v = s_off[k];
             const unsigned long long off = ((unsigned long long)sgpr((uint32_t)(off_v >> 32)) << 32) | sgpr((uint32_t)off_v);
             if (!redo) {
@@ -1121,14 +1122,13 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                 }
                 // A pair that shares more than 21 calls: its code did not fit a byte and the list is void.  The site is CpG-dense -- handed to
                 // the wave-per-site walk it takes the call-by-call path with calls beyond the registers, up to a millisecond for ONE site --
-                // so its rounds are run again in the WIDE form: ncpg << 8 | ham in 16 bits per pair (0x0100 = 0 / 1 for a skipped pair),
-                // which the chain kernel divides out itself.
+                // so its rounds are run again HERE with the ordered sum chained in the wave (one DPP add per pair, as the walk's compact
+                // finalize does it): a few thousand such sites per batch, and the chain kernel sees none of them.
                 wide = __any(over > FT_NCPG_MAX);
                 if (wide) {
-                    if (__any(over > 255u)) redo = true;
                     disc = 0;
                     ent_next = tab[P ? min(lane, P - 1) : 0];
-                    for (int k0 = 0; k0 < P && !redo; k0 += 64) {
+                    for (int k0 = 0; k0 < P; k0 += 64) {
                         const uint32_t ent = ent_next;
                         if (k0 + 64 < P) ent_next = tab[min(k0 + 64 + lane, P - 1)];
                         const int pi = (int)(ent & 0xffu), pj = (int)(ent >> 8);
@@ -1139,7 +1139,11 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                         const uint32_t ncpg = __builtin_popcount(ri[2] & rj[2]) + __builtin_popcount(ri[3] & rj[3]);
                         const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) + __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));
                         disc += (pair_ok && ham != 0u) ? 1u : 0u;
-                        reinterpret_cast<uint16_t *>(tp)[k0 + lane] = (uint16_t)(pair_ok ? (ncpg << 8) | ham : 0x0100u);
+                        const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;            // qfdrp.rs:152; +0.0 for skipped pairs
+                        float x = (lane == 0) ? q_wide + term : term;
+                        for (int stp = 0; stp < 63; ++stp)                                       // x[l] = x[l - 1] + term[l]: the reference's order
+                            x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)) + term;
+                        q_wide = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
                     }
                 }
             }
@@ -1149,7 +1153,14 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
             } else {
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) disc += __shfl_xor(disc, o, 64);
-                if (lane == 0) { a.site_off[j] = off; a.site_nz[j] = ((nS * (nS - 1u)) >> 1) | (wide ? 0x80000000u : 0u); a.site_disc[j] = disc; a.nreads[j] = nS; a.flags[j] = FD_CHAIN; }
+                if (lane == 0) {
+                    a.nreads[j] = nS;
+                    if (wide) {
+                        const unsigned long long prod = (unsigned long long)(long long)nS * (unsigned long long)((long long)nS - 1);
+                        const float den = (float)prod / 2.0f;                                   // fdrp.rs:143
+                        a.fdrp[j] = (float)disc / den; a.qfdrp[j] = q_wide / den; a.flags[j] = 1u;
+                    } else { a.site_off[j] = off; a.site_nz[j] = (nS * (nS - 1u)) >> 1; a.site_disc[j] = disc; a.flags[j] = FD_CHAIN; }
+                }
             }
         }
         // the tile's handed-back sites, appended to the list k_fdrp_walk takes them from
@@ -1171,7 +1182,7 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
 // one thread per site: the ordered f32 sum over the site's listed terms (qfdrp.rs:152), then fdrp.rs:143 / qfdrp.rs:155
 __global__ __launch_bounds__(256) void k_fdrp_chain(const FdrpArgs a) {
     const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
-    if (blockIdx.x * 256u >= n_sites) return;              // (the grid comes from the host's upper bound of the site count)
+    if (blockIdx.x * 256u >= n_sites) return;              // (the host only has an upper bound of the site count)
     __shared__ float s_q[256];
     {   // code = ncpg (ncpg + 1) / 2 + ham, ham <= ncpg <= 21: the quotient by the division the pair loop would do (0 / 0 = NaN at code 0)
         uint32_t ncpg = 0;
@@ -1179,27 +1190,12 @@ __global__ __launch_bounds__(256) void k_fdrp_chain(const FdrpArgs a) {
         s_q[threadIdx.x] = (float)((uint32_t)threadIdx.x - ncpg * (ncpg + 1u) / 2u) / (float)ncpg;
     }
     __syncthreads();
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= n_sites || a.flags[j] != FD_CHAIN) return;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n_sites; j += gridDim.x * 256u) {
+    if (a.flags[j] != FD_CHAIN) continue;
     const uint8_t *__restrict__ t = a.terms + a.site_off[j];
-    const uint32_t nzw = a.site_nz[j];
-    const uint32_t nz = nzw & 0x7fffffffu;
+    const uint32_t nz = a.site_nz[j];
     float q = 0.0f;
-    if (nzw >> 31) {                                       // the wide form (a pair sharing more than 21 calls): ncpg << 8 | ham per pair, divided here
-        // (eight codes per load, the next load requested before these are used; the codes past the list's end inside its last
-        // 128 bytes are 0x0100 = +0.0, as in the one-byte form)
-        const uint4 *__restrict__ t4 = reinterpret_cast<const uint4 *>(t);
-        uint4 v = t4[0];
-        for (uint32_t i = 0; i < nz; i += 8u) {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            if (i + 8u < nz) v = t4[(i >> 3) + 1u];
-            float f[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const uint32_t c = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu; f[k] = (float)(c & 0xffu) / (float)(c >> 8); }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) q += f[k];
-        }
-    } else {
+    {
     // A list starts on a 64-byte boundary and owns a multiple of 64 bytes: a lane takes a whole cache line per trip (four 16-byte
     // loads; 16 bytes per trip had every line fetched four times over, the L1 does not hold 64 lanes' lines), the next line is
     // requested before this one is used.  The codes past the list's end inside its last line are what the tile kernel's last
@@ -1235,6 +1231,7 @@ __global__ __launch_bounds__(256) void k_fdrp_chain(const FdrpArgs a) {
     a.fdrp[j] = (float)a.site_disc[j] / den;
     a.qfdrp[j] = q / den;
     a.flags[j] = 1u;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fdrp_emit(const uint32_t *__restrict__ flags, const int32_t *__restrict__ site_pos,
@@ -1357,9 +1354,8 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         if (const char *e = getenv("METHEOR_FDRP_TILE")) { tile = d.max_span <= 200 && atoi(e) != 0; if (tile) walk4 = 0; }
         if (tile) {
             const uint64_t dcap = std::min<uint64_t>(std::max<uint32_t>(params->max_depth, 1u), 64u);
-            // sum over sites of C(n, 2) <= (dcap - 1) / 2 x the sum of n <= (dcap - 1) / 2 x the batch's calls; two bytes per pair (the wide
-            // form of a site with a pair that shares more than 21 calls; the usual one-byte form touches half of it) + the rounding
-            const uint64_t budget = (uint64_t)d.n_cpgs * (dcap - 1) + 128 * bound + 128;
+            // sum over sites of C(n, 2) <= (dcap - 1) / 2 x the sum of n <= (dcap - 1) / 2 x the batch's calls; + the 64-byte rounding
+            const uint64_t budget = (uint64_t)d.n_cpgs * (dcap - 1) / 2 + 64 * bound + 64;
             MTH_HIP(ctx, ctx->f_terms.reserve(budget, s));
             MTH_HIP(ctx, ctx->f_soff.reserve(bound * 8, s));
             MTH_HIP(ctx, ctx->f_snz.reserve(bound * 4, s));
@@ -1373,7 +1369,7 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
             const uint32_t gridt = (uint32_t)std::min<uint64_t>((bound + FT_CORE - 1) / FT_CORE, 8192);
             if (dense) hipLaunchKernelGGL(k_fdrp_tile<16>, dim3(gridt), dim3(256), 0, s, a);
             else hipLaunchKernelGGL(k_fdrp_tile<8>, dim3(gridt), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(k_fdrp_chain, dim3((uint32_t)((bound + 255) / 256)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_fdrp_chain, dim3((uint32_t)std::min<uint64_t>((bound + 255) / 256, 8192)), dim3(256), 0, s, a);
             a.only_flag = FD_REDO;
             if (getenv("METHEOR_FDRP_DEBUG")) {          // how much the tile form handed back (synchronises: debugging only)
                 DevState st;
