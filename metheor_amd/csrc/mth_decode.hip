@@ -317,7 +317,9 @@ __global__ __launch_bounds__(256) void k_dec_contigs(const int32_t *__restrict__
     if (i >= n) return;
     const int32_t t = tid[i];
     uint32_t f = (start[i] < 0 ? 1u : 0u) | (t < 0 ? 2u : 0u);
-    if (i > 0 && tid[i - 1] == t && start[i] < start[i - 1]) f |= 4u;      // bit2: not coordinate-sorted inside a contig's run
+    // bit2: not coordinate-sorted inside a contig's run (a read without an aligned base has start -1 wherever it stands: bit0 reports it,
+    // it is not taken for disorder)
+    if (i > 0 && tid[i - 1] == t && start[i] >= 0 && start[i - 1] >= 0 && start[i] < start[i - 1]) f |= 4u;
     if (f) atomicOr(flags, f);
     if (i == 0 || tid[i - 1] != t) {
         const uint32_t k = atomicAdd(count, 1u);

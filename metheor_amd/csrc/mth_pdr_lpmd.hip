@@ -776,6 +776,73 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(const SiteRec *__r
     }
 }
 
+// k_gather, second form (round 4): one 256-thread workgroup per 64 consecutive tiles.  The per-tile form above starts a wave per tile
+// (14 311 on config 2), and every wave loads its bucket's earlier counts again (up to 1 KiB) to find its base; beside a tile kernel
+// those waves queue for slots and the gather takes 20 us instead of 11.  Here the 64 counts are scanned once, the rows of the 64
+// tiles are ONE flat range (row r -> tile by a binary search in the 65 offsets in LDS) copied 256 at a time, every load independent.
+constexpr int GATHER2_TILES = 64;
+__global__ __launch_bounds__(256) void k_gather2(const SiteRec *__restrict__ scratch, const uint32_t *__restrict__ tile_cnt,
+                                                 const unsigned long long *__restrict__ bucket, uint32_t nbk, uint32_t ntiles, int fin_only, int want_lpmd,
+                                                 DevState *__restrict__ st, const DevState *__restrict__ base_st, DevState *__restrict__ next_st,
+                                                 DevState *__restrict__ lane_st, int reset_first, uint32_t *__restrict__ batch_cnt, uint32_t tile_w,
+                                                 int32_t *__restrict__ out_pos, float *__restrict__ out_pdr, uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
+    static_assert(TILE_BUCKET_SHIFT == 8 && GATHER2_TILES == 64, "a bucket's earlier tiles are at most 192: one per thread of waves 1..3");
+    __shared__ uint32_t s_off[GATHER2_TILES + 1];
+    __shared__ uint32_t s_part[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t t0 = fin_only ? ntiles : blockIdx.x * GATHER2_TILES;
+    const uint32_t nt = fin_only ? 0u : min((uint32_t)GATHER2_TILES, ntiles - t0);
+    const uint32_t bk = t0 >> TILE_BUCKET_SHIFT;
+    const uint64_t cur = reset_first ? 0ull : base_st->cur_base;
+    uint32_t part = 0, mine = 0;
+    if (!fin_only) {
+        if (wave == 0) mine = lane < nt ? tile_cnt[t0 + lane] : 0u;
+        else { const uint32_t u = (bk << TILE_BUCKET_SHIFT) + (tid - 64u); if (u < t0) part = tile_cnt[u]; }
+        for (uint32_t b = tid; b < bk; b += 256u) part += (uint32_t)bucket[b];            // rows of one batch fit 32 bits
+    }
+    const uint32_t incl = wave_scan_incl(mine);
+    if (wave == 0) { s_off[lane + 1] = incl; if (lane == 0) s_off[0] = 0u; }
+    const uint32_t wsum = wave_sum(part);
+    if (lane == 0) s_part[wave] = wsum;
+    __syncthreads();
+    const uint32_t before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    const uint32_t total = s_off[nt];
+    const uint64_t base = cur + before;
+    for (uint32_t r = tid; r < total; r += 256u) {
+        uint32_t q = 0;                                                                   // the largest q with s_off[q] <= r
+#pragma unroll
+        for (uint32_t step = GATHER2_TILES / 2; step > 0; step >>= 1) q += (s_off[q + step] <= r) ? step : 0u;
+        const SiteRec rec = scratch[(size_t)(t0 + q) * tile_w + (r - s_off[q])];
+        out_pos[base + r] = rec.pos;
+        out_nc[base + r] = rec.n_conc;
+        out_nd[base + r] = rec.n_disc;
+        out_pdr[base + r] = (float)rec.n_disc / ((float)rec.n_conc + (float)rec.n_disc);   // pdr.rs:47-49
+    }
+    if (t0 + nt != ntiles) return;
+    // the batch's last workgroup commits it (see k_gather)
+    const uint32_t batch_total = before + total;
+    if (tid == 0) {
+        const uint32_t nb = reset_first ? 0u : st->n_batches;
+        st->n_sites = cur + batch_total;
+        batch_cnt[nb] = batch_total;
+        st->n_batches = nb + 1;
+        if (next_st) next_st->cur_base = cur + batch_total;
+        uint32_t e = reset_first ? 0u : st->err;
+        if (lane_st) { e |= lane_st->err; lane_st->err = 0; }
+        if (lane_st || reset_first) st->err = e;
+    }
+    if (wave == 0 && (want_lpmd || reset_first)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned long long x = 0;
+            if (want_lpmd) for (uint32_t b = lane; b < nbk; b += 64) x += bucket[nbk + (size_t)b * 4 + k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+            if (lane == 0) st->lpmd[k] = (reset_first ? 0ll : st->lpmd[k]) + (long long)x;
+        }
+    }
+}
+
 // first pipelined batch since ctx->stream was last joined: its lane's row base is the job's row count as that stream leaves it
 __global__ void k_pipe_seed(const DevState *__restrict__ st, DevState *__restrict__ lane_st) {
     lane_st->cur_base = st->n_sites;
@@ -968,11 +1035,19 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
             reset_first = ctx->reset_pending ? 1 : 0;
             ctx->reset_pending = false;
         }
-        hipLaunchKernelGGL(k_gather, dim3(p.want_pdr ? (ntiles + GATHER_WAVES - 1) / GATHER_WAVES : 1u), dim3(p.want_pdr ? 64 * GATHER_WAVES : 64), 0, s, b_scratch.as<SiteRec>(),
-                           b_tile_cnt.as<uint32_t>(), b_bucket.as<unsigned long long>(), nbk, ntiles,
-                           p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, L ? (const DevState *)L->st : (const DevState *)cst,
-                           L ? ctx->lane[li ^ 1].st : (DevState *)nullptr, L ? L->st : (DevState *)nullptr, reset_first,
-                           bcnt, (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
+        static const bool gather1 = getenv("MTH_GATHER") && atoi(getenv("MTH_GATHER")) == 1;       // A/B: the per-tile form
+        if (gather1)
+            hipLaunchKernelGGL(k_gather, dim3(p.want_pdr ? (ntiles + GATHER_WAVES - 1) / GATHER_WAVES : 1u), dim3(p.want_pdr ? 64 * GATHER_WAVES : 64), 0, s, b_scratch.as<SiteRec>(),
+                               b_tile_cnt.as<uint32_t>(), b_bucket.as<unsigned long long>(), nbk, ntiles,
+                               p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, L ? (const DevState *)L->st : (const DevState *)cst,
+                               L ? ctx->lane[li ^ 1].st : (DevState *)nullptr, L ? L->st : (DevState *)nullptr, reset_first,
+                               bcnt, (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
+        else
+            hipLaunchKernelGGL(k_gather2, dim3(p.want_pdr ? (ntiles + GATHER2_TILES - 1) / GATHER2_TILES : 1u), dim3(256), 0, s, b_scratch.as<SiteRec>(),
+                               b_tile_cnt.as<uint32_t>(), b_bucket.as<unsigned long long>(), nbk, ntiles,
+                               p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, L ? (const DevState *)L->st : (const DevState *)cst,
+                               L ? ctx->lane[li ^ 1].st : (DevState *)nullptr, L ? L->st : (DevState *)nullptr, reset_first,
+                               bcnt, (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
         if (L) { MTH_HIP(ctx, hipEventRecord(L->done, s)); ctx->pipe_tail = li; }
     }
 #ifdef MTH_TILE_TRACE
