@@ -228,7 +228,10 @@ int  mth_mhl_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos,
  * random from an OS-seeded RNG (fdrp.rs:90) -- not reproducible; here the draw is the counter-based
  * hash of (seed, tid, pos, n-th read) shared with the test oracle.  max_depth up to 16384: sites that hold more than 64 reads at
  * once are redone by a second pass with 256 slots in LDS, those beyond 256 by a third with max_depth rows per wave in HBM
- * scratch; max_depth above 16384 is refused with MTH_ERR_CAPACITY (never a truncated result). */
+ * scratch; max_depth above 16384 is refused with MTH_ERR_CAPACITY (never a truncated result).
+ * The reference's own panic on this path (fdrp.rs:70-72, window index -1: a reverse-strand read of 203..403 reference bases that
+ * passes min_qual, calls a CpG at its start - 1 and another one at start + 201) is reproduced as MTH_ERR_FORMAT at the next
+ * synchronising call, on sorted and unsorted input alike (k_fdrp_guard; batches whose max_span is below 203 skip the pass). */
 typedef struct {
     uint64_t min_depth;    /* -d 10 */
     uint64_t seed;         /* reservoir draws; any value */

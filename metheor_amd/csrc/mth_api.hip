@@ -103,6 +103,7 @@ int sync_and_check(mth_ctx *ctx) {
     if (e & ERRB_CRC) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block (CRC32 mismatch)");
     if (e & ERRB_FORMAT) return fail(ctx, MTH_ERR_FORMAT, "corrupt BGZF block or malformed BAM record (DEFLATE / ISIZE / block_size / field lengths inconsistent)");
     if (e & ERRB_TAGPANIC) return fail(ctx, MTH_ERR_FORMAT, "tag: a record the reference cannot tag either (unplaced or outside its contig / the FASTA, a base without a complement, or a C whose context ends in a deletion): determine_xm_tag_string panics there");
+    if (e & ERRB_FDRPPANIC) return fail(ctx, MTH_ERR_FORMAT, "fdrp / qfdrp: a reverse-strand read calls a CpG at its start - 1 and another one 202 bp further while spanning at most 403 bp: the reference's window index is -1 there and it panics (fdrp.rs:70-72, index out of bounds)");
     if (e & ERRB_NOXM) return fail(ctx, MTH_ERR_FORMAT, "a record has no XM:Z tag (the reference panics: Error reading XM tag)");
     if (e & ERRB_UNALIGNED) return fail(ctx, MTH_ERR_UNALIGNED, "a BAM record straddles two BGZF blocks: the per-block device walk does not apply (use the host walk)");
     return MTH_OK;

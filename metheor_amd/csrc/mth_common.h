@@ -28,6 +28,7 @@ enum : uint32_t {
     ERRB_NOXM = 1u << 6,       // device record decode: record without XM:Z
     ERRB_CRC = 1u << 8,        // device inflate: CRC32 of an inflated BGZF block does not match its trailer
     ERRB_TAGPANIC = 1u << 9,   // tag: a record on which the reference's determine_xm_tag_string panics (tag.rs:24, 155-170, 297)
+    ERRB_FDRPPANIC = 1u << 10, // FDRP / qFDRP: a read on which the reference's window index leaves 0..=402 (fdrp.rs:70-72) -- it panics
     ERRB_UNALIGNED = 1u << 7,  // device record walk: a record straddles two BGZF blocks (take the host walk)
 };
 

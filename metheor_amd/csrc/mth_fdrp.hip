@@ -1266,6 +1266,24 @@ __global__ __launch_bounds__(256) void k_fdrp_emit(const uint32_t *__restrict__ 
     }
 }
 
+// fdrp.rs:51-76: add_read() writes new_read[MAX_READ_LEN + (cpg - site)] for every call of the read once the read's own span has
+// passed its two window tests (start - site >= -201, end - site <= 201).  The calls of a read lie in [start - 1, end] (start - 1: a
+// reverse-strand call on the read's first base, readutil.rs:332-340), so the index leaves 0..=402 in exactly one case: a call at
+// start - 1, the site at start + 201, end <= start + 402 -- index -1, an out-of-bounds panic.  One thread per read; any such read
+// (passing mapq, as fdrp.rs:205 skips the others) raises ERRB_FDRPPANIC and the measure fails as the reference does.
+__global__ __launch_bounds__(256) void k_fdrp_guard(const int32_t *__restrict__ read_start, const int32_t *__restrict__ read_end,
+                                                    const uint8_t *__restrict__ read_mapq, const uint32_t *__restrict__ cpg_off,
+                                                    const uint32_t *__restrict__ cpg_pos, uint32_t n_reads, uint32_t min_qual, uint32_t *err) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_reads) return;
+    const int32_t s = read_start[i], e = read_end[i];
+    if (e - s < 202 || e - s > 402 || read_mapq[i] < min_qual) return;
+    const uint32_t o0 = cpg_off[i], o1 = cpg_off[i + 1];
+    if (o1 - o0 < 2u || (cpg_pos[o0] & 0x7fffffffu) != ((uint32_t)(s - 1) & 0x7fffffffu)) return;
+    for (uint32_t k = o0 + 1; k < o1; ++k)
+        if ((cpg_pos[k] & 0x7fffffffu) == (uint32_t)(s + 201)) { atomicOr(err, (uint32_t)ERRB_FDRPPANIC); return; }
+}
+
 }  // namespace mth
 
 using namespace mth;
@@ -1304,6 +1322,10 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     const size_t nb = ctx->f_batches.size() - 1;
     MTH_HIP(ctx, ctx->f_batch_rows.reserve((nb + 1) * 4, s, true, nb * 4));
 
+    // the reference's one panic on this path needs a read of >= 203 reference bases (see k_fdrp_guard): short-read batches skip the pass
+    if (d.max_span >= 203 && d.n_reads)
+        hipLaunchKernelGGL(k_fdrp_guard, dim3((uint32_t)((d.n_reads + 255) / 256)), dim3(256), 0, s, d.read_start, d.read_end, d.read_mapq, d.cpg_off,
+                           d.cpg_pos, (uint32_t)d.n_reads, (uint32_t)params->min_qual, &ctx->d_state->err);
     const int32_t ext = ((d.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
     FdrpArgs a;
     a.read_start = d.read_start; a.read_end = d.read_end; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;

@@ -95,6 +95,11 @@ __global__ __launch_bounds__(256) void k_fo_attrs(const FoArgs a) {
     } else {                                   // fdrp.rs:205-210
         contrib = mq >= a.min_qual && n > 0u;
         flush = contrib;
+        // fdrp.rs:70-72: the one read on which the reference's window index is -1 (k_fdrp_guard in mth_fdrp.hip states the case)
+        const int32_t s = a.start[t], e = a.end[t];
+        if (contrib && n >= 2u && e - s >= 202 && e - s <= 402 && (a.pos[o0] & 0x7fffffffu) == ((uint32_t)(s - 1) & 0x7fffffffu))
+            for (unsigned long long k = o0 + 1; k < o1; ++k)
+                if ((a.pos[k] & 0x7fffffffu) == (uint32_t)(s + 201)) { atomicOr(&a.st->err, (uint32_t)ERRB_FDRPPANIC); break; }
     }
     uint8_t d = 0;
     unsigned long long f = 0;

@@ -494,6 +494,8 @@ orc_result_t *orc_fdrp(const orc_reads_t *rd, uint8_t min_qual, uint64_t min_dep
         std::vector<Arr> reads;
         int32_t num_total_read = 0, num_sampled_read = 0;
     };
+    bool panicked = false;   // fdrp.rs:70-72: new_read[relative_pos] with relative_pos outside 0..=402 (a reverse-strand read whose first call
+                             // sits at start - 1, added to its own site 202 bp further) is an index panic in the reference
     auto add_read = [&](Assoc &a, const Pos &site, const Read &br) {  // fdrp.rs:51-95
         Arr nr; memset(nr.b, 0, W);
         const int32_t s = MAX_READ_LEN + (br.start_pos - site.pos);
@@ -503,7 +505,7 @@ orc_result_t *orc_fdrp(const orc_reads_t *rd, uint8_t min_qual, uint64_t min_dep
         for (int32_t p = s; p < e + 1; ++p) nr.b[p] |= 1;
         for (const CpG &c : br.cpgs) {
             const int64_t rp = (int64_t)MAX_READ_LEN + ((int64_t)c.abspos.pos - site.pos);
-            if (rp < 0 || rp >= W) { fprintf(stderr, "oracle: fdrp index out of bounds (reference panics)\n"); abort(); }
+            if (rp < 0 || rp >= W) { panicked = true; return; }
             nr.b[rp] |= 2;
             if (c.methylated) nr.b[rp] |= 4;
         }
@@ -568,6 +570,7 @@ orc_result_t *orc_fdrp(const orc_reads_t *rd, uint8_t min_qual, uint64_t min_dep
             else ++it;
         }
         for (const CpG &c : br.cpgs) add_read(cpg2reads[c.abspos], c.abspos, br);  // fdrp.rs:225-231
+        if (panicked) return nullptr;      // the caller reports the reference's panic
     }
     for (auto &kv : cpg2reads) finalize(kv.first, kv.second);  // fdrp.rs:239-243
     auto *res = new orc_result;

@@ -67,6 +67,10 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+class ReferencePanic(RuntimeError):
+    """the reference panics on this input (the message names where)"""
+
+
 class Table:
     """result rows: tid[n], pos[n,k], val[n] (f32), cnt[n,m] (u32)"""
 
@@ -177,10 +181,16 @@ class Reads:
         return Table(lib().orc_quartets(self.h, min_depth, min_qual, 1))
 
     def fdrp(self, min_qual=10, min_depth=10, max_depth=40, min_overlap=35, seed=0):
-        return Table(lib().orc_fdrp(self.h, min_qual, min_depth, max_depth, min_overlap, seed, 0))
+        return self._fdrp(min_qual, min_depth, max_depth, min_overlap, seed, 0)
 
     def qfdrp(self, min_qual=10, min_depth=10, max_depth=40, min_overlap=35, seed=0):
-        return Table(lib().orc_fdrp(self.h, min_qual, min_depth, max_depth, min_overlap, seed, 1))
+        return self._fdrp(min_qual, min_depth, max_depth, min_overlap, seed, 1)
+
+    def _fdrp(self, min_qual, min_depth, max_depth, min_overlap, seed, which):
+        h = lib().orc_fdrp(self.h, min_qual, min_depth, max_depth, min_overlap, seed, which)
+        if not h:
+            raise ReferencePanic("fdrp.rs:70-72: window index out of bounds (reverse-strand read, first call at start - 1, its own site 202 bp further)")
+        return Table(h)
 
 
 def format_f32(v):
