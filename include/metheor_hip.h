@@ -193,7 +193,13 @@ int  mth_lpmd_pairs_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_
 /* ---- ME / PM: per-quartet 16-bin epiallele histograms (me.rs:90-132, pm.rs:85-128) ------------
  * One accumulate serves both measures (they share the histogram).  Windows whose consecutive CpGs are >= 2048 bp
  * apart (reference skips, long reads) are aggregated under a 128-bit key on a side path; the calls of a read must be in
- * ascending position order (MTH_ERR_SPAN otherwise). */
+ * ascending position order (MTH_ERR_SPAN otherwise).
+ * Device-resident batches after a context's first are QUEUED: the call returns without a host sync, and the next call on the
+ * context that is not another mth_quartet_accumulate of a device-resident batch (mth_ctx_sync, any fetch, any other accumulate,
+ * decode or mth_decoded_batch) reads back whether every queued batch fitted the output it was given -- one that did not, or that
+ * has tiles for the global-table path, is replayed there together with the batches behind it.  As for every device-resident
+ * batch, the arrays must stay untouched until then.  MTH_QUARTET_QUEUE=0 restores one sync per batch.  mth_lpmd_pairs_accumulate
+ * queues the same way (MTH_PAIRS_QUEUE=0). */
 typedef struct {
     uint8_t min_qual;   /* -q 10 (lib.rs:66-68, 90-92) */
 } mth_quartet_params_t;

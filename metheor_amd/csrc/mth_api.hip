@@ -88,7 +88,15 @@ int pipe_join(mth_ctx *ctx) {
 
 int enter(mth_ctx *ctx) {
     MTH_HIP(ctx, hipSetDevice(ctx->device));
-    return pipe_join(ctx);
+    int rc = pipe_join(ctx);
+    // ME / PM / pairs batches queued without a host sync (mth_quartet.hip, mth_pairs.hip): every entry point but the call that queues
+    // the next one settles them first -- the caller may be about to rewrite what a replay would read (mth_decoded_batch rebuilds the
+    // offsets array the previous decoded batch points into), and "the next synchronising call" of the header's contract is any of them
+    if (!rc && !ctx->tile_queue_hold) {
+        if (!ctx->q_pending.empty()) rc = quartet_resolve(ctx);
+        if (!rc && !ctx->p_pending.empty()) rc = pairs_resolve(ctx);
+    }
+    return rc;
 }
 
 int sync_and_check(mth_ctx *ctx) {
@@ -241,7 +249,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
                       &ctx->inf_file, &ctx->inf_file2, &ctx->inf_tab, &ctx->inf_raw, &ctx->inf_cnt, &ctx->inf_base, &ctx->inf_recoff, &ctx->crc_mat,
                       &ctx->tag_genome, &ctx->tag_goff, &ctx->tag_ncol, &ctx->tag_coloff, &ctx->tag_xmlen, &ctx->tag_cols, &ctx->tag_xm,
                       &ctx->batch_cnt, &ctx->out_pos, &ctx->out_pdr, &ctx->out_nc, &ctx->out_nd, &ctx->q_state, &ctx->q_keys,
-                      &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_tflag, &ctx->q_tile_row0, &ctx->q_tile_rows, &ctx->q_wpos, &ctx->q_wpat, &ctx->q_wk0, &ctx->q_wk1, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
+                      &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_tflag, &ctx->q_tile_row0, &ctx->q_tile_rows, &ctx->q_wpos, &ctx->q_wpat, &ctx->q_wk0, &ctx->q_wk1, &ctx->q_snap, &ctx->p_snap, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
                       &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_aux, &ctx->w_flags,
                       &ctx->w_blk, &ctx->w_huge, &ctx->m_state, &ctx->m_pos, &ctx->m_val, &ctx->m_cov, &ctx->m_batch_rows,
                       &ctx->f_state, &ctx->f_pos, &ctx->f_val, &ctx->f_qval, &ctx->f_n, &ctx->f_batch_rows, &ctx->f_rows, &ctx->f_pairtab, &ctx->fo_sel, &ctx->fo_flag, &ctx->fo_tmp, &ctx->fo_out, &ctx->f_redo, &ctx->f_terms, &ctx->f_soff, &ctx->f_snz, &ctx->f_sdisc,
@@ -286,6 +294,7 @@ int mth_reset(mth_ctx_t *ctx) {
     ctx->lpmd_reduced = false;
     if (ctx->q_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->q_state.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     ctx->q_meta.clear();
+    ctx->q_pending.clear();                // queued batches' rows are dropped with the rest; their kernels precede the memset in stream order
     ctx->q_rows = 0;
     ctx->q_epoch += 1;
     if (ctx->m_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->m_state.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
@@ -296,6 +305,7 @@ int mth_reset(mth_ctx_t *ctx) {
     ctx->f_rows_bound = 0;
     if (ctx->p_state.p) MTH_HIP(ctx, hipMemsetAsync(ctx->p_state.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     ctx->p_meta.clear();
+    ctx->p_pending.clear();
     ctx->p_rows = 0;
     return MTH_OK;
 }

@@ -41,6 +41,9 @@ struct PdrLane {
 
 }  // namespace mth
 
+struct mth_ctx;
+namespace mth { int quartet_resolve(mth_ctx *ctx); int pairs_resolve(mth_ctx *ctx); }
+
 struct mth_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -110,7 +113,14 @@ struct mth_ctx {
     std::vector<TileBatch> q_meta;
     double q_rows_per_cpg = 0.15;          // output sizing of the next batch
     mth::DevBuf q_pos, q_cnt, q_me, q_pm, q_depth;
-    uint64_t q_cap = 0, q_rows = 0;        // row capacity, rows in use (known exactly: one sync per batch)
+    uint64_t q_cap = 0, q_rows = 0;        // row capacity, rows in use (exact as of the last synchronous batch / quartet_resolve)
+    // batches queued without a host sync (mth_quartet.hip, quartet_batch): their device-side batch, a snapshot of the state words each
+    struct QueuedBatch { mth_batch_t d; mth_quartet_params_t params; int32_t tid; uint64_t n_cpgs; };
+    std::vector<QueuedBatch> q_pending;
+    mth::DevBuf q_snap;
+    uint64_t q_rows_est = 0;               // upper bound of the rows in use while batches are queued
+    bool q_learned = false;                // a synchronous batch has set q_rows_per_cpg
+    bool tile_queue_hold = false;          // set by the accumulate call that is queueing a batch: enter() leaves the queues alone
     // the row order worked out by a count-only mth_quartet_fetch, kept for the fetch that follows it (same min_depth,
     // nothing accumulated in between: q_epoch)
     uint64_t q_epoch = 0, q_order_epoch = ~0ull;
@@ -140,6 +150,11 @@ struct mth_ctx {
     uint64_t p_cap = 0, p_rows = 0;        // row capacity of p_out_*, rows in use (known exactly: one sync per batch)
     double p_rows_per_cpg = 0.1;           // output sizing of the next batch
     std::vector<TileBatch> p_meta;
+    struct QueuedPairs { mth_batch_t d; mth_lpmd_pairs_params_t params; int32_t tid; uint64_t n_cpgs; };   // as q_pending (mth_pairs.hip)
+    std::vector<QueuedPairs> p_pending;
+    mth::DevBuf p_snap;
+    uint64_t p_rows_est = 0;
+    bool p_learned = false;
 
     // multi-GPU exchange step (mth_rccl.hip): communicator of the one-process-per-GPU form; lpmd_reduced = DevState.lpmd
     // already holds the all-reduced totals (cleared by the next batch that adds to them)

@@ -58,6 +58,7 @@ constexpr int PT_OCC = 6;
 constexpr int PT_S = 2048, PT_B = 256, PT_U = 2, PT_CHUNK = 1024, PT_GRID = 8192;   // tile kernel: LDS slots, threads, reads per thread and round (the tile
                                                    // width is a template parameter: 8192 / 16384 / 32768, chosen per batch)
 constexpr int P_STATE_WORDS = 8;
+constexpr int P_QUEUE_MAX = 4096;       // queued batches between two resolves
 constexpr int PT_NC = 8;                                 // calls of a read parked in LDS for the pair loops
 
 // COUNT: only count the updates (table sizing); otherwise insert them
@@ -422,17 +423,18 @@ __global__ __launch_bounds__(PT_B, PT_OCC) void k_pairs_tile(const PTileArgs a) 
 // restart of a batch whose rows did not fit: back to the row count before it
 __global__ void k_pairs_rewind(unsigned long long *ps, unsigned long long rows_before) { ps[1] = rows_before; ps[5] = 0; ps[6] = 0; }
 
+// a queued batch's state words as its tile kernel left them (mth_quartet.hip: k_quartet_snap)
+__global__ void k_pairs_snap(const unsigned long long *__restrict__ ps, unsigned long long *__restrict__ snap) {
+    if (threadIdx.x < P_STATE_WORDS) snap[threadIdx.x] = ps[threadIdx.x];
+}
+
 }  // namespace mth
 
 using namespace mth;
 
-extern "C" {
-
-int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_lpmd_pairs_params_t *params) {
-    if (!ctx || !batch || !params) return MTH_ERR_INVALID;
-    mth_batch_t d;
-    int rc = stage_batch(ctx, *batch, d);
-    if (rc) return rc;
+// One batch, synchronous or queued: the scheme of mth_quartet.hip's quartet_batch / quartet_resolve.
+static int pairs_batch(mth_ctx *ctx, const mth_batch_t &d, const mth_lpmd_pairs_params_t *params, int32_t batch_tid, bool queued) {
+    int rc = MTH_OK;
     hipStream_t s = ctx->stream;
     if (!ctx->p_state.p) {
         MTH_HIP(ctx, ctx->p_state.reserve(P_STATE_WORDS * sizeof(unsigned long long), s));
@@ -456,9 +458,11 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
     const int PT_W = 1 << tile_shift;
     const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + PT_W - 1) / PT_W) : 0u;
     const uint64_t tiles_before = ctx->p_meta.empty() ? 0 : ctx->p_meta.back().tile_end;
-    const uint64_t rows_before = ctx->p_rows;
-    mth_ctx::TileBatch meta{batch->tid, 0, rows_before, tiles_before + ntiles};
-    if (!ntiles) { ctx->p_meta.push_back(meta); return MTH_OK; }
+    const uint64_t rows_before = queued && !ctx->p_pending.empty() ? ctx->p_rows_est : ctx->p_rows;
+    mth_ctx::TileBatch meta{batch_tid, 0, rows_before, tiles_before + ntiles};
+    if (!ntiles && queued && !ctx->p_pending.empty()) queued = false, rc = pairs_resolve(ctx);
+    if (rc) return rc;
+    if (!ntiles) { meta.heavy0 = ctx->p_rows; ctx->p_meta.push_back(meta); return MTH_OK; }
     const bool r8 = d.cpg_rel != nullptr;
     int32_t idx_base = 0;
     uint32_t nt = 0;
@@ -473,11 +477,12 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
     unsigned long long *st = ctx->h_words;     // pinned: the read-back does not go through a staging copy
     for (int attempt = 0;; ++attempt) {
         if (want > ctx->p_cap) {
-            MTH_HIP(ctx, ctx->p_out_key.reserve(want * 8, s, true, rows_before * 8));
-            MTH_HIP(ctx, ctx->p_out_cnt.reserve(want * 8, s, true, rows_before * 8));
-            ctx->p_cap = want;
+            const uint64_t cap = want + (queued ? want / 4 : 0), used = std::min<uint64_t>(rows_before, ctx->p_cap);
+            MTH_HIP(ctx, ctx->p_out_key.reserve(cap * 8, s, true, used * 8));
+            MTH_HIP(ctx, ctx->p_out_cnt.reserve(cap * 8, s, true, used * 8));
+            ctx->p_cap = cap;
         }
-        hipLaunchKernelGGL(k_pairs_rewind, dim3(1), dim3(1), 0, s, ps, (unsigned long long)rows_before);
+        if (!queued || ctx->p_pending.empty()) hipLaunchKernelGGL(k_pairs_rewind, dim3(1), dim3(1), 0, s, ps, (unsigned long long)rows_before);
         PTileArgs a;
         a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
         a.idx = ctx->idx.as<uint32_t>(); a.cpg_rel = r8 ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
@@ -504,6 +509,16 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
                 if (r8) hipLaunchKernelGGL((k_pairs_tile<uint8_t, 16>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
                 else hipLaunchKernelGGL((k_pairs_tile<uint16_t, 16>), dim3(std::min<uint32_t>(ntiles, PT_GRID)), dim3(PT_B), 0, s, a);
             }
+        }
+        if (queued) {
+            const size_t k = ctx->p_pending.size();
+            MTH_HIP(ctx, ctx->p_snap.reserve((size_t)P_QUEUE_MAX * P_STATE_WORDS * sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(k_pairs_snap, dim3(1), dim3(64), 0, s, (const unsigned long long *)ps, ctx->p_snap.as<unsigned long long>() + k * P_STATE_WORDS);
+            MTH_HIP(ctx, hipGetLastError());
+            ctx->p_pending.push_back(mth_ctx::QueuedPairs{d, *params, batch_tid, d.n_cpgs});
+            ctx->p_rows_est = want;
+            ctx->p_meta.push_back(meta);                   // rows / heavy0: pairs_resolve
+            return MTH_OK;
         }
         MTH_HIP(ctx, hipMemcpyAsync(st, ps, P_STATE_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         MTH_HIP(ctx, hipStreamSynchronize(s));            // one sync per batch: rows, flagged tiles, fit
@@ -578,9 +593,59 @@ int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mt
     MTH_HIP(ctx, hipGetLastError());
     meta.rows = total - rows_before;
     ctx->p_rows = total;
-    if (d.n_cpgs) ctx->p_rows_per_cpg = std::max(ctx->p_rows_per_cpg * 0.5, (double)meta.rows / (double)d.n_cpgs);
+    if (d.n_cpgs) { ctx->p_rows_per_cpg = std::max(ctx->p_rows_per_cpg * 0.5, (double)meta.rows / (double)d.n_cpgs); ctx->p_learned = true; }
     ctx->p_meta.push_back(meta);
     return MTH_OK;
+}
+
+namespace mth {
+
+int pairs_resolve(mth_ctx *ctx) {
+    if (ctx->p_pending.empty()) return MTH_OK;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<mth_ctx::QueuedPairs> pend;
+    pend.swap(ctx->p_pending);
+    const size_t n = pend.size(), base = ctx->p_meta.size() - n;
+    std::vector<unsigned long long> snap(n * P_STATE_WORDS);
+    MTH_HIP(ctx, hipMemcpyAsync(snap.data(), ctx->p_snap.p, snap.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t good = 0;
+    uint64_t rows = 0, cpgs = 0;
+    for (; good < n; ++good) {
+        const unsigned long long *w = snap.data() + good * P_STATE_WORDS;
+        if (w[5] || w[6]) break;
+        mth_ctx::TileBatch &m = ctx->p_meta[base + good];
+        m.rows = w[1] - ctx->p_rows;
+        m.heavy0 = w[1];
+        rows += m.rows; cpgs += pend[good].n_cpgs;
+        ctx->p_rows = w[1];
+    }
+    if (cpgs) ctx->p_rows_per_cpg = std::max(ctx->p_rows_per_cpg * 0.5, (double)rows / (double)cpgs);
+    if (getenv("MTH_PAIRS_DEBUG")) fprintf(stderr, "[pairs] queued batches %zu, replayed %zu\n", n, n - good);     // tests
+    if (good == n) return MTH_OK;
+    ctx->p_meta.resize(base + good);
+    for (size_t k = good; k < n; ++k) {
+        const int rc = pairs_batch(ctx, pend[k].d, &pend[k].params, pend[k].tid, false);
+        if (rc) return rc;
+    }
+    return MTH_OK;
+}
+
+}  // namespace mth
+
+extern "C" {
+
+int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_lpmd_pairs_params_t *params) {
+    if (!ctx || !batch || !params) return MTH_ERR_INVALID;
+    static const bool queue_off = getenv("MTH_PAIRS_QUEUE") && atoi(getenv("MTH_PAIRS_QUEUE")) == 0;      // A/B: one sync per batch
+    const bool queued = batch->mem == MTH_MEM_DEVICE && ctx->p_learned && !ctx->timing && !queue_off && ctx->p_pending.size() < (size_t)P_QUEUE_MAX;
+    mth_batch_t d;
+    ctx->tile_queue_hold = queued;
+    int rc = stage_batch(ctx, *batch, d);
+    ctx->tile_queue_hold = false;
+    if (rc) return rc;
+    if (!queued && (rc = pairs_resolve(ctx))) return rc;
+    return pairs_batch(ctx, d, params, batch->tid, queued);
 }
 
 // rows sorted by ((tid,pos1),(tid,pos2)) given batches were submitted in (tid, region) order

@@ -36,6 +36,7 @@ constexpr int QT_QCAP = 2048;   // candidate reads per fill of the contributor q
 constexpr int QT_OCC = 6;  // waves per SIMD (LDS: 23 KiB per workgroup = 6 per CU)
 constexpr int QT_S = 512, QT_B = 256, QT_U = 2, QT_CHUNK = 512, QT_GRID = 8192;   // (the tile width is a template parameter: 8192 / 16384 / 32768, chosen per batch)
 constexpr int Q_STATE_WORDS = 8;
+constexpr int Q_QUEUE_MAX = 4096;       // queued batches between two resolves (their snapshots: 256 KB)
 
 __device__ __forceinline__ unsigned long long qhash(unsigned long long x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -509,18 +510,24 @@ __global__ __launch_bounds__(QT_B, QT_OCC) void k_quartet_tile(const QTileArgs a
 // (re)start of a batch: back to the row count before it
 __global__ void k_quartet_rewind(unsigned long long *qs, unsigned long long rows_before) { qs[1] = rows_before; qs[5] = 0; qs[6] = 0; }
 
+// a queued batch's state words as its tile kernel left them ([1] rows so far, [5] tiles for the global path and [6] tiles that did not
+// fit, both since the run of queued batches began): read back by quartet_resolve, not by the call that queued the batch
+__global__ void k_quartet_snap(const unsigned long long *__restrict__ qs, unsigned long long *__restrict__ snap) {
+    if (threadIdx.x < Q_STATE_WORDS) snap[threadIdx.x] = qs[threadIdx.x];
+}
+
 }  // namespace mth
 
 using namespace mth;
 
-extern "C" {
-
-int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_quartet_params_t *params) {
-    if (!ctx || !batch || !params) return MTH_ERR_INVALID;
-    ctx->q_epoch += 1;
-    mth_batch_t d;
-    int rc = stage_batch(ctx, *batch, d);
-    if (rc) return rc;
+// One batch.  queued = false: the call ends knowing the batch's rows (one host sync; redone with the exact size if the rows did not fit,
+// the global path for tiles the LDS table could not hold).  queued = true (device-resident batches after the first of a job): tile
+// kernel and a snapshot of the state words only -- whether everything fitted is looked at by quartet_resolve, at the next call that
+// needs the rows, and anything else than "all fitted, no tile for the global path" replays the batches from the first such one on
+// through the synchronous form (their arrays are still there: include/metheor_hip.h, device-resident batches stay untouched until
+// the next synchronising call).
+static int quartet_batch(mth_ctx *ctx, const mth_batch_t &d, const mth_quartet_params_t *params, int32_t batch_tid, bool queued) {
+    int rc = MTH_OK;
     hipStream_t s = ctx->stream;
     if (!ctx->q_state.p) {
         MTH_HIP(ctx, ctx->q_state.reserve(Q_STATE_WORDS * sizeof(unsigned long long), s));
@@ -550,9 +557,13 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
     const int QT_W = 1 << tile_shift;
     const uint32_t ntiles = (d.n_reads && region_len > 0) ? (uint32_t)((region_len + QT_W - 1) / QT_W) : 0u;
     const uint64_t tiles_before = ctx->q_meta.empty() ? 0 : ctx->q_meta.back().tile_end;
-    const uint64_t rows_before = ctx->q_rows;
-    mth_ctx::TileBatch meta{batch->tid, 0, rows_before, tiles_before + ntiles};
-    if (!ntiles) { ctx->q_meta.push_back(meta); return MTH_OK; }
+    // queued: the exact count is on the device only; q_rows_est bounds it from above (every queued batch so far within its estimate --
+    // if one was not, the resolve replays from there and none of this batch's rows survive anyway)
+    const uint64_t rows_before = queued && !ctx->q_pending.empty() ? ctx->q_rows_est : ctx->q_rows;
+    mth_ctx::TileBatch meta{batch_tid, 0, rows_before, tiles_before + ntiles};
+    if (!ntiles && queued && !ctx->q_pending.empty()) queued = false, rc = quartet_resolve(ctx);       // (rare: an empty batch inside a run)
+    if (rc) return rc;
+    if (!ntiles) { meta.heavy0 = ctx->q_rows; ctx->q_meta.push_back(meta); return MTH_OK; }
     auto grow_rows = [&](uint64_t cap, uint64_t used) -> hipError_t {      // keeps the rows of earlier batches
         hipError_t e;
         if ((e = ctx->q_pos.reserve(cap * 16, s, true, used * 16)) != hipSuccess) return e;
@@ -576,8 +587,10 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
     if (const char *e = getenv("MTH_QUARTET_ROWS_MIN")) want = rows_before + strtoull(e, nullptr, 10);   // tests: force the redo
     unsigned long long *st = ctx->h_words;     // pinned: the read-back does not go through a staging copy
     for (int attempt = 0;; ++attempt) {
-        if (want > ctx->q_cap) MTH_HIP(ctx, grow_rows(want, rows_before));
-        hipLaunchKernelGGL(k_quartet_rewind, dim3(1), dim3(1), 0, s, qs, (unsigned long long)rows_before);
+        if (want > ctx->q_cap) MTH_HIP(ctx, grow_rows(want + (queued ? want / 4 : 0), std::min<uint64_t>(rows_before, ctx->q_cap)));
+        // a run of queued batches continues from the device's own row count; its first batch (and every synchronous one) starts from
+        // the host's, which is exact then
+        if (!queued || ctx->q_pending.empty()) hipLaunchKernelGGL(k_quartet_rewind, dim3(1), dim3(1), 0, s, qs, (unsigned long long)rows_before);
         QTileArgs a;
         a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
         a.idx = ctx->idx.as<uint32_t>();
@@ -596,6 +609,16 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
             else if (tile_shift == 14) hipLaunchKernelGGL(k_quartet_tile<16384>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
             else if (tile_shift == 15) hipLaunchKernelGGL(k_quartet_tile<32768>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
             else hipLaunchKernelGGL(k_quartet_tile<65536>, dim3(std::min<uint32_t>(ntiles, QT_GRID)), dim3(QT_B), 0, s, a);
+        }
+        if (queued) {
+            const size_t k = ctx->q_pending.size();
+            MTH_HIP(ctx, ctx->q_snap.reserve((size_t)Q_QUEUE_MAX * Q_STATE_WORDS * sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(k_quartet_snap, dim3(1), dim3(64), 0, s, (const unsigned long long *)qs, ctx->q_snap.as<unsigned long long>() + k * Q_STATE_WORDS);
+            MTH_HIP(ctx, hipGetLastError());
+            ctx->q_pending.push_back(mth_ctx::QueuedBatch{d, *params, batch_tid, d.n_cpgs});
+            ctx->q_rows_est = want;
+            ctx->q_meta.push_back(meta);                   // rows / heavy0: quartet_resolve
+            return MTH_OK;
         }
         MTH_HIP(ctx, hipMemcpyAsync(st, qs, Q_STATE_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         MTH_HIP(ctx, hipStreamSynchronize(s));            // one sync per batch: rows, flagged tiles, fit
@@ -707,9 +730,64 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
     MTH_HIP(ctx, hipGetLastError());
     meta.rows = total - rows_before;
     ctx->q_rows = total;
-    if (d.n_cpgs) ctx->q_rows_per_cpg = std::max(ctx->q_rows_per_cpg * 0.5, (double)meta.rows / (double)d.n_cpgs);
+    if (d.n_cpgs) { ctx->q_rows_per_cpg = std::max(ctx->q_rows_per_cpg * 0.5, (double)meta.rows / (double)d.n_cpgs); ctx->q_learned = true; }
     ctx->q_meta.push_back(meta);
     return MTH_OK;
+}
+
+namespace mth {
+
+// The queued batches' rows: one read-back of their snapshots.  All fitted and no tile was left to the global path: the metas get
+// their row counts.  Otherwise the batches from the first one that says so are replayed synchronously, in order.
+int quartet_resolve(mth_ctx *ctx) {
+    if (ctx->q_pending.empty()) return MTH_OK;
+    MTH_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<mth_ctx::QueuedBatch> pend;
+    pend.swap(ctx->q_pending);
+    const size_t n = pend.size(), base = ctx->q_meta.size() - n;
+    std::vector<unsigned long long> snap(n * Q_STATE_WORDS);
+    MTH_HIP(ctx, hipMemcpyAsync(snap.data(), ctx->q_snap.p, snap.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t good = 0;
+    uint64_t rows = 0, cpgs = 0;
+    for (; good < n; ++good) {
+        const unsigned long long *w = snap.data() + good * Q_STATE_WORDS;
+        if (w[5] || w[6]) break;
+        mth_ctx::TileBatch &m = ctx->q_meta[base + good];
+        m.rows = w[1] - ctx->q_rows;
+        m.heavy0 = w[1];
+        rows += m.rows; cpgs += pend[good].n_cpgs;
+        ctx->q_rows = w[1];
+    }
+    if (cpgs) ctx->q_rows_per_cpg = std::max(ctx->q_rows_per_cpg * 0.5, (double)rows / (double)cpgs);
+    if (getenv("MTH_QUARTET_DEBUG")) fprintf(stderr, "[quartet] queued batches %zu, replayed %zu\n", n, n - good);     // tests
+    if (good == n) return MTH_OK;
+    ctx->q_meta.resize(base + good);
+    for (size_t k = good; k < n; ++k) {
+        const int rc = quartet_batch(ctx, pend[k].d, &pend[k].params, pend[k].tid, false);
+        if (rc) return rc;
+    }
+    return MTH_OK;
+}
+
+}  // namespace mth
+
+extern "C" {
+
+int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_quartet_params_t *params) {
+    if (!ctx || !batch || !params) return MTH_ERR_INVALID;
+    ctx->q_epoch += 1;
+    // Queued (no host sync in the call): a device-resident batch once a batch of this context has taught the output sizing, unless the
+    // launches are being timed.  MTH_QUARTET_QUEUE=0 switches it off (A/B).  Every other entry point settles the queue (mth::enter).
+    static const bool queue_off = getenv("MTH_QUARTET_QUEUE") && atoi(getenv("MTH_QUARTET_QUEUE")) == 0;
+    const bool queued = batch->mem == MTH_MEM_DEVICE && ctx->q_learned && !ctx->timing && !queue_off && ctx->q_pending.size() < (size_t)Q_QUEUE_MAX;
+    mth_batch_t d;
+    ctx->tile_queue_hold = queued;
+    int rc = stage_batch(ctx, *batch, d);
+    ctx->tile_queue_hold = false;
+    if (rc) return rc;
+    if (!queued && (rc = quartet_resolve(ctx))) return rc;
+    return quartet_batch(ctx, d, params, batch->tid, queued);
 }
 
 // rows of all batches with depth >= min_depth (me.rs:82 / pm.rs:77); any pointer may be NULL.
@@ -717,7 +795,7 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
 int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int32_t *tid, int32_t *pos4,
                       uint32_t *counts16, float *me, float *pm) {
     if (!ctx) return MTH_ERR_INVALID;
-    int rc = sync_and_check(ctx);
+    int rc = sync_and_check(ctx);          // resolves the queued batches first
     if (rc) return rc;
     // Rows live in [0, q_rows) with gaps (the unused tails of the tile kernel's chunks).  Row order: per batch, sorted by
     // (p1..p4): the tiles in position order give that for free (each tile's rows are sorted in LDS); a batch with rows from

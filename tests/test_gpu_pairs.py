@@ -167,3 +167,46 @@ def test_every_tile_width(eng, monkeypatch, shift):
     d = run_device(eng, cs, kw, regions=[shard.plan_regions(cs[0], 2), [(0, cs[1]["length"])]])
     monkeypatch.delenv("MTH_PAIRS_TILE_SHIFT")
     assert check(d, reads, kw) > 8000
+
+
+# ---- batches queued without a host sync (device-resident batches after a context's first; pairs_batch / pairs_resolve) ----
+@pytest.mark.parametrize("force", ["", "global", "unfit"])
+def test_queued_batches(monkeypatch, capfd, force):
+    """global: every tile of the queued batches refuses its LDS table -> replayed through the global path; unfit: the context learns
+    its output sizing from a tiny batch, the real ones behind it do not fit what they are given -> replayed at their exact size"""
+    import re
+    import metheor_amd
+    from metheor_amd import synth
+    rng = np.random.default_rng(41)
+    if force == "unfit":
+        cs = [synth.make_contig(0, 4_000, 40, 0.002, rng)] + [synth.make_contig(t, 1_200_000, 25_000, 0.04, rng) for t in (1, 2, 3)]
+    else:
+        cs = [synth.make_contig(t, 50_000 + 7_000 * t, 5_000 + 900 * t, 0.04, rng) for t in range(5)]
+    kw = dict(min_distance=2, max_distance=16, min_qual=10)
+    tabs = [pyoracle.Reads.decode(util.contig_to_records(c, "ctg%d" % c["tid"])).lpmd(pairs=True, **kw)["pairs"] for c in cs]
+    monkeypatch.setenv("MTH_PAIRS_DEBUG", "1")
+    e = metheor_amd.Engine(0)
+    try:
+        bts = [util.device_batch(c, device="cuda:0") for c in cs]
+        e.lpmd_pairs_accumulate(bts[0], **kw)                  # synchronous: a fresh context
+        if force == "global":
+            monkeypatch.setenv("MTH_PAIRS_FORCE_GLOBAL", "1")
+        for bt in bts[1:3]:
+            e.lpmd_pairs_accumulate(bt, **kw)
+        capfd.readouterr()
+        e.sync()                                                # resolves; more batches after it
+        q, r = map(int, re.search(r"\[pairs\] queued batches (\d+), replayed (\d+)", capfd.readouterr().err).groups())
+        assert q == 2 and r == (0 if force == "" else 2), (q, r)
+        for bt in bts[3:]:
+            e.lpmd_pairs_accumulate(bt, **kw)
+        d = e.lpmd_pairs_fetch()
+        off = 0
+        for c, t in zip(cs, tabs):
+            m = slice(off, off + len(t))
+            assert (d["tid"][m] == c["tid"]).all() and (d["pos1"][m] == t.pos[:, 0]).all() and (d["pos2"][m] == t.pos[:, 1]).all()
+            assert (d["n_concordant"][m] == t.cnt[:, 0]).all() and (d["n_discordant"][m] == t.cnt[:, 1]).all()
+            assert (d["lpmd"][m].view(np.uint32) == t.val.view(np.uint32)).all()
+            off += len(t)
+        assert off == len(d["tid"])
+    finally:
+        e.close()

@@ -303,3 +303,84 @@ def test_every_tile_width(eng, monkeypatch, shift):
     monkeypatch.delenv("MTH_QUARTET_TILE_SHIFT")
     check(d, reads, 10, 0)
     assert len(d["tid"]) > 7000
+
+
+# ---- batches queued without a host sync (device-resident batches after the first of a context; quartet_batch / quartet_resolve) ----
+def _queued_case(seed=31, n_contigs=5, length=60_000, reads=6_000):
+    from metheor_amd import synth
+    rng = np.random.default_rng(seed)
+    cs = [synth.make_contig(t, length + length // 7 * t, reads + reads // 4 * t, 0.04, rng) for t in range(n_contigs)]
+    recs = [util.contig_to_records(c, "ctg%d" % t) for t, c in enumerate(cs)]
+    tabs = [(pyoracle.Reads.decode(r).me(min_depth=2), pyoracle.Reads.decode(r).pm(min_depth=2)) for r in recs]
+    return cs, tabs
+
+
+def _check_queued(d, tabs):
+    n = 0
+    for t, (om, op) in enumerate(tabs):
+        m = d["tid"] == t
+        n += int(m.sum())
+        assert m.sum() == len(om)
+        order = np.lexsort((d["pos"][m][:, 3], d["pos"][m][:, 2], d["pos"][m][:, 1], d["pos"][m][:, 0]))
+        assert (d["pos"][m][order] == om.pos).all() and (d["cnt"][m][order] == om.cnt).all()
+        assert (d["pm"][m][order].view(np.uint32) == op.val.view(np.uint32)).all()
+        assert np.abs(d["me"][m][order].astype(np.float64) - om.val.astype(np.float64)).max() <= ME_TOL
+    assert n == len(d["tid"])
+
+
+@pytest.mark.parametrize("force", ["", "rows", "global"])
+def test_queued_batches(eng, monkeypatch, capfd, force):
+    """a job of device-resident batches: from the second batch on no call syncs; the fetch resolves them.  force = rows: the output is
+    sized too small for every queued batch (they are replayed synchronously, exact size); global: every tile refuses its LDS table"""
+    cs, tabs = _queued_case()
+    monkeypatch.setenv("MTH_QUARTET_DEBUG", "1")
+    eng.reset()
+    bts = [util.device_batch(c, device="cuda:0") for c in cs]
+    eng.quartet_accumulate(bts[0], min_qual=10)              # the first batch of a fresh context is synchronous whatever it is
+    if force == "rows":
+        eng.quartet_fetch(min_depth=2)                        # (capacity is only ever grown: start the check from a context that has little)
+    if force == "global":
+        monkeypatch.setenv("MTH_QUARTET_FORCE_GLOBAL", "1")
+    for bt in bts[1:]:
+        eng.quartet_accumulate(bt, min_qual=10)
+    capfd.readouterr()
+    d = eng.quartet_fetch(min_depth=2)
+    err = capfd.readouterr().err
+    import re
+    q, r = map(int, re.search(r"\[quartet\] queued batches (\d+), replayed (\d+)", err).groups())
+    assert q >= len(bts) - 1 and r == (len(bts) - 1 if force == "global" else 0), err        # (the first batch too, once the context has seen one)
+    _check_queued(d, tabs)
+    # the same job again after a reset, a count-only fetch first, then a batch more after the fetch (queue -> resolve -> queue)
+    monkeypatch.delenv("MTH_QUARTET_FORCE_GLOBAL", raising=False)
+    eng.reset()
+    for bt in bts[:3]:
+        eng.quartet_accumulate(bt, min_qual=10)
+    d3 = eng.quartet_fetch(min_depth=2)
+    _check_queued(d3, tabs[:3])
+    for bt in bts[3:]:
+        eng.quartet_accumulate(bt, min_qual=10)
+    _check_queued(eng.quartet_fetch(min_depth=2), tabs)
+
+
+def test_queued_batches_that_do_not_fit_are_replayed(monkeypatch, capfd):
+    """a fresh context whose first (synchronous) batch is tiny: the output sizing learnt from it is far too small for the dense
+    batches queued behind it -- they report 'did not fit' in their snapshots and the resolve replays them"""
+    import metheor_amd
+    from metheor_amd import synth
+    rng = np.random.default_rng(5)
+    tiny = synth.make_contig(0, 4_000, 40, 0.002, rng)
+    cs, tabs = _queued_case(seed=77, n_contigs=3, length=1_500_000, reads=30_000)      # shallow and long: about one quartet per site
+    monkeypatch.setenv("MTH_QUARTET_DEBUG", "1")
+    e = metheor_amd.Engine(0)
+    try:
+        keep = [util.device_batch(tiny, device="cuda:0")] + [util.device_batch(dict(c, tid=c["tid"] + 1), device="cuda:0") for c in cs]
+        for bt in keep:
+            e.quartet_accumulate(bt, min_qual=10)
+        capfd.readouterr()
+        d = e.quartet_fetch(min_depth=2)
+        err = capfd.readouterr().err
+        assert "[quartet] queued batches 3, replayed" in err and "replayed 0" not in err, err
+        m = d["tid"] >= 1
+        _check_queued({k: (v[m] - 1 if k == "tid" else v[m]) for k, v in d.items()}, tabs)
+    finally:
+        e.close()
