@@ -329,26 +329,36 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
     del bt
     # ---- config 3, all seven measures ----
     t0 = time.perf_counter()
-    resident, n_tot, c_tot = [], 0, 0
+    per_contig, lens, n_tot, c_tot = [], [], 0, 0
     for b, inf in synth_device.wgbs(n_reads=n_reads_total, device=dev):
-        resident.append(b); n_tot += inf["n_reads"]; c_tot += inf["n_calls"]
+        per_contig.append(b); lens.append(inf["length"]); n_tot += inf["n_reads"]; c_tot += inf["n_calls"]
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
+    # What the CLI submits since round 4: the contigs packed into contig GROUPS (include/metheor_hip.h; mth_decoded_group does it to the
+    # decoded stream, metheor_amd.batches.group_device_batches to these generated batches) -- 2 batches for the 24 contigs.  The
+    # per-contig batches are timed beside them (seven_measures_per_contig_ms: rounds 1-3's figure).
+    from metheor_amd import batches as _batches
+    resident = _batches.group_device_batches([eng], per_contig, lens)
     passes = {"pdr+lpmd": lambda b: eng.pdr_lpmd_accumulate(b, P0), "me/pm": lambda b: eng.quartet_accumulate(b),
               "mhl": lambda b: eng.mhl_accumulate(b), "fdrp+qfdrp": lambda b: eng.fdrp_accumulate(b),
               "lpmd --pairs": lambda b: eng.lpmd_pairs_accumulate(b)}
-    per = {}
+    per, per_c, rows_check = {}, {}, {}
+    counts = {"pdr+lpmd": lambda: eng.pdr_count(), "me/pm": lambda: eng.quartet_fetch(min_depth=10)["me"].shape[0], "mhl": lambda: eng.mhl_fetch()["pos"].shape[0],
+              "fdrp+qfdrp": lambda: eng.fdrp_fetch()["pos"].shape[0], "lpmd --pairs": lambda: eng.lpmd_pairs_fetch()["pos1"].shape[0]}
     for name, fn in passes.items():
-        best = None
-        for _ in range(3):
-            eng.reset(); eng.sync()
-            t0 = time.perf_counter()
-            for b in resident:
-                fn(b)
-            eng.sync()
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        per[name] = best
+        for which, bs in ((per_c, per_contig), (per, resident)):
+            best = None
+            for _ in range(3):
+                eng.reset(); eng.sync()
+                t0 = time.perf_counter()
+                for b in bs:
+                    fn(b)
+                eng.sync()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            which[name] = best
+            rows_check.setdefault(name, []).append(int(counts[name]()))
+        assert rows_check[name][0] == rows_check[name][1], (name, rows_check[name])      # grouped and per-contig give the same rows
     best_all = None
     for _ in range(3):
         eng.reset(); eng.sync()
@@ -371,6 +381,9 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
         for _ in range(4):
             st = torch.cuda.Stream(device=dev)
             engs.append((metheor_amd.Engine(dev.index, stream=st.cuda_stream), st))
+            for b in resident:                         # the same groups (same handles) on every context
+                if b.tid <= -2:
+                    engs[-1][0].group_copy(eng, b.tid)
         four = [lambda e, b: e.pdr_lpmd_accumulate(b, P0), lambda e, b: e.quartet_accumulate(b),
                 lambda e, b: e.mhl_accumulate(b), lambda e, b: e.fdrp_accumulate(b)]
         order = [3, 2, 1, 0]                       # the longest pass is queued first
@@ -400,10 +413,15 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
         conc = None
         out["all7_concurrent_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:200])
     out["all7"] = {"workload": "S-WGBS-200M (BASELINE config 3): %d x 150bp reads over 24 hg38-sized contigs, %.2f calls/read, every contig's batch resident, "
-                               "each measure's 24 batches queued back to back (as the CLI queues them); four passes give the seven measures "
+                               "each measure's batches queued back to back (as the CLI queues them); four passes give the seven measures "
                                "(PDR+LPMD fused, ME+PM from one quartet pass, MHL, FDRP+qFDRP from one walk), a fifth the LPMD --pairs table" % (n_tot, c_tot / n_tot),
-                   "reads": n_tot, "per_pass_ms_one_sync_each": {k: round(v * 1e3, 3) for k, v in per.items()},
+                   "reads": n_tot, "batches": "%d contig groups for the 24 contigs (%s reads), as the CLI submits them since round 4" % (len(resident), ", ".join(str(b.n_reads) for b in resident)),
+                   "per_pass_ms_one_sync_each": {k: round(v * 1e3, 3) for k, v in per.items()},
                    "seven_measures_ms": round(sum(seven.values()) * 1e3, 3), "all_five_passes_one_sync_ms": round(best_all * 1e3, 3),
+                   "per_contig_batches": {"what": "the same passes over one batch per contig (24 batches a pass: rounds 1-3's figure); same row counts asserted",
+                                          "per_pass_ms_one_sync_each": {k: round(v * 1e3, 3) for k, v in per_c.items()},
+                                          "seven_measures_ms": round(sum(v for k, v in per_c.items() if k != "lpmd --pairs") * 1e3, 3)},
+                   "rows": {k: v[1] for k, v in rows_check.items()},
                    "seven_measures_concurrent_ms": round(conc * 1e3, 3) if conc else None,
                    "seven_measures_concurrent_what": "the same four passes on four contexts of the one GPU (a stream and work buffers each), one host thread per context, wall clock from the first call to the last sync",
                    "G_reads_per_s_seven_concurrent": round(n_tot / conc / 1e9, 3) if conc else None,
@@ -412,7 +430,7 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
                    "frac_of_hbm_at_188B_per_read_unfused": round(188.0 * n_tot / sum(seven.values()) / 1e9 / HBM_PEAK_GBPS, 4),
                    "frac_of_hbm_at_39B_per_read_fused": round(39.0 * n_tot / sum(seven.values()) / 1e9 / HBM_PEAK_GBPS, 4),
                    "generate_s": round(t_gen, 2)}
-    del resident
+    del resident, per_contig
     torch.cuda.empty_cache()
     # ---- config 4 ----
     hb, hinf = synth_device.hotspots(device=dev)

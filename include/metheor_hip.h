@@ -190,6 +190,22 @@ int  mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const m
 int  mth_lpmd_pairs_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos1, int32_t *pos2, float *lpmd,
                           uint32_t *n_concordant, uint32_t *n_discordant);
 
+/* ---- contig groups: many contigs in one batch -------------------------------------------------------------------------------------
+ * A batch is a coordinate interval of ONE contig (mth_batch_t.tid).  A job over many contigs -- 24 for a human genome, thousands with
+ * alt / decoy contigs -- pays every pass's fixed costs (index build, kernel boundaries, a half-filled last wave of workgroups) once
+ * per contig.  A GROUP lays several contigs out in one virtual coordinate space: contig k's positions are shifted by voff[k], the gaps
+ * between contigs are wider than anything a measure looks across (a read's span, PDR's 150-bp flush margin, FDRP's 201-bp window), and
+ * the group is accumulated as ONE batch whose `tid` is the group's handle (<= -2).  No measure looks at a tid: the reference's
+ * per-contig behaviour -- a record on a later contig flushes every earlier site (is_before(), readutil.rs:304-310) -- is what a larger
+ * virtual position does too.  Every fetch maps a grouped batch's rows back: (handle, virtual position) -> (tids[k], position - voff[k])
+ * with k the last contig whose voff is <= the (first) position of the row; row order stays the (tid, pos) order when tids ascend.
+ * The reservoir draw of FDRP / qFDRP (keyed by tid and position) is made on the mapped-back site.
+ * voff: ascending, voff[0] >= 0, voff[k + 1] >= voff[k] + contig k's extent + max_span + 152 + 202 (checked only for order), all
+ * virtual positions below 2^31 - 1.  mth_group_clear forgets all groups (results fetched afterwards would keep their handles).
+ * mth_pdr_device_view hands out the virtual positions unmapped. */
+int  mth_group_define(mth_ctx_t *ctx, uint32_t n_contigs, const int32_t *tids, const int64_t *voff, int32_t *handle);
+int  mth_group_clear(mth_ctx_t *ctx);
+
 /* ---- ME / PM: per-quartet 16-bin epiallele histograms (me.rs:90-132, pm.rs:85-128) ------------
  * One accumulate serves both measures (they share the histogram).  Windows whose consecutive CpGs are >= 2048 bp
  * apart (reference skips, long reads) are aggregated under a 128-bit key on a side path; the calls of a read must be in
@@ -314,6 +330,15 @@ int  mth_decoded_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *start, int32_t *en
  * predecessor on the same contig (the input is not coordinate-sorted) */
 int  mth_decoded_contigs(mth_ctx_t *ctx, uint32_t cap, int32_t *tids, uint64_t *read_beg, uint64_t *read_end,
                          uint32_t *n_runs, uint32_t *flags);
+/* Contig groups for the decoded stream (see "contig groups" above): the runs of mth_decoded_contigs (n_contigs of them, tids strictly
+ * ascending, consecutive read ranges) are packed greedily into groups of at most 2^31 - 2^22 virtual positions; the reads' and calls'
+ * positions of every group with more than one contig are shifted IN PLACE on the device (mth_decoded_fetch then returns the shifted
+ * values) and the groups are registered.  Returns per group g < *n_groups: the contigs [first_contig[g], first_contig[g + 1]) and
+ * batch_tid[g] = the group's handle, or the contig's own tid for a group of one; the caller batches a group with
+ * mth_decoded_batch(ctx, read_beg[first_contig[g]], read_end[first_contig[g + 1] - 1], batch_tid[g], 0, -1, &b).
+ * *n_groups = 0: nothing was changed (tids not ascending, a call at position -1, or a previous grouping in place). */
+int  mth_decoded_group(mth_ctx_t *ctx, uint32_t n_contigs, const int32_t *tids, const uint64_t *read_beg, const uint64_t *read_end,
+                       uint32_t *n_groups, uint32_t *first_contig /* [n_contigs + 1] */, int32_t *batch_tid /* [n_contigs] */);
 /* re-order the decoded stream by (tid, start), stably, on the device -- for the measures whose result does not depend on the
  * record order (lpmd.rs:175-200, me.rs:106-125, pm.rs:101-121): an input that is not coordinate-sorted or not grouped by contig
  * can then be batched like a sorted one.  Every record must have a contig and an aligned base (flags bit0 / bit1 clear). */

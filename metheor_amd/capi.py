@@ -16,7 +16,7 @@ SYMBOLS = [
     "mth_pdr_fetch", "mth_result_buffer_alloc", "mth_result_buffer_free", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_add_unbatched", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
     "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
-    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_bgzf_stage", "mth_decode_reserve", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_sort", "mth_fileorder_run", "mth_fileorder_fetch", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
+    "mth_decode_records", "mth_decode_set_cpg_filter", "mth_decode_set_xm_min_mapq", "mth_bgzf_inflate", "mth_bgzf_decode", "mth_bgzf_stage", "mth_decode_reserve", "mth_decoded_fetch", "mth_decoded_contigs", "mth_decoded_sort", "mth_decoded_group", "mth_group_define", "mth_group_clear", "mth_fileorder_run", "mth_fileorder_fetch", "mth_decoded_batch", "mth_tag_set_genome", "mth_tag_records",
     "mth_timing_enable", "mth_timing_reset", "mth_timing_get", "mth_timing_num_kernels",
     "mth_timing_kernel_name",
 ]
@@ -142,6 +142,9 @@ def lib():
         L.mth_decoded_fetch.argtypes = [vp] * 9
         L.mth_decoded_contigs.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.mth_decoded_sort.argtypes = [vp]
+        L.mth_decoded_group.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(C.c_uint32), vp, vp]
+        L.mth_group_define.argtypes = [vp, C.c_uint32, vp, vp, C.POINTER(C.c_int32)]
+        L.mth_group_clear.argtypes = [vp]
         L.mth_fileorder_run.argtypes = [vp, C.POINTER(mth_fileorder_params_t)]
         L.mth_fileorder_fetch.argtypes = [vp, C.POINTER(C.c_uint64)] + [vp] * 6
         L.mth_decoded_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(mth_batch_t)]
@@ -459,6 +462,31 @@ class Engine:
         self._check(self.L.mth_decoded_contigs(self.h, cap, tids.ctypes.data, beg.ctypes.data, end.ctypes.data, C.byref(n), C.byref(fl)))
         k = min(n.value, cap)
         return tids[:k], beg[:k], end[:k], fl.value
+
+    def group_define(self, tids, voff):
+        """contigs `tids` laid out at virtual offsets `voff` (ascending): the handle to use as the tid of their one batch"""
+        t, v = np.ascontiguousarray(tids, np.int32), np.ascontiguousarray(voff, np.int64)
+        assert len(t) == len(v)
+        h = C.c_int32(0)
+        self._check(self.L.mth_group_define(self.h, len(t), t.ctypes.data, v.ctypes.data, C.byref(h)))
+        self.__dict__.setdefault("_groups", {})[h.value] = (t.copy(), v.copy())
+        return h.value
+
+    def group_copy(self, other, handle):
+        """define on this engine the group `handle` of engine `other` (must come out under the same handle)"""
+        g = other._groups[handle]
+        assert self.group_define(*g) == handle
+
+    def group_clear(self):
+        self._check(self.L.mth_group_clear(self.h))
+
+    def decoded_group(self, tids, read_beg, read_end):
+        """pack the decoded stream's contigs into groups (positions shifted in place): [(batch_tid, read_beg, read_end, [tids])], [] if not grouped"""
+        t = np.ascontiguousarray(tids, np.int32); b = np.ascontiguousarray(read_beg, np.uint64); e = np.ascontiguousarray(read_end, np.uint64)
+        n = len(t)
+        first, bt, ng = np.zeros(n + 1, np.uint32), np.zeros(max(n, 1), np.int32), C.c_uint32(0)
+        self._check(self.L.mth_decoded_group(self.h, n, t.ctypes.data, b.ctypes.data, e.ctypes.data, C.byref(ng), first.ctypes.data, bt.ctypes.data))
+        return [(int(bt[g]), int(b[first[g]]), int(e[first[g + 1] - 1]), [int(x) for x in t[first[g]:first[g + 1]]]) for g in range(ng.value)]
 
     def decoded_sort(self):
         """the decoded stream re-ordered by (tid, start) on the device (order-free measures on unsorted input)"""

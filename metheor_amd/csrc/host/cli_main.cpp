@@ -506,6 +506,29 @@ bool load_on_device(Input &in, const char *cpg_set, CtxFuture &cf) {
         c.tid = tids[k]; c.r0 = rb[k]; c.r1 = re[k]; c.n_reads = (size_t)(re[k] - rb[k]); c.n_cpgs = 0;
         c.region_beg = reg_beg; c.region_end = reg_end;
     }
+    // Several contigs per batch (include/metheor_hip.h, "contig groups"): every pass pays its fixed costs per batch, and a human BAM
+    // has 24 to a few thousand contigs.  The library shifts the decoded positions into one virtual coordinate space per group and maps
+    // the rows back at the fetch, so nothing below this line knows.  Not under a shard / region plan (those own parts of contigs);
+    // METHEOR_GROUP=0 keeps one batch per contig (A/B, tests).
+    if (!g_shard.planned() && in.contigs.size() > 1 && !(getenv("METHEOR_GROUP") && atoi(getenv("METHEOR_GROUP")) == 0)) {
+        Phase pg("  contig groups");
+        const uint32_t nc = (uint32_t)in.contigs.size();
+        std::vector<int32_t> gt(nc), bt(nc);
+        std::vector<uint64_t> gb(nc), ge(nc);
+        std::vector<uint32_t> first((size_t)nc + 1);
+        for (uint32_t k = 0; k < nc; ++k) { gt[k] = in.contigs[k].tid; gb[k] = in.contigs[k].r0; ge[k] = in.contigs[k].r1; }
+        uint32_t ng = 0;
+        check(in.ctx, mth_decoded_group(in.ctx, nc, gt.data(), gb.data(), ge.data(), &ng, first.data(), bt.data()));
+        if (ng) {
+            std::vector<Contig> grouped((size_t)ng);
+            for (uint32_t g = 0; g < ng; ++g) {
+                Contig &c = grouped[g];
+                c.tid = bt[g]; c.r0 = gb[first[g]]; c.r1 = ge[first[g + 1] - 1]; c.n_reads = (size_t)(c.r1 - c.r0); c.n_cpgs = 0;
+                c.region_beg = 0; c.region_end = -1;
+            }
+            in.contigs.swap(grouped);
+        }
+    }
     in.device = true;
     return true;
 }

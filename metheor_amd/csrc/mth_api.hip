@@ -99,6 +99,45 @@ int enter(mth_ctx *ctx) {
     return rc;
 }
 
+bool has_group_batch(const mth_ctx *ctx, int which) {
+    if (ctx->groups.empty()) return false;
+    auto any = [](const auto &v) { for (const auto &m : v) if (m.tid <= -2) return true; return false; };
+    switch (which) {
+        case 0: return any(ctx->batches);
+        case 1: return any(ctx->m_batches);
+        case 2: return any(ctx->f_batches);
+        case 3: return any(ctx->q_meta);
+        default: return any(ctx->p_meta);
+    }
+}
+
+const int32_t *group_table(const mth_ctx *ctx, int32_t tid, uint32_t *n) {
+    *n = 0;
+    if (tid > -2 || (size_t)(-2 - (int64_t)tid) >= ctx->groups.size()) return nullptr;
+    const mth_ctx::ContigGroup &g = ctx->groups[(size_t)(-2 - (int64_t)tid)];
+    *n = (uint32_t)g.tids.size();
+    return g.d_tab.as<int32_t>();
+}
+
+int ungroup_rows(mth_ctx *ctx, uint64_t n, int32_t *tid, int32_t *pos_a, int stride, int cols, int32_t *pos_b) {
+    if (ctx->groups.empty() || !tid || !pos_a) return MTH_OK;
+    for (uint64_t i = 0; i < n; ++i) {
+        const int32_t h = tid[i];
+        if (h > -2) continue;
+        const size_t gi = (size_t)(-2 - (int64_t)h);
+        if (gi >= ctx->groups.size()) return fail(ctx, MTH_ERR_STATE, "a result row carries the handle of a contig group that is not defined (any more)");
+        const mth_ctx::ContigGroup &g = ctx->groups[gi];
+        const int64_t v = pos_a[i * (uint64_t)stride];
+        const size_t k = (size_t)(std::upper_bound(g.voff.begin(), g.voff.end(), v) - g.voff.begin());
+        if (k == 0) return fail(ctx, MTH_ERR_STATE, "a grouped batch's row lies before the group's first contig");
+        const int32_t off = (int32_t)g.voff[k - 1];
+        tid[i] = g.tids[k - 1];
+        for (int c = 0; c < cols; ++c) pos_a[i * (uint64_t)stride + c] -= off;
+        if (pos_b) pos_b[i] -= off;
+    }
+    return MTH_OK;
+}
+
 int sync_and_check(mth_ctx *ctx) {
     MTH_ENTER(ctx);   // every entry point passes through here or stage_batch: the calling thread may be new
     MTH_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
@@ -255,6 +294,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
                       &ctx->f_state, &ctx->f_pos, &ctx->f_val, &ctx->f_qval, &ctx->f_n, &ctx->f_batch_rows, &ctx->f_rows, &ctx->f_pairtab, &ctx->fo_sel, &ctx->fo_flag, &ctx->fo_tmp, &ctx->fo_out, &ctx->f_redo, &ctx->f_terms, &ctx->f_soff, &ctx->f_snz, &ctx->f_sdisc,
                       &ctx->p_state, &ctx->p_keys, &ctx->p_cnt, &ctx->p_out_key, &ctx->p_out_cnt, &ctx->p_batch_rows, &ctx->p_tflag, &ctx->p_tile_row0, &ctx->p_tile_rows})
         b->release();
+    for (auto &g : ctx->groups) g.d_tab.release();
     for (auto &t : ctx->timed) { (void)hipEventDestroy(t.beg); (void)hipEventDestroy(t.end); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->d_state) (void)hipFree(ctx->d_state);
@@ -279,6 +319,36 @@ int mth_ctx_set_stream(mth_ctx_t *ctx, void *hip_stream) {
 int mth_ctx_sync(mth_ctx_t *ctx) {
     if (!ctx) return MTH_ERR_INVALID;
     return sync_and_check(ctx);
+}
+
+int mth_group_define(mth_ctx_t *ctx, uint32_t n_contigs, const int32_t *tids, const int64_t *voff, int32_t *handle) {
+    if (!ctx || !n_contigs || !tids || !voff || !handle) return MTH_ERR_INVALID;
+    for (uint32_t k = 0; k < n_contigs; ++k) {
+        if (tids[k] < 0) return fail(ctx, MTH_ERR_INVALID, "contig group: a tid below 0");
+        if (voff[k] < 0 || voff[k] >= INT32_MAX || (k && voff[k] <= voff[k - 1])) return fail(ctx, MTH_ERR_INVALID, "contig group: offsets must ascend within [0, 2^31 - 1)");
+    }
+    if (ctx->groups.size() >= (size_t)(1u << 30)) return fail(ctx, MTH_ERR_CAPACITY, "too many contig groups");
+    MTH_ENTER(ctx);
+    mth_ctx::ContigGroup g;
+    g.tids.assign(tids, tids + n_contigs);
+    g.voff.assign(voff, voff + n_contigs);
+    std::vector<int32_t> tab(2 * (size_t)n_contigs);
+    for (uint32_t k = 0; k < n_contigs; ++k) { tab[k] = (int32_t)voff[k]; tab[n_contigs + k] = tids[k]; }
+    MTH_HIP(ctx, g.d_tab.reserve(tab.size() * 4, ctx->stream));
+    MTH_HIP(ctx, hipMemcpyAsync(g.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));      // tab is a local
+    *handle = -2 - (int32_t)ctx->groups.size();
+    ctx->groups.push_back(std::move(g));
+    return MTH_OK;
+}
+
+int mth_group_clear(mth_ctx_t *ctx) {
+    if (!ctx) return MTH_ERR_INVALID;
+    MTH_ENTER(ctx);
+    MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));      // a kernel in flight may be reading a table
+    for (auto &g : ctx->groups) g.d_tab.release();
+    ctx->groups.clear();
+    return MTH_OK;
 }
 
 int mth_reset(mth_ctx_t *ctx) {
@@ -397,14 +467,23 @@ int mth_pdr_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *pos, float *pdr, uint32
     if (nc) MTH_HIP(ctx, hipMemcpyAsync(nc, ctx->out_nc.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (nd) MTH_HIP(ctx, hipMemcpyAsync(nd, ctx->out_nd.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (tid) {
+    // rows of contig groups come back under their own contig: both columns are needed for that, whichever the caller asked for
+    const bool grouped = (tid || pos) && has_group_batch(ctx, 0);
+    std::vector<int32_t> tmp;
+    if (grouped && !(tid && pos)) {
+        tmp.resize(n);
+        if (!pos) MTH_HIP(ctx, hipMemcpy(tmp.data(), ctx->out_pos.p, n * 4, hipMemcpyDeviceToHost));
+    }
+    int32_t *tid_w = tid ? tid : (grouped ? tmp.data() : nullptr), *pos_w = pos ? pos : (grouped ? tmp.data() : nullptr);
+    if (tid_w) {
         std::vector<uint32_t> cnt(ctx->batches.size());
         if (!cnt.empty()) MTH_HIP(ctx, hipMemcpy(cnt.data(), ctx->batch_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost));
         uint64_t o = 0;
         for (size_t b = 0; b < cnt.size(); ++b)
-            for (uint32_t j = 0; j < cnt[b] && o < n; ++j) tid[o++] = ctx->batches[b].tid;
+            for (uint32_t j = 0; j < cnt[b] && o < n; ++j) tid_w[o++] = ctx->batches[b].tid;
         if (o != n) return fail(ctx, MTH_ERR_STATE, "per-batch row counts do not add up to the row count");
     }
+    if (grouped) return ungroup_rows(ctx, n, tid_w, pos_w, 1, 1, nullptr);
     return MTH_OK;
 }
 

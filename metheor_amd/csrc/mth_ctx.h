@@ -98,6 +98,10 @@ struct mth_ctx {
     std::vector<uint64_t> tag_h_off;
     std::vector<uint32_t> tag_h_len;
     std::vector<uint8_t> tag_h_xm;
+    // contig groups (include/metheor_hip.h, "contig groups"): handle -2 - k is groups[k]
+    struct ContigGroup { std::vector<int32_t> tids; std::vector<int64_t> voff; mth::DevBuf d_tab; };   // d_tab: n voff (int32) then n tids
+    std::vector<ContigGroup> groups;
+    bool dec_grouped = false;                // mth_decoded_group has shifted the decoded stream's positions
     // results (PDR columns)
     mth::DevBuf out_pos, out_pdr, out_nc, out_nd;
     uint64_t out_cap = 0;        // rows
@@ -181,6 +185,12 @@ int  fail(mth_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess)
 // first thing every entry point does: make the context's device current for the calling thread (it may be new) and order
 // ctx->stream behind whatever the PDR + LPMD pipeline lanes still hold
 int  enter(mth_ctx *ctx);
+// rows of grouped batches back to (tid, position): tid[i] <= -2 is a group handle, pos_a[i * stride .. + cols) and pos_b[i] (optional)
+// its virtual positions (mth_api.hip)
+int  ungroup_rows(mth_ctx *ctx, uint64_t n, int32_t *tid, int32_t *pos_a, int stride, int cols, int32_t *pos_b);
+bool has_group_batch(const mth_ctx *ctx, int which);      // any grouped batch among the accumulated ones of measure `which` (0 pdr 1 mhl 2 fdrp 3 quartet 4 pairs)
+// device table of a group handle (n voff as int32, then n tids), nullptr / 0 for a plain tid
+const int32_t *group_table(const mth_ctx *ctx, int32_t tid, uint32_t *n);
 int  pipe_join(mth_ctx *ctx);
 #define MTH_ENTER(ctx)                                                  \
     do {                                                                \

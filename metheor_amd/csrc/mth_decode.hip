@@ -277,6 +277,45 @@ __global__ __launch_bounds__(256) void k_dec_offsets(const uint32_t *__restrict_
     if (i0 < n_rec && i0 + DS_PER >= n_rec) off[n_rec] = run;     // the thread holding the last record closes the array
 }
 
+// ---- contig groups (include/metheor_hip.h): extents per run of the decoded stream, then the in-place shift ----------------------------
+__device__ __forceinline__ uint32_t grp_run_of(const unsigned long long *__restrict__ run_beg, uint32_t n_runs, unsigned long long i) {
+    uint32_t lo = 0, hi = n_runs;                             // last run whose first read is <= i
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (run_beg[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ext[k] = last covered position + 1 over run k's reads; st[0] = widest read, st[1] = calls at position -1 (a reverse read at 0:
+// not representable once shifted) + reads without an aligned base
+__global__ __launch_bounds__(256) void k_grp_extent(const int32_t *__restrict__ start, const int32_t *__restrict__ end,
+                                                    const unsigned long long *__restrict__ off, const uint32_t *__restrict__ pos,
+                                                    unsigned long long r0, unsigned long long n, const unsigned long long *__restrict__ run_beg,
+                                                    uint32_t n_runs, uint32_t *__restrict__ ext, uint32_t *__restrict__ st) {
+    for (unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * 256) {
+        const unsigned long long i = r0 + t;
+        const int32_t s = start[i], e = end[i];
+        if (s < 0 || e < s) { atomicAdd(&st[1], 1u); continue; }
+        const uint32_t k = grp_run_of(run_beg, n_runs, i);
+        // (sorted reads: a wave's ends are close to each other -- the maximum rarely moves, so most atomics are skipped)
+        if ((uint32_t)e + 1u > ext[k]) atomicMax(&ext[k], (uint32_t)e + 1u);
+        if ((uint32_t)(e - s + 1) > st[0]) atomicMax(&st[0], (uint32_t)(e - s + 1));
+        if (s == 0)
+            for (unsigned long long c = off[i]; c < off[i + 1]; ++c)
+                if ((pos[c] & 0x7fffffffu) == 0x7fffffffu) atomicAdd(&st[1], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grp_shift(int32_t *__restrict__ start, int32_t *__restrict__ end, const unsigned long long *__restrict__ off,
+                                                   uint32_t *__restrict__ pos, unsigned long long r0, unsigned long long n,
+                                                   const unsigned long long *__restrict__ run_beg, const int32_t *__restrict__ run_voff, uint32_t n_runs) {
+    for (unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * 256) {
+        const unsigned long long i = r0 + t;
+        const int32_t v = run_voff[grp_run_of(run_beg, n_runs, i)];
+        if (!v) continue;
+        start[i] += v; end[i] += v;
+        for (unsigned long long c = off[i]; c < off[i + 1]; ++c) { const uint32_t w = pos[c]; pos[c] = ((w & 0x7fffffffu) + (uint32_t)v) | (w & 0x80000000u); }
+    }
+}
+
 // a contiguous read range of ONE contig as a device-resident batch: 32-bit offsets rebased to the range's first call,
 // and the widest read (max_span) reduced on the device
 __global__ __launch_bounds__(256) void k_dec_rebase(const unsigned long long *__restrict__ off, uint64_t r0, uint32_t n_reads,
@@ -357,7 +396,8 @@ int scan_u32_to_u64(mth_ctx *ctx, const uint32_t *n, uint32_t count, unsigned lo
 // the decode proper: d_raw / d_off are device-resident
 int decode_core(mth_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_off, uint64_t n_rec, int append, mth_decoded_t *out) {
     hipStream_t s = ctx->stream;
-    if (!append) { ctx->dec_reads = 0; ctx->dec_cpgs = 0; }
+    if (append && ctx->dec_grouped) return fail(ctx, MTH_ERR_STATE, "records appended to a decoded stream whose positions mth_decoded_group has shifted");
+    if (!append) { ctx->dec_reads = 0; ctx->dec_cpgs = 0; ctx->dec_grouped = false; }
     // the SoA grows geometrically when windows are appended (a reallocation copies what is already decoded)
     const size_t R0 = (size_t)ctx->dec_reads, C0 = (size_t)ctx->dec_cpgs, nr = (size_t)n_rec, R1 = R0 + nr;
     auto grow = [&](DevBuf &b, size_t need, size_t used) -> hipError_t {
@@ -525,6 +565,79 @@ int mth_decoded_fetch(mth_ctx_t *ctx, int32_t *tid, int32_t *start, int32_t *end
     if (cpg_off) MTH_HIP(ctx, hipMemcpy(cpg_off, ctx->dec_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost));
     if (cpg_pos && nc) MTH_HIP(ctx, hipMemcpy(cpg_pos, ctx->dec_pos.p, nc * 4, hipMemcpyDeviceToHost));
     if (cpg_rel && nc) MTH_HIP(ctx, hipMemcpy(cpg_rel, ctx->dec_rel.p, nc * 2, hipMemcpyDeviceToHost));
+    return MTH_OK;
+}
+
+int mth_decoded_group(mth_ctx_t *ctx, uint32_t n_contigs, const int32_t *tids, const uint64_t *read_beg, const uint64_t *read_end,
+                      uint32_t *n_groups, uint32_t *first_contig, int32_t *batch_tid) {
+    if (!ctx || !n_groups || (n_contigs && (!tids || !read_beg || !read_end || !first_contig || !batch_tid))) return MTH_ERR_INVALID;
+    *n_groups = 0;
+    if (n_contigs < 2 || ctx->dec_grouped || ctx->dec_contig_flags) return MTH_OK;
+    for (uint32_t k = 0; k < n_contigs; ++k) {
+        if (tids[k] < 0 || read_end[k] < read_beg[k] || read_end[k] > ctx->dec_reads) return MTH_ERR_INVALID;
+        if (k && (tids[k] <= tids[k - 1] || read_beg[k] != read_end[k - 1])) return MTH_OK;        // not one ascending, gap-free sequence of runs
+    }
+    MTH_ENTER(ctx);
+    hipStream_t s = ctx->stream;
+    const uint64_t r0 = read_beg[0], n = read_end[n_contigs - 1] - r0;
+    if (n == 0) return MTH_OK;
+    // device: the runs' first reads, their extents, two status words, later their offsets
+    MTH_HIP(ctx, ctx->dec_runs.reserve((size_t)n_contigs * 16 + 64, s));
+    uint8_t *base = static_cast<uint8_t *>(ctx->dec_runs.p);
+    unsigned long long *d_beg = reinterpret_cast<unsigned long long *>(base);
+    uint32_t *d_ext = reinterpret_cast<uint32_t *>(base + (size_t)n_contigs * 8);
+    int32_t *d_voff = reinterpret_cast<int32_t *>(base + (size_t)n_contigs * 12);
+    uint32_t *d_st = reinterpret_cast<uint32_t *>(base + (size_t)n_contigs * 16);
+    std::vector<unsigned long long> hb(read_beg, read_beg + n_contigs);
+    MTH_HIP(ctx, hipMemcpyAsync(d_beg, hb.data(), (size_t)n_contigs * 8, hipMemcpyHostToDevice, s));
+    MTH_HIP(ctx, hipMemsetAsync(d_ext, 0, (size_t)n_contigs * 8 + 16, s));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_grp_extent, dim3(grid), dim3(256), 0, s, ctx->dec_start.as<int32_t>(), ctx->dec_end.as<int32_t>(),
+                       ctx->dec_off.as<unsigned long long>(), ctx->dec_pos.as<uint32_t>(), (unsigned long long)r0, (unsigned long long)n,
+                       d_beg, n_contigs, d_ext, d_st);
+    std::vector<uint32_t> ext(n_contigs);
+    uint32_t st[2] = {0, 0};
+    std::vector<unsigned long long> coff((size_t)n_contigs + 1);
+    MTH_HIP(ctx, hipMemcpyAsync(ext.data(), d_ext, (size_t)n_contigs * 4, hipMemcpyDeviceToHost, s));
+    MTH_HIP(ctx, hipMemcpyAsync(st, d_st, 8, hipMemcpyDeviceToHost, s));
+    for (uint32_t k = 0; k <= n_contigs; ++k)
+        MTH_HIP(ctx, hipMemcpyAsync(&coff[k], ctx->dec_off.as<unsigned long long>() + (k < n_contigs ? read_beg[k] : read_end[n_contigs - 1]), 8, hipMemcpyDeviceToHost, s));
+    MTH_HIP(ctx, hipStreamSynchronize(s));
+    if (st[1]) return MTH_OK;                                  // a call at -1 / a read without an aligned base: leave the stream as it is
+    // The gap after a contig: wider than anything a measure looks across -- a read's span, PDR's flush margin (pdr.rs:162: 150), the
+    // FDRP window (fdrp.rs:10: 201) and the index quanta -- and a multiple of the dense tile width.
+    const int64_t gap = (int64_t)st[0] + 1024;
+    const int64_t vmax = ((int64_t)1 << 31) - ((int64_t)1 << 22);
+    std::vector<int32_t> voff(n_contigs, 0);
+    std::vector<uint32_t> first;
+    int64_t vlen = 0;
+    uint64_t g_reads = 0, g_calls = 0;
+    for (uint32_t k = 0; k < n_contigs; ++k) {
+        const int64_t e = (((int64_t)ext[k] + gap + 4095) / 4096) * 4096;
+        const uint64_t kr = read_end[k] - read_beg[k], kc = coff[k + 1] - coff[k];
+        if (first.empty() || vlen + e > vmax || g_reads + kr >= (1ull << 32) - 1 || g_calls + kc >= (1ull << 32)) { first.push_back(k); vlen = 0; g_reads = g_calls = 0; }
+        voff[k] = (int32_t)vlen;
+        vlen += e; g_reads += kr; g_calls += kc;
+    }
+    if (first.size() == n_contigs) return MTH_OK;              // nothing to merge
+    MTH_HIP(ctx, hipMemcpyAsync(d_voff, voff.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_grp_shift, dim3(grid), dim3(256), 0, s, ctx->dec_start.as<int32_t>(), ctx->dec_end.as<int32_t>(),
+                       ctx->dec_off.as<unsigned long long>(), ctx->dec_pos.as<uint32_t>(), (unsigned long long)r0, (unsigned long long)n,
+                       d_beg, (const int32_t *)d_voff, n_contigs);
+    MTH_HIP(ctx, hipGetLastError());
+    MTH_HIP(ctx, hipStreamSynchronize(s));                      // voff / hb are locals
+    ctx->dec_grouped = true;
+    first.push_back(n_contigs);
+    for (size_t g = 0; g + 1 < first.size(); ++g) {
+        const uint32_t k0 = first[g], k1 = first[g + 1];
+        first_contig[g] = k0;
+        if (k1 - k0 == 1) { batch_tid[g] = tids[k0]; continue; }
+        std::vector<int64_t> vo(voff.begin() + k0, voff.begin() + k1);
+        const int rc = mth_group_define(ctx, k1 - k0, tids + k0, vo.data(), &batch_tid[g]);
+        if (rc) return rc;
+    }
+    first_contig[first.size() - 1] = n_contigs;
+    *n_groups = (uint32_t)first.size() - 1;
     return MTH_OK;
 }
 

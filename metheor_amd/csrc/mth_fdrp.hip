@@ -53,6 +53,8 @@ struct FdrpArgs {
     const DevState *sites_st;
     const int32_t  *site_pos;
     const uint32_t *site_nc, *site_nd;   // discovery's per-site read counts (reads passing mapq that call the site)
+    const int32_t *grp_tab;              // a contig group's batch: n voff then n tids (else nullptr); the draw below is keyed by the real site
+    uint32_t grp_n;
     DevState *st;
     float    *fdrp, *qfdrp;     // per candidate site
     uint32_t *nreads, *flags;
@@ -83,6 +85,17 @@ __device__ __forceinline__ int32_t sample_j(unsigned long long seed, int32_t tid
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
     z = z ^ (z >> 31);
     return (int32_t)(z % (unsigned long long)(uint32_t)total) + 1;
+}
+
+// the reservoir draw of site c of the batch: on the site's own contig and position when the batch is a contig group
+__device__ __forceinline__ int32_t sample_site(const int32_t *__restrict__ grp_tab, uint32_t grp_n, unsigned long long seed, int32_t tid, int32_t c, int32_t total) {
+    if (grp_tab) {
+        uint32_t lo = 0, hi = grp_n;                              // last contig whose offset is <= c
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (grp_tab[mid] <= c) lo = mid; else hi = mid; }
+        tid = grp_tab[grp_n + lo];
+        c -= grp_tab[lo];
+    }
+    return sample_j(seed, tid, c, total);
 }
 
 // PMC of the first version (profiles/r01_fdrp_pmc.md): the per-CU scalar unit was ~81 % busy -- wave-uniform
@@ -547,7 +560,7 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
                     slot = total; total += 1; sampled += 1;
                 } else {                                                       // fdrp.rs:87-94 (reservoir)
                     total += 1;
-                    const int32_t jr = sample_j(a.seed, a.tid, c, total);
+                    const int32_t jr = sample_site(a.grp_tab, a.grp_n, a.seed, a.tid, c, total);
                     if (jr > (int32_t)a.max_depth) continue;
                     slot = jr - 1;
                 }
@@ -1063,7 +1076,7 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
             if (!redo && a.max_depth > 64u && n_sel > 64u) redo = true;                         // more than this kernel's 64 slots are in use
             if (!redo && n_sel > nS) {
                 for (uint32_t t = nS + (uint32_t)lane; t < n_sel; t += 64u) {
-                    const int32_t jr = sample_j(a.seed, a.tid, c, (int32_t)t + 1);
+                    const int32_t jr = sample_site(a.grp_tab, a.grp_n, a.seed, a.tid, c, (int32_t)t + 1);
                     draw[t] = (uint8_t)(jr <= (int32_t)nS ? jr : 0);                            // (max_depth <= 64 here: nS = max_depth)
                 }
             }
@@ -1334,6 +1347,8 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     a.fdrp = ctx->w_val.as<float>(); a.qfdrp = reinterpret_cast<float *>(ctx->w_aux.p); a.nreads = ctx->w_cov.as<uint32_t>();
     a.flags = ctx->w_flags.as<uint32_t>();
     a.seed = params->seed; a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.tid = d.tid;
+    a.grp_tab = group_table(ctx, batch->tid, &a.grp_n);
+    if (batch->tid <= -2 && !a.grp_tab) return fail(ctx, MTH_ERR_INVALID, "batch.tid is not a defined contig group's handle");
     a.min_overlap = params->min_overlap; a.n_reads = d.n_reads; a.n_cpgs = d.n_cpgs; a.region_beg = d.region_beg; a.region_end = d.region_end;
     a.min_depth = (uint32_t)std::min<uint64_t>(params->min_depth, 0xffffffffull); a.max_depth = params->max_depth;
     a.min_qual = params->min_qual;
@@ -1459,13 +1474,21 @@ int mth_fdrp_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos,
     if (fdrp) MTH_HIP(ctx, hipMemcpy(fdrp, ctx->f_val.p, n * 4, hipMemcpyDeviceToHost));
     if (qfdrp) MTH_HIP(ctx, hipMemcpy(qfdrp, ctx->f_qval.p, n * 4, hipMemcpyDeviceToHost));
     if (n_reads) MTH_HIP(ctx, hipMemcpy(n_reads, ctx->f_n.p, n * 4, hipMemcpyDeviceToHost));
-    if (tid) {
+    const bool grouped = (tid || pos) && has_group_batch(ctx, 2);          // rows of contig groups: back under their own contig
+    std::vector<int32_t> tmp;
+    if (grouped && !(tid && pos)) {
+        tmp.resize(n);
+        if (!pos) MTH_HIP(ctx, hipMemcpy(tmp.data(), ctx->f_pos.p, n * 4, hipMemcpyDeviceToHost));
+    }
+    int32_t *tid_w = tid ? tid : (grouped ? tmp.data() : nullptr), *pos_w = pos ? pos : (grouped ? tmp.data() : nullptr);
+    if (tid_w) {
         std::vector<uint32_t> rows(ctx->f_batches.size());
         if (!rows.empty()) MTH_HIP(ctx, hipMemcpy(rows.data(), ctx->f_batch_rows.p, rows.size() * 4, hipMemcpyDeviceToHost));
         uint64_t o = 0;
         for (size_t b = 0; b < rows.size(); ++b)
-            for (uint32_t j = 0; j < rows[b]; ++j) tid[o++] = ctx->f_batches[b].tid;
+            for (uint32_t j = 0; j < rows[b]; ++j) tid_w[o++] = ctx->f_batches[b].tid;
     }
+    if (grouped) return ungroup_rows(ctx, n, tid_w, pos_w, 1, 1, nullptr);
     return MTH_OK;
 }
 

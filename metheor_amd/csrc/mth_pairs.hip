@@ -691,6 +691,10 @@ int mth_lpmd_pairs_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t
     const uint64_t n = order.size();
     if (n_rows) *n_rows = n;
     if (n == 0 || (!tid && !pos1 && !pos2 && !lpmd && !n_concordant && !n_discordant)) return MTH_OK;
+    const bool grouped = (tid || pos1 || pos2) && has_group_batch(ctx, 4);      // rows of contig groups: back under their own contig
+    std::vector<int32_t> tmp_tid, tmp_p1;
+    if (grouped && !tid) { tmp_tid.resize(n); tid = tmp_tid.data(); }
+    if (grouped && !pos1) { tmp_p1.resize(n); pos1 = tmp_p1.data(); }
     std::vector<unsigned long long> key(extent);
     std::vector<uint32_t> cnt(2 * extent);
     MTH_HIP(ctx, hipMemcpy(key.data(), ctx->p_out_key.p, extent * 8, hipMemcpyDeviceToHost));
@@ -711,6 +715,7 @@ int mth_lpmd_pairs_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t
         if (n_discordant) n_discordant[r] = dd;
         if (lpmd) lpmd[r] = (float)dd / ((float)c + (float)dd);           // lpmd.rs:111
     }
+    if (grouped) return ungroup_rows(ctx, n, tid, pos1, 1, 1, pos2);
     return MTH_OK;
 }
 

@@ -850,6 +850,11 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
     if (!tid && !pos4 && !counts16 && !me && !pm) return MTH_OK;
     std::vector<uint32_t> hc(counts16 ? total * 16 : 0);
     std::vector<float> hme(me ? total : 0), hpm(pm ? total : 0);
+    // rows of contig groups go back under their own contig: tid and positions are both needed for that, whichever was asked for
+    const bool grouped = (tid || pos4) && has_group_batch(ctx, 3);
+    std::vector<int32_t> tmp_tid, tmp_pos;
+    if (grouped && !tid) { tmp_tid.resize(n); tid = tmp_tid.data(); }
+    if (grouped && !pos4) { tmp_pos.resize(n * 4); pos4 = tmp_pos.data(); }
     if (total) {
         if (pos4 && hp.empty()) { hp.resize(total * 4); MTH_HIP(ctx, hipMemcpy(hp.data(), ctx->q_pos.p, total * 16, hipMemcpyDeviceToHost)); }
         if (counts16) MTH_HIP(ctx, hipMemcpy(hc.data(), ctx->q_cnt.p, total * 64, hipMemcpyDeviceToHost));
@@ -864,6 +869,7 @@ int mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int3
         if (me) me[o] = hme[i];
         if (pm) pm[o] = hpm[i];
     }
+    if (grouped) return ungroup_rows(ctx, n, tid, pos4, 4, 4, nullptr);
     return MTH_OK;
 }
 

@@ -790,13 +790,21 @@ int mth_mhl_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos, 
     if (pos) MTH_HIP(ctx, hipMemcpy(pos, ctx->m_pos.p, n * 4, hipMemcpyDeviceToHost));
     if (mhl) MTH_HIP(ctx, hipMemcpy(mhl, ctx->m_val.p, n * 4, hipMemcpyDeviceToHost));
     if (coverage) MTH_HIP(ctx, hipMemcpy(coverage, ctx->m_cov.p, n * 4, hipMemcpyDeviceToHost));
-    if (tid) {
+    const bool grouped = (tid || pos) && has_group_batch(ctx, 1);          // rows of contig groups: back under their own contig
+    std::vector<int32_t> tmp;
+    if (grouped && !(tid && pos)) {
+        tmp.resize(n);
+        if (!pos) MTH_HIP(ctx, hipMemcpy(tmp.data(), ctx->m_pos.p, n * 4, hipMemcpyDeviceToHost));
+    }
+    int32_t *tid_w = tid ? tid : (grouped ? tmp.data() : nullptr), *pos_w = pos ? pos : (grouped ? tmp.data() : nullptr);
+    if (tid_w) {
         std::vector<uint32_t> rows(ctx->m_batches.size());
         if (!rows.empty()) MTH_HIP(ctx, hipMemcpy(rows.data(), ctx->m_batch_rows.p, rows.size() * 4, hipMemcpyDeviceToHost));
         uint64_t o = 0;
         for (size_t b = 0; b < rows.size(); ++b)
-            for (uint32_t j = 0; j < rows[b]; ++j) tid[o++] = ctx->m_batches[b].tid;
+            for (uint32_t j = 0; j < rows[b]; ++j) tid_w[o++] = ctx->m_batches[b].tid;
     }
+    if (grouped) return ungroup_rows(ctx, n, tid_w, pos_w, 1, 1, nullptr);
     return MTH_OK;
 }
 
