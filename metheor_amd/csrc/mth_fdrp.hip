@@ -1253,30 +1253,9 @@ __global__ __launch_bounds__(256) void k_fdrp_emit(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ blk, const unsigned long long *__restrict__ base,
                                                    int32_t *__restrict__ out_pos, float *__restrict__ out_f,
                                                    float *__restrict__ out_q, uint32_t *__restrict__ out_n) {
-    const uint32_t n = (uint32_t)sites_st->n_sites;
-    const uint32_t s0 = (blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
-    uint32_t m = 0, fl[SCAN_PER];
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) { fl[k] = (s0 + k < n) ? (flags[s0 + k] & 1u) : 0u; m += fl[k]; }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = m;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-    __shared__ uint32_t ws[5];
-    if (lane == 63) ws[wave + 1] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) { ws[0] = 0; for (int w = 1; w <= 4; ++w) ws[w] += ws[w - 1]; }
-    __syncthreads();
-    unsigned long long o = *base + blk[blockIdx.x] + ws[wave] + incl - m;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) {
-        if (!fl[k]) continue;
-        out_pos[o] = site_pos[s0 + k]; out_f[o] = f[s0 + k]; out_q[o] = q[s0 + k]; out_n[o] = nr[s0 + k];
-        ++o;
-    }
+    emit_block(flags, sites_st->n_sites, *base + blk[blockIdx.x], [&](unsigned long long e, unsigned long long o) {
+        out_pos[o] = site_pos[e]; out_f[o] = f[e]; out_q[o] = q[e]; out_n[o] = nr[e];
+    });
 }
 
 // fdrp.rs:51-76: add_read() writes new_read[MAX_READ_LEN + (cpg - site)] for every call of the read once the read's own span has

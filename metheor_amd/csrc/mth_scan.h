@@ -15,4 +15,36 @@ __global__ void k_flags_blockcount(const uint32_t *flags, const unsigned long lo
 __global__ void k_block_scan(uint32_t *blk, uint32_t nblk, unsigned long long *total, unsigned long long *base,
                              uint32_t *batch_rows, uint32_t batch_idx, const unsigned long long *n_ptr = nullptr);
 
+#ifdef __HIPCC__
+// The emitters' compaction of one block's 256 x SCAN_PER entries, wave-cooperative: wave w takes the block's entries [w * 512, w * 512 + 512)
+// in SCAN_PER steps of 64 CONSECUTIVE entries -- coalesced loads, and the kept entries of a step go to consecutive rows -- instead of
+// SCAN_PER consecutive entries per lane (every load and store a 32-byte stride across the wave).  put(entry, row) for every entry
+// with bit 0 of its flag set; rows ascend with the entries.  row0 = the block's first row.  All 256 threads must call.
+template <class Put>
+__device__ __forceinline__ void emit_block(const uint32_t *__restrict__ flags, unsigned long long n, unsigned long long row0, Put put) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long e0 = (unsigned long long)blockIdx.x * (256 * SCAN_PER) + (unsigned long long)wave * (64 * SCAN_PER) + lane;
+    unsigned long long bal[SCAN_PER];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        const unsigned long long e = e0 + 64ull * k;
+        bal[k] = __ballot(e < n && (flags[e] & 1u));
+        tot += (uint32_t)__builtin_popcountll(bal[k]);
+    }
+    __shared__ uint32_t ws[5];
+    if (lane == 0) ws[wave + 1] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) { ws[0] = 0; for (int w = 1; w <= 4; ++w) ws[w] += ws[w - 1]; }
+    __syncthreads();
+    unsigned long long o = row0 + ws[wave];
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        if ((bal[k] >> lane) & 1ull) put(e0 + 64ull * k, o + (unsigned long long)__builtin_popcountll(bal[k] & below));
+        o += (unsigned long long)__builtin_popcountll(bal[k]);
+    }
+}
+#endif
+
 }  // namespace mth

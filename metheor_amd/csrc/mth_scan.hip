@@ -7,10 +7,11 @@ __global__ __launch_bounds__(256) void k_flags_blockcount(const uint32_t *__rest
                                                           const unsigned long long *__restrict__ n_ptr,
                                                           uint32_t *__restrict__ blk) {
     const unsigned long long n = *n_ptr;
-    const unsigned long long s0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
+    // (the block's 2048 entries in SCAN_PER sweeps of 256 consecutive ones: coalesced)
+    const unsigned long long s0 = (unsigned long long)blockIdx.x * (256 * SCAN_PER) + threadIdx.x;
     uint32_t m = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) m += (s0 + k < n) ? (flags[s0 + k] & 1u) : 0u;
+    for (int k = 0; k < SCAN_PER; ++k) m += (s0 + 256ull * k < n) ? (flags[s0 + 256ull * k] & 1u) : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
     __shared__ uint32_t ws[4];

@@ -509,33 +509,9 @@ __global__ __launch_bounds__(256) void k_mhl_emit(const uint32_t *__restrict__ f
                                                   const unsigned long long *__restrict__ base,
                                                   int32_t *__restrict__ out_pos, float *__restrict__ out_val,
                                                   uint32_t *__restrict__ out_cov) {
-    const uint32_t n = (uint32_t)sites_st->n_sites;
-    const uint32_t s0 = (blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
-    uint32_t m = 0;
-    uint32_t f[SCAN_PER];
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) { f[k] = (s0 + k < n) ? (flags[s0 + k] & 1u) : 0u; m += f[k]; }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = m;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-    __shared__ uint32_t ws[5];
-    if (lane == 63) ws[wave + 1] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) { ws[0] = 0; for (int w = 1; w <= 4; ++w) ws[w] += ws[w - 1]; }
-    __syncthreads();
-    unsigned long long o = *base + blk[blockIdx.x] + ws[wave] + incl - m;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) {
-        if (!f[k]) continue;
-        out_pos[o] = site_pos[s0 + k];
-        out_val[o] = val[s0 + k];
-        out_cov[o] = cov[s0 + k];
-        ++o;
-    }
+    emit_block(flags, sites_st->n_sites, *base + blk[blockIdx.x], [&](unsigned long long e, unsigned long long o) {
+        out_pos[o] = site_pos[e]; out_val[o] = val[e]; out_cov[o] = cov[e];
+    });
 }
 
 // ---- PDR with the exact flush / re-open semantics (pdr.rs:139-210) ------------------------------
@@ -598,30 +574,9 @@ __global__ __launch_bounds__(256) void k_pdr_walk_emit(const uint32_t *__restric
                                                        const uint32_t *__restrict__ blk, DevState *__restrict__ st,
                                                        int32_t *__restrict__ out_pos, float *__restrict__ out_pdr,
                                                        uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
-    const uint32_t n = (uint32_t)sites_st->n_sites;
-    const uint32_t s0 = (blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
-    uint32_t m = 0, f[SCAN_PER];
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) { f[k] = (s0 + k < n) ? (flags[s0 + k] & 1u) : 0u; m += f[k]; }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = m;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-    __shared__ uint32_t ws[5];
-    if (lane == 63) ws[wave + 1] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) { ws[0] = 0; for (int w = 1; w <= 4; ++w) ws[w] += ws[w - 1]; }
-    __syncthreads();
-    unsigned long long o = st->cur_base + blk[blockIdx.x] + ws[wave] + incl - m;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) {
-        if (!f[k]) continue;
-        out_pos[o] = site_pos[s0 + k]; out_pdr[o] = pdr[s0 + k]; out_nc[o] = nc[s0 + k]; out_nd[o] = nd[s0 + k];
-        ++o;
-    }
+    emit_block(flags, sites_st->n_sites, st->cur_base + blk[blockIdx.x], [&](unsigned long long e, unsigned long long o) {
+        out_pos[o] = site_pos[e]; out_pdr[o] = pdr[e]; out_nc[o] = nc[e]; out_nd[o] = nd[e];
+    });
 }
 
 __global__ void k_bump_batches(DevState *st) { st->n_batches += 1; }
