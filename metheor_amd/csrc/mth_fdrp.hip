@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(256) void k_fdrp_emit(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ blk, const unsigned long long *__restrict__ base,
                                                    int32_t *__restrict__ out_pos, float *__restrict__ out_f,
                                                    float *__restrict__ out_q, uint32_t *__restrict__ out_n) {
-    emit_block(flags, sites_st->n_sites, *base + blk[blockIdx.x], [&](unsigned long long e, unsigned long long o) {
+    emit_block(flags, sites_st->n_sites, *base, blk, [&](unsigned long long e, unsigned long long o) {
         out_pos[o] = site_pos[e]; out_f[o] = f[e]; out_q[o] = q[e]; out_n[o] = nr[e];
     });
 }
@@ -1426,11 +1426,11 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     MTH_HIP(ctx, ctx->w_blk.reserve((size_t)nblk * 4, s));
     {
         LaunchTimer lt(ctx, K_FDRPEMIT);
-        hipLaunchKernelGGL(k_flags_blockcount, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
+        hipLaunchKernelGGL(k_flags_blockcount, dim3(std::min(nblk, SCAN_GRID_MAX)), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
                            (const unsigned long long *)&ctx->d_state2->n_sites, ctx->w_blk.as<uint32_t>());
         hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk, fs, fs + 1,
                            ctx->f_batch_rows.as<uint32_t>(), (uint32_t)nb, (const unsigned long long *)&ctx->d_state2->n_sites);
-        hipLaunchKernelGGL(k_fdrp_emit, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
+        hipLaunchKernelGGL(k_fdrp_emit, dim3(std::min(nblk, SCAN_GRID_MAX)), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
                            ctx->w_val.as<float>(), reinterpret_cast<const float *>(ctx->w_aux.p), ctx->w_cov.as<uint32_t>(),
                            ctx->d_state2, ctx->w_blk.as<uint32_t>(), fs + 1, ctx->f_pos.as<int32_t>(), ctx->f_val.as<float>(),
                            ctx->f_qval.as<float>(), ctx->f_n.as<uint32_t>());

@@ -7,17 +7,21 @@ __global__ __launch_bounds__(256) void k_flags_blockcount(const uint32_t *__rest
                                                           const unsigned long long *__restrict__ n_ptr,
                                                           uint32_t *__restrict__ blk) {
     const unsigned long long n = *n_ptr;
-    // (the block's 2048 entries in SCAN_PER sweeps of 256 consecutive ones: coalesced)
-    const unsigned long long s0 = (unsigned long long)blockIdx.x * (256 * SCAN_PER) + threadIdx.x;
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) m += (s0 + 256ull * k < n) ? (flags[s0 + 256ull * k] & 1u) : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
     __shared__ uint32_t ws[4];
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) blk[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+    const unsigned long long nb = (n + 256ull * SCAN_PER - 1ull) / (256ull * SCAN_PER);
+    for (unsigned long long b = blockIdx.x; b < nb; b += gridDim.x) {      // (see emit_block: the grid comes from an upper bound of n)
+        // the block's 2048 entries in SCAN_PER sweeps of 256 consecutive ones: coalesced
+        const unsigned long long s0 = b * (256 * SCAN_PER) + threadIdx.x;
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) m += (s0 + 256ull * k < n) ? (flags[s0 + 256ull * k] & 1u) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) blk[b] = ws[0] + ws[1] + ws[2] + ws[3];
+        __syncthreads();
+    }
 }
 
 // single block: exclusive scan of the per-block row counts; appends the batch to the totals

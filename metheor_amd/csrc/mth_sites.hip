@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_mhl_emit(const uint32_t *__restrict__ f
                                                   const unsigned long long *__restrict__ base,
                                                   int32_t *__restrict__ out_pos, float *__restrict__ out_val,
                                                   uint32_t *__restrict__ out_cov) {
-    emit_block(flags, sites_st->n_sites, *base + blk[blockIdx.x], [&](unsigned long long e, unsigned long long o) {
+    emit_block(flags, sites_st->n_sites, *base, blk, [&](unsigned long long e, unsigned long long o) {
         out_pos[o] = site_pos[e]; out_val[o] = val[e]; out_cov[o] = cov[e];
     });
 }
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void k_pdr_walk_emit(const uint32_t *__restric
                                                        const uint32_t *__restrict__ blk, DevState *__restrict__ st,
                                                        int32_t *__restrict__ out_pos, float *__restrict__ out_pdr,
                                                        uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
-    emit_block(flags, sites_st->n_sites, st->cur_base + blk[blockIdx.x], [&](unsigned long long e, unsigned long long o) {
+    emit_block(flags, sites_st->n_sites, st->cur_base, blk, [&](unsigned long long e, unsigned long long o) {
         out_pos[o] = site_pos[e]; out_pdr[o] = pdr[e]; out_nc[o] = nc[e]; out_nd[o] = nd[e];
     });
 }
@@ -629,13 +629,13 @@ int launch_pdr_exact(mth_ctx *ctx, const mth_batch_t &d, const mth_pdr_lpmd_para
     {
         LaunchTimer lt(ctx, K_PDRWALK);
         hipLaunchKernelGGL(k_pdr_walk, dim3(grid), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_flags_blockcount, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
+        hipLaunchKernelGGL(k_flags_blockcount, dim3(std::min(nblk, SCAN_GRID_MAX)), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
                            (const unsigned long long *)&ctx->d_state2->n_sites, ctx->w_blk.as<uint32_t>());
         // totals live in the main DevState: n_sites is the running total, cur_base the batch's base
         hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk,
                            (unsigned long long *)&ctx->d_state->n_sites, (unsigned long long *)&ctx->d_state->cur_base,
                            ctx->batch_cnt.as<uint32_t>(), (uint32_t)ctx->batches.size(), (const unsigned long long *)&ctx->d_state2->n_sites);
-        hipLaunchKernelGGL(k_pdr_walk_emit, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
+        hipLaunchKernelGGL(k_pdr_walk_emit, dim3(std::min(nblk, SCAN_GRID_MAX)), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
                            ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->w_aux.as<uint32_t>(), ctx->d_state2,
                            ctx->w_blk.as<uint32_t>(), ctx->d_state, ctx->out_pos.as<int32_t>(), ctx->out_pdr.as<float>(),
                            ctx->out_nc.as<uint32_t>(), ctx->out_nd.as<uint32_t>());
@@ -721,11 +721,11 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
     MTH_HIP(ctx, ctx->w_blk.reserve((size_t)nblk * 4, s));
     {
         LaunchTimer lt(ctx, K_MHLEMIT);
-        hipLaunchKernelGGL(k_flags_blockcount, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
+        hipLaunchKernelGGL(k_flags_blockcount, dim3(std::min(nblk, SCAN_GRID_MAX)), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(),
                            (const unsigned long long *)&ctx->d_state2->n_sites, ctx->w_blk.as<uint32_t>());
         hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, s, ctx->w_blk.as<uint32_t>(), nblk, ms, ms + 1,
                            ctx->m_batch_rows.as<uint32_t>(), (uint32_t)nb, (const unsigned long long *)&ctx->d_state2->n_sites);
-        hipLaunchKernelGGL(k_mhl_emit, dim3(nblk), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
+        hipLaunchKernelGGL(k_mhl_emit, dim3(std::min(nblk, SCAN_GRID_MAX)), dim3(256), 0, s, ctx->w_flags.as<uint32_t>(), ctx->s_pos.as<int32_t>(),
                            ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->d_state2, ctx->w_blk.as<uint32_t>(),
                            ms + 1, ctx->m_pos.as<int32_t>(), ctx->m_val.as<float>(), ctx->m_cov.as<uint32_t>());
     }
