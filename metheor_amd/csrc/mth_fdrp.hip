@@ -755,6 +755,7 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
         const uint16_t *const tab = s_tab + (uint32_t)(nS > 2 ? nS * (nS - 1) * (nS - 2) : 0) / 6u;
         uint32_t disc = 0;
         float q = 0.0f;
+        unsigned long long inexact = 0;                                          // lanes that have held a non-dyadic term this step (wave-uniform value)
         for (int r = 0; r < rounds; ++r) {
             const int k = GL * r + gl;
             const uint32_t ent = tab[P ? min(k, P - 1) : 0];
@@ -770,6 +771,21 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
             const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;        // qfdrp.rs:152; +0.0 for skipped pairs
             const unsigned long long nz = __ballot(term != 0.0f);
             if (nz == 0ull) continue;                                            // wave-uniform: x + 0.0 == x
+            // The ordered f32 sum (qfdrp.rs:152) needs its order only once a term is not a dyadic fraction.  ham / ncpg with ncpg a
+            // power of two is exact, <= 1 and a multiple of 1/64; at most 496 of them per site add up exactly in 24 bits whatever
+            // the order -- so while every term of every site of the wave has been such a one (most pairs at WGBS depth share one
+            // or two calls), the round is a tree sum over the site's lanes; from the first other term on, the chain.
+            inexact |= __ballot(term != 0.0f && (ncpg & (ncpg - 1u)) != 0u);
+            if (inexact == 0ull) {
+                float t = term;
+                if (GL == 32) t += __shfl_xor(t, 16, 64);
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x128 /*row_ror:8*/, 0xf, 0xf, true));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x124 /*row_ror:4*/, 0xf, 0xf, true));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4e /*quad_perm [2,3,0,1]*/, 0xf, 0xf, true));
+                t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, true));
+                q += t;
+                continue;
+            }
             // chain length: the highest lane of any site that holds a non-zero term (later lanes add +0.0: exact)
             int steps = 0;
 #pragma unroll
