@@ -144,10 +144,10 @@ def _run(env, *args):
     return subprocess.run([EXE, *[str(a) for a in args]], capture_output=True, text=True, cwd=ROOT, timeout=900, env=dict(os.environ, **env))
 
 
-def _bam(tmp_path, n_contigs, seed, reads=(40, 400), length=(2_000, 9_000)):
+def _bam(tmp_path, n_contigs, seed, reads=(40, 400), length=(2_000, 9_000), read_len=150):
     from metheor_amd import synth
     rng = np.random.default_rng(seed)
-    cs = [synth.make_contig(t, int(rng.integers(*length)), int(rng.integers(*reads)), 0.06, rng) for t in range(n_contigs)]
+    cs = [synth.make_contig(t, int(rng.integers(*length)), int(rng.integers(*reads)), 0.06, rng, read_len=read_len) for t in range(n_contigs)]
     recs = [util.contig_to_records(c, "ctg%d" % t) for t, c in enumerate(cs)]
     rec = bamio.Records([r.refs[0] for r in recs], np.concatenate([r.tid + t for t, r in enumerate(recs)]), np.concatenate([r.pos for r in recs]),
                         np.concatenate([r.flag for r in recs]), np.concatenate([r.mapq for r in recs]), sum((r.cigars for r in recs), []), sum((r.xms for r in recs), []))
@@ -156,9 +156,9 @@ def _bam(tmp_path, n_contigs, seed, reads=(40, 400), length=(2_000, 9_000)):
     return bam, rec
 
 
-@pytest.mark.parametrize("n_contigs,seed", [(6, 1), (400, 2)])
-def test_cli_groups_equal_one_batch_per_contig(tmp_path, n_contigs, seed):
-    bam, rec = _bam(tmp_path, n_contigs, seed)
+@pytest.mark.parametrize("n_contigs,seed,read_len", [(6, 1, 150), (400, 2, 150), (7, 3, 230)])      # 230: the exact PDR walk, FDRP's general walk
+def test_cli_groups_equal_one_batch_per_contig(tmp_path, n_contigs, seed, read_len):
+    bam, rec = _bam(tmp_path, n_contigs, seed, read_len=read_len)
     reads = pyoracle.Reads.decode(rec)
     names = [r[0] for r in rec.refs]
     for sub, extra in (("pdr", ["-d", 2, "-p", 2]), ("mhl", ["-d", 2, "-p", 2]), ("fdrp", ["-d", 2, "-D", 5]), ("qfdrp", ["-d", 2]),
@@ -167,6 +167,9 @@ def test_cli_groups_equal_one_batch_per_contig(tmp_path, n_contigs, seed):
         for grp in ("1", "0"):
             o = tmp_path / ("o%s.tsv" % grp)
             r = _run({"METHEOR_GROUP": grp, "METHEOR_TIMING": "1"}, sub, "-i", bam, "-o", o, *extra)
+            if r.returncode == 101 and "fdrp.rs:70-72" in r.stderr and sub in ("fdrp", "qfdrp"):      # reads beyond 201 bases can hit the reference's own panic: both ways then
+                outs.append("panic")
+                continue
             assert r.returncode == 0, (sub, grp, r.stderr)
             assert ("contig groups" in r.stderr) == (grp == "1"), r.stderr
             outs.append(o.read_text() + ((tmp_path / "pairs.tsv").read_text() if sub == "lpmd" else ""))
