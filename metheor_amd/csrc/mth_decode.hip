@@ -607,7 +607,15 @@ int mth_decoded_group(mth_ctx_t *ctx, uint32_t n_contigs, const int32_t *tids, c
     // The gap after a contig: wider than anything a measure looks across -- a read's span, PDR's flush margin (pdr.rs:162: 150), the
     // FDRP window (fdrp.rs:10: 201) and the index quanta -- and a multiple of the dense tile width.
     const int64_t gap = (int64_t)st[0] + 1024;
-    const int64_t vmax = ((int64_t)1 << 31) - ((int64_t)1 << 22);
+    // ... and no wider than the work buffers can be: the passes keep per-position scratch rows (16 B a position for the PDR / MHL tile
+    // passes and site discovery, a few 4-byte columns on top) -- 64 B a position of what is free now, so that a GPU shared with other
+    // work falls back towards one batch per contig instead of failing an allocation
+    int64_t vmax = ((int64_t)1 << 31) - ((int64_t)1 << 22);
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) vmax = std::min<int64_t>(vmax, (int64_t)(fr / 64));
+        if (const char *e = getenv("MTH_GROUP_MAX_POSITIONS")) vmax = std::min<int64_t>(vmax, std::max<long long>(atoll(e), 4096));      // tests
+    }
     std::vector<int32_t> voff(n_contigs, 0);
     std::vector<uint32_t> first;
     int64_t vlen = 0;

@@ -182,3 +182,19 @@ def test_cli_groups_equal_one_batch_per_contig(tmp_path, n_contigs, seed, read_l
         if sub == "mhl":
             t = reads.mhl(min_depth=2, min_cpgs=2)
             assert outs[0] == "".join("%s\t%d\t%d\t%s\n" % (names[ti], p, p + 2, pyoracle.format_f32(v)) for ti, p, v in zip(t.tid, t.pos[:, 0], t.val))
+
+
+def test_cli_several_groups_and_single_contig_groups(tmp_path):
+    """MTH_GROUP_MAX_POSITIONS (what free device memory does on a shared GPU) cuts the packing short: several groups, some of one contig"""
+    bam, rec = _bam(tmp_path, 9, 5)
+    reads = pyoracle.Reads.decode(rec)
+    names = [r[0] for r in rec.refs]
+    for cap in (12_000, 30_000):
+        o = tmp_path / "o.tsv"
+        r = _run({"MTH_GROUP_MAX_POSITIONS": str(cap)}, "pdr", "-i", bam, "-o", o, "-d", 2, "-p", 2)
+        assert r.returncode == 0, r.stderr
+        assert o.read_text() == util.oracle_tsv_pdr(reads, names, min_depth=2, min_cpgs=2, min_qual=10)
+        r = _run({"MTH_GROUP_MAX_POSITIONS": str(cap)}, "fdrp", "-i", bam, "-o", o, "-d", 2, "-D", 6)
+        assert r.returncode == 0, r.stderr
+        t = reads.fdrp(min_depth=2, max_depth=6)
+        assert o.read_text() == "".join("%s\t%d\t%d\t%s\n" % (names[ti], p, p + 2, pyoracle.format_f32(v)) for ti, p, v in zip(t.tid, t.pos[:, 0], t.val))
