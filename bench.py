@@ -400,9 +400,6 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
         for _ in range(4):
             st = torch.cuda.Stream(device=dev)
             engs.append((metheor_amd.Engine(dev.index, stream=st.cuda_stream), st))
-            for b in resident:                         # the same groups (same handles) on every context
-                if b.tid <= -2:
-                    engs[-1][0].group_copy(eng, b.tid)
         four = [lambda e, b: e.pdr_lpmd_accumulate(b, P0), lambda e, b: e.quartet_accumulate(b),
                 lambda e, b: e.mhl_accumulate(b), lambda e, b: e.fdrp_accumulate(b)]
         order = [3, 2, 1, 0]                       # the longest pass is queued first
@@ -412,8 +409,8 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
             # one host thread per context (ME / PM syncs once per batch: it must not hold up the other passes' queues)
             import threading
             def run_pass(k):
-                for b in resident:
-                    four[k](engs[k][0], b)
+                for b in per_contig:               # one batch per contig here: four more contexts with group-sized work buffers (16 B a position
+                    four[k](engs[k][0], b)         # each, beside the first context's) do not fit 288 GB, and two big batches fill the chip anyway
                 engs[k][0].sync()
             th = [threading.Thread(target=run_pass, args=(k,)) for k in order]
             t0 = time.perf_counter()
@@ -442,7 +439,7 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
                                           "seven_measures_ms": round(sum(v for k, v in per_c.items() if k != "lpmd --pairs") * 1e3, 3)},
                    "rows": {k: v[1] for k, v in rows_check.items()},
                    "seven_measures_concurrent_ms": round(conc * 1e3, 3) if conc else None,
-                   "seven_measures_concurrent_what": "the same four passes on four contexts of the one GPU (a stream and work buffers each), one host thread per context, wall clock from the first call to the last sync",
+                   "seven_measures_concurrent_what": "the four passes over ONE BATCH PER CONTIG on four contexts of the one GPU (a stream and work buffers each), one host thread per context, wall clock from the first call to the last sync -- the way to fill the chip before the contig groups; compare with per_contig_batches.seven_measures_ms",
                    "G_reads_per_s_seven_concurrent": round(n_tot / conc / 1e9, 3) if conc else None,
                    "G_reads_per_s_seven": round(n_tot / sum(seven.values()) / 1e9, 3),
                    "variant": "unfused: one pass per measure group, each rebuilding the read index",
