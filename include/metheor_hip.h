@@ -365,7 +365,8 @@ typedef struct {
 } mth_fileorder_params_t;
 int  mth_fileorder_run(mth_ctx_t *ctx, const mth_fileorder_params_t *params);
 int  mth_fileorder_fetch(mth_ctx_t *ctx, uint64_t *n_rows, int32_t *tid, int32_t *pos, float *v0, float *v1, uint32_t *c0, uint32_t *c1);
-/* reads [read_beg, read_end) of the decoded stream -- ONE contig's reads (or a region slice of them) -- as a
+/* reads [read_beg, read_end) of the decoded stream -- ONE contig's reads (or a region slice of them), or one contig GROUP's after
+ * mth_decoded_group (tid = the group's handle, region_beg 0, region_end -1) -- as a
  * device-resident batch for the accumulate calls: 32-bit offsets rebased on the device, max_span reduced on
  * the device.  region_end < 0 = up to the last position these reads cover (reduced on the device too): what a
  * whole-contig batch should pass -- the reference emits every site it sees, also past the header's LN.
