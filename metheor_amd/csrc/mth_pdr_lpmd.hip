@@ -37,8 +37,8 @@ namespace mth {
 // idx[q] = first read i with read_start[i] >= idx_base + q*IDX_Q   (q = 0..nq)
 // One thread handles 4 consecutive reads (one 16-byte load + the element before them); the thread
 // whose group contains index n_reads also plays the sentinel that closes the index.
-constexpr int IDX_GROUPS = 2;   // groups of 4 reads per thread.  Alone the kernel is no faster with 2 or 4 (4, all loads hoisted: 0.0177 against 0.0157 ms on config 2), but half the
-                                // workgroups beside a tile kernel is: interleaved A/B of the pipelined step on one box (tools/ab_lib.sh, 4 rounds) 1: 0.0870-0.0879, 2: 0.0858-0.0872, 4: 0.0880-0.0916 ms
+constexpr int IDX_GROUPS = 1;   // groups of 4 reads per thread; 4 (all loads hoisted) measured slower: 0.0177 against 0.0157 ms on config 2.  Under the batch
+                                // pipeline 2 looked 1.4 % better in one interleaved A/B (tools/ab_lib.sh) -- and three copies of ONE build differed by up to 3 % in the next: not adopted
 // NIDX = 1: the fine index (QSHIFT = IDX_QSHIFT, 32-bp quanta) every tile / site kernel can look any position up in.
 // NIDX = 2 (the dense PDR + LPMD tile kernel's own, round 4): that kernel asks two questions per 4096-bp tile only -- the first
 // read starting at or after T0 - max_span + 1 and the first one starting after T0 + W -- so two indices with ONE entry per tile
