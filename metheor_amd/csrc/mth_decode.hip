@@ -304,6 +304,13 @@ __global__ __launch_bounds__(256) void k_grp_extent(const int32_t *__restrict__ 
     }
 }
 
+// out[k] = off[at[k]]: the call offsets at the runs' boundaries in one read-back (a BAM can have thousands of contigs)
+__global__ __launch_bounds__(256) void k_grp_pick(const unsigned long long *__restrict__ off, const unsigned long long *__restrict__ at, uint32_t n,
+                                                  unsigned long long *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) out[k] = off[at[k]];
+}
+
 __global__ __launch_bounds__(256) void k_grp_shift(int32_t *__restrict__ start, int32_t *__restrict__ end, const unsigned long long *__restrict__ off,
                                                    uint32_t *__restrict__ pos, unsigned long long r0, unsigned long long n,
                                                    const unsigned long long *__restrict__ run_beg, const int32_t *__restrict__ run_voff, uint32_t n_runs) {
@@ -582,15 +589,18 @@ int mth_decoded_group(mth_ctx_t *ctx, uint32_t n_contigs, const int32_t *tids, c
     const uint64_t r0 = read_beg[0], n = read_end[n_contigs - 1] - r0;
     if (n == 0) return MTH_OK;
     // device: the runs' first reads, their extents, two status words, later their offsets
-    MTH_HIP(ctx, ctx->dec_runs.reserve((size_t)n_contigs * 16 + 64, s));
+    MTH_HIP(ctx, ctx->dec_runs.reserve(((size_t)n_contigs + 1) * 16 + (size_t)n_contigs * 8 + 64, s));
     uint8_t *base = static_cast<uint8_t *>(ctx->dec_runs.p);
-    unsigned long long *d_beg = reinterpret_cast<unsigned long long *>(base);
-    uint32_t *d_ext = reinterpret_cast<uint32_t *>(base + (size_t)n_contigs * 8);
-    int32_t *d_voff = reinterpret_cast<int32_t *>(base + (size_t)n_contigs * 12);
-    uint32_t *d_st = reinterpret_cast<uint32_t *>(base + (size_t)n_contigs * 16);
+    unsigned long long *d_beg = reinterpret_cast<unsigned long long *>(base);          // n_contigs + 1 entries: the runs' first reads, then the end
+    unsigned long long *d_coff = d_beg + n_contigs + 1;                                // the call offsets there
+    uint32_t *d_ext = reinterpret_cast<uint32_t *>(d_coff + n_contigs + 1);
+    int32_t *d_voff = reinterpret_cast<int32_t *>(d_ext + n_contigs);
+    uint32_t *d_st = reinterpret_cast<uint32_t *>(d_voff + n_contigs);
     std::vector<unsigned long long> hb(read_beg, read_beg + n_contigs);
-    MTH_HIP(ctx, hipMemcpyAsync(d_beg, hb.data(), (size_t)n_contigs * 8, hipMemcpyHostToDevice, s));
+    hb.push_back(read_end[n_contigs - 1]);
+    MTH_HIP(ctx, hipMemcpyAsync(d_beg, hb.data(), ((size_t)n_contigs + 1) * 8, hipMemcpyHostToDevice, s));
     MTH_HIP(ctx, hipMemsetAsync(d_ext, 0, (size_t)n_contigs * 8 + 16, s));
+    hipLaunchKernelGGL(k_grp_pick, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, s, ctx->dec_off.as<unsigned long long>(), d_beg, n_contigs + 1, d_coff);
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 8192);
     hipLaunchKernelGGL(k_grp_extent, dim3(grid), dim3(256), 0, s, ctx->dec_start.as<int32_t>(), ctx->dec_end.as<int32_t>(),
                        ctx->dec_off.as<unsigned long long>(), ctx->dec_pos.as<uint32_t>(), (unsigned long long)r0, (unsigned long long)n,
@@ -600,8 +610,7 @@ int mth_decoded_group(mth_ctx_t *ctx, uint32_t n_contigs, const int32_t *tids, c
     std::vector<unsigned long long> coff((size_t)n_contigs + 1);
     MTH_HIP(ctx, hipMemcpyAsync(ext.data(), d_ext, (size_t)n_contigs * 4, hipMemcpyDeviceToHost, s));
     MTH_HIP(ctx, hipMemcpyAsync(st, d_st, 8, hipMemcpyDeviceToHost, s));
-    for (uint32_t k = 0; k <= n_contigs; ++k)
-        MTH_HIP(ctx, hipMemcpyAsync(&coff[k], ctx->dec_off.as<unsigned long long>() + (k < n_contigs ? read_beg[k] : read_end[n_contigs - 1]), 8, hipMemcpyDeviceToHost, s));
+    MTH_HIP(ctx, hipMemcpyAsync(coff.data(), d_coff, ((size_t)n_contigs + 1) * 8, hipMemcpyDeviceToHost, s));
     MTH_HIP(ctx, hipStreamSynchronize(s));
     if (st[1]) return MTH_OK;                                  // a call at -1 / a read without an aligned base: leave the stream as it is
     // The gap after a contig: wider than anything a measure looks across -- a read's span, PDR's flush margin (pdr.rs:162: 150), the
