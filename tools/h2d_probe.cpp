@@ -5,6 +5,8 @@
 //   2  as 1, the threads memcpy() from the mmap instead of pread()
 //   3  mmap with MAP_POPULATE, then as 0
 //   4  N threads, each ONE pageable hipMemcpyAsync of its share of the mmap'ed file on its own stream (round 4)
+//   5  hipHostRegister of the whole mapping (MAP_SHARED), then one hipMemcpyAsync from it (round 4)
+//   6  N threads, each registering its next piece of the mapping, copying it asynchronously, unregistering the piece before (round 4)
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -52,6 +54,38 @@ int main(int argc, char **argv) {
             if (off >= n) return;
             const size_t len = std::min(share, n - off);
             (void)hipMemcpyAsync((uint8_t *)dev + off, m + off, len, hipMemcpyHostToDevice, st[(size_t)k]);
+            (void)hipStreamSynchronize(st[(size_t)k]);
+        });
+        for (auto &t : th) t.join();
+    } else if (variant == 5) {
+        void *m = mmap(nullptr, n, PROT_READ, MAP_SHARED, fd, 0);
+        const double ta = now();
+        hipError_t e = hipHostRegister(m, n, hipHostRegisterDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister(m, n, 0x08 /* hipHostRegisterReadOnly */); }
+        if (e != hipSuccess) { fprintf(stderr, "hipHostRegister: %s\n", hipGetErrorString(e)); return 1; }
+        const double tb = now();
+        t_setup = 0;
+        CK(hipMemcpyAsync(dev, m, n, hipMemcpyHostToDevice, 0));
+        CK(hipDeviceSynchronize());
+        fprintf(stderr, "  hipHostRegister %.3f s, copy %.3f s\n", tb - ta, now() - tb);
+    } else if (variant == 6) {
+        uint8_t *m = (uint8_t *)mmap(nullptr, n, PROT_READ, MAP_SHARED, fd, 0);
+        std::vector<hipStream_t> st((size_t)nthr);
+        for (auto &s : st) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        t_setup = now() - t1;
+        std::vector<std::thread> th;
+        for (int k = 0; k < nthr; ++k) th.emplace_back([&, k] {
+            (void)hipSetDevice(0);
+            uint8_t *prev = nullptr;
+            for (size_t off = (size_t)k * piece; off < n; off += (size_t)nthr * piece) {
+                const size_t len = std::min(piece, n - off);
+                hipError_t e = hipHostRegister(m + off, len, hipHostRegisterDefault);
+                if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister(m + off, len, 0x08); }
+                if (e != hipSuccess) { fprintf(stderr, "hipHostRegister piece: %s\n", hipGetErrorString(e)); return; }
+                (void)hipMemcpyAsync((uint8_t *)dev + off, m + off, len, hipMemcpyHostToDevice, st[(size_t)k]);
+                if (prev) { (void)hipStreamSynchronize(st[(size_t)k]); (void)hipHostUnregister(prev); (void)hipHostUnregister(m + off); prev = nullptr; }
+                else prev = m + off;
+            }
             (void)hipStreamSynchronize(st[(size_t)k]);
         });
         for (auto &t : th) t.join();
