@@ -698,6 +698,591 @@ __global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent form of the dense tile kernel (round 5): k_pdr_lpmd_runs + k_gather_runs, two launches per batch, no read index,
+// no global atomic.  (A first persistent form drew tiles from per-XCD ticket counters and kept the per-tile row atomics: a
+// device-scope atomic on one address costs ~100 ns on this part and they serialise -- 14 311 tickets over 8 addresses added
+// 0.16 ms, 57 k row atomics over 56 addresses 0.14 ms; profiles/r05_persistent.md.)
+//
+// The grid is the chip's resident slots (8 workgroups on each of 256 CUs).  Workgroup w owns a RUN of consecutive tiles: the reads are
+// cut into G equal pieces at r_w = w n / G and the run is [tile of start[r_w], tile of start[r_w+1]) -- runs are balanced by reads,
+// not by positions, found with two loads and no index.  Inside a run everything a tile needs first comes from the tile before it:
+//   * candidate reads of a tile are a contiguous range of the sorted reads.  Its first one is known from the previous tile (the waves
+//     note, while they stream, where the reads that start before the next tile's lower bound end: one ds_max each); its end is
+//     found by streaming: wave k takes the chunks lo + 256 j + 64 k of 64 reads until one holds no read starting at or before the
+//     tile's last position + 1.  A read's start and call offsets are fetched one iteration ahead, so that test never waits;
+//   * the run's first lower bound is a wave-cooperative 64-ary search next to r_w (two round trips when the window fits);
+//   * sortedness is validated on the workgroup's own piece of read_start in the preamble (every adjacent pair, whatever the data);
+//   * the compaction is wave-private: a wave owns 1024 consecutive positions and its own quarter of the tile's scratch slice
+//     (tile_cnt holds four counts per tile), so it needs no cross-wave prefix and no barrier, and it zeroes the counters behind it:
+//     two workgroup barriers per tile (after the read loop, after the compaction) instead of three;
+//   * LPMD counters and the span-error bit stay in registers across the run; one set of plain stores per workgroup at the end (the
+//     gather's last workgroup adds them up), the run's row total likewise -- k_gather_runs takes its row base from the totals of the
+//     runs before it (G <= 2048 words) instead of bucket sums kept by atomics;
+//   * calls and relative positions are fetched through buffer descriptors: the hardware bounds check replaces the CLAMP
+//     instantiation for the batch's last reads (an 8-slot window that runs past the arrays reads zeros into dead slots);
+//   * a stretch of tiles without reads is skipped in one step (their counts written as zeros);
+//   * a tile with more candidate reads than a 16-bit counter can count (deep amplicons) is taken in passes of 255 iterations, the
+//     counters added into the tile's scratch slice (used as dense 32-bit rows) in between.
+// 8-bit relative positions only (reads of <= 255 bases); launch_pdr_lpmd keeps the one-tile-per-workgroup form for the rest.
+constexpr uint32_t PT_PASS_ITERS = 255u;   // iterations of 256 reads per pass over 16-bit counters (255 x 256 <= 65 535)
+
+struct RunArgs {
+    uint32_t *run_tile0;             // [G + 1] first tile of each run (written by the tile kernel)
+    uint32_t *run_rows;              // [G] rows of each run
+    unsigned long long *run_lpmd;    // [G][4] LPMD partial sums of each run
+    DevState *cst;                   // the sink's / job's counters: cur_base is set here for unpipelined batches (nullptr: pipelined)
+    uint32_t hint_stride;            // probe spacing of the first search round (~ reads per tile / 48)
+    unsigned long long *trace;       // -DMTH_RUNS_TRACE builds: 8 words per workgroup (tools/runs_trace.py)
+};
+#ifdef MTH_RUNS_TRACE
+#define RT_NOW() __builtin_readcyclecounter()
+#define RT_ADD(acc, t0) do { const unsigned long long n__ = RT_NOW(); acc += n__ - t0; t0 = n__; } while (0)
+#else
+#define RT_NOW() 0ull
+#define RT_ADD(acc, t0) do {} while (0)
+#endif
+
+__device__ __forceinline__ unsigned long long wave_sum64(uint32_t v) {
+    unsigned long long x = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// first index i in [0, n] with a[i] >= bound (n if none), for sorted a; every lane of the wave calls it with the same arguments.
+// Round 0 probes 64 elements `stride` apart ending at `hint` (the caller expects the answer just below it); then 64-ary rounds.
+__device__ __forceinline__ uint32_t wave_lower_bound(const int32_t *__restrict__ a, uint32_t n, int32_t bound, uint32_t hint, uint32_t stride) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (n == 0) return 0;
+    uint32_t lo, hi;
+    {
+        const uint32_t top = min(hint, n - 1u);
+        const uint32_t back = (63u - lane) * stride;
+        const bool in = back <= top;
+        const uint32_t q = in ? top - back : 0u;
+        const int32_t v = a[q];
+        const unsigned long long below = __ballot(in && v < bound);      // a prefix of the probes that exist
+        const unsigned long long exist = __ballot(in);
+        const uint32_t first = (uint32_t)__builtin_ctzll(exist);         // lowest existing probe (lane 63 always exists)
+        const uint32_t c = (uint32_t)__builtin_popcountll(below);
+        if (c == 0) { lo = 0; hi = top - (63u - first) * stride; }        // a[lowest probe] >= bound
+        else {
+            const uint32_t lastb = first + c - 1u;                        // lane of the last probe below the bound
+            lo = top - (63u - lastb) * stride + 1u;
+            hi = lastb == 63u ? n : top - (63u - lastb - 1u) * stride;
+        }
+    }
+    while (hi > lo) {                                                     // answer in [lo, hi]; a[hi] >= bound or hi == n
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint32_t q = lo + (lane + 1u) * step - 1u;
+        const bool in = q < hi;
+        const int32_t v = in ? a[q] : 0;
+        const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(in && v < bound));
+        const uint32_t qc = lo + (c + 1u) * step - 1u;
+        lo += c * step;
+        if (qc < hi) hi = qc;
+    }
+    return lo;
+}
+
+#ifndef MTH_RUNS_OCC
+#define MTH_RUNS_OCC 8
+#endif
+template <int W, int MG>
+__global__ __launch_bounds__(256, MTH_RUNS_OCC) void k_pdr_lpmd_runs(const TileArgs a, const RunArgs ra, const uint32_t ntiles) {
+    constexpr int B = 256, NB = 8;
+    constexpr bool MARGIN = MG > 0;
+    static_assert(W == 4096, "a wave owns 1024 positions: 16 per lane");
+    __shared__ __attribute__((aligned(16))) uint32_t cnt_raw[MG ? MG + W + MG : W + 64];
+    __shared__ __attribute__((aligned(16))) SlotTabs tabs;
+    __shared__ uint32_t s_lon[2], s_more[2], s_rows[4];
+    __shared__ unsigned long long s_lp[4][4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *const cnt = cnt_raw + MG;
+    const uint32_t nr = a.n_reads, G = gridDim.x;
+    // which run: workgroup b runs on XCD b % 8 (observed; speed only).  MTH_RUNS_MAP 1: each XCD takes a contiguous eighth of the runs;
+    // 2: and the workgroups that share a CU (dispatched 32 apart within the XCD) take neighbouring runs
+#ifndef MTH_RUNS_MAP
+#define MTH_RUNS_MAP 0
+#endif
+    uint32_t w = blockIdx.x;
+    if (MTH_RUNS_MAP && (G & 255u) == 0) {
+        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3, cpx = G >> 3, k = cpx >> 5;
+        w = MTH_RUNS_MAP == 1 ? x * cpx + j : x * cpx + (j & 31u) * k + (j >> 5);
+    }
+    [[maybe_unused]] const unsigned long long rt_beg = RT_NOW();
+    [[maybe_unused]] unsigned long long rt_loop = 0, rt_b1 = 0, rt_comp = 0, rt_b2 = 0, rt_pre = 0, rt_t = rt_beg, rt_ntile = 0, rt_wait = 0, rt_iters = 0;
+    for (int i = tid; i < W / 4; i += B) reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0, 0, 0, 0);
+    slot_tabs_init(tabs, tid);
+    if (tid < 2) { s_lon[tid] = 0; s_more[tid] = 0; }
+    if (tid < 4) s_rows[tid] = 0;
+    if (tid < 16) s_lp[tid >> 2][tid & 3] = 0ull;
+    if (w == 0 && tid == 0 && ra.cst) ra.cst->cur_base = ra.cst->n_sites;      // (pipelined batches: the base travels along the chain of gathers)
+
+    // the run: tiles [tb, te)
+    const uint32_t r0 = (uint32_t)(((unsigned long long)w * nr) / G), r1 = (uint32_t)(((unsigned long long)(w + 1u) * nr) / G);
+    auto tile_of = [&](uint32_t r) -> uint32_t {
+        const int64_t d = (int64_t)a.read_start[r] - a.region_beg;
+        return d <= 0 ? 0u : (uint32_t)min((int64_t)ntiles, d / W);
+    };
+    const uint32_t tb = __builtin_amdgcn_readfirstlane((w == 0 || nr == 0) ? 0u : tile_of(r0));
+    const uint32_t te = __builtin_amdgcn_readfirstlane((w + 1u == G || nr == 0) ? ntiles : max(tb, tile_of(r1)));
+    // sortedness of the piece: the pairs (i - 1, i) for i in (r0, r1] (workgroup 0's piece starts at the pair (0, 1)).  Four reads and
+    // the one before them per thread and step; the first eight steps' loads are all requested before the first is looked at
+    {
+        uint32_t err = 0;
+        const uint32_t vend = min(r1 + 1u, nr);                      // one past the last i of the piece
+        auto check4 = [&](const u32x4_a4 x, int32_t pv, uint32_t i0) {
+            const int32_t e0 = (int32_t)x.x, e1 = (int32_t)x.y, e2 = (int32_t)x.z, e3 = (int32_t)x.w;
+            if (i0 < vend) err |= e0 < pv ? 1u : 0u;
+            if (i0 + 1u < vend) err |= e1 < e0 ? 1u : 0u;
+            if (i0 + 2u < vend) err |= e2 < e1 ? 1u : 0u;
+            if (i0 + 3u < vend) err |= e3 < e2 ? 1u : 0u;
+        };
+        constexpr int VSTEPS = 8;
+        u32x4_a4 vx[VSTEPS]; int32_t vp[VSTEPS];
+#pragma unroll
+        for (int j = 0; j < VSTEPS; ++j) {
+            const uint32_t i0 = r0 + 1u + 4u * ((uint32_t)tid + 256u * (uint32_t)j);
+            vx[j] = u32x4_a4{0, 0, 0, 0}; vp[j] = 0;
+            if (i0 < vend) {
+                vp[j] = a.read_start[i0 - 1u];
+                if (i0 + 4u <= nr) vx[j] = *reinterpret_cast<const u32x4_a4 *>(a.read_start + i0);
+                else { vx[j].x = (uint32_t)a.read_start[i0]; vx[j].y = i0 + 1u < nr ? (uint32_t)a.read_start[i0 + 1u] : 0u; vx[j].z = i0 + 2u < nr ? (uint32_t)a.read_start[i0 + 2u] : 0u; vx[j].w = 0u; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VSTEPS; ++j) check4(vx[j], vp[j], r0 + 1u + 4u * ((uint32_t)tid + 256u * (uint32_t)j));
+        for (uint32_t i = r0 + 1u + 1024u * VSTEPS + (uint32_t)tid; i < vend; i += B) err |= a.read_start[i] < a.read_start[i - 1u] ? 1u : 0u;   // (pieces of more than 8192 reads)
+        if (err) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_UNSORTED);
+    }
+    if (tid == 0) { ra.run_tile0[w] = tb; if (w + 1u == G) ra.run_tile0[G] = ntiles; }
+
+    const __amdgpu_buffer_rsrc_t rs_pos = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(a.cpg_pos), 0, a.n_cpgs * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rel = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.cpg_rel), 0, a.n_cpgs, 0x00020000);
+    const bool do_lp = a.want_lpmd != 0;
+    const int32_t maxd = min(a.max_dist, 255);
+    const int32_t mind = max(a.min_dist, 0);
+    const bool lp_range = maxd >= a.min_dist && maxd >= 0;
+    const uint32_t KA = (0x8000u - (uint32_t)mind) * 0x10001u, KB = (0x8000u + (uint32_t)maxd) * 0x10001u;
+
+    // per-thread LPMD counters across the run.  nrv: reads owned (bits 0-14), of them with mapq >= min_qual (bits 15-29), a span
+    // violation seen (bit 31).  Moved to the wave's 64-bit sums in LDS when a lane nears its field's top.
+    uint32_t lp_c = 0, lp_d = 0, nrv = 0;
+    auto flush_lpmd = [&]() {
+        const unsigned long long f0 = wave_sum64(lp_c), f1 = wave_sum64(lp_d), f2 = wave_sum64(nrv & 0x7fffu), f3 = wave_sum64((nrv >> 15) & 0x7fffu);
+        if (lane == 0) { s_lp[wave][0] += f0; s_lp[wave][1] += f1; s_lp[wave][2] += f2; s_lp[wave][3] += f3; }      // the wave's own row
+        lp_c = lp_d = 0; nrv &= 0x80000000u;
+    };
+
+    uint32_t t = tb;
+    uint32_t lo = 0;
+    if (t < te) {
+        const int32_t T0 = a.region_beg + (int32_t)(t * W);
+        lo = __builtin_amdgcn_readfirstlane(wave_lower_bound(a.read_start, nr, (int32_t)max((int64_t)T0 - a.max_span + 1, (int64_t)INT32_MIN), r0, ra.hint_stride));
+    }
+    __syncthreads();
+    uint32_t par = 0;
+    // the thread's read of the coming iteration: index, start, call offsets (INT32_MAX start: no such read)
+    uint32_t i = 0, o0 = 0, o1 = 0;
+    int32_t s = INT32_MAX;
+    auto fetch = [&](uint32_t idx) {
+        i = idx; s = INT32_MAX; o0 = 0; o1 = 0;
+        if (idx < nr) { s = a.read_start[idx]; o0 = a.cpg_off[idx]; o1 = a.cpg_off[idx + 1u]; }
+    };
+    int32_t s_first = INT32_MAX;                              // start of read lo (uniform)
+    if (t < te) { fetch(lo + (uint32_t)tid); s_first = __builtin_amdgcn_readfirstlane(lo < nr ? a.read_start[lo] : INT32_MAX); }
+    uint32_t lon_run = 0;                                     // deep tiles: where the next tile's candidates begin, over the passes so far
+
+    RT_ADD(rt_pre, rt_t);
+    while (t < te) {
+        const int32_t T0 = a.region_beg + (int32_t)(t * W);
+        const int64_t T0W = (int64_t)T0 + W;
+        const int32_t T1 = (int32_t)min(T0W, (int64_t)a.region_end);
+        const uint32_t Wp = (uint32_t)(T1 - T0);
+        const int32_t P0 = T0;
+        if ((int64_t)s_first > T0W) {
+            // no read can touch this tile, nor the ones before the tile that holds read lo's start - 1: zero counts, same lo
+            uint32_t tnext = te;
+            if (lo < nr) tnext = (uint32_t)min((int64_t)te, max((int64_t)t + 1, ((int64_t)s_first - a.region_beg + W - 1) / W - 1));
+            if (a.want_pdr) for (uint32_t q = 4u * t + (uint32_t)tid; q < 4u * tnext; q += B) a.tile_cnt[q] = 0u;
+            t = tnext;
+            continue;
+        }
+        const int32_t cmax = (int32_t)min(T0W, (int64_t)INT32_MAX);          // candidates start at or before T0 + W
+        const int32_t nb = (int32_t)max(T0W - a.max_span + 1, (int64_t)INT32_MIN);   // the next tile's lower bound
+        bool first = true, last;
+        do {
+            uint32_t below_end = 0;                                            // wave: one past the last read seen that starts before nb
+            uint32_t it = 0;
+            bool cand = s <= cmax;
+            while (it < PT_PASS_ITERS && __any(cand)) {
+                uint32_t v[NB];
+                const uint32_t n = o1 - o0;
+#ifdef MTH_RUNS_GLOBAL_LOADS      // experiment: plain loads (may run past the arrays for the batch's last reads)
+                {
+                    const u32x4_a4 x0 = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0);
+                    const u32x4_a4 x1 = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0 + 4);
+                    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                }
+                uint32_t rraw0 = 0, rraw1 = 0;
+                if (do_lp) { const u32x2_a1 x = *reinterpret_cast<const u32x2_a1 *>(reinterpret_cast<const uint8_t *>(a.cpg_rel) + o0); rraw0 = x.x; rraw1 = x.y; }
+#else
+                {
+                    const u32x4_a4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rs_pos, o0 * 4u, 0, 0);
+                    const u32x4_a4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rs_pos, o0 * 4u + 16u, 0, 0);
+                    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                }
+                uint32_t rraw0 = 0, rraw1 = 0;
+                if (do_lp) { const u32x2_a1 x = __builtin_amdgcn_raw_buffer_load_b64(rs_rel, o0, 0, 0); rraw0 = x.x; rraw1 = x.y; }
+#endif
+                const uint32_t mq = cand ? a.read_mapq[i] : 0u;
+                // the thread's next read (start and offsets): requested now, tested at the bottom
+                const uint32_t inx = i + B;
+                int32_t sn = INT32_MAX; uint32_t o0n = 0, o1n = 0;
+                if (inx < nr) { sn = a.read_start[inx]; o0n = a.cpg_off[inx]; o1n = a.cpg_off[inx + 1u]; }
+#ifdef MTH_RUNS_TRACE
+                { const unsigned long long w0 = RT_NOW(); __builtin_amdgcn_s_waitcnt(0); rt_wait += RT_NOW() - w0; rt_iters += 1; }
+#endif
+                {
+                    const unsigned long long bm = __ballot(cand && s < nb);
+                    if (bm) below_end = max(below_end, i - (uint32_t)lane + 64u - (uint32_t)__builtin_clzll(bm));
+                }
+                const bool owned = cand && (s >= T0) && (s < T1);
+                const bool lp_ok = do_lp && owned && (mq >= a.lpmd_min_qual);                 // lpmd.rs:176-179
+                if (do_lp && owned) nrv += lp_ok ? 0x8001u : 1u;
+                const bool pdr_ok = cand && a.want_pdr && (n >= a.min_cpgs) && (mq >= a.pdr_min_qual) && (n > 0);   // pdr.rs:147-157
+                const bool work = (lp_ok || pdr_ok) && n != 0;
+                const bool any_lp = lp_range && __any(work && lp_ok && n > 1);
+                if (work) {
+                    const uint32_t sm1 = (uint32_t)(s - 1);
+                    const uint32_t dead_w = ((MARGIN ? (uint32_t)(P0 - MG + lane) : (uint32_t)T0 + (1u << 28)) & 0x7fffffffu) | (v[0] & 0x80000000u);
+                    const uint32_t n_lp = lp_ok ? min(n, (uint32_t)NB) : 0u;
+                    uint32_t acc = 0, xmax;
+                    {
+                        const uint32_t nrow = min(n, 8u);
+                        const uint4 ma = reinterpret_cast<const uint4 *>(&tabs.mtab[nrow][0])[0], mb = reinterpret_cast<const uint4 *>(&tabs.mtab[nrow][0])[1];
+                        const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+                        uint32_t xs[8];
+                        xs[0] = (v[0] & 0x7fffffffu) - sm1;
+#pragma unroll
+                        for (int k = 1; k < 8; ++k) {
+                            xs[k] = __builtin_amdgcn_bitop3_b32(v[k] - sm1, mk[k], 0x7fffffffu, 0x80);       // a & b & c
+                            v[k] = __builtin_amdgcn_bitop3_b32(v[k], dead_w, mk[k], 0xe4);                    // c ? a : b
+                            acc = __builtin_amdgcn_bitop3_b32(acc, v[k], v[0], 0xf6);                         // a | (b ^ c)
+                        }
+                        xmax = max(max(max(xs[0], xs[1]), max(xs[2], xs[3])), max(max(xs[4], xs[5]), max(xs[6], xs[7])));
+                    }
+                    uint32_t bad_it = (xmax > (uint32_t)a.max_span) ? 1u : 0u;
+                    uint32_t disc = acc >> 31;
+                    const bool any_long = __any(n > (uint32_t)NB);
+                    if (any_long && n > (uint32_t)NB) {
+                        const uint32_t firstst = v[0] >> 31;
+                        for (uint32_t k = NB; k < n; ++k) {
+                            const uint32_t x = a.cpg_pos[o0 + k];
+                            disc |= (x >> 31) ^ firstst;
+                            bad_it |= ((x & 0x7fffffffu) - sm1 > (uint32_t)a.max_span) ? 1u : 0u;
+                        }
+                    }
+                    nrv |= bad_it << 31;
+                    if (any_lp) {       // windowed pair counts, two pairs per instruction (see tile_pass)
+                        if (__any(o0 + 8u > a.n_cpgs)) {      // the batch's last few reads: the bounds check drops whole dwords of a window that crosses the end
+                            if (o0 + 8u > a.n_cpgs) {
+                                const uint8_t *__restrict__ rel = reinterpret_cast<const uint8_t *>(a.cpg_rel);
+                                rraw0 = rraw1 = 0;
+#pragma unroll 1
+                                for (uint32_t k = 0; k < 8u && o0 + k < a.n_cpgs; ++k) {
+                                    const uint32_t bte = rel[o0 + k];
+                                    if (k < 4) rraw0 |= bte << (8 * k); else rraw1 |= bte << (8 * (k - 4));
+                                }
+                            }
+                        }
+                        uint32_t SQ[4], SO[4], Q[4], O[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) SQ[e] = __builtin_amdgcn_perm(v[2 * e + 1], v[2 * e], 0x070c030cu);
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) SO[e] = __builtin_amdgcn_perm(v[2 * e + 2], v[2 * e + 1], 0x070c030cu);
+                        SO[3] = __builtin_amdgcn_perm(0u, v[7], 0x070c030cu);
+                        Q[0] = __builtin_amdgcn_perm(0u, rraw0, 0x0c010c00u); Q[1] = __builtin_amdgcn_perm(0u, rraw0, 0x0c030c02u);
+                        Q[2] = __builtin_amdgcn_perm(0u, rraw1, 0x0c010c00u); Q[3] = __builtin_amdgcn_perm(0u, rraw1, 0x0c030c02u);
+                        O[0] = __builtin_amdgcn_perm(0u, rraw0, 0x0c020c01u); O[1] = __builtin_amdgcn_perm(rraw1, rraw0, 0x0c040c03u);
+                        O[2] = __builtin_amdgcn_perm(0u, rraw1, 0x0c020c01u); O[3] = __builtin_amdgcn_perm(0u, rraw1, 0x0c0c0c03u);
+                        {
+                            const uint4 da = reinterpret_cast<const uint4 *>(&tabs.dtab[n_lp][0])[0], db = reinterpret_cast<const uint4 *>(&tabs.dtab[n_lp][0])[1];
+                            Q[0] += da.x; Q[1] += da.y; Q[2] += da.z; Q[3] += da.w; O[0] += db.x; O[1] += db.y; O[2] += db.z; O[3] += db.w;
+                        }
+                        uint32_t accIN = 0, accDD = 0;
+#pragma unroll
+                        for (int g = 1; g < 8; ++g) {
+                            uint32_t orB = 0;
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) {
+                                const int li = (g & 1) ? (g - 1) / 2 + m : g / 2 + m;
+                                if (li > 3) break;
+                                const uint32_t later = (g & 1) ? O[li] : Q[li], sl = (g & 1) ? SO[li] : SQ[li];
+                                const uint32_t D = later - Q[m];
+                                const uint32_t Bw = KB - D;
+                                const uint32_t IN = __builtin_amdgcn_bitop3_b32(D + KA, Bw, 0x80008000u, 0x80);   // readutil.rs:184, 196
+                                const uint32_t DD = IN & (sl ^ SQ[m]);
+                                accIN += __builtin_popcount(IN);
+                                accDD += __builtin_popcount(DD);
+                                orB |= Bw;
+                            }
+                            if (!__any((orB & 0x80008000u) != 0u)) break;
+                        }
+                        lp_c += accIN - accDD;
+                        lp_d += accDD;
+                    }
+                    if (any_long && lp_ok && n > (uint32_t)NB) {      // pairs whose later call is the 9th or beyond: from memory (rare)
+                        const uint8_t *__restrict__ rel = reinterpret_cast<const uint8_t *>(a.cpg_rel);
+                        for (uint32_t k = NB; k < n; ++k) {
+                            const int32_t rk = (int32_t)rel[o0 + k];
+                            const uint32_t mk = a.cpg_pos[o0 + k] >> 31;
+                            for (uint32_t j = k; j-- > 0;) {
+                                const int32_t dist = rk - (int32_t)rel[o0 + j];
+                                if (dist > a.max_dist) break;          // readutil.rs:184
+                                if (dist < a.min_dist) continue;       // readutil.rs:196
+                                if ((a.cpg_pos[o0 + j] >> 31) == mk) lp_c += 1; else lp_d += 1;
+                            }
+                        }
+                    }
+                    // scatter (pdr.rs:180-191); see tile_pass for the two address forms
+                    if (MARGIN) {
+                        if (pdr_ok && !bad_it && (uint32_t)s - (uint32_t)(P0 - MG + 1) <= (uint32_t)(W + MG - 1)) {
+                            const uint32_t one = disc ? 0x10001u : 1u;
+                            const uint32_t base4 = (uint32_t)(P0 - MG) << 2;
+#pragma unroll
+                            for (int k = 0; k < NB; ++k)
+                                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt_raw) + ((v[k] << 2) - base4)), one);
+                            if (any_long) {
+                                for (uint32_t k = NB; k < n; ++k) {
+                                    const uint32_t pk = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)P0;
+                                    if (pk < Wp) atomicAdd(cnt + pk, one);
+                                }
+                            }
+                        }
+                    } else {
+                        const uint32_t one = disc ? 0x10001u : 1u;
+                        const uint32_t base4 = ((uint32_t)P0 << 2) - (pdr_ok ? 0u : (1u << 30));
+                        const uint32_t trash4 = (uint32_t)(W + lane) << 2;
+#pragma unroll
+                        for (int k = 0; k < NB; ++k) {
+                            const uint32_t a4 = min((v[k] << 2) - base4, trash4);
+                            atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt) + a4), one);
+                        }
+                        if (any_long && pdr_ok) {
+                            for (uint32_t k = NB; k < n; ++k) {
+                                const uint32_t pk = (a.cpg_pos[o0 + k] & 0x7fffffffu) - (uint32_t)P0;
+                                if (pk < Wp) atomicAdd(cnt + pk, one);
+                            }
+                        }
+                    }
+                }   // work
+                i = inx; s = sn; o0 = o0n; o1 = o1n;
+                cand = s <= cmax;
+                ++it;
+            }
+            // the wave is through with this pass: where the next tile's candidates begin as far as it has seen, and whether it stopped
+            // at the pass limit with candidates left
+            const bool more_w = __any(cand);
+            if (lane == 0) {
+                if (below_end) atomicMax(&s_lon[par], below_end);
+                if (more_w) s_more[par] = 1u;
+            }
+            if (__any((lp_c | lp_d) >> 24 | (nrv & 0x20004000u))) flush_lpmd();
+            RT_ADD(rt_loop, rt_t);
+            __syncthreads();
+            RT_ADD(rt_b1, rt_t);
+            last = __builtin_amdgcn_readfirstlane(s_more[par]) == 0u;
+            lon_run = max(lon_run, (uint32_t)__builtin_amdgcn_readfirstlane(s_lon[par]));
+            const uint32_t lo_next = max(lo, lon_run);
+            int32_t s_first_v = INT32_MAX;
+            if (last) {
+                // the thread's first read of the next tile (and the start of its first candidate): they travel under the compaction
+                fetch(lo_next + (uint32_t)tid);
+                if (lo_next < nr) s_first_v = a.read_start[lo_next];
+            }
+            if (a.want_pdr) {
+                SiteRec *__restrict__ slice = a.scratch + (size_t)t * W;
+                if (first && last) {
+                    // wave-private compaction of the wave's 1024 positions, counters zeroed behind
+                    uint32_t below = 0;
+#pragma unroll
+                    for (int q = 3; q >= 0; --q) {
+                        const uint4 x = reinterpret_cast<const uint4 *>(cnt)[tid * 4 + q];
+                        below = __builtin_amdgcn_alignbit(below, (x.w & 0xffffu) - a.min_cov, 31);
+                        below = __builtin_amdgcn_alignbit(below, (x.z & 0xffffu) - a.min_cov, 31);
+                        below = __builtin_amdgcn_alignbit(below, (x.y & 0xffffu) - a.min_cov, 31);
+                        below = __builtin_amdgcn_alignbit(below, (x.x & 0xffffu) - a.min_cov, 31);
+                    }
+                    uint32_t qual = ~below & 0xffffu;
+                    {
+                        const int32_t left = (int32_t)Wp - tid * 16;
+                        qual &= left >= 16 ? 0xffffu : (left > 0 ? (1u << left) - 1u : 0u);
+                    }
+                    const uint32_t mine = __builtin_popcount(qual);
+                    const uint32_t incl = wave_scan_incl(mine);
+                    uint32_t o = incl - mine;
+                    SiteRec *__restrict__ out = slice + (size_t)wave * (W / 4);
+                    while (qual) {
+                        const uint32_t idx = (uint32_t)tid * 16u + (uint32_t)__builtin_ctz(qual);
+                        qual &= qual - 1;
+                        const uint32_t x = cnt[idx];
+                        SiteRec rr; rr.pos = P0 + (int32_t)idx; rr.pad = 0;
+                        rr.n_disc = x >> 16; rr.n_conc = (x & 0xffffu) - rr.n_disc;
+                        out[o++] = rr;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) reinterpret_cast<uint4 *>(cnt)[tid * 4 + q] = make_uint4(0, 0, 0, 0);
+                    if (lane == 63) { a.tile_cnt[4u * t + (uint32_t)wave] = incl; s_rows[wave] += incl; }
+                } else {
+                    // deep tile: the pass's counters into the slice's dense rows (row p: coverage in n_conc, discordant reads in n_disc;
+                    // the thread owns rows tid*16 ..), and after the last pass the wave compacts its 1024 rows in place, 64 per round
+                    // (a round's rows are read before any of them is overwritten, and rows land at or before where they came from)
+#pragma unroll 1
+                    for (uint32_t k = 0; k < 16; ++k) {
+                        const uint32_t p = (uint32_t)tid * 16u + k;
+                        const uint32_t x = cnt[p];
+                        cnt[p] = 0;
+                        SiteRec rr = slice[p];
+                        if (first) { rr.n_conc = 0; rr.n_disc = 0; }
+                        rr.n_conc += x & 0xffffu; rr.n_disc += x >> 16;
+                        slice[p] = rr;
+                    }
+                    if (last) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        uint32_t nout = 0;
+#pragma unroll 1
+                        for (uint32_t r = 0; r < 16; ++r) {
+                            const uint32_t p = (uint32_t)wave * 1024u + r * 64u + (uint32_t)lane;
+                            SiteRec rr = slice[p];
+                            const bool q = p < Wp && rr.n_conc >= a.min_cov;
+                            const unsigned long long m = __ballot(q);
+                            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            if (q) {
+                                rr.pos = P0 + (int32_t)p; rr.pad = 0;
+                                rr.n_conc -= rr.n_disc;
+                                slice[(size_t)wave * 1024u + nout + before] = rr;
+                            }
+                            nout += (uint32_t)__builtin_popcountll(m);
+                        }
+                        if (lane == 63) { a.tile_cnt[4u * t + (uint32_t)wave] = nout; s_rows[wave] += nout; }
+                    }
+                }
+            }
+            if (tid == 0) { s_lon[par ^ 1u] = 0u; s_more[par ^ 1u] = 0u; }      // the words of the next pass / tile
+            RT_ADD(rt_comp, rt_t);
+            __syncthreads();
+            RT_ADD(rt_b2, rt_t);
+            rt_ntile += 1;
+            first = false;
+            par ^= 1u;
+            if (last) { lo = lo_next; lon_run = 0; s_first = __builtin_amdgcn_readfirstlane(s_first_v); }
+        } while (!last);
+        ++t;
+    }
+    // the run's totals: plain stores, summed by the gather
+    if (nrv >> 31) atomicOr(const_cast<uint32_t *>(&a.st->err), (uint32_t)ERRB_SPAN);
+    flush_lpmd();
+    __syncthreads();
+#ifdef MTH_RUNS_TRACE
+    if (ra.trace && lane == 0) {
+        unsigned long long *tr = ra.trace + ((size_t)w * 4u + (uint32_t)wave) * 8u;
+        tr[0] = rt_wait; tr[1] = RT_NOW() - rt_beg; tr[2] = rt_pre; tr[3] = rt_loop; tr[4] = rt_b1; tr[5] = rt_comp; tr[6] = rt_b2; tr[7] = rt_ntile | (rt_iters << 32);
+    }
+#endif
+    if (tid == 0) ra.run_rows[w] = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3];
+    if (tid < 4) ra.run_lpmd[(size_t)w * 4u + tid] = s_lp[0][tid] + s_lp[1][tid] + s_lp[2][tid] + s_lp[3][tid];
+}
+
+// Gather of the run form: one 256-thread workgroup per run.  Row base = the batch's base + the rows of the runs before it (one
+// word per run, <= 2048); the run's slots (four per tile) are scanned 1024 at a time and their rows copied as one flat range.  The
+// last run's workgroup commits the batch (rows, LPMD counters summed over the runs) as k_gather does.
+__global__ __launch_bounds__(256) void k_gather_runs(const SiteRec *__restrict__ scratch, const uint32_t *__restrict__ slot_cnt,
+                                                     const uint32_t *__restrict__ run_tile0, const uint32_t *__restrict__ run_rows,
+                                                     const unsigned long long *__restrict__ run_lpmd, uint32_t G, int fin_only, int want_lpmd,
+                                                     DevState *__restrict__ st, const DevState *__restrict__ base_st, DevState *__restrict__ next_st,
+                                                     DevState *__restrict__ lane_st, int reset_first, uint32_t *__restrict__ batch_cnt, uint32_t slot_w,
+                                                     int32_t *__restrict__ out_pos, float *__restrict__ out_pdr, uint32_t *__restrict__ out_nc, uint32_t *__restrict__ out_nd) {
+    __shared__ uint32_t s_off[1025];
+    __shared__ uint32_t s_part[4], s_w[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t w = fin_only ? G - 1u : blockIdx.x;
+    const uint64_t cur = reset_first ? 0ull : base_st->cur_base;
+    uint32_t part = 0;
+    if (!fin_only) for (uint32_t r = tid; r < w; r += 256u) part += run_rows[r];          // rows of one batch fit 32 bits
+    const uint32_t wsum = wave_sum(part);
+    if (lane == 0) s_part[wave] = wsum;
+    __syncthreads();
+    const uint32_t before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    uint32_t done = 0;                                                                      // rows of the run copied so far
+    if (!fin_only) {
+        const uint32_t e_beg = run_tile0[w] * 4u, e_end = run_tile0[w + 1u] * 4u;
+        const uint32_t mine_total = run_rows[w];
+        for (uint32_t e0 = e_beg; e0 < e_end && done < mine_total; e0 += 1024u) {
+            // four slots (one tile) per thread
+            uint4 c = make_uint4(0, 0, 0, 0);
+            if (e0 + 4u * tid < e_end) c = *reinterpret_cast<const uint4 *>(slot_cnt + e0 + 4u * tid);
+            const uint32_t mine = c.x + c.y + c.z + c.w;
+            const uint32_t incl = wave_scan_incl(mine);
+            __syncthreads();                                                                // (the previous chunk's s_off / s_w are no longer read)
+            if (lane == 63) s_w[wave] = incl;
+            __syncthreads();
+            const uint32_t wbefore = (wave > 0 ? s_w[0] : 0u) + (wave > 1 ? s_w[1] : 0u) + (wave > 2 ? s_w[2] : 0u);
+            const uint32_t x0 = wbefore + incl - mine;
+            s_off[4u * tid] = x0; s_off[4u * tid + 1u] = x0 + c.x; s_off[4u * tid + 2u] = x0 + c.x + c.y; s_off[4u * tid + 3u] = x0 + c.x + c.y + c.z;
+            if (tid == 255u) s_off[1024] = x0 + mine;
+            __syncthreads();
+            const uint32_t total = s_off[1024];
+            const uint64_t base = cur + before + done;
+            for (uint32_t r = tid; r < total; r += 256u) {
+                uint32_t q = 0;                                                             // the largest q with s_off[q] <= r
+#pragma unroll
+                for (uint32_t step = 512; step > 0; step >>= 1) q += (s_off[q + step] <= r) ? step : 0u;
+                const SiteRec rec = scratch[(size_t)(e0 + q) * slot_w + (r - s_off[q])];
+                out_pos[base + r] = rec.pos;
+                out_nc[base + r] = rec.n_conc;
+                out_nd[base + r] = rec.n_disc;
+                out_pdr[base + r] = (float)rec.n_disc / ((float)rec.n_conc + (float)rec.n_disc);   // pdr.rs:47-49
+            }
+            done += total;
+        }
+    }
+    if (w + 1u != G) return;
+    // the batch's last workgroup commits it (see k_gather)
+    const uint32_t batch_total = fin_only ? 0u : before + run_rows[w];
+    if (tid == 0) {
+        const uint32_t nb = reset_first ? 0u : st->n_batches;
+        st->n_sites = cur + batch_total;
+        batch_cnt[nb] = batch_total;
+        st->n_batches = nb + 1;
+        if (next_st) next_st->cur_base = cur + batch_total;
+        uint32_t e = reset_first ? 0u : st->err;
+        if (lane_st) { e |= lane_st->err; lane_st->err = 0; }
+        if (lane_st || reset_first) st->err = e;
+    }
+    if (want_lpmd || reset_first) {
+        __shared__ unsigned long long s_l[4][4];
+        unsigned long long x[4] = {0, 0, 0, 0};
+        if (want_lpmd) for (uint32_t r = tid; r < G; r += 256u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] += run_lpmd[(size_t)r * 4u + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x[k] += __shfl_down(x[k], o, 64);
+            if (lane == 0) s_l[wave][k] = x[k];
+        }
+        __syncthreads();
+        if (tid < 4) st->lpmd[tid] = (reset_first ? 0ll : st->lpmd[tid]) + (long long)(s_l[0][tid] + s_l[1][tid] + s_l[2][tid] + s_l[3][tid]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One wave per tile.  base = cur_base + rows of the buckets before the tile's bucket + rows of the bucket's
 // earlier tiles (a few coalesced loads per lane, two wave reductions); then scratch -> final sorted SoA with
 // the reference's f32 PDR (pdr.rs:47-49).  The wave of the batch's last tile also commits the batch to
@@ -861,6 +1446,23 @@ static void launch_tile(const TileArgs &a, uint32_t ntiles, hipStream_t s) {
     else hipLaunchKernelGGL((k_pdr_lpmd_tile<W, B, 8, RelT, 0>), dim3(grid), dim3(B), 0, s, a, ntiles);
 }
 
+// run form: the chip's resident slots (8 workgroups per CU), or fewer for a batch with fewer tiles
+static uint32_t runs_grid(uint32_t ntiles) {
+    static const uint32_t slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char *e = getenv("MTH_RUNS_WGS_PER_CU");
+        const int per = e && atoi(e) > 0 ? atoi(e) : MTH_RUNS_OCC;
+        return (uint32_t)std::max(cus, 1) * (uint32_t)per;
+    }();
+    return std::max(1u, std::min(slots, ntiles));
+}
+static void launch_runs(const TileArgs &a, const RunArgs &ra, uint32_t ntiles, uint32_t G, hipStream_t s) {
+    static const bool no_margin = getenv("MTH_TILE_NO_MARGIN") != nullptr;   // A/B switch
+    if (a.max_span <= TILE_MARGIN && !no_margin) hipLaunchKernelGGL((k_pdr_lpmd_runs<(1 << DENSE_TILE_SHIFT), TILE_MARGIN>), dim3(G), dim3(256), 0, s, a, ra, ntiles);
+    else hipLaunchKernelGGL((k_pdr_lpmd_runs<(1 << DENSE_TILE_SHIFT), 0>), dim3(G), dim3(256), 0, s, a, ra, ntiles);
+}
+
 // the linear read index alone (for kernels that find a tile's candidate reads without running the PDR/LPMD pass):
 // idx lives in ctx->idx; same origin and quantum as launch_pdr_lpmd builds
 int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &idx_base, uint32_t &ntiles) {
@@ -985,23 +1587,32 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     const bool coarse = !sink && wide_shift == 0 && !coarse_off;
     const uint32_t coarse_stride = (ntiles + 2u + 3u) & ~3u;
     MTH_HIP(ctx, b_idx.reserve(coarse ? (size_t)coarse_stride * 2 * 4 : (size_t)(nq + 1) * 4, s));
-    MTH_HIP(ctx, b_tile_cnt.reserve((size_t)ntiles * 4, s));
+    // the run form of the dense kernel (k_pdr_lpmd_runs; persistent workgroups, no index, no atomics): opt-in with MTH_TILE_RUNS=1 --
+    // parity-green on every PDR / LPMD case, measured SLOWER than the one-tile-per-workgroup form on config 2 (0.127 against 0.084 ms;
+    // profiles/r05_persistent.md).  8-bit relative positions, call offsets that fit a buffer descriptor's 32-bit byte offset.
+    const char *runs_env = getenv("MTH_TILE_RUNS");          // (read per call: the tests switch it per case)
+    const bool runs = wide_shift == 0 && b.cpg_rel != nullptr && b.n_cpgs < (1u << 30) && runs_env && atoi(runs_env) == 1;
+    const uint32_t G = runs ? runs_grid(ntiles) : 0u;
+    MTH_HIP(ctx, b_tile_cnt.reserve((size_t)ntiles * 4 * (runs ? 4 : 1), s));
     const uint32_t nbk = (ntiles + (1u << TILE_BUCKET_SHIFT) - 1) >> TILE_BUCKET_SHIFT;
-    MTH_HIP(ctx, b_bucket.reserve((size_t)nbk * 5 * sizeof(unsigned long long), s));
+    const uint32_t n_bucket_words = nbk * 5u;      // rows, 4 LPMD sums per bucket
+    // run form: [G + 1] first tiles, [G] rows (32-bit words), then [G][4] LPMD sums
+    const size_t run_words = ((size_t)G + 2u) / 2u + ((size_t)G + 1u) / 2u;
+    MTH_HIP(ctx, b_bucket.reserve(((size_t)n_bucket_words + run_words + (size_t)G * 4u) * sizeof(unsigned long long), s));
     if (p.want_pdr) MTH_HIP(ctx, b_scratch.reserve((size_t)ntiles * (size_t)tile_w * sizeof(SiteRec), s));
 
-    {
+    if (!runs || sink) {      // (the run form needs no index; site discovery leaves the fine one behind for the walks)
         LaunchTimer lt(ctx, K_INDEX);
         const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK * IDX_GROUPS - 1) / (BLOCK * IDX_GROUPS);
         const int al16 = (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0);
         if (coarse)
             hipLaunchKernelGGL(k_build_index<2>, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, b.region_beg - b.max_span + 1, b.region_beg + 1,
                                DENSE_TILE_SHIFT, ntiles + 1u, al16, b_idx.as<uint32_t>(), b_idx.as<uint32_t>() + coarse_stride, lane_st,
-                               L ? (DevState *)nullptr : cst, b_bucket.as<unsigned long long>(), nbk * 5u, b.cpg_off, b.n_cpgs);
+                               L ? (DevState *)nullptr : cst, b_bucket.as<unsigned long long>(), n_bucket_words, b.cpg_off, b.n_cpgs);
         else
             hipLaunchKernelGGL(k_build_index<1>, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, idx_base, 0, (int)IDX_QSHIFT, nq, al16,
                                b_idx.as<uint32_t>(), (uint32_t *)nullptr, lane_st, L ? (DevState *)nullptr : cst,
-                               b_bucket.as<unsigned long long>(), nbk * 5u, b.cpg_off, b.n_cpgs);
+                               b_bucket.as<unsigned long long>(), n_bucket_words, b.cpg_off, b.n_cpgs);
     }
     TileArgs a;
     a.read_start = b.read_start; a.read_mapq = b.read_mapq; a.cpg_off = b.cpg_off; a.cpg_pos = b.cpg_pos;
@@ -1016,6 +1627,18 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     a.min_dist = p.lpmd_min_distance; a.max_dist = p.lpmd_max_distance;
     a.pdr_min_qual = p.pdr_min_qual; a.lpmd_min_qual = p.lpmd_min_qual;
     a.want_pdr = p.want_pdr; a.want_lpmd = p.want_lpmd;
+    RunArgs ra;
+    ra.run_tile0 = reinterpret_cast<uint32_t *>(b_bucket.as<unsigned long long>() + n_bucket_words);
+    ra.run_rows = ra.run_tile0 + (((size_t)G + 2u) / 2u) * 2u;
+    ra.run_lpmd = b_bucket.as<unsigned long long>() + n_bucket_words + run_words;
+    ra.cst = L ? (DevState *)nullptr : cst;
+    ra.trace = nullptr;
+#ifdef MTH_RUNS_TRACE
+    static unsigned long long *d_rtrace = nullptr;
+    if (!d_rtrace) (void)hipMalloc((void **)&d_rtrace, 8 * 8 * 4 * 4096);
+    ra.trace = G <= 4096 ? d_rtrace : nullptr;
+#endif
+    ra.hint_stride = (uint32_t)std::max(1.0, std::ceil((double)b.n_reads / (double)ntiles * (1.0 + (double)b.max_span / (double)tile_w) * 1.3 / 63.0));
 #ifdef MTH_TILE_TRACE
     static unsigned long long *d_ttrace = nullptr;
     if (!d_ttrace) (void)hipMalloc((void **)&d_ttrace, 8 * 8 * 262144);
@@ -1025,6 +1648,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
         LaunchTimer lt(ctx, wide_shift ? K_WIDE : K_TILE);
         const bool r8 = b.cpg_rel != nullptr;
         if (wide_shift) launch_tile_wide(a, ntiles, wide_shift, r8, s);
+        else if (runs) launch_runs(a, ra, ntiles, G, s);
         else if (r8) launch_tile<(1 << DENSE_TILE_SHIFT), 256, uint8_t>(a, ntiles, s); else launch_tile<(1 << DENSE_TILE_SHIFT), 256, uint16_t>(a, ntiles, s);
     }
     {
@@ -1037,7 +1661,13 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
             ctx->reset_pending = false;
         }
         static const bool gather1 = getenv("MTH_GATHER") && atoi(getenv("MTH_GATHER")) == 1;       // A/B: the per-tile form
-        if (gather1)
+        if (runs)
+            hipLaunchKernelGGL(k_gather_runs, dim3(p.want_pdr ? G : 1u), dim3(256), 0, s, b_scratch.as<SiteRec>(),
+                               b_tile_cnt.as<uint32_t>(), ra.run_tile0, ra.run_rows, ra.run_lpmd, G,
+                               p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, L ? (const DevState *)L->st : (const DevState *)cst,
+                               L ? ctx->lane[li ^ 1].st : (DevState *)nullptr, L ? L->st : (DevState *)nullptr, reset_first,
+                               bcnt, (uint32_t)tile_w / 4u, o_pos, o_pdr, o_nc, o_nd);
+        else if (gather1)
             hipLaunchKernelGGL(k_gather, dim3(p.want_pdr ? (ntiles + GATHER_WAVES - 1) / GATHER_WAVES : 1u), dim3(p.want_pdr ? 64 * GATHER_WAVES : 64), 0, s, b_scratch.as<SiteRec>(),
                                b_tile_cnt.as<uint32_t>(), b_bucket.as<unsigned long long>(), nbk, ntiles,
                                p.want_pdr ? 0 : 1, (int)p.want_lpmd, cst, L ? (const DevState *)L->st : (const DevState *)cst,
@@ -1051,6 +1681,15 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
                                bcnt, (uint32_t)tile_w, o_pos, o_pdr, o_nc, o_nd);
         if (L) { MTH_HIP(ctx, hipEventRecord(L->done, s)); ctx->pipe_tail = li; }
     }
+#ifdef MTH_RUNS_TRACE
+    if (getenv("MTH_RUNS_TRACE_OUT") && runs && G <= 4096) {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> tt(8 * 4 * (size_t)G);
+        (void)hipMemcpy(tt.data(), d_rtrace, tt.size() * 8, hipMemcpyDeviceToHost);
+        FILE *f = fopen(getenv("MTH_RUNS_TRACE_OUT"), "wb");
+        if (f) { fwrite(tt.data(), 8, tt.size(), f); fclose(f); }
+    }
+#endif
 #ifdef MTH_TILE_TRACE
     if (getenv("MTH_TILE_TRACE_OUT") && ntiles <= 262144) {
         (void)hipStreamSynchronize(s);

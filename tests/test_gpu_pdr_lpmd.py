@@ -16,14 +16,19 @@ pytestmark = pytest.mark.gpu
 f32 = np.float32
 
 
-@pytest.fixture(autouse=True, params=["auto", "tile", "wide14", "wide15", "wide16"])
+@pytest.fixture(autouse=True, params=["auto", "tile", "runs", "wide14", "wide15", "wide16"])
 def kernel_form(request, monkeypatch):
     """every case runs with the engine's own choice of kernel form (MTH_PDR_WIDE unset: the density chooser of
-    launch_pdr_lpmd, the path production takes), through the dense tile kernel (forced: MTH_PDR_WIDE=0) and through the
+    launch_pdr_lpmd, the path production takes), through the dense tile kernel (forced: MTH_PDR_WIDE=0), through the
+    persistent run form of the dense kernel (round 5: k_pdr_lpmd_runs + k_gather_runs, MTH_TILE_RUNS=1) and through the
     hashed-site form for sparse batches (mth_pdr_wide.hip) with 16384-, 32768- and 65536-bp tiles forced"""
     monkeypatch.delenv("MTH_PDR_WIDE", raising=False)
+    monkeypatch.delenv("MTH_TILE_RUNS", raising=False)
     if request.param == "tile":
         monkeypatch.setenv("MTH_PDR_WIDE", "0")
+    elif request.param == "runs":
+        monkeypatch.setenv("MTH_PDR_WIDE", "0")
+        monkeypatch.setenv("MTH_TILE_RUNS", "1")
     elif request.param.startswith("wide"):
         monkeypatch.setenv("MTH_PDR_WIDE", request.param[4:])
     return request.param

@@ -43,8 +43,15 @@ def _submit(eng, cs, p, keep, regions=None):
 
 @pytest.mark.parametrize("kw", [dict(min_depth=10, min_cpgs=4, min_qual=10), dict(min_depth=0, min_cpgs=0, min_qual=0),
                                 dict(min_depth=3, min_cpgs=1, min_qual=10, want_lpmd=False), dict(want_pdr=False)])
-def test_pipelined_job_equals_serial_and_oracle(monkeypatch, kw):
+@pytest.mark.parametrize("runs", [False, True])
+def test_pipelined_job_equals_serial_and_oracle(monkeypatch, kw, runs):
+    """runs: the dense batches through the persistent run form (k_pdr_lpmd_runs + k_gather_runs, MTH_TILE_RUNS=1) -- its gather is a
+    link of the same chain"""
     from metheor_amd import PdrLpmdParams, shard, synth
+    if runs:
+        monkeypatch.setenv("MTH_TILE_RUNS", "1")
+    else:
+        monkeypatch.delenv("MTH_TILE_RUNS", raising=False)
     cs = _contigs(101)
     reads = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(cs))
     regions = [[(0, c["length"])] for c in cs]
