@@ -111,6 +111,12 @@ int  mth_ctx_set_stream(mth_ctx_t *ctx, void *hip_stream);
 int  mth_ctx_sync(mth_ctx_t *ctx);
 const char *mth_strerror(int status);
 const char *mth_last_error(const mth_ctx_t *ctx);
+/* Non-fatal findings of the device-side record decode so far (sticky; as of the latest synchronising call).
+ * MTH_NOTE_CIGAR_PAD: a record's CIGAR holds a P (padding) operation.  readutil.rs:28,326 take the read's positions from
+ * rust-htslib's reference_positions_full(), whose aligned-pairs iterator is believed to panic on Cigar::Pad (the crate is not part
+ * of the reference tree and cannot be checked here); this engine treats P as "no query base, no reference base". */
+#define MTH_NOTE_CIGAR_PAD 1u
+uint32_t mth_notes(const mth_ctx_t *ctx);
 /* forget all accumulated results (a new input file) */
 int  mth_reset(mth_ctx_t *ctx);
 

@@ -40,6 +40,9 @@ enum {
 int  mth_host_open(const char *path, mth_host_t **out, char *errbuf, int errbuf_len);
 void mth_host_close(mth_host_t *h);
 const char *mth_host_last_error(const mth_host_t *h);
+/* non-fatal findings of the host-side record decode so far (process-wide, sticky): bit 0 = a record's CIGAR holds a P (padding)
+ * operation -- see MTH_NOTE_CIGAR_PAD in metheor_hip.h (rust-htslib is believed to panic there; this decoder takes P as "no base") */
+uint32_t mth_host_notes(void);
 int  mth_host_n_refs(const mth_host_t *h);
 const char *mth_host_ref_name(const mth_host_t *h, int tid);
 int64_t mth_host_ref_len(const mth_host_t *h, int tid);

@@ -12,7 +12,7 @@ MTH_MEM_HOST, MTH_MEM_DEVICE = 0, 1
 # every symbol include/metheor_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
-    "mth_strerror", "mth_last_error", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
+    "mth_strerror", "mth_last_error", "mth_notes", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_result_buffer_alloc", "mth_result_buffer_free", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_add_unbatched", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
     "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
@@ -105,6 +105,7 @@ def lib():
         L.mth_ctx_sync.argtypes = [vp]
         L.mth_strerror.restype = C.c_char_p; L.mth_strerror.argtypes = [C.c_int]
         L.mth_last_error.restype = C.c_char_p; L.mth_last_error.argtypes = [vp]
+        L.mth_notes.restype = C.c_uint32; L.mth_notes.argtypes = [vp]
         L.mth_reset.argtypes = [vp]
         L.mth_pdr_lpmd_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_pdr_lpmd_params_t)]
         L.mth_pdr_count.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -240,6 +241,17 @@ class Engine:
             raise MthError(rc, self.L.mth_strerror(rc).decode())
         if stream is not None:
             self._check(self.L.mth_ctx_set_stream(self.h, C.c_void_p(stream)))
+        # Batches whose kernels may still be queued or may be REPLAYED from their arrays at a later entry point (pipelined PDR + LPMD
+        # batches; queued ME / PM and pairs batches: include/metheor_hip.h).  The engine keeps them alive until its next synchronising
+        # call, so that a caller who drops or recycles a temporary batch right after the accumulate call cannot have the replay read
+        # freed memory.  Keyed by id: a loop over one resident batch holds it once.
+        self._inflight = {}
+
+    def _hold(self, batch):
+        self._inflight[id(batch)] = batch
+
+    def _settled(self):
+        self._inflight.clear()
 
     def close(self):
         if getattr(self, "h", None) and self.h:
@@ -261,15 +273,22 @@ class Engine:
     def reset(self):
         self._check(self.L.mth_reset(self.h))
 
+    def notes(self):
+        """non-fatal findings of the device decode so far (bit 0: a CIGAR P operation was decoded)"""
+        return int(self.L.mth_notes(self.h))
+
     def sync(self):
         self._check(self.L.mth_ctx_sync(self.h))
+        self._settled()
 
     def pdr_lpmd_accumulate(self, batch, params):
+        self._hold(batch)
         self._check(self.L.mth_pdr_lpmd_accumulate(self.h, C.byref(batch.c), C.byref(params.c)))
 
     def pdr_count(self):
         n = C.c_uint64(0)
         self._check(self.L.mth_pdr_count(self.h, C.byref(n)))
+        self._settled()
         return n.value
 
     def pdr_fetch(self):
@@ -284,6 +303,7 @@ class Engine:
         g = (C.c_int64 * 4)()
         v = C.c_float(0)
         self._check(self.L.mth_lpmd_global(self.h, C.byref(g), C.byref(v)))
+        self._settled()
         return dict(n_concordant=g[0], n_discordant=g[1], n_read=g[2], n_valid_read=g[3],
                     lpmd=np.float32(v.value))
 
@@ -320,12 +340,14 @@ class Engine:
 
     def quartet_accumulate(self, batch, min_qual=10):
         p = mth_quartet_params_t(min_qual)
+        self._hold(batch)
         self._check(self.L.mth_quartet_accumulate(self.h, C.byref(batch.c), C.byref(p)))
 
     def quartet_fetch(self, min_depth=10):
         """rows (depth >= min_depth) of the HashMap<Quartet,...>: tid, pos[n,4], cnt[n,16], me, pm"""
         n = C.c_uint64(0)
         self._check(self.L.mth_quartet_fetch(self.h, min_depth, C.byref(n), None, None, None, None, None))
+        self._settled()
         k = n.value
         out = dict(tid=np.zeros(k, np.int32), pos=np.zeros((k, 4), np.int32), cnt=np.zeros((k, 16), np.uint32),
                    me=np.zeros(k, np.float32), pm=np.zeros(k, np.float32))
@@ -361,11 +383,13 @@ class Engine:
 
     def lpmd_pairs_accumulate(self, batch, min_distance=2, max_distance=16, min_qual=10):
         p = mth_lpmd_pairs_params_t(min_distance, max_distance, min_qual)
+        self._hold(batch)
         self._check(self.L.mth_lpmd_pairs_accumulate(self.h, C.byref(batch.c), C.byref(p)))
 
     def lpmd_pairs_fetch(self):
         n = C.c_uint64(0)
         self._check(self.L.mth_lpmd_pairs_fetch(self.h, C.byref(n), None, None, None, None, None, None))
+        self._settled()
         k = n.value
         out = dict(tid=np.zeros(k, np.int32), pos1=np.zeros(k, np.int32), pos2=np.zeros(k, np.int32),
                    lpmd=np.zeros(k, np.float32), n_concordant=np.zeros(k, np.uint32), n_discordant=np.zeros(k, np.uint32))

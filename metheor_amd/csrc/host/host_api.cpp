@@ -127,6 +127,7 @@ int mth_host_open(const char *path, mth_host_t **out, char *errbuf, int errbuf_l
 
 void mth_host_close(mth_host_t *h) { delete h; }
 const char *mth_host_last_error(const mth_host_t *h) { return h ? h->last_error.c_str() : ""; }
+uint32_t mth_host_notes(void) { return mthh::g_decode_notes.load(); }
 int mth_host_n_refs(const mth_host_t *h) { return (int)h->reader.refs().size(); }
 const char *mth_host_ref_name(const mth_host_t *h, int tid) {
     return (tid >= 0 && tid < (int)h->reader.refs().size()) ? h->reader.refs()[tid].name.c_str() : "";

@@ -34,6 +34,8 @@
 
 namespace mthh {
 
+std::atomic<uint32_t> g_decode_notes{0};      // non-fatal findings of the host decode (bit 0: a CIGAR P operation), mth_host_notes()
+
 namespace {
 
 struct Block { size_t coff; uint32_t csize, isize; size_t uoff; };   // payload offset/size in the file, uncompressed size/offset
@@ -177,6 +179,8 @@ int decode_record(const uint8_t *p, uint32_t len, const std::unordered_set<uint6
             q += ln;
         } else if (op == 2 || op == 3) {
             r += ln;
+        } else if (op == 6) {
+            g_decode_notes.fetch_or(1u, std::memory_order_relaxed);      // P: see MTH_NOTE_CIGAR_PAD (include/metheor_hip.h)
         }
     }
     out.tid.push_back(tid); out.start.push_back(first); out.end.push_back(last);

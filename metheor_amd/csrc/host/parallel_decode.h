@@ -6,7 +6,11 @@
 #include <unordered_set>
 #include <vector>
 
+#include <atomic>
+
 namespace mthh {
+
+extern std::atomic<uint32_t> g_decode_notes;     // bit 0: a record with a CIGAR P operation was decoded (see MTH_NOTE_CIGAR_PAD)
 
 struct DecodedSoA {
     std::vector<int32_t> tid, start, end;

@@ -143,6 +143,7 @@ int sync_and_check(mth_ctx *ctx) {
     MTH_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
     MTH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t e = ctx->h_state->err;
+    ctx->notes |= ctx->h_state->pad_;          // non-fatal findings of the device decode (sticky on the host: mth_reset clears the device word)
     if (e & ERRB_UNSORTED) return fail(ctx, MTH_ERR_UNSORTED, "reads of a batch are not sorted by start position");
     if (e & ERRB_SPAN) return fail(ctx, MTH_ERR_SPAN, "a read spans more reference bases than batch.max_span");
     if (e & ERRB_RANGE) return fail(ctx, MTH_ERR_RANGE, "CpG position outside the declared range");
@@ -167,6 +168,8 @@ static int stage(mth_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, const
 
 int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &d, bool join) {
     if (b.region_end < b.region_beg || b.max_span < 0) return fail(ctx, MTH_ERR_INVALID, "bad region / max_span");
+    // a contig group's handle must be defined -- checked here, before any accumulate entry point has recorded anything of the batch
+    if (b.tid <= -2 && (size_t)(-2 - (int64_t)b.tid) >= ctx->groups.size()) return fail(ctx, MTH_ERR_INVALID, "batch.tid is not a defined contig group's handle");
     if (b.n_reads && (!b.read_start || !b.read_end || !b.read_mapq || !b.cpg_off))
         return fail(ctx, MTH_ERR_INVALID, "batch arrays missing");
     if (b.n_cpgs && (!b.cpg_pos || (!b.cpg_rel == !b.cpg_rel16)))
@@ -315,6 +318,8 @@ int mth_ctx_set_stream(mth_ctx_t *ctx, void *hip_stream) {
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return MTH_OK;
 }
+
+uint32_t mth_notes(const mth_ctx_t *ctx) { return ctx ? ctx->notes : 0u; }
 
 int mth_ctx_sync(mth_ctx_t *ctx) {
     if (!ctx) return MTH_ERR_INVALID;

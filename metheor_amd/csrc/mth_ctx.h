@@ -49,6 +49,7 @@ struct mth_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string last_error;
+    uint32_t notes = 0;                 // mth_notes(): non-fatal findings so far (MTH_NOTE_*)
 
     mth::DevState *d_state = nullptr;   // device
     mth::DevState *h_state = nullptr;   // pinned host mirror

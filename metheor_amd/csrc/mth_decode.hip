@@ -31,6 +31,7 @@ struct DecArgs {
     uint32_t *cpg_pos;
     uint16_t *cpg_rel;
     uint32_t *err;                // DevState.err
+    uint32_t *notes;              // DevState.pad_: non-fatal findings (bit 0: a CIGAR P operation), read back with the error bits
     const unsigned long long *filt;   // --cpg-set: sorted keys tid << 32 | pos, or nullptr (no filter)
     uint64_t n_filt;
     uint32_t xm_min_mapq;         // a record WITHOUT XM:Z is an error only if its mapq >= this (lpmd.rs:176-181 filters on mapq first)
@@ -199,6 +200,10 @@ __global__ __launch_bounds__(256) void k_decode(const DecArgs a) {
                     q += ln;
                 } else if (op == 2 || op == 3) {                              // D, N: reference only
                     r += ln;
+                } else if (op == 6 && !FILL) {
+                    // P (padding): no query base, no reference base here -- rust-htslib's aligned-pairs iterator is believed to panic on
+                    // it (readutil.rs:28 reference_positions_full; the crate is not under /root/reference): noted, the CLI says so
+                    atomicOr(a.notes, 1u);
                 }
             }
         }
@@ -423,7 +428,7 @@ int decode_core(mth_ctx *ctx, const uint8_t *d_raw, const uint64_t *d_off, uint6
     a.raw = d_raw; a.off = d_off; a.n_rec = (uint32_t)n_rec;
     a.tid = ctx->dec_tid.as<int32_t>() + R0; a.start = ctx->dec_start.as<int32_t>() + R0; a.end = ctx->dec_end.as<int32_t>() + R0;
     a.mapq = ctx->dec_mapq.as<uint8_t>() + R0; a.fwd = ctx->dec_fwd.as<uint8_t>() + R0; a.ncpg = ctx->dec_n.as<uint32_t>(); a.xm_loc = ctx->dec_xm.as<uint2>();
-    a.err = &ctx->d_state->err;
+    a.err = &ctx->d_state->err; a.notes = &ctx->d_state->pad_;
     a.xm_min_mapq = ctx->dec_xm_min_mapq;
     a.filt = ctx->dec_filter_on ? ctx->dec_filter.as<unsigned long long>() : nullptr; a.n_filt = ctx->dec_filter_n;
     if (ctx->dec_filter_on && ctx->dec_filter_n == 0) a.filt = reinterpret_cast<const unsigned long long *>(ctx->d_state);   // empty set: drops every call

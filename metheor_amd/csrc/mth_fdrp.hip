@@ -1300,6 +1300,7 @@ extern "C" {
 
 int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp_params_t *params) {
     if (!ctx || !batch || !params) return MTH_ERR_INVALID;
+    // (a group handle that is not defined is refused by stage_batch, before anything of the batch is recorded: ADVICE r04)
     mth_batch_t d;
     int rc = stage_batch(ctx, *batch, d);
     if (rc) return rc;
@@ -1384,10 +1385,16 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         // METHEOR_FDRP_TILE=0 / 1 forces the choice (A/B, tests).
         bool tile = d.max_span <= 200 && !walk4;
         if (const char *e = getenv("METHEOR_FDRP_TILE")) { tile = d.max_span <= 200 && atoi(e) != 0; if (tile) walk4 = 0; }
+        const uint64_t dcap = std::min<uint64_t>(std::max<uint32_t>(params->max_depth, 1u), 64u);
+        // sum over sites of C(n, 2) <= (dcap - 1) / 2 x the sum of n <= (dcap - 1) / 2 x the batch's calls; + the 64-byte rounding
+        const uint64_t budget = (uint64_t)d.n_cpgs * (dcap - 1) / 2 + 64 * bound + 64;
+        if (tile && budget > ctx->f_terms.cap) {
+            // a contig group can hold 2^32 calls: ~80 GB of term codes at -D 40.  The list is a bound, not a need -- when it would take
+            // more than half of what the device has free, the batch keeps the walk kernels (same rows)
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || budget > fr / 2) tile = false;
+        }
         if (tile) {
-            const uint64_t dcap = std::min<uint64_t>(std::max<uint32_t>(params->max_depth, 1u), 64u);
-            // sum over sites of C(n, 2) <= (dcap - 1) / 2 x the sum of n <= (dcap - 1) / 2 x the batch's calls; + the 64-byte rounding
-            const uint64_t budget = (uint64_t)d.n_cpgs * (dcap - 1) / 2 + 64 * bound + 64;
             MTH_HIP(ctx, ctx->f_terms.reserve(budget, s));
             MTH_HIP(ctx, ctx->f_soff.reserve(bound * 8, s));
             MTH_HIP(ctx, ctx->f_snz.reserve(bound * 4, s));

@@ -103,6 +103,10 @@ __global__ __launch_bounds__(256) void k_fo_attrs(const FoArgs a) {
     }
     uint8_t d = 0;
     unsigned long long f = 0;
+    // a record without a contig (tid -1) that carries CpG calls: in the reference's i32 order (readutil.rs:290-314) it sorts BEFORE every
+    // contig and flushes nothing, and its rows would reach the writer's tid2name(-1); the key below packs the tid as unsigned, which
+    // would make it the largest.  Refused: the run fails with MTH_ERR_RANGE instead of a silently different flush order.
+    if (n && a.tid[t] < 0 && (flush || contrib)) atomicOr(&a.st->err, (uint32_t)ERRB_RANGE);
     if (n) {
         const uint32_t w0 = a.pos[o0];
         if (flush) f = fo_key(a.tid[t], w0 & 0x7fffffffu);

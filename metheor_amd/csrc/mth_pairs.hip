@@ -489,7 +489,8 @@ static int pairs_batch(mth_ctx *ctx, const mth_batch_t &d, const mth_lpmd_pairs_
         a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
         a.min_dist = params->min_distance; a.max_dist = params->max_distance; a.n_reads = d.n_reads; a.ntiles = ntiles; a.n_cpgs = (uint32_t)d.n_cpgs;
         a.min_qual = params->min_qual; a.force_heavy = getenv("MTH_PAIRS_FORCE_GLOBAL") ? 1 : 0;
-        a.row_total = ps + 1; a.row_cap = ctx->p_cap; a.unfit = ps + 6; a.n_heavy = ps + 5;
+        // (a queued batch must stay within its estimate: see quartet_batch)
+        a.row_total = ps + 1; a.row_cap = queued ? std::min<uint64_t>(ctx->p_cap, want) : ctx->p_cap; a.unfit = ps + 6; a.n_heavy = ps + 5;
         a.tile_flag = ctx->p_tflag.as<uint32_t>();
         a.tile_row0 = ctx->p_tile_row0.as<unsigned long long>() + tiles_before;
         a.tile_rows = ctx->p_tile_rows.as<uint32_t>() + tiles_before;

@@ -597,7 +597,10 @@ static int quartet_batch(mth_ctx *ctx, const mth_batch_t &d, const mth_quartet_p
         a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
         a.n_reads = d.n_reads; a.ntiles = ntiles; a.n_cpgs = (uint32_t)d.n_cpgs; a.min_qual = params->min_qual;
         a.force_heavy = getenv("MTH_QUARTET_FORCE_GLOBAL") ? 1 : 0;
-        a.row_total = qs + 1; a.row_cap = ctx->q_cap; a.unfit = qs + 6; a.n_heavy = qs + 5;
+        // a queued batch must stay within its ESTIMATE, not just within the buffer: the next queued batch takes the estimate as the
+        // rows in use and keeps only that many when it grows the buffer (rows between the estimate and the device's count
+        // were lost without a flag); beyond the estimate the batch is unfit and quartet_resolve replays it
+        a.row_total = qs + 1; a.row_cap = queued ? std::min<uint64_t>(ctx->q_cap, want) : ctx->q_cap; a.unfit = qs + 6; a.n_heavy = qs + 5;
         a.tile_flag = ctx->q_tflag.as<uint32_t>();
         a.tile_row0 = ctx->q_tile_row0.as<unsigned long long>() + tiles_before;
         a.tile_rows = ctx->q_tile_rows.as<uint32_t>() + tiles_before;

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SYMBOLS = [
-    "mth_host_open", "mth_host_close", "mth_host_last_error", "mth_host_n_refs", "mth_host_ref_name",
+    "mth_host_open", "mth_host_close", "mth_host_last_error", "mth_host_notes", "mth_host_n_refs", "mth_host_ref_name",
     "mth_host_ref_len", "mth_host_ref_tid", "mth_host_set_xm_min_mapq", "mth_host_decode", "mth_host_decode_stream", "mth_host_bgzf_blocks", "mth_host_plan_shard", "mth_host_plan_region", "mth_host_cpg_set_keys", "mth_host_n_reads", "mth_host_n_cpgs",
     "mth_host_read_tid", "mth_host_read_start", "mth_host_read_end", "mth_host_read_mapq",
     "mth_host_read_fwd", "mth_host_cpg_off", "mth_host_cpg_pos", "mth_host_cpg_rel", "mth_host_format_f32", "mth_host_write_synthetic_bam",
@@ -51,6 +51,7 @@ def lib():
         L.mth_host_open.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_int]
         L.mth_host_close.argtypes = [vp]; L.mth_host_close.restype = None
         L.mth_host_last_error.argtypes = [vp]; L.mth_host_last_error.restype = C.c_char_p
+        L.mth_host_notes.argtypes = []; L.mth_host_notes.restype = C.c_uint32
         L.mth_host_n_refs.argtypes = [vp]
         L.mth_host_ref_name.argtypes = [vp, C.c_int]; L.mth_host_ref_name.restype = C.c_char_p
         L.mth_host_ref_len.argtypes = [vp, C.c_int]; L.mth_host_ref_len.restype = C.c_int64

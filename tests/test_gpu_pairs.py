@@ -210,3 +210,38 @@ def test_queued_batches(monkeypatch, capfd, force):
         assert off == len(d["tid"])
     finally:
         e.close()
+
+
+def test_queued_batch_beyond_its_estimate_is_replayed_not_truncated(monkeypatch, capfd):
+    """ADVICE r04 (high), the pairs table's half: a queued batch that produces more rows than its estimate but still fits the buffer
+    (grown to 1.25 x the estimate) used to lose the rows beyond the estimate when the next queued batch grew the buffer.  It is unfit
+    now and the resolve replays it (mth_pairs.hip, pairs_batch)."""
+    import metheor_amd
+    from metheor_amd import synth
+    rng = np.random.default_rng(2025)
+    cs = [synth.make_contig(t, ln, nr, 0.04, rng) for t, (ln, nr) in enumerate([(100_000, 10_000), (600_000, 60_000), (900_000, 90_000)])]
+    kw = dict(min_distance=2, max_distance=16, min_qual=10)
+    tabs = [pyoracle.Reads.decode(util.contig_to_records(c, "ctg%d" % c["tid"])).lpmd(pairs=True, **kw)["pairs"] for c in cs]
+    monkeypatch.setenv("MTH_PAIRS_DEBUG", "1")
+    e = metheor_amd.Engine(0)
+    try:
+        bts = [util.device_batch(c, device="cuda:0") for c in cs]
+        e.lpmd_pairs_accumulate(bts[0], **kw)                                   # synchronous: a fresh context
+        monkeypatch.setenv("MTH_PAIRS_ROWS_MIN", str(int(len(tabs[1]) / 1.1)))  # B: estimate < rows <= 1.25 x estimate
+        e.lpmd_pairs_accumulate(bts[1], **kw)
+        monkeypatch.setenv("MTH_PAIRS_ROWS_MIN", str(2 * len(tabs[2]) + 100_000))   # C: forces the buffer to grow
+        e.lpmd_pairs_accumulate(bts[2], **kw)
+        monkeypatch.delenv("MTH_PAIRS_ROWS_MIN")
+        capfd.readouterr()
+        d = e.lpmd_pairs_fetch()
+        err = capfd.readouterr().err
+        assert "[pairs] queued batches 2, replayed" in err and "replayed 0" not in err, err
+        off = 0
+        for c, t in zip(cs, tabs):
+            m = slice(off, off + len(t))
+            assert (d["tid"][m] == c["tid"]).all() and (d["pos1"][m] == t.pos[:, 0]).all() and (d["pos2"][m] == t.pos[:, 1]).all()
+            assert (d["n_concordant"][m] == t.cnt[:, 0]).all() and (d["n_discordant"][m] == t.cnt[:, 1]).all()
+            off += len(t)
+        assert off == len(d["tid"])
+    finally:
+        e.close()

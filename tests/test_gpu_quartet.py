@@ -384,3 +384,36 @@ def test_queued_batches_that_do_not_fit_are_replayed(monkeypatch, capfd):
         _check_queued({k: (v[m] - 1 if k == "tid" else v[m]) for k, v in d.items()}, tabs)
     finally:
         e.close()
+
+
+def test_queued_batch_beyond_its_estimate_is_replayed_not_truncated(monkeypatch, capfd):
+    """a queued batch may produce more rows than its estimate and still fit the buffer (grown to 1.25 x the
+    estimate); the next queued batch took the ESTIMATE as the rows in use and kept only that many when it grew the buffer -- the rows
+    in between were lost without any flag.  Now a queued batch that exceeds its estimate is unfit and the resolve replays it.
+    Batch B is given an estimate 10 % below its true row count (MTH_QUARTET_ROWS_MIN), batch C one that forces the buffer to grow."""
+    import metheor_amd
+    from metheor_amd import synth
+    rng = np.random.default_rng(2024)
+    shapes = [(100_000, 10_000), (600_000, 60_000), (900_000, 90_000)]
+    cs = [synth.make_contig(t, ln, nr, 0.04, rng) for t, (ln, nr) in enumerate(shapes)]
+    recs = [util.contig_to_records(c, "ctg%d" % t) for t, c in enumerate(cs)]
+    tabs = [(pyoracle.Reads.decode(r).me(min_depth=2), pyoracle.Reads.decode(r).pm(min_depth=2)) for r in recs]
+    rows_b = len(pyoracle.Reads.decode(recs[1]).me(min_depth=0))           # distinct quartets of batch B
+    rows_c = len(pyoracle.Reads.decode(recs[2]).me(min_depth=0))
+    monkeypatch.setenv("MTH_QUARTET_DEBUG", "1")
+    e = metheor_amd.Engine(0)
+    try:
+        bts = [util.device_batch(c, device="cuda:0") for c in cs]
+        e.quartet_accumulate(bts[0], min_qual=10)                           # synchronous: the context's first batch
+        monkeypatch.setenv("MTH_QUARTET_ROWS_MIN", str(int(rows_b / 1.1)))  # B: estimate < rows <= 1.25 x estimate (fits the buffer)
+        e.quartet_accumulate(bts[1], min_qual=10)
+        monkeypatch.setenv("MTH_QUARTET_ROWS_MIN", str(2 * rows_c + 100_000))   # C: forces the buffer to grow
+        e.quartet_accumulate(bts[2], min_qual=10)
+        monkeypatch.delenv("MTH_QUARTET_ROWS_MIN")
+        capfd.readouterr()
+        d = e.quartet_fetch(min_depth=2)
+        err = capfd.readouterr().err
+        assert "[quartet] queued batches 2, replayed" in err and "replayed 0" not in err, err
+        _check_queued(d, tabs)
+    finally:
+        e.close()
