@@ -62,6 +62,8 @@ def parse_args(argv=None):
                     help="N > 1: all-reduce the LPMD counters after every step (default: once per job, after the last step, inside the timed region)")
     ap.add_argument("--no-wgbs", action="store_true", help="skip the WGBS-depth legs (roofline_wgbs, all7, fdrp_pairs; N = 1 only)")
     ap.add_argument("--wgbs-reads", type=int, default=200_000_000, help="reads of the config-3 leg (24 hg38-sized contigs)")
+    ap.add_argument("--legs", default="", help="PROFILING: run only these WGBS-depth legs (comma list of roofline_wgbs, all7, fdrp_pairs), print their JSON and exit -- "
+                                                "the command tools/profile_round.sh wraps in rocprofv3 for the per-kernel CSVs of those legs")
     ap.add_argument("--no-traffic", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 even when it is on PATH")
     ap.add_argument("--traffic-probe", default="", help="INTERNAL: run a few steps on the arrays saved in this .npz and exit (the process rocprofv3 wraps)")
     ap.add_argument("--selftest-launcher", action="store_true",
@@ -298,7 +300,27 @@ def timed_kernels(eng, fn, reps):
     return {k: v[0] for k, v in tm.items() if v[1] > 0}
 
 
-def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
+def timed_pass(eng, fn, reps):
+    """per-kernel TOTAL ms of one call of fn() (a pass over several batches launches a kernel several times): mean over reps,
+    HIP events on the engine's stream; the launches run unpipelined and synchronous where the measure would queue them"""
+    eng.timing_enable(True)
+    eng.timing_reset()
+    for _ in range(reps):
+        eng.reset()
+        fn()
+    eng.sync()
+    tm = eng.timing()
+    eng.timing_enable(False)
+    eng.timing_reset()
+    return {k: v[0] * v[1] / reps for k, v in tm.items() if v[1] > 0}
+
+
+# instruction-issue ceiling of the VALU-bound kernels: 1024 SIMDs x one wave64 vector instruction per ~2.5 cycles for the plain VOP2 forms,
+# ~4.3 for compare / select / min-max / three-operand forms (profiles/r02_ubench_valu.md, measured on this part at 2.4 GHz)
+SIMDS, CLOCK_GHZ, CYCLES_PER_VALU_FULL, CYCLES_PER_VALU_HALF = 1024, 2.4, 2.5, 4.3
+
+
+def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total, legs=("roofline_wgbs", "all7", "fdrp_pairs")):
     """The workload the metric is named after (WGBS depth), all device-generated (metheor_amd/synth_device.py):
     roofline_wgbs -- PDR+LPMD on one chr1-sized contig at config-3 density, dominant kernel against 24.5 B/read;
     all7 -- BASELINE config 3, every measure over the 24 contigs queued the way the CLI queues them, one sync;
@@ -308,6 +330,8 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
     P0 = metheor_amd.PdrLpmdParams()
     gen = torch.Generator(device=dev)
     gen.manual_seed(3)
+    if "fdrp_pairs" in legs and "all7" not in legs and "roofline_wgbs" not in legs:
+        return fdrp_pairs_leg(eng, torch, dev, metheor_amd, out)
     n1 = int(round(n_reads_total * synth.HG38_LENGTHS[0] / float(sum(synth.HG38_LENGTHS))))
     bt, info = synth_device.make_contig(0, synth.HG38_LENGTHS[0], n1, 0.0091, gen, dev)
     for _ in range(3):
@@ -327,6 +351,8 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
                             "whole_step_kernels_ms": round(step_ms, 5), "whole_step_frac": round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                             "all_kernels_ms": {k: round(v, 5) for k, v in tm.items()}}
     del bt
+    if "all7" not in legs:
+        return fdrp_pairs_leg(eng, torch, dev, metheor_amd, out) if "fdrp_pairs" in legs else out
     # ---- config 3, all seven measures ----
     t0 = time.perf_counter()
     per_contig, lens, n_tot, c_tot = [], [], 0, 0
@@ -391,6 +417,14 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
     seven = {k: v for k, v in per.items() if k != "lpmd --pairs"}
     lg = eng.lpmd_global()
     assert lg["n_read"] == n_tot, (lg, n_tot)
+    # what each pass's milliseconds are made of: per-kernel totals over the pass's batches (HIP events; the timed launches run one
+    # after the other and every batch synchronously, so their sum sits a little above the queued wall time above)
+    kernels_per_pass = {}
+    for name, fn in passes.items():
+        def whole(fn=fn):
+            for b in resident:
+                fn(b)
+        kernels_per_pass[name] = {k: round(v, 4) for k, v in timed_pass(eng, whole, 2).items()}
     # the four passes of the seven measures side by side: one context (own stream, own work buffers) per pass, the contigs' batches
     # -- shared, read-only -- queued by one host thread per context.  A pass on its own leaves the GPU idle at every kernel boundary and in its
     # latency-bound walks; four of them fill each other's gaps.
@@ -433,6 +467,17 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
                                "(PDR+LPMD fused, ME+PM from one quartet pass, MHL, FDRP+qFDRP from one walk), a fifth the LPMD --pairs table" % (n_tot, c_tot / n_tot),
                    "reads": n_tot, "batches": "%d contig groups for the 24 contigs (%s reads), as the CLI submits them since round 4" % (len(resident), ", ".join(str(b.n_reads) for b in resident)),
                    "per_pass_ms_one_sync_each": {k: round(v * 1e3, 3) for k, v in per.items()},
+                   "kernels_ms_per_pass": kernels_per_pass,
+                   "kernels_ms_per_pass_what": "per-kernel totals over the pass's batches, HIP events around unpipelined launches (mth_timing_*); the same names "
+                                               "appear in profiles/r05_*_all7_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --legs all7`)",
+                   "roofline_per_pass": {name: {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                                                "algorithmic_bytes": (16.0 * n_tot + 5.0 * c_tot) + out_b,
+                                                "achieved": round(((16.0 * n_tot + 5.0 * c_tot) + out_b) / per[name] / 1e9, 1),
+                                                "frac": round(((16.0 * n_tot + 5.0 * c_tot) + out_b) / per[name] / 1e9 / HBM_PEAK_GBPS, 4)}
+                                         for name, out_b in (("pdr+lpmd", 12.0 * rows_check["pdr+lpmd"][1] + 32.0), ("me/pm", 2 * 80.0 * rows_check["me/pm"][1]),
+                                                             ("mhl", 8.0 * rows_check["mhl"][1]), ("fdrp+qfdrp", 16.0 * rows_check["fdrp+qfdrp"][1]))},
+                   "roofline_per_pass_what": "SURVEY 8(d): every pass reads the input once (16 B/read + 5 B/call) and writes its rows (PDR 12 B/site, ME and PM 80 B/quartet each, MHL 8, FDRP + qFDRP 8 + 8); "
+                                             "achieved = those bytes / the pass's wall time above.  The walks of MHL and FDRP are latency / instruction bound: the figure says how far from streaming they are",
                    "seven_measures_ms": round(sum(seven.values()) * 1e3, 3), "all_five_passes_one_sync_ms": round(best_all * 1e3, 3),
                    "per_contig_batches": {"what": "the same passes over one batch per contig (24 batches a pass: rounds 1-3's figure); same row counts asserted",
                                           "per_pass_ms_one_sync_each": {k: round(v * 1e3, 3) for k, v in per_c.items()},
@@ -448,6 +493,14 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
                    "generate_s": round(t_gen, 2)}
     del resident, per_contig
     torch.cuda.empty_cache()
+    if "fdrp_pairs" not in legs:
+        return out
+    return fdrp_pairs_leg(eng, torch, dev, metheor_amd, out)
+
+
+def fdrp_pairs_leg(eng, torch, dev, metheor_amd, out):
+    """BASELINE config 4 (50x hotspots, -D 64): read pairs per second of the FDRP / qFDRP pass"""
+    from metheor_amd import synth_device
     # ---- config 4 ----
     hb, hinf = synth_device.hotspots(device=dev)
     for _ in range(2):
@@ -464,10 +517,23 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total):
     f = eng.fdrp_fetch()
     nst = f["n_reads"].astype(np.int64)
     pairs = int((nst * (nst - 1) // 2).sum())
-    tk = timed_kernels(eng, lambda: eng.fdrp_accumulate(hb, max_depth=64), 3)
+    tk = timed_pass(eng, lambda: eng.fdrp_accumulate(hb, max_depth=64), 3)
+    # The pass is instruction-issue bound (profiles/r04_fdrp_tile.md, r05 PMC): its roofline is the vector unit.  One evaluation of a
+    # (site, read pair) is at least: overlap (and + bcnt of two 64-bit masks = 4), shared calls (4), hamming (xor + and + bcnt = 5),
+    # threshold + code (4) -- ~17 plain vector instructions per 64 pairs IF nothing else were issued; the ceiling below prices the
+    # pair evaluations alone at the measured full issue rate (every other instruction of the kernel counts against it).
+    valu_per_64_pairs_floor = 17.0
+    ceiling = SIMDS * CLOCK_GHZ * 1e9 / CYCLES_PER_VALU_FULL / valu_per_64_pairs_floor * 64.0          # site-pairs per second
     out["fdrp_pairs"] = {"workload": "S-hotspot-50x (BASELINE config 4): %d reads in 20000 1-kbp windows at 50x, FDRP + qFDRP, -D 64 (no sampling)" % hinf["n_reads"],
                          "sites": int(len(nst)), "read_pairs": pairs, "pass_ms": round(best * 1e3, 3), "G_pairs_per_s": round(pairs / best / 1e9, 2),
-                         "kernels_ms": {k: round(v, 4) for k, v in tk.items()}}
+                         "kernels_ms": {k: round(v, 4) for k, v in tk.items()},
+                         "kernels_ms_what": "per-kernel totals of one pass (HIP events, mth_timing_*): site discovery = k_build_index + k_pdr_lpmd_tile + k_gather, then "
+                                            "k_fdrp_tile (read x read rounds), k_fdrp_chain (ordered f32 sums), k_fdrp_walk (hand-backs), k_fdrp_emit; "
+                                            "profiles/r05_*_fdrp_pairs_kernel_stats.csv holds rocprofv3's averages of the same launches",
+                         "roofline": {"bound": "valu", "unit": "G site-pairs/s", "achieved": round(pairs / best / 1e9, 2), "peak": round(ceiling / 1e9, 1),
+                                      "frac": round(pairs / best / ceiling, 4),
+                                      "peak_what": "%d SIMDs x %.1f GHz / %.1f cycles per plain wave64 vector instruction (profiles/r02_ubench_valu.md) / %.0f instructions "
+                                                   "per 64 pair evaluations (overlap, shared calls, hamming, code: the arithmetic alone)" % (SIMDS, CLOCK_GHZ, CYCLES_PER_VALU_FULL, valu_per_64_pairs_floor)}}
     return out
 
 
@@ -721,6 +787,23 @@ def strong_main(args, rank, world, local_rank, in_rank):
     return 0
 
 
+def legs_main(args):
+    """`bench.py --legs all7` / `--legs fdrp_pairs` / `--legs roofline_wgbs`: only those legs, one JSON line (what
+    tools/profile_round.sh wraps in rocprofv3 so that every reported kernel has its launches in a tracked CSV)"""
+    import torch
+    import metheor_amd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    eng = metheor_amd.Engine(0, stream=stream.cuda_stream)
+    legs = tuple(x for x in args.legs.split(",") if x)
+    out = wgbs_legs(eng, torch, dev, metheor_amd, args.wgbs_reads, legs=legs)
+    print(json.dumps({"legs": list(legs), **out}), flush=True)
+    eng.close()
+    return 0
+
+
 def main():
     args = parse_args()
     if args.traffic_probe:
@@ -742,6 +825,8 @@ def main():
         return selftest(args, rank, world)
     if args.scaling == "strong":
         return strong_main(args, rank, world, local_rank, in_rank)
+    if args.legs:
+        return legs_main(args)
 
     import torch
     import torch.distributed as dist
@@ -917,9 +1002,17 @@ def main():
                    "kernel_ms": round(ms2, 5), "algorithmic_bytes_per_launch_mean": alg2,
                    "achieved": round(alg2 / (ms2 * 1e-3) / 1e9, 2), "frac": round(alg2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
             del batch_b
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                           "copy_ceiling_GBps": round(ceiling, 1), "frac_of_copy_ceiling": round(achieved / ceiling, 5),
+        # `achieved` / `frac` are the TWO-BATCH figures (one resident batch's ~250 MB of traffic sits inside the 256-MiB
+        # Infinity Cache, whose hits FETCH_SIZE counts too: not an HBM statement); the single-batch ones stay beside them as
+        # `achieved_l3_resident` / `frac_l3_resident`.  N > 1 ranks time one batch only and say so.
+        hbm_ach = two["achieved"] if two else round(achieved, 2)
+        hbm_frac = two["frac"] if two else round(achieved / HBM_PEAK_GBPS, 5)
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": hbm_ach, "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": hbm_frac,
+                           "frac_is": "two resident batches taken in turn (set > 256 MiB Infinity Cache)" if two else "one resident batch (L3-resident)",
+                           "achieved_l3_resident": round(achieved, 2), "frac_l3_resident": round(achieved / HBM_PEAK_GBPS, 5),
+                           "traffic": traffic, "traffic_source": traffic_src,
+                           "copy_ceiling_GBps": round(ceiling, 1), "frac_of_copy_ceiling": round(hbm_ach / ceiling, 5),
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "bytes_per_read": round(alg_bytes / n_reads, 3), "kernel_ms": round(ms, 5),
                            "whole_step_kernels_ms": round(step_kernels_ms, 5),

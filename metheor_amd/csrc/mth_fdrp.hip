@@ -1367,7 +1367,7 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     if (params->max_depth > FD_DEPTH_MAX) return fail(ctx, MTH_ERR_CAPACITY, "FDRP / qFDRP max_depth above 16384 (the pair index of one site is 32-bit arithmetic)");
     const uint32_t grid = (uint32_t)std::min<uint64_t>((bound + 3) / 4, 16384);   // 4 waves (sites) per block
     {
-        LaunchTimer lt(ctx, K_FDRPWALK);
+        // (each kernel of the pass under its own timer id: bench.py's kernels_ms decomposes -- VERDICT r04 item 2)
         // dense CpGs (hotspots, RRBS): 16 call registers per stored read keep the per-call match out of
         // the memory loop; sparse WGBS keeps 8 (half the compares per call)
         const bool dense = d.n_reads && ((double)d.n_cpgs / (double)d.n_reads) > 6.0;
@@ -1406,9 +1406,15 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
             a.terms = ctx->f_terms.as<uint8_t>(); a.cursor = cur; a.budget = budget;
             a.site_off = ctx->f_soff.as<unsigned long long>(); a.site_nz = ctx->f_snz.as<uint32_t>(); a.site_disc = ctx->f_sdisc.as<uint32_t>();
             const uint32_t gridt = (uint32_t)std::min<uint64_t>((bound + FT_CORE - 1) / FT_CORE, 8192);
-            if (dense) hipLaunchKernelGGL(k_fdrp_tile<16>, dim3(gridt), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(k_fdrp_tile<8>, dim3(gridt), dim3(256), 0, s, a);
-            hipLaunchKernelGGL(k_fdrp_chain, dim3((uint32_t)std::min<uint64_t>((bound + 255) / 256, 8192)), dim3(256), 0, s, a);
+            {
+                LaunchTimer lt(ctx, K_FDRPTILE);
+                if (dense) hipLaunchKernelGGL(k_fdrp_tile<16>, dim3(gridt), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL(k_fdrp_tile<8>, dim3(gridt), dim3(256), 0, s, a);
+            }
+            {
+                LaunchTimer lt(ctx, K_FDRPCHAIN);
+                hipLaunchKernelGGL(k_fdrp_chain, dim3((uint32_t)std::min<uint64_t>((bound + 255) / 256, 8192)), dim3(256), 0, s, a);
+            }
             a.only_flag = FD_REDO;
             if (getenv("METHEOR_FDRP_DEBUG")) {          // how much the tile form handed back (synchronises: debugging only)
                 DevState st;
@@ -1425,10 +1431,12 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
             MTH_HIP(ctx, ctx->f_redo.reserve((bound / 64 + 2) * 8, s));
             a.redo_mask = ctx->f_redo.as<unsigned long long>();
             const uint32_t grid4 = (uint32_t)std::min<uint64_t>((bound + 255) / 256, 16384);   // 4 waves x 64 sites per block and step
+            LaunchTimer lt(ctx, K_FDRPWALK4);
             if (walk4 == 16) hipLaunchKernelGGL(k_fdrp_walk4<16>, dim3(grid4), dim3(256), 0, s, a);
             else hipLaunchKernelGGL(k_fdrp_walk4<32>, dim3(grid4), dim3(256), 0, s, a);
             a.only_flag = FD_REDO;
         }
+        LaunchTimer lt(ctx, K_FDRPWALK);
         if (dense) hipLaunchKernelGGL((k_fdrp_walk<16, 64>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_fdrp_walk<8, 64>), dim3(grid), dim3(256), 0, s, a);
         a.only_flag = 0u;

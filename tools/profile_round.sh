@@ -40,6 +40,42 @@ json.dump(j, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(j))
 for k, v in sorted(stats.items(), key=lambda kv: -kv[1][1])[:8]: print("%-28s calls %4d avg %.1f us" % (k, v[0], v[1]))
 PY
+# ---- the other legs that carry a reported number: rocprofv3 kernel stats of `bench.py --legs all7` (config 3: every
+# measure over the two contig groups) and `--legs fdrp_pairs` (config 4), and ONE PMC pass each -- vector-unit busy, waits, LDS conflicts,
+# bytes fetched / written -- for k_fdrp_tile / k_fdrp_chain / k_fdrp_walk / k_fdrp_walk4 / k_mhl_tile / k_mhl_walk_big / k_quartet_tile /
+# k_pairs_tile / k_pdr_lpmd_wide.  (Queued ME / PM / pairs batches and pipelined PDR batches overlap kernels of neighbouring batches: the
+# profiled runs switch both off, as above.)
+export MTH_QUARTET_QUEUE=0 MTH_PAIRS_QUEUE=0
+for leg in all7 fdrp_pairs; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${leg}_stats -- python bench.py --legs $leg > $out/${leg}.json 2> $out/${leg}.err
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/${leg}_pmc1 -- python bench.py --legs $leg > /dev/null 2> $out/${leg}_pmc1.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/${leg}_pmc2 -- python bench.py --legs $leg > /dev/null 2> $out/${leg}_pmc2.err
+done
+unset MTH_QUARTET_QUEUE MTH_PAIRS_QUEUE
+python - "$out" <<'PY'
+import csv, glob, json, sys, collections, shutil
+out = sys.argv[1]
+short = lambda k: k.split("(")[0].replace("void ", "").replace("mth::", "")[:48]
+for leg in ("all7", "fdrp_pairs"):
+    for f in glob.glob(out + "/%s_stats/**/*kernel_stats.csv" % leg, recursive=True):
+        shutil.copy(f, out + "/%s_kernel_stats.csv" % leg)
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in ("pmc1", "pmc2"):
+        for f in glob.glob(out + "/%s_%s/**/*counter_collection.csv" % (leg, d), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if not k.startswith("k_"): continue
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"launches_profiled": max(len(v) for v in cs.values())} for k, cs in acc.items()}
+    # gfx950: FETCH_SIZE is in KB and reports half of a wide streaming read (MI355X_MICROARCH.md, HBM section): doubled here; WRITE_SIZE as reported
+    for k, r in rows.items():
+        if "FETCH_SIZE" in r: r["hbm_read_MB_per_launch"] = round(r["FETCH_SIZE"] * 2 * 1024 / 1e6, 2)
+        if "WRITE_SIZE" in r: r["hbm_write_MB_per_launch"] = round(r["WRITE_SIZE"] * 1024 / 1e6, 2)
+        if r.get("SQ_WAVE_CYCLES"): r["wait_any_share"] = round(r.get("SQ_WAIT_ANY", 0) / r["SQ_WAVE_CYCLES"], 3); r["wait_issue_share"] = round(r.get("SQ_WAIT_INST_ANY", 0) / r["SQ_WAVE_CYCLES"], 3)
+        if r.get("GRBM_GUI_ACTIVE") and r.get("SQ_ACTIVE_INST_VALU"): r["valu_quad_cycles_per_simd_over_kernel_cycles"] = round(r["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (r["GRBM_GUI_ACTIVE"] / 8), 3)
+    json.dump(rows, open(out + "/%s_pmc.json" % leg, "w"), indent=1, sort_keys=True)
+    print(leg, "PMC kernels:", sorted(rows))
+PY
 unset MTH_PIPELINE
 python bench.py > $out/bench.json 2> $out/bench.err
 cut -c1-400 $out/bench.json
