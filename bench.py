@@ -417,6 +417,31 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total, legs=("roofline_wgbs"
     seven = {k: v for k, v in per.items() if k != "lpmd --pairs"}
     lg = eng.lpmd_global()
     assert lg["n_read"] == n_tot, (lg, n_tot)
+    # the same passes over PREPARED batches (mth_batch_prepare, round 5): one read index per batch, built once, shared by the passes
+    per_p, prep_s = {}, None
+    try:
+        eng.sync()
+        t0 = time.perf_counter()
+        prepared = [eng.batch_prepare(b) for b in resident]
+        eng.sync()
+        prep_s = time.perf_counter() - t0
+        for name, fn in passes.items():
+            best = None
+            for _ in range(3):
+                eng.reset(); eng.sync()
+                t0 = time.perf_counter()
+                for b in prepared:
+                    fn(b)
+                eng.sync()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            per_p[name] = best
+            assert int(counts[name]()) == rows_check[name][1], (name, "prepared batches give other rows")
+        eng.reset(); eng.sync()
+        for p_ in prepared:
+            p_.release()
+    except Exception as ex:
+        per_p = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
     # what each pass's milliseconds are made of: per-kernel totals over the pass's batches (HIP events; the timed launches run one
     # after the other and every batch synchronously, so their sum sits a little above the queued wall time above)
     kernels_per_pass = {}
@@ -479,6 +504,11 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total, legs=("roofline_wgbs"
                    "roofline_per_pass_what": "SURVEY 8(d): every pass reads the input once (16 B/read + 5 B/call) and writes its rows (PDR 12 B/site, ME and PM 80 B/quartet each, MHL 8, FDRP + qFDRP 8 + 8); "
                                              "achieved = those bytes / the pass's wall time above.  The walks of MHL and FDRP are latency / instruction bound: the figure says how far from streaming they are",
                    "seven_measures_ms": round(sum(seven.values()) * 1e3, 3), "all_five_passes_one_sync_ms": round(best_all * 1e3, 3),
+                   "prepared_batches": ({"what": "the same passes over batches prepared once with mth_batch_prepare (one read index per batch, shared by the passes; same row counts asserted)",
+                                         "prepare_ms_once": round(prep_s * 1e3, 3), "per_pass_ms_one_sync_each": {k: round(v * 1e3, 3) for k, v in per_p.items()},
+                                         "seven_measures_ms": round(sum(v for k, v in per_p.items() if k != "lpmd --pairs") * 1e3, 3),
+                                         "seven_measures_ms_incl_prepare": round((prep_s + sum(v for k, v in per_p.items() if k != "lpmd --pairs")) * 1e3, 3)}
+                                        if "error" not in per_p else per_p),
                    "per_contig_batches": {"what": "the same passes over one batch per contig (24 batches a pass: rounds 1-3's figure); same row counts asserted",
                                           "per_pass_ms_one_sync_each": {k: round(v * 1e3, 3) for k, v in per_c.items()},
                                           "seven_measures_ms": round(sum(v for k, v in per_c.items() if k != "lpmd --pairs") * 1e3, 3)},

@@ -56,7 +56,7 @@ enum {
     MTH_ERR_RCCL = -12      /* librccl could not be loaded, or an RCCL call failed (mth_last_error has the text) */
 };
 
-enum { MTH_MEM_HOST = 0, MTH_MEM_DEVICE = 1 };
+enum { MTH_MEM_HOST = 0, MTH_MEM_DEVICE = 1, MTH_MEM_PREPARED = 2 /* only in batches made by mth_batch_prepare */ };
 
 /*
  * One batch = the reads of ONE contig that can touch the genomic region [region_beg, region_end),
@@ -101,6 +101,19 @@ typedef struct {
     int32_t  lpmd_min_distance; /* -m 2  */
     int32_t  lpmd_max_distance; /* -M 16 */
 } mth_pdr_lpmd_params_t;
+
+/* ---- prepared batches: one read index per batch, shared by the measures ----------------------------------
+ * Every measure's entry point builds the linear read index of its batch ("first read starting at or after q x 32 bp", plus the
+ * sortedness check) before its kernels can find a tile's or a site's candidate reads -- once per call: PDR + LPMD, ME / PM, MHL,
+ * FDRP / qFDRP and the pairs table over the same batch build it five times (each replaces one pass of the reference's
+ * compute_helper over the file: pdr.rs:119, me.rs:90, mhl.rs:135, fdrp.rs:176, lpmd.rs:154).  mth_batch_prepare makes the batch
+ * device-resident ONCE (a host batch is copied into buffers the prepared batch owns; a device batch is borrowed) and builds the index
+ * ONCE; `*prepared` is then a batch (mem = MTH_MEM_PREPARED, its arrays are the device arrays, read_fwd carries the handle) that
+ * every mth_*_accumulate entry point takes in place of the original and gives the same rows for.  Contract: the arrays of the batch
+ * given to mth_batch_prepare (device batches) stay untouched until mth_batch_release; release only after a synchronising call has
+ * returned for every measure that used it.  An unsorted batch is reported by the first synchronising call after a measure used it. */
+int  mth_batch_prepare(mth_ctx_t *ctx, const mth_batch_t *batch, mth_batch_t *prepared);
+int  mth_batch_release(mth_ctx_t *ctx, mth_batch_t *prepared);
 
 /* ---- context ------------------------------------------------------------------------- */
 int  mth_abi_version(void);

@@ -12,7 +12,7 @@ MTH_MEM_HOST, MTH_MEM_DEVICE = 0, 1
 # every symbol include/metheor_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "mth_abi_version", "mth_ctx_create", "mth_ctx_destroy", "mth_ctx_set_stream", "mth_ctx_sync",
-    "mth_strerror", "mth_last_error", "mth_notes", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
+    "mth_strerror", "mth_last_error", "mth_notes", "mth_batch_prepare", "mth_batch_release", "mth_reset", "mth_pdr_lpmd_accumulate", "mth_pdr_count",
     "mth_pdr_fetch", "mth_result_buffer_alloc", "mth_result_buffer_free", "mth_pdr_device_view", "mth_lpmd_global", "mth_lpmd_add_unbatched", "mth_lpmd_from_counts",
     "mth_lpmd_export_device", "mth_device_count", "mth_allreduce_lpmd", "mth_rccl_unique_id", "mth_rccl_init_rank",
     "mth_allreduce_lpmd_rank", "mth_quartet_accumulate", "mth_quartet_fetch", "mth_mhl_accumulate", "mth_mhl_fetch", "mth_fdrp_accumulate", "mth_fdrp_fetch", "mth_lpmd_pairs_accumulate", "mth_lpmd_pairs_fetch",
@@ -106,6 +106,8 @@ def lib():
         L.mth_strerror.restype = C.c_char_p; L.mth_strerror.argtypes = [C.c_int]
         L.mth_last_error.restype = C.c_char_p; L.mth_last_error.argtypes = [vp]
         L.mth_notes.restype = C.c_uint32; L.mth_notes.argtypes = [vp]
+        L.mth_batch_prepare.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_batch_t)]
+        L.mth_batch_release.argtypes = [vp, C.POINTER(mth_batch_t)]
         L.mth_reset.argtypes = [vp]
         L.mth_pdr_lpmd_accumulate.argtypes = [vp, C.POINTER(mth_batch_t), C.POINTER(mth_pdr_lpmd_params_t)]
         L.mth_pdr_count.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -176,6 +178,23 @@ class DeviceBatch:
 
     def __init__(self):
         self.c = mth_batch_t()
+
+
+class PreparedBatch:
+    """what Engine.batch_prepare returns: a batch (mem = MTH_MEM_PREPARED) every *_accumulate method takes in place of the original --
+    device-resident, its read index built once and shared by the measures.  Keeps the original alive; release() (or the engine's
+    close) frees the index and the device copies of a host batch."""
+
+    def __init__(self, eng, orig):
+        self.eng, self.orig = eng, orig
+        self.c = mth_batch_t()
+        eng._check(eng.L.mth_batch_prepare(eng.h, C.byref(orig.c), C.byref(self.c)))
+        self.n_reads, self.n_cpgs, self.tid = orig.n_reads, orig.n_cpgs, orig.tid
+
+    def release(self):
+        if self.eng is not None and getattr(self.eng, "h", None):
+            self.eng._check(self.eng.L.mth_batch_release(self.eng.h, C.byref(self.c)))
+        self.eng = None
 
 
 class Batch:
@@ -272,6 +291,10 @@ class Engine:
 
     def reset(self):
         self._check(self.L.mth_reset(self.h))
+
+    def batch_prepare(self, batch):
+        """one device-resident copy and ONE read index for all the measures of this batch (include/metheor_hip.h, "prepared batches")"""
+        return PreparedBatch(self, batch)
 
     def notes(self):
         """non-fatal findings of the device decode so far (bit 0: a CIGAR P operation was decoded)"""

@@ -171,6 +171,17 @@ int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &d, bool join) {
     if (b.region_end < b.region_beg || b.max_span < 0) return fail(ctx, MTH_ERR_INVALID, "bad region / max_span");
     // a contig group's handle must be defined -- checked here, before any accumulate entry point has recorded anything of the batch
     if (b.tid <= -2 && (size_t)(-2 - (int64_t)b.tid) >= ctx->groups.size()) return fail(ctx, MTH_ERR_INVALID, "batch.tid is not a defined contig group's handle");
+    ctx->cur_prep = nullptr; ctx->cur_idx = nullptr;
+    if (b.mem == MTH_MEM_PREPARED) {
+        // a batch made by mth_batch_prepare: device-resident, its read index built -- the handle rides in read_fwd
+        Prepared *pr = const_cast<Prepared *>(reinterpret_cast<const Prepared *>(b.read_fwd));
+        if (!pr || pr->magic != Prepared::MAGIC || pr->owner != ctx) return fail(ctx, MTH_ERR_INVALID, "not a batch prepared by this context (mth_batch_prepare)");
+        if (join) MTH_ENTER(ctx); else MTH_HIP(ctx, hipSetDevice(ctx->device));
+        d = pr->dev;
+        d.tid = b.tid;                                   // (the caller may submit it under a contig group's handle)
+        ctx->cur_prep = pr;
+        return MTH_OK;
+    }
     if (b.n_reads && (!b.read_start || !b.read_end || !b.read_mapq || !b.cpg_off))
         return fail(ctx, MTH_ERR_INVALID, "batch arrays missing");
     if (b.n_cpgs && (!b.cpg_pos || (!b.cpg_rel == !b.cpg_rel16)))
@@ -321,6 +332,72 @@ int mth_ctx_set_stream(mth_ctx_t *ctx, void *hip_stream) {
 }
 
 uint32_t mth_notes(const mth_ctx_t *ctx) { return ctx ? ctx->notes : 0u; }
+
+int mth_batch_prepare(mth_ctx_t *ctx, const mth_batch_t *batch, mth_batch_t *prepared) {
+    if (!ctx || !batch || !prepared) return MTH_ERR_INVALID;
+    if (batch->mem == MTH_MEM_PREPARED) return mth::fail(ctx, MTH_ERR_INVALID, "the batch is a prepared one already");
+    MTH_ENTER(ctx);
+    hipStream_t s = ctx->stream;
+    const mth_batch_t &b = *batch;
+    if (b.region_end < b.region_beg || b.max_span < 0) return mth::fail(ctx, MTH_ERR_INVALID, "bad region / max_span");
+    if (b.n_reads && (!b.read_start || !b.read_end || !b.read_mapq || !b.cpg_off)) return mth::fail(ctx, MTH_ERR_INVALID, "batch arrays missing");
+    if (b.n_cpgs && (!b.cpg_pos || (!b.cpg_rel == !b.cpg_rel16))) return mth::fail(ctx, MTH_ERR_INVALID, "exactly one of cpg_rel / cpg_rel16 must be given");
+    if (b.mem != MTH_MEM_HOST && b.mem != MTH_MEM_DEVICE) return mth::fail(ctx, MTH_ERR_INVALID, "batch.mem");
+    std::unique_ptr<mth::Prepared> pr(new mth::Prepared());
+    auto drop = [&]() { for (mth::DevBuf &x : pr->own) x.release(); pr->idx.release(); if (pr->st) (void)hipFree(pr->st); };
+#define PREP_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { drop(); return mth::fail(ctx, MTH_ERR_HIP, #call, e__); } } while (0)
+    pr->owner = ctx;
+    pr->dev = b;
+    pr->dev.read_fwd = nullptr;
+    if (b.mem == MTH_MEM_HOST) {
+        const size_t nr = b.n_reads, nc = b.n_cpgs;
+        auto up = [&](mth::DevBuf &buf, const void *src, size_t bytes, const void **dst) -> hipError_t {
+            *dst = nullptr;
+            if (!src || !bytes) return hipSuccess;
+            hipError_t e = buf.reserve(bytes, s);
+            if (e != hipSuccess) return e;
+            *dst = buf.p;
+            return hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, s);
+        };
+        PREP_HIP(up(pr->own[0], b.read_start, nr * 4, (const void **)&pr->dev.read_start));
+        PREP_HIP(up(pr->own[1], b.read_end, nr * 4, (const void **)&pr->dev.read_end));
+        PREP_HIP(up(pr->own[2], b.read_mapq, nr, (const void **)&pr->dev.read_mapq));
+        PREP_HIP(up(pr->own[3], b.cpg_off, (nr + 1) * 4, (const void **)&pr->dev.cpg_off));
+        PREP_HIP(up(pr->own[4], b.cpg_pos, nc * 4, (const void **)&pr->dev.cpg_pos));
+        if (b.cpg_rel) PREP_HIP(up(pr->own[5], b.cpg_rel, nc, (const void **)&pr->dev.cpg_rel));
+        else PREP_HIP(up(pr->own[5], b.cpg_rel16, nc * 2, (const void **)&pr->dev.cpg_rel16));
+        PREP_HIP(hipStreamSynchronize(s));                // the caller's host arrays may go away after this call
+    }
+    pr->dev.mem = MTH_MEM_DEVICE;
+    if (b.n_cpgs == 0 && !pr->dev.cpg_rel && !pr->dev.cpg_rel16) pr->dev.cpg_rel = reinterpret_cast<const uint8_t *>(ctx->d_state);
+    PREP_HIP(hipMalloc((void **)&pr->st, sizeof(mth::DevState)));
+    PREP_HIP(hipMemsetAsync(pr->st, 0, sizeof(mth::DevState), s));
+    mth::fine_index_extent(pr->dev, pr->idx_base, pr->nq);
+    PREP_HIP(pr->idx.reserve((size_t)(pr->nq + 1) * 4, s));
+    const int rc = mth::build_fine_index(ctx, pr->dev, pr->idx_base, pr->nq, pr->idx.as<uint32_t>(), pr->st);
+    if (rc) { drop(); return rc; }
+#undef PREP_HIP
+    *prepared = pr->dev;
+    prepared->mem = MTH_MEM_PREPARED;
+    prepared->read_fwd = reinterpret_cast<const uint8_t *>(pr.release());
+    return MTH_OK;
+}
+
+int mth_batch_release(mth_ctx_t *ctx, mth_batch_t *prepared) {
+    if (!ctx || !prepared || prepared->mem != MTH_MEM_PREPARED) return MTH_ERR_INVALID;
+    mth::Prepared *pr = const_cast<mth::Prepared *>(reinterpret_cast<const mth::Prepared *>(prepared->read_fwd));
+    if (!pr || pr->magic != mth::Prepared::MAGIC || pr->owner != ctx) return mth::fail(ctx, MTH_ERR_INVALID, "not a batch prepared by this context");
+    MTH_ENTER(ctx);
+    (void)hipStreamSynchronize(ctx->stream);             // nothing queued may still read the index or the owned arrays
+    if (ctx->cur_prep == pr) { ctx->cur_prep = nullptr; ctx->cur_idx = nullptr; }
+    for (mth::DevBuf &x : pr->own) x.release();
+    pr->idx.release();
+    if (pr->st) (void)hipFree(pr->st);
+    pr->magic = 0;
+    delete pr;
+    prepared->read_fwd = nullptr;                        // still marked MTH_MEM_PREPARED, without a handle: every entry point refuses it
+    return MTH_OK;
+}
 
 int mth_ctx_sync(mth_ctx_t *ctx) {
     if (!ctx) return MTH_ERR_INVALID;

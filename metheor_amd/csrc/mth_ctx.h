@@ -2,6 +2,7 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -44,11 +45,29 @@ struct PdrLane {
 struct mth_ctx;
 namespace mth { int quartet_resolve(mth_ctx *ctx); int pairs_resolve(mth_ctx *ctx); }
 
+namespace mth {
+// a prepared batch (include/metheor_hip.h, "prepared batches"): the device-resident batch, the buffers it owns when it was made
+// from a host batch, its fine read index, and a device block with what k_build_index found (error bits, safe_hi)
+struct Prepared {
+    static constexpr uint64_t MAGIC = 0x6d74685f70726570ull;
+    uint64_t magic = MAGIC;
+    mth_ctx *owner = nullptr;
+    mth_batch_t dev{};
+    DevBuf own[7];
+    DevBuf idx;
+    int32_t idx_base = 0;
+    uint32_t nq = 0;
+    DevState *st = nullptr;
+};
+}  // namespace mth
+
 struct mth_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string last_error;
+    mth::Prepared *cur_prep = nullptr;   // the batch of the entry point in progress is a prepared one (set by stage_batch, every call)
+    const uint32_t *cur_idx = nullptr;   // the fine read index the call's kernels use: the prepared batch's, or ctx->idx after a build
     uint32_t notes = 0;                 // mth_notes(): non-fatal findings so far (MTH_NOTE_*)
 
     mth::DevState *d_state = nullptr;   // device
@@ -237,6 +256,18 @@ struct TileSink {
     uint32_t *batch_cnt;
 };
 int build_read_index(mth_ctx *ctx, const mth_batch_t &dev_batch, int tile_w, int32_t &idx_base, uint32_t &ntiles);
+// the fine index of a batch into a caller-owned buffer; errors (unsorted) and safe_hi land in *st (mth_batch_prepare)
+int build_fine_index(mth_ctx *ctx, const mth_batch_t &dev_batch, int32_t idx_base, uint32_t nq, uint32_t *idx, DevState *st);
+// the index the kernels of the call in progress look reads up in (after build_read_index / launch_pdr_lpmd)
+inline const uint32_t *idx_ptr(const mth_ctx *ctx) { return ctx->cur_idx ? ctx->cur_idx : ctx->idx.as<uint32_t>(); }
+// extent of the fine index of a batch: origin and entries, for any tile width up to 65536
+inline void fine_index_extent(const mth_batch_t &b, int32_t &idx_base, uint32_t &nq) {
+    const int64_t region_len = (int64_t)b.region_end - b.region_beg;
+    const int32_t ext = ((b.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
+    idx_base = b.region_beg - ext;
+    const int64_t padded = ((region_len + 65535) / 65536) * 65536;
+    nq = (uint32_t)((padded + ext) >> IDX_QSHIFT) + 2;
+}
 // MHL as one tile pass (mth_mhl_tile.hip): candidate-site arrays filled with finished rows and the sites left to the exact walk
 int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_mhl_params_t &p, uint64_t &bound);
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p,

@@ -1338,7 +1338,7 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     const int32_t ext = ((d.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
     FdrpArgs a;
     a.read_start = d.read_start; a.read_end = d.read_end; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
-    a.idx = ctx->idx.as<uint32_t>(); a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>(); a.st = ctx->d_state;
+    a.idx = idx_ptr(ctx); a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>(); a.st = ctx->d_state;
     a.site_nc = ctx->s_nc.as<uint32_t>(); a.site_nd = ctx->s_nd.as<uint32_t>();
     a.fdrp = ctx->w_val.as<float>(); a.qfdrp = reinterpret_cast<float *>(ctx->w_aux.p); a.nreads = ctx->w_cov.as<uint32_t>();
     a.flags = ctx->w_flags.as<uint32_t>();

@@ -637,7 +637,7 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     MTH_HIP(ctx, hipMemsetAsync(ctx->tile_bucket.p, 0, (size_t)nbk * sizeof(unsigned long long), s));
     MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * W * sizeof(MhlRec), s));
     MhlTileArgs a;
-    a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos; a.idx = ctx->idx.as<uint32_t>();
+    a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos; a.idx = idx_ptr(ctx);
     a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
     a.n_reads = d.n_reads; a.ntiles = ntiles; a.n_cpgs = (uint32_t)d.n_cpgs; a.min_depth = p.min_depth; a.min_cpgs = p.min_cpgs;
     a.min_qual = p.min_qual;
@@ -671,7 +671,7 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     if (!getenv("MTH_MHL_NO_WAVE_WALK")) {
         LaunchTimer lt(ctx, K_MHLWALK);
         MhlWaveArgs w;
-        w.read_mapq = d.read_mapq; w.cpg_off = d.cpg_off; w.cpg_pos = d.cpg_pos; w.idx = ctx->idx.as<uint32_t>();
+        w.read_mapq = d.read_mapq; w.cpg_off = d.cpg_off; w.cpg_pos = d.cpg_pos; w.idx = idx_ptr(ctx);
         w.sites_st = ctx->d_state2; w.hand_list = ctx->w_aux.as<uint32_t>(); w.site_pos = ctx->s_pos.as<int32_t>();
         w.val = ctx->w_val.as<float>(); w.cov = ctx->w_cov.as<uint32_t>(); w.flags = ctx->w_flags.as<uint32_t>();
         w.idx_base = idx_base; w.max_span = d.max_span; w.n_reads = d.n_reads; w.n_cpgs = (uint32_t)d.n_cpgs;

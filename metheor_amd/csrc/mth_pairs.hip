@@ -485,7 +485,7 @@ static int pairs_batch(mth_ctx *ctx, const mth_batch_t &d, const mth_lpmd_pairs_
         if (!queued || ctx->p_pending.empty()) hipLaunchKernelGGL(k_pairs_rewind, dim3(1), dim3(1), 0, s, ps, (unsigned long long)rows_before);
         PTileArgs a;
         a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
-        a.idx = ctx->idx.as<uint32_t>(); a.cpg_rel = r8 ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
+        a.idx = idx_ptr(ctx); a.cpg_rel = r8 ? (const void *)d.cpg_rel : (const void *)d.cpg_rel16;
         a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
         a.min_dist = params->min_distance; a.max_dist = params->max_distance; a.n_reads = d.n_reads; a.ntiles = ntiles; a.n_cpgs = (uint32_t)d.n_cpgs;
         a.min_qual = params->min_qual; a.force_heavy = getenv("MTH_PAIRS_FORCE_GLOBAL") ? 1 : 0;

@@ -1465,6 +1465,30 @@ static void launch_runs(const TileArgs &a, const RunArgs &ra, uint32_t ntiles, u
 
 // the linear read index alone (for kernels that find a tile's candidate reads without running the PDR/LPMD pass):
 // idx lives in ctx->idx; same origin and quantum as launch_pdr_lpmd builds
+// first kernel of a PDR + LPMD batch whose index exists already (prepared batches): what k_build_index does beside the index -- the row
+// base, the bucket sums, safe_hi and the batch's own findings (unsorted) into the lane's block
+__global__ __launch_bounds__(256) void k_batch_begin(DevState *__restrict__ lane_st, DevState *__restrict__ cst, const DevState *__restrict__ prep_st,
+                                                     unsigned long long *__restrict__ bucket_sums, uint32_t n_bucket_words) {
+    if (threadIdx.x == 0) {
+        if (cst) cst->cur_base = cst->n_sites;
+        lane_st->safe_hi = prep_st->safe_hi;
+        if (prep_st->err) atomicOr(&lane_st->err, prep_st->err);
+    }
+    for (uint32_t w = threadIdx.x; w < n_bucket_words; w += 256) bucket_sums[w] = 0ull;
+}
+__global__ void k_batch_err(DevState *__restrict__ st, const DevState *__restrict__ prep_st) { if (prep_st->err) atomicOr(&st->err, prep_st->err); }
+
+int build_fine_index(mth_ctx *ctx, const mth_batch_t &b, int32_t idx_base, uint32_t nq, uint32_t *idx, DevState *st) {
+    hipStream_t s = ctx->stream;
+    LaunchTimer lt(ctx, K_INDEX);
+    const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK * IDX_GROUPS - 1) / (BLOCK * IDX_GROUPS);
+    hipLaunchKernelGGL(k_build_index<1>, dim3(nb), dim3(BLOCK), 0, s, b.read_start, b.n_reads, idx_base, 0, (int)IDX_QSHIFT, nq,
+                       (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0), idx, (uint32_t *)nullptr, st,
+                       (DevState *)nullptr, (unsigned long long *)nullptr, 0u, b.cpg_off, b.n_cpgs);
+    MTH_HIP(ctx, hipGetLastError());
+    return MTH_OK;
+}
+
 int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &idx_base, uint32_t &ntiles) {
     hipStream_t s = ctx->stream;
     const int64_t region_len = (int64_t)b.region_end - b.region_beg;
@@ -1472,6 +1496,15 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &id
     const int32_t ext = ((b.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
     idx_base = b.region_beg - ext;
     const uint32_t nq = (uint32_t)(((int64_t)ntiles * tile_w + ext) >> IDX_QSHIFT) + 2;
+    ctx->cur_idx = nullptr;
+    if (Prepared *pr = ctx->cur_prep) {
+        // a prepared batch: its index was built once (same origin and quantum; it covers every tile width up to 65536)
+        if (pr->idx_base == idx_base && nq <= pr->nq) {
+            ctx->cur_idx = pr->idx.as<uint32_t>();
+            hipLaunchKernelGGL(k_batch_err, dim3(1), dim3(1), 0, s, ctx->d_state, (const DevState *)pr->st);      // an unsorted batch is this measure's error too
+            return MTH_OK;
+        }
+    }
     MTH_HIP(ctx, ctx->idx.reserve((size_t)(nq + 1) * 4, s));
     LaunchTimer lt(ctx, K_INDEX);
     const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK * IDX_GROUPS - 1) / (BLOCK * IDX_GROUPS);
@@ -1584,9 +1617,14 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     // The dense tile kernel's own index: one entry per tile in each of two families (k_build_index<2>).  Site discovery for the walk
     // measures (sink) leaves the fine index behind for them; the wide form looks up arbitrary stretch bounds.  MTH_COARSE_INDEX=0: A/B.
     static const bool coarse_off = getenv("MTH_COARSE_INDEX") && atoi(getenv("MTH_COARSE_INDEX")) == 0;
-    const bool coarse = !sink && wide_shift == 0 && !coarse_off;
+    // a prepared batch brings its fine index: no index kernel in this call (k_batch_begin does what else that kernel did)
+    Prepared *prep = ctx->cur_prep;
+    if (prep && !(prep->idx_base == idx_base && nq <= prep->nq)) prep = nullptr;
+    const bool coarse = !sink && wide_shift == 0 && !coarse_off && !prep;
     const uint32_t coarse_stride = (ntiles + 2u + 3u) & ~3u;
-    MTH_HIP(ctx, b_idx.reserve(coarse ? (size_t)coarse_stride * 2 * 4 : (size_t)(nq + 1) * 4, s));
+    if (!prep) MTH_HIP(ctx, b_idx.reserve(coarse ? (size_t)coarse_stride * 2 * 4 : (size_t)(nq + 1) * 4, s));
+    const uint32_t *fine_idx = prep ? prep->idx.as<uint32_t>() : nullptr;
+    ctx->cur_idx = fine_idx;                      // (the walks that follow a discovery pass read the index this call used)
     // the run form of the dense kernel (k_pdr_lpmd_runs; persistent workgroups, no index, no atomics): opt-in with MTH_TILE_RUNS=1 --
     // parity-green on every PDR / LPMD case, measured SLOWER than the one-tile-per-workgroup form on config 2 (0.127 against 0.084 ms;
     // profiles/r05_persistent.md).  8-bit relative positions, call offsets that fit a buffer descriptor's 32-bit byte offset.
@@ -1601,7 +1639,11 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     MTH_HIP(ctx, b_bucket.reserve(((size_t)n_bucket_words + run_words + (size_t)G * 4u) * sizeof(unsigned long long), s));
     if (p.want_pdr) MTH_HIP(ctx, b_scratch.reserve((size_t)ntiles * (size_t)tile_w * sizeof(SiteRec), s));
 
-    if (!runs || sink) {      // (the run form needs no index; site discovery leaves the fine one behind for the walks)
+    if (prep) {
+        if (runs) hipLaunchKernelGGL(k_batch_err, dim3(1), dim3(1), 0, s, lane_st, (const DevState *)prep->st);
+        else hipLaunchKernelGGL(k_batch_begin, dim3(1), dim3(256), 0, s, lane_st, L ? (DevState *)nullptr : cst, (const DevState *)prep->st,
+                                b_bucket.as<unsigned long long>(), n_bucket_words);
+    } else if (!runs || sink) {      // (the run form needs no index; site discovery leaves the fine one behind for the walks)
         LaunchTimer lt(ctx, K_INDEX);
         const uint32_t nb = (b.n_reads / 4 + 1 + BLOCK * IDX_GROUPS - 1) / (BLOCK * IDX_GROUPS);
         const int al16 = (int)((reinterpret_cast<uintptr_t>(b.read_start) & 15u) == 0);
@@ -1617,7 +1659,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     TileArgs a;
     a.read_start = b.read_start; a.read_mapq = b.read_mapq; a.cpg_off = b.cpg_off; a.cpg_pos = b.cpg_pos;
     a.cpg_rel = b.cpg_rel ? (const void *)b.cpg_rel : (const void *)b.cpg_rel16;
-    a.idx = b_idx.as<uint32_t>(); a.idx2 = coarse ? b_idx.as<uint32_t>() + coarse_stride : nullptr; a.st = lane_st;
+    a.idx = fine_idx ? fine_idx : b_idx.as<uint32_t>(); a.idx2 = coarse ? b_idx.as<uint32_t>() + coarse_stride : nullptr; a.st = lane_st;
     a.tile_cnt = b_tile_cnt.as<uint32_t>(); a.bucket = b_bucket.as<unsigned long long>(); a.nbk = nbk;
     a.scratch = b_scratch.as<SiteRec>();
     a.region_beg = b.region_beg; a.region_end = b.region_end; a.idx_base = idx_base; a.max_span = b.max_span;

@@ -593,7 +593,7 @@ static int quartet_batch(mth_ctx *ctx, const mth_batch_t &d, const mth_quartet_p
         if (!queued || ctx->q_pending.empty()) hipLaunchKernelGGL(k_quartet_rewind, dim3(1), dim3(1), 0, s, qs, (unsigned long long)rows_before);
         QTileArgs a;
         a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
-        a.idx = ctx->idx.as<uint32_t>();
+        a.idx = idx_ptr(ctx);
         a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
         a.n_reads = d.n_reads; a.ntiles = ntiles; a.n_cpgs = (uint32_t)d.n_cpgs; a.min_qual = params->min_qual;
         a.force_heavy = getenv("MTH_QUARTET_FORCE_GLOBAL") ? 1 : 0;

@@ -617,7 +617,7 @@ int launch_pdr_exact(mth_ctx *ctx, const mth_batch_t &d, const mth_pdr_lpmd_para
     MTH_HIP(ctx, ctx->w_flags.reserve(bound * 4, s));
     const int32_t ext = ((d.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
     PdrWalkArgs a;
-    a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos; a.idx = ctx->idx.as<uint32_t>();
+    a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos; a.idx = idx_ptr(ctx);
     a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>();
     a.pdr = ctx->w_val.as<float>(); a.nc = ctx->w_cov.as<uint32_t>(); a.nd = ctx->w_aux.as<uint32_t>();
     a.flags = ctx->w_flags.as<uint32_t>();
@@ -693,7 +693,7 @@ int mth_mhl_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_mhl_p
     const int32_t ext = ((d.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
     WalkArgs a;
     a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
-    a.idx = ctx->idx.as<uint32_t>(); a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>();
+    a.idx = idx_ptr(ctx); a.sites_st = ctx->d_state2; a.site_pos = ctx->s_pos.as<int32_t>();
     a.site_nc = ctx->s_nc.as<uint32_t>(); a.site_nd = ctx->s_nd.as<uint32_t>();
     a.st = ctx->d_state; a.val = ctx->w_val.as<float>(); a.cov = ctx->w_cov.as<uint32_t>(); a.flags = ctx->w_flags.as<uint32_t>();
     a.idx_base = d.region_beg - ext; a.max_span = d.max_span; a.n_reads = d.n_reads;
