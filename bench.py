@@ -253,6 +253,32 @@ def e2e_leg(c, n_reads, large_copies=10):
                "median_run": _split(*med), "best_run": _split(*runs[0]),
                "load_phase_M_reads_per_s_median": round(n_reads / max(_split(*med)["load_s"], 1e-9) / 1e6, 1),
                "input_in_page_cache_frac": _resident_fraction(bam), "bam_write_s": round(t_write, 1)}
+        # ---- the floor of this load path on THIS box: the file's bytes reach the GPU through one pageable copy out of the
+        # page cache -- page-locking the cache's pages is what that copy spends its time on, and it does not parallelise
+        # (profiles/r04_h2d_register.md) -- so   wall >= start-up + file bytes / pageable rate + kernels + tail   whatever the kernels do
+        try:
+            import torch
+            m = np.memmap(bam, dtype=np.uint8, mode="r")
+            dst = torch.empty(size, dtype=torch.uint8, device="cuda")
+            best_cp = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dst.copy_(torch.from_numpy(np.asarray(m)))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best_cp = dt if best_cp is None else min(best_cp, dt)
+            del dst, m
+            sp = _split(*med)
+            floor_s = sp["startup_s"] + best_cp + sp["kernels_s"] + sp["tail_s"]
+            out["floor"] = {"what": "start-up + ONE pageable host-to-device copy of the file (measured here: torch copy_ from the mmap'ed file, best of 3) + kernels + tail of the median run: "
+                                    "the least this load path can take on this box; the load phase also inflates, walks and decodes, overlapped with the copy in pieces",
+                            "pageable_copy_s": round(best_cp, 4), "pageable_copy_GBps": round(size / best_cp / 1e9, 2),
+                            "floor_s": round(floor_s, 4), "floor_M_reads_per_s": round(n_reads / floor_s / 1e6, 2),
+                            "load_over_copy": round(sp["load_s"] / best_cp, 3),
+                            "needed_for_50M_reads_per_s_s": round(n_reads / 50e6, 4)}
+        except Exception as ex:
+            out["floor"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
         os.remove(bam)
         # ---- the larger file ----
         try:
@@ -320,7 +346,7 @@ def timed_pass(eng, fn, reps):
 SIMDS, CLOCK_GHZ, CYCLES_PER_VALU_FULL, CYCLES_PER_VALU_HALF = 1024, 2.4, 2.5, 4.3
 
 
-def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total, legs=("roofline_wgbs", "all7", "fdrp_pairs")):
+def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total, legs=("roofline_wgbs", "all7", "fdrp_pairs"), quick=False):
     """The workload the metric is named after (WGBS depth), all device-generated (metheor_amd/synth_device.py):
     roofline_wgbs -- PDR+LPMD on one chr1-sized contig at config-3 density, dominant kernel against 24.5 B/read;
     all7 -- BASELINE config 3, every measure over the 24 contigs queued the way the CLI queues them, one sync;
@@ -391,7 +417,7 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total, legs=("roofline_wgbs"
     counts = {"pdr+lpmd": lambda: eng.pdr_count(), "me/pm": lambda: eng.quartet_fetch(min_depth=10)["me"].shape[0], "mhl": lambda: eng.mhl_fetch()["pos"].shape[0],
               "fdrp+qfdrp": lambda: eng.fdrp_fetch()["pos"].shape[0], "lpmd --pairs": lambda: eng.lpmd_pairs_fetch()["pos1"].shape[0]}
     for name, fn in passes.items():
-        for which, bs in ((per_c, per_contig), (per, resident)):
+        for which, bs in (((per, resident),) if quick else ((per_c, per_contig), (per, resident))):      # (quick: profiling runs, the grouped form only)
             best = None
             for _ in range(3):
                 eng.reset(); eng.sync()
@@ -403,6 +429,8 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total, legs=("roofline_wgbs"
                 best = dt if best is None else min(best, dt)
             which[name] = best
             rows_check.setdefault(name, []).append(int(counts[name]()))
+        if quick:
+            rows_check[name].append(rows_check[name][0]); per_c[name] = per[name]
         assert rows_check[name][0] == rows_check[name][1], (name, rows_check[name])      # grouped and per-contig give the same rows
     best_all = None
     for _ in range(3):
@@ -455,6 +483,8 @@ def wgbs_legs(eng, torch, dev, metheor_amd, n_reads_total, legs=("roofline_wgbs"
     # latency-bound walks; four of them fill each other's gaps.
     conc = None
     try:
+        if quick:
+            raise RuntimeError("skipped in a profiling run (--legs)")
         engs = []
         for _ in range(4):
             st = torch.cuda.Stream(device=dev)
@@ -828,7 +858,7 @@ def legs_main(args):
     torch.cuda.set_stream(stream)
     eng = metheor_amd.Engine(0, stream=stream.cuda_stream)
     legs = tuple(x for x in args.legs.split(",") if x)
-    out = wgbs_legs(eng, torch, dev, metheor_amd, args.wgbs_reads, legs=legs)
+    out = wgbs_legs(eng, torch, dev, metheor_amd, args.wgbs_reads, legs=legs, quick=True)
     print(json.dumps({"legs": list(legs), **out}), flush=True)
     eng.close()
     return 0

@@ -1522,7 +1522,7 @@ int build_read_index(mth_ctx *ctx, const mth_batch_t &b, int tile_w, int32_t &id
 // error bits / safe_hi / row base each -- and each gather waits for the event behind the previous one:
 //     lane 0:  index 0 | tile 0 ........ | gather 0 | index 2 | tile 2 ........ |        gather 2
 //     lane 1:            index 1 | tile 1 ........ |  gather 1 | index 3 | tile 3 ...
-// so a tile kernel's drain (a third of a 10 M-read launch is filling and draining the chip) is covered by the
+// so a tile kernel's drain (a third of a 10 M-read launch is filling and draining the chip, profiles/HISTORY.md section 6) is covered by the
 // next batch's fill, and the small index / gather kernels run beside a tile kernel instead of between two.  ctx->stream is
 // ordered behind the lanes by mth::enter() at every other entry point; the lanes wait for ctx->stream's work as of the call
 // (the caller's producers of the batch arrays).

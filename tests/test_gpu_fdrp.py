@@ -314,7 +314,7 @@ def test_reservoir_set_size_and_unbiased_estimates(eng):
     reads; FDRP and qFDRP of a uniformly drawn 40-subset are unbiased estimates of the full-depth values (a pair is kept with
     the same probability whatever its two reads), so over thousands of sampled sites the mean difference to -D 64 must vanish
     within its standard error -- a reservoir that favoured early (= leftmost) reads would not: neighbours in coordinate order
-    overlap more, fewer of their pairs fall under --min-overlap.  Bound stated in DESIGN section 12: |z| < 5."""
+    overlap more, fewer of their pairs fall under --min-overlap.  Bound stated in profiles/HISTORY.md section 12: |z| < 5."""
     from metheor_amd import synth
     c = synth.hotspots(n_windows=500, window=1000, depth=50, density=0.08, seed=51)
     full = run_device(eng, [c], dict(min_qual=10, min_depth=10, max_depth=64, min_overlap=35, seed=1))

@@ -112,13 +112,16 @@ def test_random_scenario_all_measures(eng, seed):
     # the same through the hashed-site form for sparse batches (mth_pdr_wide.hip) whatever the batch's density, and through the dense
     # form forced: identical rows and counters
     import os
-    for env, val in (("MTH_PDR_WIDE", str(14 + seed % 3)), ("MTH_PDR_WIDE", "0")):
-        os.environ[env] = val
+    # ... and through the persistent run form of the dense kernel (round 5: k_pdr_lpmd_runs + k_gather_runs, MTH_TILE_RUNS=1; it takes
+    # the batches with 8-bit relative positions, the others fall back to the tile form)
+    for envs in ({"MTH_PDR_WIDE": str(14 + seed % 3)}, {"MTH_PDR_WIDE": "0"}, {"MTH_PDR_WIDE": "0", "MTH_TILE_RUNS": "1"}):
+        os.environ.update(envs)
         try:
             d2, l2 = T_pdr.run_device(eng, cs, p, regions=regions, rel16=rel16)
         finally:
-            del os.environ[env]
-        assert all((d[k].view(np.uint32) == d2[k].view(np.uint32)).all() for k in d) and all(l[k] == l2[k] for k in l if k != "lpmd"), (env, val)
+            for k_ in envs:
+                del os.environ[k_]
+        assert all((d[k].view(np.uint32) == d2[k].view(np.uint32)).all() for k in d) and all(l[k] == l2[k] for k in l if k != "lpmd"), envs
 
     # LPMD per-pair table
     T_pairs.check(T_pairs.run_device(eng, cs, lk, regions=regions), reads, lk)

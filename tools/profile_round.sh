@@ -11,9 +11,9 @@ B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-wgbs --
 # passes switch it off (MTH_PIPELINE=0: the same kernels, one after the other on one stream -- what bench.py's own roofline leg
 # times with HIP events); the bench line below is taken with the pipeline on, as shipped.
 export MTH_PIPELINE=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B > $out/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- $B > $out/write.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B > $out/stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- $B > $out/write.log 2>&1
 python - "$out" "$commit" <<'PY'
 import csv, glob, json, sys, collections
 out, commit = sys.argv[1], sys.argv[2]
@@ -47,9 +47,13 @@ PY
 # profiled runs switch both off, as above.)
 export MTH_QUARTET_QUEUE=0 MTH_PAIRS_QUEUE=0
 for leg in all7 fdrp_pairs; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${leg}_stats -- python bench.py --legs $leg > $out/${leg}.json 2> $out/${leg}.err
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/${leg}_pmc1 -- python bench.py --legs $leg > /dev/null 2> $out/${leg}_pmc1.err
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/${leg}_pmc2 -- python bench.py --legs $leg > /dev/null 2> $out/${leg}_pmc2.err
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${leg}_stats -- python bench.py --legs $leg > $out/${leg}.json 2> $out/${leg}.err
+  timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/${leg}_pmc1 -- python bench.py --legs $leg > /dev/null 2> $out/${leg}_pmc1.err
+  # (FETCH_SIZE and WRITE_SIZE in passes of their own: together with a third counter the request "exceeds the capabilities of the hardware"
+  # and rocprofv3 then hangs in its abort handler -- every profiled command runs under `timeout`)
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${leg}_pmc2 -- python bench.py --legs $leg > /dev/null 2> $out/${leg}_pmc2.err
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${leg}_pmc3 -- python bench.py --legs $leg > /dev/null 2> $out/${leg}_pmc3.err
+  timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/${leg}_pmc4 -- python bench.py --legs $leg > /dev/null 2> $out/${leg}_pmc4.err
 done
 unset MTH_QUARTET_QUEUE MTH_PAIRS_QUEUE
 python - "$out" <<'PY'
@@ -60,7 +64,7 @@ for leg in ("all7", "fdrp_pairs"):
     for f in glob.glob(out + "/%s_stats/**/*kernel_stats.csv" % leg, recursive=True):
         shutil.copy(f, out + "/%s_kernel_stats.csv" % leg)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for d in ("pmc1", "pmc2"):
+    for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
         for f in glob.glob(out + "/%s_%s/**/*counter_collection.csv" % (leg, d), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
@@ -77,5 +81,5 @@ for leg in ("all7", "fdrp_pairs"):
     print(leg, "PMC kernels:", sorted(rows))
 PY
 unset MTH_PIPELINE
-python bench.py > $out/bench.json 2> $out/bench.err
+timeout 900 python bench.py > $out/bench.json 2> $out/bench.err
 cut -c1-400 $out/bench.json
