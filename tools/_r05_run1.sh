@@ -1,8 +1,7 @@
-mkdir -p gpurun_out/r05b
-timeout 1500 python -m pytest tests/test_gpu_fdrp.py -x -q -m gpu 2>&1 | tail -4
-for l in tree tree; do
-timeout 300 python bench.py --legs fdrp_pairs 2>/dev/null | python -c "
+for l in tree mt5 mt7 mt8 pw6 pw8 tree; do
+if [ $l = tree ]; then unset METHEOR_HIP_LIB; else export METHEOR_HIP_LIB=$PWD/abx/lib$l.so; fi
+timeout 300 python bench.py --legs all7 2>/dev/null | python -c "
 import json,sys
-j=json.loads([l for l in sys.stdin if l.startswith('{')][-1])['fdrp_pairs']
-print('$l config4 pass_ms', j['pass_ms'], j['kernels_ms'])"
+j=json.loads([l for l in sys.stdin if l.startswith('{')][-1])['all7']
+print('$l', j['per_pass_ms_one_sync_each'], 'prepared', j['prepared_batches']['per_pass_ms_one_sync_each'])"
 done
