@@ -477,7 +477,7 @@ int mth_pdr_lpmd_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_
     if (ctx->pipe_mode < 0) { const char *e = getenv("MTH_PIPELINE"); ctx->pipe_mode = (e && atoi(e) == 0) ? 0 : 1; }
     // (not for a batch of more than 2^29 positions -- a contig group: its kernels fill the chip for a millisecond, the boundary the
     // pipeline hides is nothing beside that, and the second lane's scratch rows would be another 16 B a position)
-    const bool eligible = ctx->pipe_mode == 1 && b.mem == MTH_MEM_DEVICE && !pdr_exact && !ctx->timing &&
+    const bool eligible = ctx->pipe_mode == 1 && (b.mem == MTH_MEM_DEVICE || b.mem == MTH_MEM_PREPARED) && !pdr_exact && !ctx->timing &&
                           (int64_t)b.region_end - (int64_t)b.region_beg <= ((int64_t)1 << 29);
     mth_batch_t d;
     {

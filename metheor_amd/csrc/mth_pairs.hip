@@ -603,6 +603,9 @@ namespace mth {
 
 int pairs_resolve(mth_ctx *ctx) {
     if (ctx->p_pending.empty()) return MTH_OK;
+    // (a replay below rebuilds its batch's read index in the context's own buffer: whatever prepared batch the latest entry point
+    // worked on is not this one's)
+    ctx->cur_prep = nullptr; ctx->cur_idx = nullptr;
     MTH_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<mth_ctx::QueuedPairs> pend;
     pend.swap(ctx->p_pending);
@@ -639,7 +642,7 @@ extern "C" {
 int mth_lpmd_pairs_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_lpmd_pairs_params_t *params) {
     if (!ctx || !batch || !params) return MTH_ERR_INVALID;
     static const bool queue_off = getenv("MTH_PAIRS_QUEUE") && atoi(getenv("MTH_PAIRS_QUEUE")) == 0;      // A/B: one sync per batch
-    const bool queued = batch->mem == MTH_MEM_DEVICE && ctx->p_learned && !ctx->timing && !queue_off && ctx->p_pending.size() < (size_t)P_QUEUE_MAX;
+    const bool queued = (batch->mem == MTH_MEM_DEVICE || batch->mem == MTH_MEM_PREPARED) && ctx->p_learned && !ctx->timing && !queue_off && ctx->p_pending.size() < (size_t)P_QUEUE_MAX;
     mth_batch_t d;
     ctx->tile_queue_hold = queued;
     int rc = stage_batch(ctx, *batch, d);

@@ -744,6 +744,9 @@ namespace mth {
 // their row counts.  Otherwise the batches from the first one that says so are replayed synchronously, in order.
 int quartet_resolve(mth_ctx *ctx) {
     if (ctx->q_pending.empty()) return MTH_OK;
+    // (a replay below rebuilds its batch's read index in the context's own buffer: whatever prepared batch the latest entry point
+    // worked on is not this one's)
+    ctx->cur_prep = nullptr; ctx->cur_idx = nullptr;
     MTH_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<mth_ctx::QueuedBatch> pend;
     pend.swap(ctx->q_pending);
@@ -783,7 +786,7 @@ int mth_quartet_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_q
     // Queued (no host sync in the call): a device-resident batch once a batch of this context has taught the output sizing, unless the
     // launches are being timed.  MTH_QUARTET_QUEUE=0 switches it off (A/B).  Every other entry point settles the queue (mth::enter).
     static const bool queue_off = getenv("MTH_QUARTET_QUEUE") && atoi(getenv("MTH_QUARTET_QUEUE")) == 0;
-    const bool queued = batch->mem == MTH_MEM_DEVICE && ctx->q_learned && !ctx->timing && !queue_off && ctx->q_pending.size() < (size_t)Q_QUEUE_MAX;
+    const bool queued = (batch->mem == MTH_MEM_DEVICE || batch->mem == MTH_MEM_PREPARED) && ctx->q_learned && !ctx->timing && !queue_off && ctx->q_pending.size() < (size_t)Q_QUEUE_MAX;
     mth_batch_t d;
     ctx->tile_queue_hold = queued;
     int rc = stage_batch(ctx, *batch, d);
