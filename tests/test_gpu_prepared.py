@@ -154,13 +154,13 @@ def test_prepared_batches_are_queued_and_pipelined_like_device_batches(monkeypat
             r["quartet"] = eng.quartet_fetch(min_depth=2)
             err = capfd.readouterr().err
             assert "[quartet] queued batches" in err and "queued batches 0" not in err, err
-            # force a replay: the third batch gets an output estimate that is far too small
+            # force a replay: every tile of the third batch refuses its LDS table (its snapshot says so, the resolve replays it)
             eng.reset()
             for k, b in enumerate(bts):
                 if k == 2:
-                    monkeypatch.setenv("MTH_PAIRS_ROWS_MIN", "50")
+                    monkeypatch.setenv("MTH_PAIRS_FORCE_GLOBAL", "1")
                 eng.lpmd_pairs_accumulate(b)
-                monkeypatch.delenv("MTH_PAIRS_ROWS_MIN", raising=False)
+                monkeypatch.delenv("MTH_PAIRS_FORCE_GLOBAL", raising=False)
             capfd.readouterr()
             r["pairs"] = eng.lpmd_pairs_fetch()
             err = capfd.readouterr().err
