@@ -623,8 +623,11 @@ __device__ __forceinline__ uint32_t tile_pass(const TileArgs &a, const uint32_t 
 // is called at most once per candidate read, so while the tile has <= 65535 candidates both counts fit 16 bits
 // (packed).  Heavier tiles (deep amplicons) take two passes over their reads with 32-bit counters, each
 // covering half of the tile's positions -- same LDS footprint, no extra launch, exact.
+#ifndef MTH_TILE_OCC
+#define MTH_TILE_OCC 8      // workgroups per CU the kernel is compiled for (7 / 6 / 5: 72 / 80 / 96 VGPRs -- A/B in round 5)
+#endif
 template <int W, int B, int NB, typename RelT, int MG>
-__global__ __launch_bounds__(B, 8) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
+__global__ __launch_bounds__(B, MTH_TILE_OCC) void k_pdr_lpmd_tile(const TileArgs a, const uint32_t ntiles) {
     static_assert(MG == 0 || (MG >= 64 && MG % 4 == 0), "the wide passes keep their trash words in the high margin");
     __shared__ __attribute__((aligned(16))) uint32_t cnt[MG ? MG + W + MG : W + 64];   // [margin,] counters, then margin / one trash word per lane
     __shared__ uint32_t red[4][B / 64];
