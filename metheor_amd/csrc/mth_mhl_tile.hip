@@ -112,7 +112,8 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
     uint32_t rows_out = 0;
     int sub_shift = a.force_sub ? 8 : MT_SHIFT;            // log2 of the sub-range width (block-uniform)
 #ifdef MTH_MT_TRACE
-    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    tk[8] = __builtin_readcyclecounter();
 #define MT_TK(k) do { tk[k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MT_TK(k) do {} while (0)
@@ -243,6 +244,11 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
             // lane -- so that their LDS atomics do not meet on one address changed nothing, here (0.211 against 0.212 ms) or in the
             // one-phase form.  The cycle trace (-DMTH_MT_TRACE) puts a config-2 tile at 37 % phase 1, 32 % phase 2, 19 % rows, the rest
             // barriers: every phase is a couple of dependent round trips with four waves to hide them.)
+            // (NEGATIVE, round 5, config-3 density, same box, three runs each -- profiles/r05_mhl_tile.md: a read's calls spread over 8 lanes
+            // when the queue is short (one wave walked eight compare-and-swap chains while three waited): phase 2 9.7 k -> 8.4 k of a
+            // tile's 32.6 k cycles, the kernel 0.168 -> 0.178 ms (every lane of a read re-derives its runs); the flusher bitmap in 64-bit
+            // words (half the atomics per stretch): + 0.005 ms; four reads per thread and trip: + 0.003 ms.  With 6 / 4 / 3 workgroups per
+            // CU the kernel takes 0.187 / 0.208 / 0.258 ms: at six it is bound by what it issues, not by the round trips.)
             for (uint32_t j0 = 0; j0 < qn; j0 += MT_B) {
                 const uint32_t j = j0 + tid;
                 const bool act = j < qn;
@@ -414,7 +420,8 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
         __syncthreads();                                    // the table is cleared by the next trip
         MT_TK(7);
 #ifdef MTH_MT_TRACE
-        if (tid == 0 && a.trace) { for (int k = 1; k < 8; ++k) atomicAdd(a.trace + k, tk[k] - tk[k - 1]); atomicAdd(a.trace, 1ull); }
+        // (plain stores per tile: atomics on eight shared addresses serialise at ~100 ns each and quadrupled the traced kernel's time)
+        if (tid == 0 && a.trace && P0 == T0) { for (int k = 1; k < 8; ++k) a.trace[(size_t)t * 8 + k] = tk[k] - tk[k - 1]; a.trace[(size_t)t * 8] = 1ull | ((tk[0] - tk[8]) << 8); }
 #endif
     }
     if (bad & 1u) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
@@ -648,8 +655,9 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     a.trace = nullptr;
 #ifdef MTH_MT_TRACE
     static unsigned long long *d_trace = nullptr;
-    if (!d_trace) MTH_HIP(ctx, hipMalloc((void **)&d_trace, 64));
-    MTH_HIP(ctx, hipMemsetAsync(d_trace, 0, 64, s));
+    static size_t d_trace_n = 0;
+    if (d_trace_n < (size_t)ntiles * 8) { if (d_trace) (void)hipFree(d_trace); d_trace_n = (size_t)ntiles * 8; MTH_HIP(ctx, hipMalloc((void **)&d_trace, d_trace_n * 8)); }
+    MTH_HIP(ctx, hipMemsetAsync(d_trace, 0, (size_t)ntiles * 64, s));
     a.trace = d_trace;
 #endif
     const uint32_t grid = ((ntiles + 7) / 8) * 8;
@@ -680,11 +688,13 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     }
 #ifdef MTH_MT_TRACE
     {
-        unsigned long long h[8];
+        std::vector<unsigned long long> hv((size_t)ntiles * 8);
         MTH_HIP(ctx, hipStreamSynchronize(s));
-        MTH_HIP(ctx, hipMemcpy(h, a.trace, 64, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[mhl tile trace] sub-ranges %llu; cycles per sub-range: clear %.0f  phase1 %.0f  barrier %.0f  phase2 %.0f  barrier %.0f  rows %.0f  barrier %.0f\n", h[0],
-                (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0], (double)h[5] / h[0], (double)h[6] / h[0], (double)h[7] / h[0]);
+        MTH_HIP(ctx, hipMemcpy(hv.data(), a.trace, hv.size() * 8, hipMemcpyDeviceToHost));
+        double h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, idxw = 0;
+        for (size_t q = 0; q < ntiles; ++q) { for (int k = 1; k < 8; ++k) h[k] += (double)hv[q * 8 + k]; h[0] += (double)(hv[q * 8] & 1ull); idxw += (double)(hv[q * 8] >> 8); }
+        fprintf(stderr, "[mhl tile trace] tiles %.0f; cycles of a tile's first sub-range: index look-up %.0f  clear %.0f  phase1 %.0f  barrier %.0f  phase2 %.0f  barrier %.0f  rows %.0f  barrier %.0f\n", h[0],
+                idxw / h[0], h[1] / h[0], h[2] / h[0], h[3] / h[0], h[4] / h[0], h[5] / h[0], h[6] / h[0], h[7] / h[0]);
     }
 #endif
     MTH_HIP(ctx, hipGetLastError());
