@@ -372,8 +372,9 @@ int  mth_decoded_sort(mth_ctx_t *ctx);
  * it was decoded: rows sorted by (tid, pos) as the reference's BTreeMap gives them.
  *   MTH_FO_PDR  v0 = pdr, c0 = n_concordant, c1 = n_discordant        (min_depth, min_cpgs, min_qual)
  *   MTH_FO_MHL  v0 = mhl, c0 = coverage                                (min_depth, min_cpgs, min_qual)
- *   MTH_FO_FDRP v0 = fdrp, v1 = qfdrp, c0 = stored reads               (min_depth, min_qual, max_depth <= 256, min_overlap, seed)
- * Synchronous.  MTH_ERR_CAPACITY beyond 2^31 records / calls, MHL reads with > 1024 CpGs, --max-depth > 256. */
+ *   MTH_FO_FDRP v0 = fdrp, v1 = qfdrp, c0 = stored reads               (min_depth, min_qual, max_depth <= 16384, min_overlap, seed)
+ * Synchronous.  MTH_ERR_CAPACITY beyond 2^31 records / calls, MHL reads with > 1024 CpGs, --max-depth > 16384 (as on the sorted
+ * path; up to 256 stored reads a site's slots live in LDS, beyond that in a per-wave row of HBM scratch). */
 enum { MTH_FO_PDR = 0, MTH_FO_MHL = 1, MTH_FO_FDRP = 2 };
 typedef struct {
     int32_t  measure;

@@ -405,12 +405,13 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
 #define MTH_FD_DPP x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)) + term;
             for (int k0 = 0; k0 < P; k0 += 64) {
                 const int k = min(k0 + lane, P - 1);
-                int pi = (int)((bq - __builtin_sqrtf(bq * bq - 8.0f * (float)k)) * 0.5f);
+                // f32 estimate of the row, then exact integer steps: beyond ~12 000 stored reads the estimate can be two rows off near the
+                // end of the list (one conditional step each way was not enough: nS = 12 000, pair 71 993 996)
+                int pi = (int)((bq - __builtin_sqrtf(fmaxf(bq * bq - 8.0f * (float)k, 0.0f))) * 0.5f);
                 pi = max(0, min(pi, nS - 2));
                 int off = (pi * (twoN - pi - 1)) >> 1;
-                if (k < off) { pi -= 1; off = (pi * (twoN - pi - 1)) >> 1; }
-                const int off1 = ((pi + 1) * (twoN - pi - 2)) >> 1;
-                if (k >= off1) { pi += 1; off = off1; }
+                while (k < off) { pi -= 1; off = (pi * (twoN - pi - 1)) >> 1; }
+                while (pi + 2 < nS && k >= (((pi + 1) * (twoN - pi - 2)) >> 1)) { pi += 1; off = (pi * (twoN - pi - 1)) >> 1; }
                 const int pj = k - off + pi + 1;
                 const uint32_t *ri = rows + pi * ROW, *rj = rows + pj * ROW;
                 const int32_t si = (int32_t)ri[2], ei = (int32_t)ri[3], sj = (int32_t)rj[2], ej = (int32_t)rj[3];

@@ -22,7 +22,8 @@
 //   6  rows compacted in key order = the BTreeMap's.
 // Nothing here is tuned: an unsorted Bismark file gives these measures mostly one-read segments, and nobody waits for them.
 // Limits (loud, MTH_ERR_CAPACITY): < 2^31 calls of contributing records in one file; MHL reads with > 1024 CpGs or segment
-// denominators >= 2^24; FDRP / qFDRP --max-depth > 256.
+// denominators >= 2^24; FDRP / qFDRP --max-depth > 16384 (as on the sorted path; up to 256 stored reads a site's slots live in LDS, beyond
+// that in a per-wave row of HBM scratch).
 #include <hipcub/hipcub.hpp>
 
 #include "mth_ctx.h"
@@ -31,7 +32,8 @@ namespace mth {
 
 constexpr int FO_BLK = 32;          // records per block of the range-maximum structure
 constexpr int FO_MHL_MAXN = 1024;   // CpGs of a read the MHL evaluation holds
-constexpr int FO_FDRP_SLOTS = 256;  // stored reads of a site the FDRP evaluation holds
+constexpr int FO_FDRP_SLOTS = 256;  // stored reads of a site the FDRP evaluation holds in LDS (more: rows_deep)
+constexpr uint32_t FO_FDRP_DEPTH_MAX = 16384;   // the pair index of one site is 32-bit arithmetic (mth_fdrp.hip: FD_DEPTH_MAX)
 constexpr int FO_WIN = 201;         // MAX_READ_LEN, fdrp.rs:10
 
 struct FoArgs {
@@ -61,6 +63,7 @@ struct FoArgs {
     // per contribution that starts a site: the chosen segment [sel_a, sel_b) (sel_b = 0: none), then the row
     uint32_t *sel_a, *sel_b;
     uint32_t *rowflag;
+    uint32_t *rows_deep;             // FDRP with max_depth > FO_FDRP_SLOTS: max_depth slots per wave of the launch
     float *v0, *v1;
     uint32_t *c0, *c1;
     DevState *st;
@@ -261,8 +264,8 @@ __global__ __launch_bounds__(256) void k_fo_mhl(const FoArgs a) {
 __global__ __launch_bounds__(256) void k_fo_fdrp(const FoArgs a) {
     __shared__ uint32_t s_rows[4][FO_FDRP_SLOTS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *rows = s_rows[wave];
     const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t *rows = a.rows_deep ? a.rows_deep + (size_t)(blockIdx.x * 4u + (uint32_t)wave) * a.max_depth : s_rows[wave];
     for (uint32_t i0 = (blockIdx.x * 4u + (uint32_t)wave) * 64u; i0 < a.n_contrib; i0 += n_waves * 64u) {
         const uint32_t il = i0 + (uint32_t)lane;
         unsigned long long todo = __ballot(il < a.n_contrib && a.sel_b[il] != 0u);
@@ -298,12 +301,13 @@ __global__ __launch_bounds__(256) void k_fo_fdrp(const FoArgs a) {
             float q = 0.0f;
             for (int k0 = 0; k0 < P; k0 += 64) {
                 const int k = min(k0 + lane, P - 1);
-                int pi = (int)((bq - __builtin_sqrtf(bq * bq - 8.0f * (float)k)) * 0.5f);           // k -> (i, j), lexicographic (fdrp.rs:128)
+                // k -> (i, j), lexicographic (fdrp.rs:128): an f32 estimate of the row, then exact integer steps (beyond ~12 000 stored reads
+                // the estimate can be two rows off near the end of the list: one conditional step each way is not enough)
+                int pi = (int)((bq - __builtin_sqrtf(fmaxf(bq * bq - 8.0f * (float)k, 0.0f))) * 0.5f);
                 pi = max(0, min(pi, nS - 2));
                 int offp = (pi * (twoN - pi - 1)) >> 1;
-                if (k < offp) { pi -= 1; offp = (pi * (twoN - pi - 1)) >> 1; }
-                const int off1 = ((pi + 1) * (twoN - pi - 2)) >> 1;
-                if (k >= off1) { pi += 1; offp = off1; }
+                while (k < offp) { pi -= 1; offp = (pi * (twoN - pi - 1)) >> 1; }
+                while (pi + 2 < nS && k >= (((pi + 1) * (twoN - pi - 2)) >> 1)) { pi += 1; offp = (pi * (twoN - pi - 1)) >> 1; }
                 const int pj = k - offp + pi + 1;
                 const uint32_t ti = rows[pi], tj = rows[pj];
                 const int32_t si = a.start[ti], ei = a.end[ti], sj = a.start[tj], ej = a.end[tj];
@@ -375,11 +379,11 @@ int mth_fileorder_run(mth_ctx_t *ctx, const mth_fileorder_params_t *p) {
     const uint64_t R = ctx->dec_reads;
     if (R == 0) return MTH_OK;
     if (R >= (1ull << 31)) return fail(ctx, MTH_ERR_CAPACITY, "file-order measures: more than 2^31 records");
-    if (p->measure == MTH_FO_FDRP && p->max_depth > (uint32_t)FO_FDRP_SLOTS)
-        return fail(ctx, MTH_ERR_CAPACITY, "FDRP / qFDRP on input that is not coordinate-sorted: --max-depth above 256 (sort the file: samtools sort)");
+    if (p->measure == MTH_FO_FDRP && p->max_depth > FO_FDRP_DEPTH_MAX)
+        return fail(ctx, MTH_ERR_CAPACITY, "FDRP / qFDRP max_depth above 16384 (the pair index of one site is 32-bit arithmetic)");
     const uint32_t n = (uint32_t)R, nb = (n + 255) / 256;
-    DevBuf F, cnt, disc, coff, ckey, ckey2, cval, cval2, tmp, bm, rank;
-    auto drop = [&]() { for (DevBuf *b : {&F, &cnt, &disc, &coff, &ckey, &ckey2, &cval, &cval2, &tmp, &bm, &rank}) b->release(); };
+    DevBuf F, cnt, disc, coff, ckey, ckey2, cval, cval2, tmp, bm, rank, deep;
+    auto drop = [&]() { for (DevBuf *b : {&F, &cnt, &disc, &coff, &ckey, &ckey2, &cval, &cval2, &tmp, &bm, &rank, &deep}) b->release(); };
 #define FO_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { drop(); return fail(ctx, MTH_ERR_HIP, #call, e__); } } while (0)
     FO_HIP(F.reserve((size_t)n * 8 + 8, s)); FO_HIP(cnt.reserve((size_t)n * 4 + 4, s)); FO_HIP(disc.reserve((size_t)n + 4, s));
     FO_HIP(coff.reserve(((size_t)n + 1) * 8, s));
@@ -426,7 +430,18 @@ int mth_fileorder_run(mth_ctx_t *ctx, const mth_fileorder_params_t *p) {
     FO_HIP(hipMemsetAsync(ctx->fo_tmp.p, 0, (size_t)M * 16, s));
     hipLaunchKernelGGL(k_fo_sites, dim3(mb), dim3(256), 0, s, a);
     if (p->measure == MTH_FO_MHL) hipLaunchKernelGGL(k_fo_mhl, dim3(std::min<uint32_t>((M + 255) / 256, 2048u)), dim3(256), 0, s, a);
-    if (p->measure == MTH_FO_FDRP) hipLaunchKernelGGL(k_fo_fdrp, dim3(std::min<uint32_t>((M + 255) / 256, 2048u)), dim3(256), 0, s, a);
+    if (p->measure == MTH_FO_FDRP) {
+        uint32_t grid = std::min<uint32_t>((M + 255) / 256, 2048u);
+        a.rows_deep = nullptr;
+        if (p->max_depth > (uint32_t)FO_FDRP_SLOTS) {
+            // a row of max_depth record numbers per wave in HBM; as many waves as ~256 MB of rows allow (such sites are bound by their
+            // pair count, not by the number of waves)
+            grid = std::max<uint32_t>(1u, std::min<uint32_t>(grid, (uint32_t)(((size_t)256 << 20) / ((size_t)p->max_depth * 4 * 4))));
+            FO_HIP(deep.reserve((size_t)grid * 4 * p->max_depth * 4, s));
+            a.rows_deep = deep.as<uint32_t>();
+        }
+        hipLaunchKernelGGL(k_fo_fdrp, dim3(grid), dim3(256), 0, s, a);
+    }
     // rank of every row = exclusive scan of the flags
     FO_HIP(rank.reserve(((size_t)M + 1) * 8, s));
     unsigned long long rows = 0;

@@ -82,18 +82,46 @@ def test_random_unsorted_files(tmp_path, seed):
             assert o.read_text() == rows(tab, names), (sub, d, D, l, mq, sd)
 
 
-def test_limits_are_loud(tmp_path):
-    """--max-depth above 256 on unsorted input: exit 101 with the reason (the sorted path has no such limit)"""
+def _deep_unsorted(tmp_path, n_reads, seed=5):
     from metheor_amd import synth
-    rng = np.random.default_rng(5)
-    c = synth.make_contig(0, 5_000, 600, 0.05, rng)
+    rng = np.random.default_rng(seed)
+    c = synth.make_contig(0, 900, n_reads, 0.05, rng)                # 2000 reads: ~330 over every position
     r0 = util.contig_to_records(c, "ctg0")
-    perm = rng.permutation(len(r0.tid))
+    # nearly sorted (blocks of the sorted file moved): segments stay long, so the stored-read counts do exceed 256
+    perm = np.arange(len(r0.tid))
+    for _ in range(3):
+        a, b = sorted(rng.integers(0, len(perm), size=2))
+        perm = np.concatenate([perm[:a], perm[b:], perm[a:b]])
     sh = bamio.Records(r0.refs, r0.tid[perm], r0.pos[perm], r0.flag[perm], r0.mapq[perm], [r0.cigars[i] for i in perm], [r0.xms[i] for i in perm])
     bam = str(tmp_path / "u.bam")
     bamio.write_bam(bam, sh)
-    r = run({}, "fdrp", "-i", bam, "-o", tmp_path / "o.tsv", "-D", 1000)
-    assert r.returncode == 101 and "max-depth" in r.stderr, r.stderr
+    return bam, sh
+
+
+@pytest.mark.parametrize("D", [300, 1000])
+def test_deep_sites_on_unsorted_input(tmp_path, D):
+    """--max-depth above 256 on input that is not coordinate-sorted: the stored reads of a site live in a per-wave row of HBM scratch
+    (round 5; rounds 3-4 refused it).  D = 300 is below the depth of most sites (reservoir branch, shared counter-based draw),
+    D = 1000 above it."""
+    bam, sh = _deep_unsorted(tmp_path, 2000)
+    reads = pyoracle.Reads.decode(sh)
+    o = tmp_path / "o.tsv"
+    deepest = 0
+    for sub in ("fdrp", "qfdrp"):
+        r = run({"METHEOR_SEED": "11"}, sub, "-i", bam, "-o", o, "-q", 10, "-d", 2, "-D", D, "-l", 35)
+        assert r.returncode == 0, r.stderr
+        tab = getattr(reads, sub)(min_qual=10, min_depth=2, max_depth=D, min_overlap=35, seed=11)
+        assert o.read_text() == rows(tab, ["ctg0"]), (sub, D)
+        deepest = max(deepest, int(tab.cnt.max()) if tab.cnt.size else 0)
+    # the case is only worth its name if some site did hold more reads than the LDS slots
+    assert deepest > 256, deepest
+
+
+def test_limits_are_loud(tmp_path):
+    """--max-depth above 16384 (the sorted path's limit too): exit 101 with the reason"""
+    bam, _ = _deep_unsorted(tmp_path, 200)
+    r = run({}, "fdrp", "-i", bam, "-o", tmp_path / "o.tsv", "-D", 20000)
+    assert r.returncode == 101 and "max_depth" in r.stderr.replace("-", "_"), r.stderr
 
 
 def _panic_records():
