@@ -103,6 +103,41 @@ __global__ __launch_bounds__(BLOCK) void k_build_index(const int32_t *__restrict
         // slower: 0.0171 against 0.0163 ms; the load hits the line its neighbour fetches and waits for nothing extra)
         if (i0 > 0 && i0 <= n_reads) sp[u] = read_start[i0 - 1];
     }
+    // ---- the fine index (NIDX = 1), usual case: every thread's four reads open at most FAST_SPAN entries between them.  Entry q of
+    // (g_prev, g_last] is the first of the four reads whose quantum reaches q: i0 + the number of reads whose quantum lies below q --
+    // one loop over the thread's entries, three compares each, 32-bit quantum arithmetic (the values of a valid batch are >= idx_base;
+    // anything below it counts as quantum -1, as in the general form).  A wave where some thread spans more (assembly gaps), and
+    // NIDX = 2, take the general form below.  (Round 5: the general form alone was 85 % vector-unit bound at WGBS depth -- 0.31 ms
+    // per pass on config 3, paid by every measure's pass.)
+    if (NIDX == 1 && IDX_GROUPS == 1) {
+        constexpr int FAST_SPAN = 16;
+        const uint32_t i0 = gi[0];
+        const bool gact = i0 <= n_reads;
+        auto q32 = [&](const int32_t sx) -> int32_t { return sx < idx_base ? -1 : (int32_t)min(((uint32_t)sx - (uint32_t)idx_base) >> qshift, nq); };
+        int32_t g[4];
+        uint32_t errf = 0;
+        int32_t s_prev = sp[0];
+        bool have_prev = gact && i0 > 0;
+        int32_t g_prev = have_prev ? q32(s_prev) : -1, g_run = g_prev;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + (uint32_t)k;
+            if (gact && i < n_reads) {
+                const int32_t sx = sv[0][k];
+                if (have_prev && sx < s_prev) errf |= ERRB_UNSORTED;
+                s_prev = sx; have_prev = true;
+                g_run = max(g_run, q32(sx));                     // (an unsorted batch is an error; the running maximum keeps the stores in range)
+            } else if (gact) g_run = (int32_t)nq;               // the sentinel (i == n_reads) and what lies beyond it close the index
+            g[k] = g_run;
+        }
+        const int32_t span = gact ? g[3] - g_prev : 0;
+        if (!__any(span > FAST_SPAN)) {
+            for (int32_t q = g_prev + 1; q <= g[3]; ++q)
+                idx[q] = i0 + (g[0] < q ? 1u : 0u) + (g[1] < q ? 1u : 0u) + (g[2] < q ? 1u : 0u);
+            if (errf) atomicOr(&st->err, errf);
+            return;
+        }
+    }
     // The fine quantum is 32 bp (it was 256: the candidates of a tile or a site then carried up to 362 bp of reads that cannot
     // touch it, 8 % of a 4096-bp tile's loop iterations), so a read usually opens an entry or two; a stretch without reads
     // (assembly gaps: megabases) is filled by the whole wave, 64 entries per step, not by the one lane that found it.
