@@ -267,6 +267,28 @@ __device__ __forceinline__ uint32_t tile_compact(const TileArgs &a, const uint32
         // mask from the right by one funnel shift, last position first -- 3 instructions against the compare / select / or chain's
         // 5 (half-rate, profiles/r02_ubench_valu.md) of the form that kept concordant | discordant and had to add the halves first.
         uint32_t below = 0;
+#ifdef MTH_TILE_ROT
+        // A/B switch, not the default (round 5, built after three rounds of "counted, not built"; bit-identical, 145 tests; same box, three
+        // runs each: kernel 0.0826 / 0.0852 / 0.0844 ms against 0.0829 / 0.0838 / 0.0840 without, two batches in turn 0.0938 / 0.0927 / 0.0922
+        // against 0.0918 -- the LDS pipe is not what the kernel waits for): a thread's four 16-byte reads in an order rotated by (lane >> 2) & 3, so
+        // that the four lanes of a 16-lane group that share a 16-byte slot (16 words apart: same banks) read different slots in every
+        // instruction; the 16-bit mask comes out rotated by 4 rot bits and is turned back by one shift of its doubled copy.
+        static_assert(PER == 16 || WIDE, "the rotation is written for 16 positions per thread");
+        const uint32_t rot = ((uint32_t)lane >> 2) & 3u;
+#pragma unroll
+        for (int q = PER / 4 - 1; q >= 0; --q) {
+            const uint4 x = reinterpret_cast<const uint4 *>(cnt)[tid * (PER / 4) + (((uint32_t)q + rot) & 3u)];
+            below = __builtin_amdgcn_alignbit(below, (x.w & 0xffffu) - a.min_cov, 31);
+            below = __builtin_amdgcn_alignbit(below, (x.z & 0xffffu) - a.min_cov, 31);
+            below = __builtin_amdgcn_alignbit(below, (x.y & 0xffffu) - a.min_cov, 31);
+            below = __builtin_amdgcn_alignbit(below, (x.x & 0xffffu) - a.min_cov, 31);
+        }
+        // bits 4 s .. 4 s + 3 of `below` belong to chunk (s + rot) & 3: rotate left by 4 rot within the 16 bits
+        {
+            const uint32_t dbl = below | (below << 16);
+            below = (dbl >> (16u - 4u * rot)) & 0xffffu;
+        }
+#else
 #pragma unroll
         for (int q = PER / 4 - 1; q >= 0; --q) {
             const uint4 x = reinterpret_cast<const uint4 *>(cnt)[tid * (PER / 4) + q];
@@ -275,6 +297,7 @@ __device__ __forceinline__ uint32_t tile_compact(const TileArgs &a, const uint32
             below = __builtin_amdgcn_alignbit(below, (x.y & 0xffffu) - a.min_cov, 31);
             below = __builtin_amdgcn_alignbit(below, (x.x & 0xffffu) - a.min_cov, 31);
         }
+#endif
         qual = ~below & (PER == 32 ? 0xffffffffu : (1u << PER) - 1u);
     }
     {   // only the pass's positions [0, Wp) exist (the last tile of a region is short)
