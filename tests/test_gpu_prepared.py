@@ -172,3 +172,47 @@ def test_prepared_batches_are_queued_and_pipelined_like_device_batches(monkeypat
         finally:
             eng.close()
     _same(out[False], out[True])
+
+
+def test_prepared_group_and_region_batches():
+    """the two other shapes a batch takes -- a contig GROUP (several contigs in one virtual coordinate space, mth_group_define) and
+    REGION pieces of one contig (region_beg > 0, halo reads before the region) -- prepared once each: every measure equals the plain
+    entry points bit for bit, and PDR / MHL the oracle's rows"""
+    import metheor_amd
+    from metheor_amd import shard, synth
+    from tests import test_gpu_groups as G
+    cs = G._contigs(21, n=4)
+    voff, v = [], 0
+    for c in cs:
+        voff.append(v); v += ((c["length"] + 150 + 1024 + 4095) // 4096) * 4096
+    tids = [2, 4, 9, 10]
+    for c, t in zip(cs, tids):
+        c["tid"] = t
+    rng = np.random.default_rng(5)
+    big = synth.make_contig(0, 500_000, 60_000, 0.03, rng)
+    cuts = [(0, 170_000), (170_000, 333_333), (333_333, 500_000)]
+    eng = metheor_amd.Engine(0)
+    try:
+        h = eng.group_define(tids, voff)
+        plain = [G._group_batch(cs, voff, h, "cuda:0")]
+        want = _all_seven(eng, plain)
+        prepared = [eng.batch_prepare(b) for b in plain]
+        _same(want, _all_seven(eng, prepared))
+        ora = G._oracle(cs)
+        t_, p_, v_, c_ = G._cat([o.mhl(min_depth=3, min_cpgs=2) for o in ora], tids)
+        assert (want["mhl"]["tid"] == t_).all() and (want["mhl"]["pos"] == p_[:, 0]).all()
+        for p in prepared:
+            p.release()
+        # region pieces of one contig
+        eng.reset()
+        plain = [util.device_batch(shard.slice_region(big, b, e), region=(b, e), device="cuda:0") for (b, e) in cuts]
+        want = _all_seven(eng, plain)
+        prepared = [eng.batch_prepare(b) for b in plain]
+        _same(want, _all_seven(eng, prepared))
+        reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(big))
+        o = reads.pdr(min_depth=3, min_cpgs=2, min_qual=10)
+        assert (want["pdr"]["pos"] == o.pos[:, 0]).all() and (want["pdr"]["n_concordant"] == o.cnt[:, 0]).all()
+        o = reads.mhl(min_depth=3, min_cpgs=2)
+        assert (want["mhl"]["pos"] == o.pos[:, 0]).all() and np.abs(want["mhl"]["mhl"].astype(np.float64) - o.val).max() <= 1e-6
+    finally:
+        eng.close()
