@@ -28,6 +28,8 @@
 //
 // Reservoir branch (depth > max_depth): the reference draws from an OS-seeded RNG (fdrp.rs:90), so
 // there is nothing to be bit-equal to; device and oracle share the counter-based sample_j below.
+#include <type_traits>
+
 #include "mth_ctx.h"
 #include "mth_scan.h"
 
@@ -595,9 +597,14 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
 // reads past c + 1" order, at most max_depth hits, spans <= 200 bp (host side), the 64 sites around c covering +-200 bp.
 // Anything else is handed back (flags = 4) and done by k_fdrp_walk<8, 64> with only_flag = 4 -- same results either way.
 constexpr uint32_t FD_REDO = 4u;
-template <int GL>      // lanes (= candidate reads, stored reads, pairs per round) of a site: 16 or 32
+// WIN: sites of the window around c that the call masks index, 64 or 32.  At WGBS density the +-200 bp a stored read can reach hold ~4
+// sites: 32 are plenty (a denser stretch fails `compact` and is handed back, as with 64), and the masks, the rows and the popcounts of a
+// pair round are single words (round 5).
+template <int GL, int WIN>      // GL: lanes (= candidate reads, stored reads, pairs per round) of a site: 16 or 32
 __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
-    constexpr int NG = 64 / GL, WS = 64 / GL;      // sites per wave; sites of the 64-site window per lane
+    static_assert(WIN == 64 || WIN == 32, "mask words");
+    typedef typename std::conditional<WIN == 64, unsigned long long, uint32_t>::type mask_t;
+    constexpr int NG = 64 / GL, WS = WIN / GL;      // sites per wave; sites of the window per lane
     constexpr uint32_t GMASK = GL == 32 ? 0xffffffffu : (1u << GL) - 1u;
     constexpr int NTAB = (GL + 1) * GL * (GL - 1) / 6;   // pairs of n = 2..GL stored reads, one list after the other
     const int lane = threadIdx.x & 63, gl = lane & (GL - 1), row0 = lane & ~(GL - 1), g = lane / GL, wave = threadIdx.x >> 6;
@@ -641,8 +648,8 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
         const int32_t c = a.site_pos[jj];
         const bool act = jv;                                                // site-uniform (as everything named per site below)
         bool redo = false;
-        // the 64 sites around c, WS per lane
-        const uint32_t j0w = (jj >= 32u) ? min(jj - 32u, n_sites > 64u ? n_sites - 64u : 0u) : 0u;
+        // the WIN sites around c, WS per lane
+        const uint32_t j0w = (jj >= (uint32_t)(WIN / 2)) ? min(jj - (uint32_t)(WIN / 2), n_sites > (uint32_t)WIN ? n_sites - (uint32_t)WIN : 0u) : 0u;
         int32_t sp[WS];
 #pragma unroll
         for (int t = 0; t < WS; ++t) { const uint32_t si = j0w + (uint32_t)(WS * gl + t); sp[t] = si < n_sites ? a.site_pos[si] : 0x7fffffff; }
@@ -727,22 +734,24 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (fin && pass && hit) {
-            unsigned long long mC = 0, mM = 0;
+            mask_t mC = 0, mM = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t rel_p = (cw[k] & 0x7fffffffu) - (uint32_t)(c - FD_WIN);
-                const unsigned long long b = 1ull << bit_of[rel_p];
+                const mask_t b = (mask_t)1 << bit_of[rel_p];
                 mC |= b;
-                mM |= b & (unsigned long long)((long long)(int32_t)cw[k] >> 31);
+                mM |= b & (mask_t)((long long)(int32_t)cw[k] >> 31);
             }
             const uint32_t p0 = cw[0] & 0x7fffffffu;
-            const unsigned long long b0 = 1ull << bit_of[p0 - (uint32_t)(c - FD_WIN)];
-            const unsigned long long mA = ((int32_t)p0 >= cs) ? mC : mC & ~b0;   // the one call that can lie outside the covered bases: start - 1
+            const mask_t b0 = (mask_t)1 << bit_of[p0 - (uint32_t)(c - FD_WIN)];
+            const mask_t mA = ((int32_t)p0 >= cs) ? mC : mC & ~b0;   // the one call that can lie outside the covered bases: start - 1
             mM &= mA;
             uint32_t *r = rows + 8 * __builtin_popcount(mh & ((1u << gl) - 1u));   // slot = arrival order
             r[0] = (uint32_t)cs; r[1] = (uint32_t)ce;
-            r[2] = (uint32_t)mC; r[3] = (uint32_t)(mC >> 32); r[4] = (uint32_t)mA; r[5] = (uint32_t)(mA >> 32);
-            r[6] = (uint32_t)mM; r[7] = (uint32_t)(mM >> 32);
+            if (WIN == 64) {
+                r[2] = (uint32_t)mC; r[3] = (uint32_t)((unsigned long long)mC >> 32); r[4] = (uint32_t)mA; r[5] = (uint32_t)((unsigned long long)mA >> 32);
+                r[6] = (uint32_t)mM; r[7] = (uint32_t)((unsigned long long)mM >> 32);
+            } else { r[2] = (uint32_t)mC; r[3] = (uint32_t)mA; r[4] = (uint32_t)mM; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -765,9 +774,15 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
             const int32_t si = (int32_t)ri[0], ei = (int32_t)ri[1], sj = (int32_t)rj[0], ej = (int32_t)rj[1];
             const int32_t ov = min(ei, ej) - max(si, sj) + 1;                  // get_num_overlap_bases, fdrp.rs:97-107
             const bool pair_ok = (k < P) & (max(ov, 0) >= a.min_overlap);        // fdrp.rs:134
-            const uint32_t ncpg = __builtin_popcount(ri[2] & rj[2]) + __builtin_popcount(ri[3] & rj[3]);   // qfdrp.rs:109-119
-            const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) +
-                                 __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));                      // fdrp.rs:114-115
+            uint32_t ncpg, ham;
+            if (WIN == 64) {
+                ncpg = __builtin_popcount(ri[2] & rj[2]) + __builtin_popcount(ri[3] & rj[3]);   // qfdrp.rs:109-119
+                ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) +
+                      __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));                      // fdrp.rs:114-115
+            } else {
+                ncpg = __builtin_popcount(ri[2] & rj[2]);
+                ham = __builtin_popcount(ri[3] & rj[3] & (ri[4] ^ rj[4]));
+            }
             disc += (pair_ok && ham != 0u) ? 1u : 0u;                            // fdrp.rs:138-140
             const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;        // qfdrp.rs:152; +0.0 for skipped pairs
             const unsigned long long nz = __ballot(term != 0.0f);
@@ -1433,8 +1448,14 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
             a.redo_mask = ctx->f_redo.as<unsigned long long>();
             const uint32_t grid4 = (uint32_t)std::min<uint64_t>((bound + 255) / 256, 16384);   // 4 waves x 64 sites per block and step
             LaunchTimer lt(ctx, K_FDRPWALK4);
-            if (walk4 == 16) hipLaunchKernelGGL(k_fdrp_walk4<16>, dim3(grid4), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(k_fdrp_walk4<32>, dim3(grid4), dim3(256), 0, s, a);
+            // 32-site windows where 32 sites reach well beyond +- 200 bp (at the batch's site density; METHEOR_FDRP_WIN=64 / 32 forces it)
+            const double sites_per_bp = d.n_reads ? (double)d.n_cpgs / (double)d.n_reads / (double)std::max(d.max_span, 1) : 0.0;   // (the site count itself is on the device)
+            int win = sites_per_bp * 402.0 <= 12.0 ? 32 : 64;
+            if (const char *e = getenv("METHEOR_FDRP_WIN")) win = atoi(e) == 32 ? 32 : 64;
+            if (walk4 == 16 && win == 32) hipLaunchKernelGGL((k_fdrp_walk4<16, 32>), dim3(grid4), dim3(256), 0, s, a);
+            else if (walk4 == 16) hipLaunchKernelGGL((k_fdrp_walk4<16, 64>), dim3(grid4), dim3(256), 0, s, a);
+            else if (win == 32) hipLaunchKernelGGL((k_fdrp_walk4<32, 32>), dim3(grid4), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((k_fdrp_walk4<32, 64>), dim3(grid4), dim3(256), 0, s, a);
             a.only_flag = FD_REDO;
         }
         LaunchTimer lt(ctx, K_FDRPWALK);
