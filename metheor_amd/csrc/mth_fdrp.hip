@@ -615,6 +615,11 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
     __shared__ uint16_t s_tab[NTAB + 1];
     for (int t = threadIdx.x; t < NTAB; t += 256) s_tab[t] = a.pair_tab[t];
     if (threadIdx.x == 0) s_tab[NTAB] = 0;
+    // ham / ncpg of a pair round from a table: a candidate holds at most 8 calls here (more: handed back), so ncpg <= 8; the entries
+    // are made by the same f32 division the round would do (12 instructions per round otherwise, a fifth of its vector work)
+    constexpr int W4_QN = 9;
+    __shared__ float s_quot4[W4_QN * W4_QN];
+    for (int t = threadIdx.x; t < W4_QN * W4_QN; t += 256) s_quot4[t] = (float)(t / W4_QN) / (float)(t % W4_QN);
     __syncthreads();
     uint8_t *const bit_of = s_bit[wave][g];
     uint32_t *const rows = s_rows[wave][g];
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
         unsigned long long inexact = 0;                                          // lanes that have held a non-dyadic term this step (wave-uniform value)
         for (int r = 0; r < rounds; ++r) {
             const int k = GL * r + gl;
-            const uint32_t ent = tab[P ? min(k, P - 1) : 0];
+            const uint32_t ent = tab[P ? min(k, P - 1) : 0];                     // (requested one round ahead: measured, no change)
             const int pi = (int)(ent & 0xffu) & (GL - 1), pj = (int)(ent >> 8) & (GL - 1);
             const uint32_t *ri = rows + pi * 8, *rj = rows + pj * 8;
             const int32_t si = (int32_t)ri[0], ei = (int32_t)ri[1], sj = (int32_t)rj[0], ej = (int32_t)rj[1];
@@ -784,7 +789,7 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
                 ham = __builtin_popcount(ri[3] & rj[3] & (ri[4] ^ rj[4]));
             }
             disc += (pair_ok && ham != 0u) ? 1u : 0u;                            // fdrp.rs:138-140
-            const float term = pair_ok ? (float)ham / (float)ncpg : 0.0f;        // qfdrp.rs:152; +0.0 for skipped pairs
+            const float term = pair_ok ? s_quot4[min(ham, 8u) * W4_QN + min(ncpg, 8u)] : 0.0f;   // qfdrp.rs:152 ((float)ham / (float)ncpg); +0.0 for skipped pairs
             const unsigned long long nz = __ballot(term != 0.0f);
             if (nz == 0ull) continue;                                            // wave-uniform: x + 0.0 == x
             // The ordered f32 sum (qfdrp.rs:152) needs its order only once a term is not a dyadic fraction.  ham / ncpg with ncpg a
