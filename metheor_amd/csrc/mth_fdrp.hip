@@ -637,10 +637,19 @@ __global__ __launch_bounds__(256, 8) void k_fdrp_walk4(const FdrpArgs a) {
             const uint32_t cov_l = in ? a.site_nc[jl] + a.site_nd[jl] : 0u;
             const bool active = in && cov_l >= a.min_depth;
             if (in && !active) { a.fdrp[jl] = 0.0f; a.qfdrp[jl] = 0.0f; a.nreads[jl] = 0u; a.flags[jl] = 0u; }
-            const unsigned long long m_act = __ballot(active);
-            n_act = (uint32_t)__popcll(m_act);
+            // The list in order of the sites' read counts (16 classes, a ballot each): the NG sites of a step run max-over-sites pair
+            // rounds, ceil(n (n - 1) / 2 / GL) each -- 2 at 8 stored reads, 6 at 14 -- so sites of a kind go together (round 5).
+            const uint32_t cls = active ? min(cov_l, 15u) : 16u;
+            uint32_t at = 0, base_l = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 16u; ++b) {
+                const unsigned long long m = __ballot(cls == b);
+                if (cls == b) at = base_l + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                base_l += (uint32_t)__popcll(m);
+            }
+            n_act = base_l;
             __builtin_amdgcn_wave_barrier();                                     // the previous block's list reads are done
-            if (active) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_act, 0u))] = jl;
+            if (active) list[at] = jl;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
