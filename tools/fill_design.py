@@ -1,4 +1,4 @@
-"""fill the @@PLACEHOLDERS@@ of DESIGN.md from a bench line: python tools/fill_design.py profiles/r05_v1_bench.json"""
+"""fill the @@PLACEHOLDERS@@ of DESIGN.md from a bench line: python tools/fill_design.py profiles/r05_v6_bench.json"""
 import json, re, sys
 j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 r = j["roofline"]; ak = r.get("all_kernels_ms", {})
