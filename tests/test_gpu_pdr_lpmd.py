@@ -414,3 +414,34 @@ def test_density_chooser_takes_the_wide_form_on_sparse_batches(eng, kernel_form)
         ran = {k for k, v in t.items() if v[1] > 0 and k.startswith("k_pdr_lpmd")}
         assert ran == {want}, (dens, t)
         check_against_oracle(p, l, reads, kw, dict())
+
+
+def test_read_clusters_with_megabase_gaps(eng):
+    """reads in clusters with megabases of nothing between them (assembly gaps, capture panels): the fine read index is built by the
+    one-loop fast form where a thread's four reads open few entries and by the general form where a wave meets a gap (round 5), the
+    tile-granular families skip empty tiles; PDR + LPMD in every kernel form, MHL, ME / PM and FDRP / qFDRP against the oracle"""
+    from metheor_amd import PdrLpmdParams, synth
+    rng = np.random.default_rng(77)
+    length = 10_000_000
+    starts = np.sort(np.concatenate([
+        rng.integers(0, 60_000, size=6_000),                    # a dense cluster at the contig's start
+        rng.integers(5_200_000, 6_000_000, size=3_000),         # a sparse stretch 5 Mbp further
+        rng.integers(6_000_100, 6_000_400, size=300),           # a pile right behind it
+        np.array([9_900_000]),                                  # one read near the end
+    ])).astype(np.int32)
+    c = synth.make_contig(1, length, len(starts), 0.03, rng, starts=starts)
+    reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
+    for kw in (dict(min_depth=3, min_cpgs=2, min_qual=10), dict(min_depth=0, min_cpgs=0, min_qual=0)):
+        p, l = run_device(eng, [c], PdrLpmdParams(**kw), device="cuda:0")
+        check_against_oracle(p, l, reads, kw, dict())
+        assert len(p["pos"]) > 500
+    bt = util.device_batch(c, device="cuda:0")
+    eng.reset(); eng.mhl_accumulate(bt, min_depth=3, min_cpgs=2)
+    d, o = eng.mhl_fetch(), reads.mhl(min_depth=3, min_cpgs=2)
+    assert (d["pos"] == o.pos[:, 0]).all() and np.abs(d["mhl"].astype(np.float64) - o.val).max() <= 1e-6 and len(o) > 100
+    eng.reset(); eng.quartet_accumulate(bt)
+    d, o = eng.quartet_fetch(min_depth=2), reads.pm(min_depth=2)
+    assert len(d["pm"]) == len(o) and (np.sort(d["pm"].view(np.uint32)) == np.sort(o.val.view(np.uint32))).all()
+    eng.reset(); eng.fdrp_accumulate(bt, min_depth=2)
+    d, o, q = eng.fdrp_fetch(), reads.fdrp(min_depth=2), reads.qfdrp(min_depth=2)
+    assert (d["pos"] == o.pos[:, 0]).all() and (d["fdrp"].view(np.uint32) == o.val.view(np.uint32)).all() and (d["qfdrp"].view(np.uint32) == q.val.view(np.uint32)).all()
