@@ -17,7 +17,7 @@ ARCH = "gfx950"
 # a*b+c); hipcc's default is contract=fast
 HIP_FLAGS = os.environ.get("MTH_EXTRA_HIPFLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off", "-Wno-unused-result"]
 
-HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip", "mth_pdr_wide.hip", "mth_quartet.hip", "mth_scan.hip", "mth_sites.hip", "mth_mhl_tile.hip", "mth_fdrp.hip", "mth_pairs.hip", "mth_decode.hip", "mth_sort.hip", "mth_fileorder.hip", "mth_inflate.hip", "mth_rccl.hip", "mth_tag.hip"]
+HIP_SOURCES = ["mth_api.hip", "mth_pdr_lpmd.hip", "mth_pdr_wide.hip", "mth_quartet.hip", "mth_scan.hip", "mth_sites.hip", "mth_mhl_tile.hip", "mth_fdrp.hip", "mth_fdrp_wtile.hip", "mth_pairs.hip", "mth_decode.hip", "mth_sort.hip", "mth_fileorder.hip", "mth_inflate.hip", "mth_rccl.hip", "mth_tag.hip"]
 HOST_LIB = os.path.join(HERE, "libmetheor_host.so")
 HOST_SOURCES = [os.path.join("host", "bam_reader.cpp"), os.path.join("host", "host_api.cpp"),
                 os.path.join("host", "parallel_decode.cpp"), os.path.join("host", "synth_bam.cpp"), os.path.join("host", "bai_index.cpp"), os.path.join("host", "sam_text.cpp")]

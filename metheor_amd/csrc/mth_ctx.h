@@ -270,6 +270,9 @@ inline void fine_index_extent(const mth_batch_t &b, int32_t &idx_base, uint32_t 
 }
 // MHL as one tile pass (mth_mhl_tile.hip): candidate-site arrays filled with finished rows and the sites left to the exact walk
 int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_mhl_params_t &p, uint64_t &bound);
+// FDRP + qFDRP at WGBS depth as one tile pass (mth_fdrp_wtile.hip): candidate-site arrays filled with finished rows and the sites left
+// to k_fdrp_walk (listed in redo_list / *redo_cnt)
+int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_fdrp_params_t &p, uint32_t *redo_list, uint32_t *redo_cnt);
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p,
                     const TileSink *sink = nullptr, bool pipelined = false);
 

@@ -76,7 +76,8 @@ struct FdrpArgs {
     unsigned long long budget;
     unsigned long long *site_off;     // per site: first byte of its list
     uint32_t *site_nz, *site_disc;    // per site: listed terms, discordant pairs
-    uint32_t *redo_list, *redo_cnt;   // the sites k_fdrp_tile handed back, one after the other (k_fdrp_walk takes them wave by wave)
+    uint32_t *redo_list, *redo_cnt;   // the sites k_fdrp_tile / k_fdrp_wtile handed back, one after the other (k_fdrp_walk takes them wave by wave)
+    uint32_t no_compact;              // the site list holds only the sites that can produce a row (k_fdrp_wtile): no window of ALL sites around c
 };
 
 // the oracle's orc_sample_j: splitmix64 over (seed, tid, pos, total) -> 1..=total
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256, (FD_NB == 8 && SLOTS == 64) ? 8 : 1) void k_fd
             unsigned long long mC = 0, mA = 0, mM = 0;
             bool compact = false;
             // (halo reads of a region slice call positions outside the region; those are not in the site list)
-            if (!win_check && (int64_t)c - 200 >= a.region_beg && (int64_t)c + 200 < a.region_end) {
+            if (!win_check && !a.no_compact && (int64_t)c - 200 >= a.region_beg && (int64_t)c + 200 < a.region_end) {
                 const uint32_t j0 = j0w;
                 const int32_t sp = spw;
                 const int32_t sp_lo = __builtin_amdgcn_readlane(sp, 0), sp_hi = __builtin_amdgcn_readlane(sp, 63);
@@ -1336,8 +1337,21 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     if (rc) return rc;
     hipStream_t s = ctx->stream;
     uint64_t bound = 0;
-    // sites = positions called by reads passing mapq with >= 1 CpG (fdrp.rs:205-231)
-    if ((rc = discover_sites(ctx, d, 0, params->min_qual, bound))) return rc;
+    // WGBS depth (about a dozen candidate reads per site -- reads starting in [c - max_span + 1, c + 1]), sparse calls, spans <= 200 bp:
+    // ONE tile pass finds the sites and computes them (k_fdrp_wtile, round 6); the general walk only redoes what it hands back.
+    // METHEOR_FDRP_WTILE=0 / 1 forces the choice (A/B, tests).
+    const bool dense = d.n_reads && ((double)d.n_cpgs / (double)d.n_reads) > 6.0;
+    const double cand = (double)d.n_reads * ((double)d.max_span + 2.0) / std::max<double>(1.0, (double)d.region_end - (double)d.region_beg);
+    bool wtile = !dense && d.max_span <= 200 && cand <= 16.0 && !getenv("METHEOR_FDRP_WALK4") && !getenv("METHEOR_FDRP_TILE");
+    if (const char *e = getenv("METHEOR_FDRP_WTILE")) wtile = d.max_span <= 200 && atoi(e) != 0;
+    if (wtile) {
+        // the candidate-site arrays the tile pass fills itself (no discovery pass)
+        const uint64_t region_len = (uint64_t)((int64_t)d.region_end - d.region_beg);
+        bound = d.n_cpgs < region_len ? d.n_cpgs : region_len;
+        if (!ctx->d_state2) MTH_HIP(ctx, hipMalloc((void **)&ctx->d_state2, sizeof(DevState)));
+        MTH_HIP(ctx, hipMemsetAsync(ctx->d_state2, 0, sizeof(DevState), s));
+        MTH_HIP(ctx, ctx->s_pos.reserve((bound + 1) * 4, s));
+    } else if ((rc = discover_sites(ctx, d, 0, params->min_qual, bound))) return rc;   // sites = positions called by reads passing mapq with >= 1 CpG (fdrp.rs:205-231)
     ctx->f_batches.push_back(BatchMeta{batch->tid});
     if (bound == 0) bound = 1;
     MTH_HIP(ctx, ctx->w_val.reserve(bound * 4, s));
@@ -1379,7 +1393,7 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     a.min_depth = (uint32_t)std::min<uint64_t>(params->min_depth, 0xffffffffull); a.max_depth = params->max_depth;
     a.min_qual = params->min_qual;
     a.rows_scratch = nullptr; a.slots_cap = 0;
-    a.redo_list = nullptr; a.redo_cnt = nullptr;
+    a.redo_list = nullptr; a.redo_cnt = nullptr; a.no_compact = 0u;
     a.terms = nullptr; a.cursor = nullptr; a.budget = 0; a.site_off = nullptr; a.site_nz = nullptr; a.site_disc = nullptr;
     if (!ctx->f_pairtab.p) {
         // the pairs of n stored reads in the reference's (i, j) loop order (fdrp.rs:129-141), n = 2..64, one after the other
@@ -1400,21 +1414,37 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
         // (each kernel of the pass under its own timer id: bench.py's kernels_ms decomposes -- VERDICT r04 item 2)
         // dense CpGs (hotspots, RRBS): 16 call registers per stored read keep the per-call match out of
         // the memory loop; sparse WGBS keeps 8 (half the compares per call)
-        const bool dense = d.n_reads && ((double)d.n_cpgs / (double)d.n_reads) > 6.0;
         // WGBS depth: when a site has about a dozen reads that can call it (reads starting in [c - max_span + 1, c + 1]), four
         // sites share a wave (k_fdrp_walk4<16>) and the general walk only redoes what that kernel handed back.  Measured on a
         // chr1-sized contig (profiles/r02_fdrp_walk4.md): ~10 such reads per site 0.887 -> 0.568 ms, 12 1.29 -> 0.94, 14.6 1.58 -> 1.39,
         // 17 1.79 -> 1.83 (the switch is at 16), ~19.5 per site 1.95 -> 2.17
         // (16 lanes) / 2.13 (32 lanes) -- deeper sites are bound by their pair rounds and keep the wave-per-site walk.
         // METHEOR_FDRP_WALK4=0 / 16 / 32 (1 = 16) forces the choice (A/B, tests).
-        const double cand = (double)d.n_reads * ((double)d.max_span + 2.0) / std::max<double>(1.0, (double)d.region_end - (double)d.region_beg);
-        int walk4 = (!dense && d.max_span <= 200 && cand <= 16.0) ? 16 : 0;                                 // lanes per site
+        int walk4 = (!wtile && !dense && d.max_span <= 200 && cand <= 16.0) ? 16 : 0;                        // lanes per site
         if (const char *e = getenv("METHEOR_FDRP_WALK4")) { const int k = atoi(e); walk4 = d.max_span <= 200 ? (k == 1 ? 16 : (k == 16 || k == 32 ? k : 0)) : 0; }
         a.only_flag = 0u; a.redo_mask = nullptr;
         // The read x read form (k_fdrp_tile + k_fdrp_chain) for everything the four-sites-per-wave kernel does not take:
         // METHEOR_FDRP_TILE=0 / 1 forces the choice (A/B, tests).
-        bool tile = d.max_span <= 200 && !walk4;
-        if (const char *e = getenv("METHEOR_FDRP_TILE")) { tile = d.max_span <= 200 && atoi(e) != 0; if (tile) walk4 = 0; }
+        bool tile = d.max_span <= 200 && !walk4 && !wtile;
+        if (const char *e = getenv("METHEOR_FDRP_TILE")) { tile = d.max_span <= 200 && atoi(e) != 0 && !wtile; if (tile) walk4 = 0; }
+        if (wtile) {
+            walk4 = 0;
+            MTH_HIP(ctx, ctx->f_redo.reserve((bound + 2) * 4, s));
+            unsigned long long *cur = ctx->f_state.as<unsigned long long>() + 2;
+            MTH_HIP(ctx, hipMemsetAsync(cur, 0, 16, s));
+            a.redo_list = ctx->f_redo.as<uint32_t>(); a.redo_cnt = reinterpret_cast<uint32_t *>(cur + 1);
+            if ((rc = launch_fdrp_wtile(ctx, d, *params, a.redo_list, a.redo_cnt))) return rc;
+            a.idx = idx_ptr(ctx);
+            a.only_flag = FD_REDO; a.no_compact = 1u;
+            if (getenv("METHEOR_FDRP_DEBUG")) {          // how much the tile pass handed back (synchronises: debugging only)
+                DevState st;
+                uint32_t redo = 0;
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(&st, ctx->d_state2, sizeof st, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&redo, a.redo_cnt, 4, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[fdrp wtile] candidate rows %llu handed back %u\n", (unsigned long long)st.n_sites, redo);
+            }
+        }
         const uint64_t dcap = std::min<uint64_t>(std::max<uint32_t>(params->max_depth, 1u), 64u);
         // sum over sites of C(n, 2) <= (dcap - 1) / 2 x the sum of n <= (dcap - 1) / 2 x the batch's calls; + the 64-byte rounding
         const uint64_t budget = (uint64_t)d.n_cpgs * (dcap - 1) / 2 + 64 * bound + 64;

@@ -76,12 +76,14 @@ def scenario(seed):
 
 def fdrp_checked(eng, cs, fk, regions, reads):
     """FDRP / qFDRP against the oracle with the engine's own choice of kernel form, then once more with each form forced --
-    k_fdrp_walk4 (four sites per wave, hand-back to the general walk), the read x read form (k_fdrp_tile + k_fdrp_chain), the
+    the one-pass tile form (k_fdrp_wtile, also from 256-position stretches, and switched off), k_fdrp_walk4 (four sites per wave,
+    hand-back to the general walk), the read x read form (k_fdrp_tile + k_fdrp_chain), the
     wave-per-site walk alone: the same rows bit for bit"""
     import os
     d0 = T_fdrp.run_device(eng, cs, fk, regions=regions)
     T_fdrp.check(d0, reads, fk)
-    for env in (dict(METHEOR_FDRP_WALK4="16", METHEOR_FDRP_TILE="0"), dict(METHEOR_FDRP_TILE="1"), dict(METHEOR_FDRP_WALK4="0", METHEOR_FDRP_TILE="0")):
+    for env in (dict(METHEOR_FDRP_WTILE="1"), dict(METHEOR_FDRP_WTILE="1", METHEOR_FDRP_WTILE_SUB="1"), dict(METHEOR_FDRP_WTILE="0"),
+                dict(METHEOR_FDRP_WALK4="16", METHEOR_FDRP_TILE="0"), dict(METHEOR_FDRP_TILE="1"), dict(METHEOR_FDRP_WALK4="0", METHEOR_FDRP_TILE="0")):
         os.environ.update(env)
         try:
             d1 = T_fdrp.run_device(eng, cs, fk, regions=regions)
