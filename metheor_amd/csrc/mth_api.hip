@@ -306,7 +306,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
                       &ctx->q_hist, &ctx->q_blk, &ctx->q_batch_rows, &ctx->q_tflag, &ctx->q_tile_row0, &ctx->q_tile_rows, &ctx->q_wpos, &ctx->q_wpat, &ctx->q_wk0, &ctx->q_wk1, &ctx->q_snap, &ctx->p_snap, &ctx->q_pos, &ctx->q_cnt, &ctx->q_me, &ctx->q_pm, &ctx->q_depth,
                       &ctx->s_pos, &ctx->s_pdr, &ctx->s_nc, &ctx->s_nd, &ctx->s_batch_cnt, &ctx->w_val, &ctx->w_cov, &ctx->w_aux, &ctx->w_flags,
                       &ctx->w_blk, &ctx->w_huge, &ctx->m_state, &ctx->m_pos, &ctx->m_val, &ctx->m_cov, &ctx->m_batch_rows,
-                      &ctx->f_state, &ctx->f_pos, &ctx->f_val, &ctx->f_qval, &ctx->f_n, &ctx->f_batch_rows, &ctx->f_rows, &ctx->f_pairtab, &ctx->fo_sel, &ctx->fo_flag, &ctx->fo_tmp, &ctx->fo_out, &ctx->f_redo, &ctx->f_terms, &ctx->f_soff, &ctx->f_snz, &ctx->f_sdisc,
+                      &ctx->f_state, &ctx->f_pos, &ctx->f_val, &ctx->f_qval, &ctx->f_n, &ctx->f_batch_rows, &ctx->f_rows, &ctx->f_pairtab, &ctx->fo_sel, &ctx->fo_flag, &ctx->fo_tmp, &ctx->fo_out, &ctx->f_redo, &ctx->f_terms, &ctx->f_soff, &ctx->f_snz, &ctx->f_sdisc, &ctx->f_quot,
                       &ctx->p_state, &ctx->p_keys, &ctx->p_cnt, &ctx->p_out_key, &ctx->p_out_cnt, &ctx->p_batch_rows, &ctx->p_tflag, &ctx->p_tile_row0, &ctx->p_tile_rows})
         b->release();
     for (auto &g : ctx->groups) g.d_tab.release();

@@ -161,7 +161,7 @@ struct mth_ctx {
     std::vector<mth::BatchMeta> m_batches;
 
     // FDRP / qFDRP result rows (mth_fdrp.hip)
-    mth::DevBuf f_state, f_pos, f_val, f_qval, f_n, f_batch_rows, f_rows, f_pairtab, f_redo, f_terms, f_soff, f_snz, f_sdisc;
+    mth::DevBuf f_state, f_pos, f_val, f_qval, f_n, f_batch_rows, f_rows, f_pairtab, f_redo, f_terms, f_soff, f_snz, f_sdisc, f_quot;
     uint64_t f_cap = 0, f_rows_bound = 0;
     std::vector<mth::BatchMeta> f_batches;
 
@@ -272,7 +272,7 @@ inline void fine_index_extent(const mth_batch_t &b, int32_t &idx_base, uint32_t 
 int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_mhl_params_t &p, uint64_t &bound);
 // FDRP + qFDRP at WGBS depth as one tile pass (mth_fdrp_wtile.hip): candidate-site arrays filled with finished rows and the sites left
 // to k_fdrp_walk (listed in redo_list / *redo_cnt)
-int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_fdrp_params_t &p, uint32_t *redo_list, uint32_t *redo_cnt);
+int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_fdrp_params_t &p, const uint16_t *pair_tab, uint32_t *redo_list, uint32_t *redo_cnt);
 int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &dev_batch, const mth_pdr_lpmd_params_t &p,
                     const TileSink *sink = nullptr, bool pipelined = false);
 

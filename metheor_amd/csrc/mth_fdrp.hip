@@ -1433,7 +1433,7 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
             unsigned long long *cur = ctx->f_state.as<unsigned long long>() + 2;
             MTH_HIP(ctx, hipMemsetAsync(cur, 0, 16, s));
             a.redo_list = ctx->f_redo.as<uint32_t>(); a.redo_cnt = reinterpret_cast<uint32_t *>(cur + 1);
-            if ((rc = launch_fdrp_wtile(ctx, d, *params, a.redo_list, a.redo_cnt))) return rc;
+            if ((rc = launch_fdrp_wtile(ctx, d, *params, a.pair_tab, a.redo_list, a.redo_cnt))) return rc;
             a.idx = idx_ptr(ctx);
             a.only_flag = FD_REDO; a.no_compact = 1u;
             if (getenv("METHEOR_FDRP_DEBUG")) {          // how much the tile pass handed back (synchronises: debugging only)
