@@ -1503,8 +1503,10 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
             a.only_flag = FD_REDO;
         }
         LaunchTimer lt(ctx, K_FDRPWALK);
-        if (dense) hipLaunchKernelGGL((k_fdrp_walk<16, 64>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_fdrp_walk<8, 64>), dim3(grid), dim3(256), 0, s, a);
+        // (the tile pass's hand-backs are a few per thousand sites, taken from a list: a small grid -- 16 384 workgroups that find nothing took 40 us)
+        const uint32_t grid1 = wtile ? std::min(grid, std::max(1024u, (uint32_t)std::min<uint64_t>(bound / 4096, 16384))) : grid;
+        if (dense) hipLaunchKernelGGL((k_fdrp_walk<16, 64>), dim3(grid1), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_fdrp_walk<8, 64>), dim3(grid1), dim3(256), 0, s, a);
         a.only_flag = 0u;
         // max_depth > 64: the sites that held more than 64 reads at once were flagged, not computed: 256-slot pass over them
         if (params->max_depth > 64) hipLaunchKernelGGL((k_fdrp_walk<8, FD_SLOTS_DEEP>), dim3(grid), dim3(256), 0, s, a);

@@ -69,10 +69,10 @@ constexpr int FW_V = 4;                                 // 64-call chunks of a s
 constexpr int FW_CCAP = 64 * FW_V;                      // calls of a stretch's candidate reads (more: the stretch is halved)
 constexpr int FW_SC = 32;                               // core sites of a stretch (one per lane; a denser stretch is halved)
 constexpr int FW_LCAP = 64;                             // stored reads of a site here (more: handed back)
-constexpr int FW_NZCAP = 512;                           // non-zero qFDRP terms of a stretch's sites (more: the site is handed back)
-constexpr int FW_QN = 9;                                // ncpg <= 8 (a reader holds <= 8 calls)
+constexpr int FW_NZCAP = 1024;                           // non-zero qFDRP terms of a stretch's sites (more: the site is handed back)
+constexpr int FW_QC = 17 * 18 / 2;                      // codes ncpg (ncpg + 1) / 2 + ham, ham <= ncpg <= 16 (a reader's calls span <= 16 window sites)
 constexpr uint32_t FW_PASS = 1u, FW_BAD = 2u;           // per-read flags
-static_assert(FW_WMAX + 2 * 200 + 1 <= 64 * 32 && FW_RCAP <= 256, "one bitmap word per lane; 8-bit read slots");
+static_assert(FW_U == 2 && FW_WMAX + 2 * 200 + 1 <= 64 * 32 && FW_RCAP <= 256, "one bitmap word per lane; 8-bit read slots");
 
 __device__ __forceinline__ uint32_t fw_wave_max(uint32_t v) {   // wave-uniform result
     v = max(v, MTH_DPP(v, 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, true));
@@ -97,12 +97,45 @@ __device__ __forceinline__ uint32_t fw_writelane(uint32_t vec, const uint32_t va
     asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(idx) : "m0");   // (one SGPR operand per VALU instruction on gfx9: the lane select goes through m0)
     return vec;
 }
+// the lanes where p holds, as a mask (hip's __ballot goes through a select and a compare: two vector instructions more per call)
+__device__ __forceinline__ unsigned long long fw_ballot(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // the wave's LDS writes are visible to its later reads (one wave per workgroup: no s_barrier)
 #define FW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 __global__ void k_fw_quot(float *q) {   // ham / ncpg by the same f32 division the reference does (qfdrp.rs:152); ncpg = 0 is never looked up
-    const int t = threadIdx.x;
-    if (t < FW_QN * FW_QN) q[t] = (t % FW_QN) ? (float)(t / FW_QN) / (float)(t % FW_QN) : 0.0f;
+    const uint32_t t = threadIdx.x;
+    uint32_t ncpg = 0;
+    while ((ncpg + 1u) * (ncpg + 2u) / 2u <= t) ++ncpg;
+    if (t < (uint32_t)FW_QC) q[t] = ncpg ? (float)(t - ncpg * (ncpg + 1u) / 2u) / (float)ncpg : 0.0f;
+}
+
+// every pair of the n readers in s_list, lane = pair in the reference's loop order (fdrp.rs:128-141): the discordant pairs (returned) and,
+// appended to s_nz at nzbase in that order, their terms ham / ncpg (qfdrp.rs:152) -- the pairs with a zero term add +0.0 and are not kept
+__device__ __forceinline__ uint32_t fw_rounds(const uint16_t *s_list, const uint32_t *s_row, uint8_t *s_nz, const uint16_t *__restrict__ pair_tab,
+                                              const int lane, const uint32_t n, uint32_t ent_next, uint32_t &nzbase, const bool mo_any, const int32_t mo_m1) {
+    const uint32_t P = n * (n - 1u) / 2u;
+    const uint16_t *const tab = pair_tab + (n * (n - 1u) * (n - 2u)) / 6u;              // (n <= 1: no pair, the table is not read)
+    uint32_t disc = 0;
+    for (uint32_t k0p = 0; k0p < P; k0p += 64u) {
+        const uint32_t ent = ent_next;
+        if (k0p + 64u < P) ent_next = tab[min(k0p + 64u + (uint32_t)lane, P - 1u)];
+        const uint32_t li = s_list[ent & 0xffu], lj = s_list[ent >> 8];
+        const uint4 ri = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(s_row) + li), rj = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(s_row) + lj);
+        // get_num_overlap_bases (fdrp.rs:97-107) = max(min(end) - max(start) + 1, 0) >= min_overlap (fdrp.rs:134)
+        const int32_t ovl = (int32_t)min(ri.x >> 16, rj.x >> 16) - (int32_t)max(ri.x & 0xffffu, rj.x & 0xffffu);
+        const bool pair_ok = (k0p + (uint32_t)lane < P) && (mo_any || ovl >= mo_m1);
+        const uint32_t hm = ri.z & rj.z & (ri.w ^ rj.w);                             // both cover and call, states differ: fdrp.rs:114-115
+        const bool dsc = pair_ok && hm != 0u;                                        // fdrp.rs:138-140; exactly the pairs with a non-zero term
+        const unsigned long long nzb = fw_ballot(dsc);
+        if (nzb == 0ull) continue;                                                   // wave-uniform
+        // the term ham / ncpg (qfdrp.rs:109-131, 152) as one byte, ncpg (ncpg + 1) / 2 + ham: D2 looks the quotient up
+        const uint32_t ham = (uint32_t)__builtin_popcount(hm), ncpg = (uint32_t)__builtin_popcount(ri.y & rj.y);
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzb, nzbase));
+        if (dsc && slot < (uint32_t)FW_NZCAP) s_nz[slot] = (uint8_t)(ncpg * (ncpg + 1u) / 2u + ham);
+        const uint32_t c = (uint32_t)__popcll(nzb);
+        disc += c; nzbase += c;
+    }
+    return disc;
 }
 
 // ONE WAVE per tile (~1500 positions, ~110 candidate reads at WGBS depth): no workgroup barrier anywhere, every phase's round
@@ -117,17 +150,19 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
     // 5 KB of LDS per wave: 32 waves per CU (the kernel is bound by each wave's own chain of round trips: what counts is waves in flight)
     __shared__ uint2 s_bp[64];                                // {site bits, sites in the words before}
     __shared__ __attribute__((aligned(16))) uint32_t s_row[FW_RCAP * 4];   // {start | end << 16, mC, first-call rank -> mA, mM}
-    __shared__ __attribute__((aligned(4))) uint8_t s_list[FW_LCAP];   // D1: the readers of the site in hand (read slots, file order)
-    __shared__ __attribute__((aligned(4))) float s_nz[FW_NZCAP];   // D: the sites' non-zero terms, each site's in the reference's loop order
-    uint8_t *const s_owner = reinterpret_cast<uint8_t *>(s_nz);    // A: call slot -> read slot + 1 where a read's calls begin, else 0
+    __shared__ uint16_t s_list[FW_LCAP];                      // D1: the readers of the site in hand (byte offsets of their rows, file order)
+    __shared__ float s_quot[FW_QC];                           // [ncpg (ncpg + 1) / 2 + ham] = ham / ncpg (a division is ten vector instructions)
+    __shared__ __attribute__((aligned(4))) uint8_t s_nz[FW_NZCAP];   // D: the sites' non-zero terms as codes, each site's in the reference's loop order
+    uint8_t *const s_owner = s_nz;                            // A: call slot -> read slot + 1 where a read's calls begin, else 0
     __shared__ int32_t s_cpos[FW_SC];
     __shared__ uint32_t s_sflag[FW_SC];                       // per core site: passing reads that call it | bit 31: one of them holds > 8 calls / spans > 16 window sites
-    static_assert(FW_NZCAP * 4 >= FW_CCAP, "the owner marks share the term array");
+    static_assert(FW_NZCAP >= FW_CCAP, "the owner marks share the term array");
     const int lane = threadIdx.x;
     // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
     const uint32_t per_xcd = (a.ntiles + 7) / 8;
     const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= a.ntiles) return;
+    for (int q = lane; q < FW_QC; q += 64) s_quot[q] = a.quot[q];
     const int32_t T0 = a.region_beg + (int32_t)(t * a.tile_w);
     const int32_t T1 = (int32_t)min((int64_t)T0 + a.tile_w, (int64_t)a.region_end);
     FdRec *__restrict__ out = a.scratch + (size_t)t * a.rows_per_tile;
@@ -168,7 +203,17 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         // (the calls themselves are taken one per LANE in A2 / C1: a read holds 1.4 calls at WGBS density, eight call slots per read
         // -- the first form of this kernel -- spent most of their instructions on empty slots)
         uint32_t fl[U], ncall[U];
-        const uint32_t ofirst = __builtin_amdgcn_readfirstlane(a.cpg_off[lo]), olast = __builtin_amdgcn_readfirstlane(a.cpg_off[hi]);
+        uint32_t o0[U], o1[U], mq[U];
+        int32_t rs[U], re[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                                               // every chunk's fields are requested at once, with the call range's end
+            const uint32_t r = (uint32_t)(u * 64 + lane);
+            const uint32_t i = min(lo + r, hi ? hi - 1u : 0u);
+            o0[u] = a.cpg_off[i]; o1[u] = a.cpg_off[i + 1];
+            rs[u] = a.read_start[i]; re[u] = a.read_end[i]; mq[u] = a.read_mapq[i];
+        }
+        const uint32_t olast = __builtin_amdgcn_readfirstlane(a.cpg_off[hi]);
+        const uint32_t ofirst = R ? __builtin_amdgcn_readfirstlane(o0[0]) : olast;  // (lane 0 of chunk 0 is read lo)
         const uint32_t C_n = heavy ? 0u : olast - ofirst;                            // calls of the stretch's candidate reads
         if (C_n > (uint32_t)FW_CCAP) {
             if (sub_w > 192u) { sub_w = max((sub_w >> 1) & ~31u, 192u); continue; }
@@ -183,29 +228,20 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         if (!heavy) {
             reinterpret_cast<uint32_t *>(s_owner)[lane] = 0u;
             FW_SYNC();
-            uint32_t o0[U], o1[U], mq[U];
-            int32_t rs[U], re[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {                                           // every chunk's fields are requested at once
-                const uint32_t r = (uint32_t)(u * 64 + lane);
-                const uint32_t i = lo + (r < R ? r : 0u);
-                o0[u] = a.cpg_off[i]; o1[u] = a.cpg_off[i + 1];
-                rs[u] = a.read_start[i]; re[u] = a.read_end[i]; mq[u] = a.read_mapq[i];
-            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t r = (uint32_t)(u * 64 + lane);
                 fl[u] = 0u; ncall[u] = 0u;
                 if ((uint32_t)(u * 64) >= R) continue;                              // wave-uniform
                 const uint32_t n = r < R ? o1[u] - o0[u] : 0u;
-                const bool inr = r < R && (int64_t)rs[u] >= (int64_t)P0 - a.max_span + 1 && rs[u] <= P1;
+                const bool inr = r < R && (uint32_t)rs[u] - ((uint32_t)P0 - (uint32_t)a.max_span + 1u) <= Wp + (uint32_t)a.max_span - 1u;   // start in [P0 - max_span + 1, P1]
                 const bool pass = inr && mq[u] >= (uint32_t)a.min_qual && n > 0u;   // fdrp.rs:205, 208
                 if (pass) bad |= ((uint32_t)(re[u] - rs[u]) >= (uint32_t)a.max_span) ? 1u : 0u;   // max_span >= end - start + 1 (include/metheor_hip.h)
                 // start | end << 16 as window offsets (a passing read's start offset is >= 2: the word is non-zero exactly for them)
                 const uint32_t se = pass ? ((((uint32_t)rs[u] - wbase) & 0xffffu) | ((((uint32_t)re[u] - wbase) & 0xffffu) << 16)) : 0u;
                 *reinterpret_cast<uint4 *>(&s_row[r * 4]) = make_uint4(se, 0u, 0u, 0u);
                 if (n) s_owner[o0[u] - ofirst] = (uint8_t)(r + 1u);                 // the read's first call (offsets < C_n <= FW_CCAP)
-                fl[u] = pass ? (n > 8u ? FW_PASS | FW_BAD : FW_PASS) : 0u;          // (> 8 calls: its sites are handed back -- ncpg <= 8 in the quotient table)
+                fl[u] = pass ? FW_PASS : 0u;
                 ncall[u] = n;
             }
         } else {
@@ -313,7 +349,7 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
                 const uint32_t mA = (row.z >> 31) ? mC & ~(1u << (r0 & 31u)) : mC;
                 const uint32_t mM = row.w & mA;
                 if (fl[u] & FW_BAD) {
-                    // (> 8 calls, or > 16 window sites between its first and last call): every core site it calls is handed back
+                    // (> 16 window sites between its first and last call): every core site it calls is handed back
                     const uint32_t q0 = a.cpg_off[lo + r];
                     for (uint32_t k = q0; k < q0 + ncall[u]; ++k) {
                         const uint32_t rel = (a.cpg_pos[k] & 0x7fffffffu) - wbase;
@@ -340,9 +376,12 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         // handed back: a reader with > 8 calls / > 16 window sites; reservoir (fdrp.rs:87-94) / more reads than this kernel's list holds
         bool redo = in_core && ((sf >> 31) || (n_s > cap && n_s >= mind));
         const bool act = in_core && n_s >= mind && n_s <= cap && !redo;
-        uint32_t disc_vec = 0, nzoff_vec = 0, nzcnt_vec = 0;
+        uint32_t disc_vec = 0, nzoff_vec = 0, nzcnt_vec = 0, n_seg = 0;              // n_seg: stored reads when the readers form several segments
+        bool no_row = false;
+        const bool mo_any = a.min_overlap <= 0;                                      // every pair overlaps enough
+        const int32_t mo_m1 = a.min_overlap - 1;
         uint32_t nzbase = 0;                                                         // wave-uniform
-        unsigned long long todo = __ballot(act);
+        unsigned long long todo = fw_ballot(act);
         // the k-th pair of n reads in the reference's loop order comes from a table (a.pair_tab; the closed form is a square root and two
         // corrections per round); a site's first entries are requested while the site before it is in hand
         auto first_ent = [&](const unsigned long long m) -> uint32_t {
@@ -359,73 +398,100 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
             ent_site = first_ent(todo);
             const uint32_t rq = k0 + q;
             FW_SYNC();                                                               // the site before this one is done with the list
-            // the site's readers in file order: slot = readers in the chunks before + in the lanes below; the flush rule (fdrp.rs:212-223): a
-            // passing read before one of them whose first call lies beyond the site -- the readers may form two segments, the walk decides
+            // the site's readers in file order: slot = readers in the chunks before + in the lanes below
             uint32_t n = 0;
             bool flush = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if ((uint32_t)(u * 64) >= R) continue;                              // wave-uniform
                 const bool has = rq - r0r[u] < 16u && ((mCr[u] >> (rq & 31u)) & 1u);
-                const unsigned long long b = __ballot(has);
-                flush = flush || __ballot(has && pmr[u] > rq + 1u) != 0ull;
-                if (has) s_list[min(__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, n)), (uint32_t)FW_LCAP - 1u)] = (uint8_t)(u * 64 + lane);
+                const unsigned long long b = fw_ballot(has);
+                // a passing read before one of them whose first call lies beyond the site (fdrp.rs:212): the readers may form two segments
+                flush = flush || fw_ballot(has && pmr[u] > rq + 1u) != 0ull;
+                if (has) s_list[min(__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, n)), (uint32_t)FW_LCAP - 1u)] = (uint16_t)((u * 64 + lane) * 16);
                 n += (uint32_t)__popcll(b);
             }
+#ifndef MTH_FW_FLUSH_EXACT
+            // (the segments can be told apart here -- -DMTH_FW_FLUSH_EXACT, parity-green: the kernel then takes 8 % longer for EVERY site, whether
+            // the branch's code sits here, in a loop of its own behind this one, or out of line (15 %); a site per thousand is not worth it)
             if (flush) { if ((uint32_t)lane == q) redo = true; continue; }
-            FW_SYNC();
-            const uint32_t P = n * (n - 1u) / 2u;
-            const uint16_t *const tab = a.pair_tab + (n * (n - 1u) * (n - 2u)) / 6u;   // (n <= 1: no pair, the table is not read)
-            uint32_t disc = 0, nz0 = nzbase;
-            uint32_t ent_next = ent_first;
-            for (uint32_t k0p = 0; k0p < P; k0p += 64u) {
-                const uint32_t ent = ent_next;
-                if (k0p + 64u < P) ent_next = tab[min(k0p + 64u + (uint32_t)lane, P - 1u)];
-                const uint32_t li = s_list[ent & 0xffu], lj = s_list[ent >> 8];
-                const uint4 ri = *reinterpret_cast<const uint4 *>(&s_row[li * 4]), rj = *reinterpret_cast<const uint4 *>(&s_row[lj * 4]);
-                const int32_t si = (int32_t)(ri.x & 0xffffu), ei = (int32_t)(ri.x >> 16), sj = (int32_t)(rj.x & 0xffffu), ej = (int32_t)(rj.x >> 16);
-                const int32_t ovl = min(ei, ej) - max(si, sj) + 1;                   // get_num_overlap_bases, fdrp.rs:97-107
-                const bool pair_ok = (k0p + (uint32_t)lane < P) && max(ovl, 0) >= a.min_overlap;   // fdrp.rs:134
-                const uint32_t ncpg = (uint32_t)__builtin_popcount(ri.y & rj.y);     // qfdrp.rs:109-119
-                const uint32_t ham = (uint32_t)__builtin_popcount(ri.z & rj.z & (ri.w ^ rj.w));   // fdrp.rs:114-115
-                const bool dsc = pair_ok && ham != 0u;                               // fdrp.rs:138-140; exactly the pairs with a non-zero term
-                const unsigned long long nzb = __ballot(dsc);
-                if (nzb == 0ull) continue;                                           // wave-uniform
-                const float term = (float)ham / (float)ncpg;                         // qfdrp.rs:152
-                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzb, nzbase));
-                if (dsc && slot < (uint32_t)FW_NZCAP) s_nz[slot] = term;
-                const uint32_t c = (uint32_t)__popcll(nzb);
-                disc += c; nzbase += c;
+#else
+            if (flush) {
+                // (rare: a few sites per thousand)  The flush rule, exactly (fdrp.rs:212-223): a passing read whose first call lies beyond the
+                // site closes the open segment; two readers share a segment iff no such read lies between them.  F = flushers before a
+                // reader (file order; a read's first-call rank is 0 unless it passes); the LAST segment that holds >= min_depth readers is
+                // the site's row (the map's insert overwrites).  Everything is recomputed from the per-read registers the loop holds anyway:
+                // keeping two more alive across the round loop cost 10 % for every site, a call out of line 15 %.
+                auto seg_of = [&](const int u, const uint32_t before) {              // F + 1 of the chunk's readers, 0 for the other lanes
+                    const bool has = rq - r0r[u] < 16u && ((mCr[u] >> (rq & 31u)) & 1u);
+                    const unsigned long long fm = fw_ballot(r0r[u] > rq);
+                    return has ? __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, before)) + 1u : 0u;
+                };
+                const uint32_t f0 = (uint32_t)__popcll(fw_ballot(r0r[0] > rq));       // flushers of the first chunk
+                uint32_t top = max(fw_wave_max(seg_of(0, 0u)), fw_wave_max(seg_of(1, f0)));
+                n = 0;
+                while (top) {                                                        // top - 1: the segment looked at (wave-uniform)
+                    const uint32_t sg0 = seg_of(0, 0u), sg1 = seg_of(1, f0);
+                    const uint32_t c = (uint32_t)__popcll(fw_ballot(sg0 == top)) + (uint32_t)__popcll(fw_ballot(sg1 == top));
+                    if (c >= mind) { n = c; break; }
+                    top = max(fw_wave_max(sg0 < top ? sg0 : 0u), fw_wave_max(sg1 < top ? sg1 : 0u));
+                }
+                if (n == 0u) { if ((uint32_t)lane == q) no_row = true; continue; }   // no segment reaches min_depth (fdrp.rs:239-243)
+                FW_SYNC();
+                const bool h0 = seg_of(0, 0u) == top, h1 = seg_of(1, f0) == top;
+                const unsigned long long b0 = fw_ballot(h0), b1 = fw_ballot(h1);
+                if (h0) s_list[min(__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)), (uint32_t)FW_LCAP - 1u)] = (uint16_t)(lane * 16);
+                if (h1) s_list[min(__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, (uint32_t)__popcll(b0))), (uint32_t)FW_LCAP - 1u)] = (uint16_t)((64 + lane) * 16);
+                if ((uint32_t)lane == q) n_seg = n;
             }
+#endif
+            FW_SYNC();
+            const uint32_t nz0 = nzbase;
+            // (the table entries were requested for n_s readers: another n after a flush)
+            const uint32_t Pn = n * (n - 1u) / 2u;
+            const uint32_t ent0 = !flush ? ent_first : (Pn ? (uint32_t)a.pair_tab[(n * (n - 1u) * (n - 2u)) / 6u + min((uint32_t)lane, Pn - 1u)] : 0u);
+            const uint32_t disc = fw_rounds(s_list, s_row, s_nz, a.pair_tab, lane, n, ent0, nzbase, mo_any, mo_m1);
             if (nzbase > (uint32_t)FW_NZCAP) {                                       // the term array is full: this site goes to the walk
                 nzbase = nz0;
                 if ((uint32_t)lane == q) redo = true;
-                continue;
-            }
-            if ((uint32_t)lane == q) { disc_vec = disc; nzoff_vec = nz0; nzcnt_vec = nzbase - nz0; }
+            } else if ((uint32_t)lane == q) { disc_vec = disc; nzoff_vec = nz0; nzcnt_vec = nzbase - nz0; }
         }
         FW_TK(4);
         FW_SYNC();
         // ---- D2: one lane per site ----
-        const bool emit = redo || act;
+        const bool emit = (redo || act) && !no_row;
         FdRec rec;
         rec.pos = 0; rec.f = 0.0f; rec.q = 0.0f; rec.nf = 4u << 24;
         if (emit) {
             rec.pos = s_cpos[lane & (FW_SC - 1)];
             if (!redo) {
                 float q = 0.0f;
-                for (uint32_t i = 0; i < nzcnt_vec; ++i) q += s_nz[nzoff_vec + i];   // qfdrp.rs:152, the reference's order (x + 0.0 == x: the zero terms are not kept)
+                // qfdrp.rs:152, the reference's order (x + 0.0 == x: the zero terms are not kept); four codes, then their four quotients, per trip
+                uint32_t i = 0;
+                for (; i + 4u <= nzcnt_vec; i += 4u) {
+                    const uint32_t c0 = s_nz[nzoff_vec + i], c1 = s_nz[nzoff_vec + i + 1u], c2 = s_nz[nzoff_vec + i + 2u], c3 = s_nz[nzoff_vec + i + 3u];
+                    const float t0 = s_quot[c0], t1 = s_quot[c1], t2 = s_quot[c2], t3 = s_quot[c3];
+                    q += t0; q += t1; q += t2; q += t3;
+                }
+                for (; i < nzcnt_vec; ++i) q += s_quot[s_nz[nzoff_vec + i]];
                 // (num_reads * (num_reads - 1)) as f32 / 2.0 in usize arithmetic (fdrp.rs:143)
-                const unsigned long long prod = (unsigned long long)n_s * (unsigned long long)(n_s - 1u);
+                const uint32_t nr = n_seg ? n_seg : n_s;
+                const unsigned long long prod = (unsigned long long)nr * (unsigned long long)(nr - 1u);
                 const float den = (float)prod / 2.0f;
-                rec.f = (float)disc_vec / den; rec.q = q / den; rec.nf = n_s | (1u << 24);
+                rec.f = (float)disc_vec / den; rec.q = q / den; rec.nf = nr | (1u << 24);
             }
         }
-        const unsigned long long em = __ballot(emit);
+        const unsigned long long em = fw_ballot(emit);
         if (emit && rows_out + (uint32_t)__popcll(em & lt_mask) < a.rows_per_tile) out[rows_out + (uint32_t)__popcll(em & lt_mask)] = rec;
         rows_out += (uint32_t)__popcll(em);
         FW_TK(5);
 #ifdef MTH_FW_TRACE
+        if (a.trace && P0 == T0) {   // why sites were handed back: a reader spanning > 16 window sites; more reads than the list holds; a possible flush; terms
+            const unsigned long long m1 = fw_ballot(in_core && (sf >> 31)), m2 = fw_ballot(in_core && !(sf >> 31) && n_s > cap && n_s >= mind), m3 = fw_ballot(redo) & ~m1 & ~m2;
+            unsigned long long nb = 0;
+            for (int u = 0; u < U; ++u) nb += (unsigned long long)__popcll(fw_ballot((fl[u] & FW_BAD) != 0u));
+            if (lane == 0) { a.trace[(size_t)t * 12 + 7] = (unsigned long long)__popcll(m1); a.trace[(size_t)t * 12 + 8] = (unsigned long long)__popcll(m2); a.trace[(size_t)t * 12 + 9] = (unsigned long long)__popcll(m3); a.trace[(size_t)t * 12 + 10] = nb; }
+        }
         if (lane == 0 && a.trace && P0 == T0) { a.trace[(size_t)t * 12] = 1ull; a.trace[(size_t)t * 12 + 1] = tk[0] - tk[11]; for (int k = 1; k < 6; ++k) a.trace[(size_t)t * 12 + 1 + k] = tk[k] - tk[k - 1]; }
 #endif
         P0l = P1;
@@ -526,8 +592,8 @@ int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_
     MTH_HIP(ctx, hipMemsetAsync(ctx->tile_bucket.p, 0, (size_t)nbk * sizeof(unsigned long long), s));
     MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * rows_per_tile * sizeof(FdRec), s));
     if (!ctx->f_quot.p) {
-        MTH_HIP(ctx, ctx->f_quot.reserve(128 * sizeof(float), s));
-        hipLaunchKernelGGL(k_fw_quot, dim3(1), dim3(128), 0, s, ctx->f_quot.as<float>());
+        MTH_HIP(ctx, ctx->f_quot.reserve(192 * sizeof(float), s));
+        hipLaunchKernelGGL(k_fw_quot, dim3(1), dim3(192), 0, s, ctx->f_quot.as<float>());
     }
     FwArgs a;
     a.read_start = d.read_start; a.read_end = d.read_end; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
@@ -570,6 +636,7 @@ int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_
         for (size_t q = 0; q < ntiles; ++q) for (int k = 0; k < 12; ++k) h[k] += (double)hv[q * 12 + k];
         fprintf(stderr, "[fdrp wtile trace] W %d tiles %.0f; cycles of a tile's first stretch: head %.0f  A %.0f  B %.0f  C %.0f  D1 %.0f  D2+rows %.0f\n",
                 W, h[0], h[1] / h[0], h[2] / h[0], h[3] / h[0], h[4] / h[0], h[5] / h[0], h[6] / h[0]);
+        fprintf(stderr, "[fdrp wtile trace] handed back (first stretches): wide reader %.0f  deep %.0f  flush / terms %.0f;  wide readers %.0f\n", h[7], h[8], h[9], h[10]);
     }
 #endif
     MTH_HIP(ctx, hipGetLastError());
