@@ -182,8 +182,9 @@ class DeviceBatch:
 
 class PreparedBatch:
     """what Engine.batch_prepare returns: a batch (mem = MTH_MEM_PREPARED) every *_accumulate method takes in place of the original --
-    device-resident, its read index built once and shared by the measures.  Keeps the original alive; release() (or the engine's
-    close) frees the index and the device copies of a host batch."""
+    device-resident, its read index built once and shared by the measures.  Keeps the original alive; release() frees the index and the
+    device copies of a host batch; what is not released, the engine's close frees (the context keeps a registry of its prepared
+    batches and validates a handle by look-up)."""
 
     def __init__(self, eng, orig):
         self.eng, self.orig = eng, orig

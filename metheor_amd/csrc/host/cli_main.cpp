@@ -298,12 +298,12 @@ struct Phase {
 // runtime cost tens of milliseconds that nobody reads the result of: the process leaves through _exit and the driver
 // reclaims everything (METHEOR_TEARDOWN=1 keeps the orderly release, e.g. under a leak checker).
 int finish(mth_ctx_t *ctx, mth_host_t *h) {
-    {   // a CIGAR P operation was decoded: this engine takes it as "no query base, no reference base"; the reference is believed to stop
-        // there (rust-htslib's reference_positions_full, readutil.rs:28) -- said once, on stderr, instead of silently accepted
+    {   // a CIGAR P operation was decoded: this engine takes it as "no query base, no reference base" (the SAM specification's meaning);
+        // what the reference's BAM crate does with it cannot be checked here -- the note says what THIS engine did
         static std::atomic<bool> said{false};
         if ((((ctx ? mth_notes(ctx) : 0u) | mth_host_notes()) & MTH_NOTE_CIGAR_PAD) && !said.exchange(true))
-            fprintf(stderr, "metheor: note: the input holds CIGAR 'P' (padding) operations; they were taken as covering no base -- rust-htslib 0.50 "
-                            "(reference_positions_full) is believed to panic on Cigar::Pad, so the reference may not accept this file\n");
+            fprintf(stderr, "metheor: note: the input holds CIGAR 'P' (padding) operations; they were taken as covering no query base and no "
+                            "reference base\n");
     }
     if (g_shard.world > 1) return 0;      // a shard's thread: main() writes the files and leaves
     if (getenv("METHEOR_TEARDOWN")) {

@@ -94,8 +94,13 @@ int enter(mth_ctx *ctx) {
     // the next one settles them first -- the caller may be about to rewrite what a replay would read (mth_decoded_batch rebuilds the
     // offsets array the previous decoded batch points into), and "the next synchronising call" of the header's contract is any of them
     if (!rc && !ctx->tile_queue_hold) {
+        // (the resolves clear the "prepared batch of the call in progress" for their replays: the call that is entering keeps its own --
+        // a growth sync behind stage_batch must not make it drop its prepared index and rebuild one: ADVICE r05)
+        Prepared *const prep = ctx->cur_prep;
+        const uint32_t *const idx = ctx->cur_idx;
         if (!ctx->q_pending.empty()) rc = quartet_resolve(ctx);
         if (!rc && !ctx->p_pending.empty()) rc = pairs_resolve(ctx);
+        ctx->cur_prep = prep; ctx->cur_idx = prep ? idx : nullptr;
     }
     return rc;
 }
@@ -167,6 +172,21 @@ static int stage(mth_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, const
     return MTH_OK;
 }
 
+Prepared *prepared_lookup(const mth_ctx *ctx, const void *handle) {
+    Prepared *pr = const_cast<Prepared *>(reinterpret_cast<const Prepared *>(handle));
+    return (pr && ctx->prepared.count(pr)) ? pr : nullptr;
+}
+
+void prepared_free(mth_ctx *ctx, Prepared *pr) {
+    ctx->prepared.erase(pr);
+    if (ctx->cur_prep == pr) { ctx->cur_prep = nullptr; ctx->cur_idx = nullptr; }
+    for (DevBuf &x : pr->own) x.release();
+    pr->idx.release();
+    if (pr->st) (void)hipFree(pr->st);
+    pr->magic = 0;
+    delete pr;
+}
+
 int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &d, bool join) {
     if (b.region_end < b.region_beg || b.max_span < 0) return fail(ctx, MTH_ERR_INVALID, "bad region / max_span");
     // a contig group's handle must be defined -- checked here, before any accumulate entry point has recorded anything of the batch
@@ -174,8 +194,13 @@ int stage_batch(mth_ctx *ctx, const mth_batch_t &b, mth_batch_t &d, bool join) {
     ctx->cur_prep = nullptr; ctx->cur_idx = nullptr;
     if (b.mem == MTH_MEM_PREPARED) {
         // a batch made by mth_batch_prepare: device-resident, its read index built -- the handle rides in read_fwd
-        Prepared *pr = const_cast<Prepared *>(reinterpret_cast<const Prepared *>(b.read_fwd));
-        if (!pr || pr->magic != Prepared::MAGIC || pr->owner != ctx) return fail(ctx, MTH_ERR_INVALID, "not a batch prepared by this context (mth_batch_prepare)");
+        // (validated by look-up in the context's registry: a released handle, a copy used after release, another context's)
+        Prepared *pr = prepared_lookup(ctx, b.read_fwd);
+        if (!pr) return fail(ctx, MTH_ERR_INVALID, "not a batch prepared by this context (mth_batch_prepare), or released");
+        // the entry points size their outputs from the caller's struct and run the kernels on the prepared one: they must agree
+        if (b.n_reads != pr->dev.n_reads || b.n_cpgs != pr->dev.n_cpgs || b.region_beg != pr->dev.region_beg || b.region_end != pr->dev.region_end ||
+            b.max_span != pr->dev.max_span)
+            return fail(ctx, MTH_ERR_INVALID, "a prepared batch's n_reads / n_cpgs / region / max_span were changed after mth_batch_prepare");
         if (join) MTH_ENTER(ctx); else MTH_HIP(ctx, hipSetDevice(ctx->device));
         d = pr->dev;
         d.tid = b.tid;                                   // (the caller may submit it under a contig group's handle)
@@ -289,6 +314,7 @@ void mth_ctx_destroy(mth_ctx_t *ctx) {
     if (ctx->stage_thread.joinable()) ctx->stage_thread.join();
     for (PdrLane &l : ctx->lane) if (l.stream) (void)hipStreamSynchronize(l.stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    while (!ctx->prepared.empty()) prepared_free(ctx, *ctx->prepared.begin());   // prepared batches the caller did not release
     rccl_release(ctx);
     for (PdrLane &l : ctx->lane) {
         for (DevBuf *b : {&l.idx, &l.tile_cnt, &l.tile_bucket, &l.scratch}) b->release();
@@ -379,22 +405,19 @@ int mth_batch_prepare(mth_ctx_t *ctx, const mth_batch_t *batch, mth_batch_t *pre
 #undef PREP_HIP
     *prepared = pr->dev;
     prepared->mem = MTH_MEM_PREPARED;
-    prepared->read_fwd = reinterpret_cast<const uint8_t *>(pr.release());
+    mth::Prepared *raw = pr.release();
+    ctx->prepared.insert(raw);
+    prepared->read_fwd = reinterpret_cast<const uint8_t *>(raw);
     return MTH_OK;
 }
 
 int mth_batch_release(mth_ctx_t *ctx, mth_batch_t *prepared) {
     if (!ctx || !prepared || prepared->mem != MTH_MEM_PREPARED) return MTH_ERR_INVALID;
-    mth::Prepared *pr = const_cast<mth::Prepared *>(reinterpret_cast<const mth::Prepared *>(prepared->read_fwd));
-    if (!pr || pr->magic != mth::Prepared::MAGIC || pr->owner != ctx) return mth::fail(ctx, MTH_ERR_INVALID, "not a batch prepared by this context");
+    mth::Prepared *pr = mth::prepared_lookup(ctx, prepared->read_fwd);
+    if (!pr) return mth::fail(ctx, MTH_ERR_INVALID, "not a batch prepared by this context, or released already");
     MTH_ENTER(ctx);
     (void)hipStreamSynchronize(ctx->stream);             // nothing queued may still read the index or the owned arrays
-    if (ctx->cur_prep == pr) { ctx->cur_prep = nullptr; ctx->cur_idx = nullptr; }
-    for (mth::DevBuf &x : pr->own) x.release();
-    pr->idx.release();
-    if (pr->st) (void)hipFree(pr->st);
-    pr->magic = 0;
-    delete pr;
+    mth::prepared_free(ctx, pr);
     prepared->read_fwd = nullptr;                        // still marked MTH_MEM_PREPARED, without a handle: every entry point refuses it
     return MTH_OK;
 }

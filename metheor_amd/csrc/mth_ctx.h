@@ -5,6 +5,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "mth_common.h"
@@ -66,6 +67,9 @@ struct mth_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string last_error;
+    // the prepared batches this context owns (mth_batch_prepare): a handle is valid iff it is in here -- never dereferenced to find out;
+    // mth_ctx_destroy frees what the caller did not release
+    std::unordered_set<mth::Prepared *> prepared;
     mth::Prepared *cur_prep = nullptr;   // the batch of the entry point in progress is a prepared one (set by stage_batch, every call)
     const uint32_t *cur_idx = nullptr;   // the fine read index the call's kernels use: the prepared batch's, or ctx->idx after a build
     uint32_t notes = 0;                 // mth_notes(): non-fatal findings so far (MTH_NOTE_*)
@@ -212,6 +216,9 @@ bool has_group_batch(const mth_ctx *ctx, int which);      // any grouped batch a
 // device table of a group handle (n voff as int32, then n tids), nullptr / 0 for a plain tid
 const int32_t *group_table(const mth_ctx *ctx, int32_t tid, uint32_t *n);
 int  pipe_join(mth_ctx *ctx);
+// the context's prepared batch behind a caller's handle, nullptr if it is not one of them (released, another context's, made up)
+Prepared *prepared_lookup(const mth_ctx *ctx, const void *handle);
+void prepared_free(mth_ctx *ctx, Prepared *pr);           // buffers + the object itself; the registry entry goes with it
 #define MTH_ENTER(ctx)                                                  \
     do {                                                                \
         const int rc__ = mth::enter(ctx);                               \

@@ -216,3 +216,39 @@ def test_prepared_group_and_region_batches():
         assert (want["mhl"]["pos"] == o.pos[:, 0]).all() and np.abs(want["mhl"]["mhl"].astype(np.float64) - o.val).max() <= 1e-6
     finally:
         eng.close()
+
+
+def test_handle_validation_by_registry_and_free_on_close():
+    """a prepared batch's handle is validated by look-up in the context's registry, never by dereferencing it -- a copy
+    used after release, a second release and an edited copy are refused; what the caller does not release, the context's close frees
+    (a release after the close is a no-op, not a crash)"""
+    import copy
+    import metheor_amd
+    from metheor_amd import synth
+    c = synth.make_contig(0, 200_000, 8_000, 0.02, np.random.default_rng(5))
+    eng = metheor_amd.Engine(0)
+    bt = util.device_batch(c, device="cuda:0")
+    p = eng.batch_prepare(bt)
+    eng.pdr_lpmd_accumulate(p, metheor_amd.PdrLpmdParams())
+    n0 = len(eng.pdr_fetch()["pos"])
+    assert n0 > 100
+    stale = copy.copy(p)                                   # the caller's own copy of the struct
+    stale.c = type(p.c).from_buffer_copy(p.c)
+    # an edited copy: the entry points size their outputs from the caller's struct
+    edited = copy.copy(p)
+    edited.c = type(p.c).from_buffer_copy(p.c)
+    edited.c.n_cpgs = p.c.n_cpgs // 2
+    with pytest.raises(metheor_amd.MthError) as ei:
+        eng.pdr_lpmd_accumulate(edited, metheor_amd.PdrLpmdParams())
+    assert ei.value.status == -1
+    p.release()
+    with pytest.raises(metheor_amd.MthError):              # the copy still carries the pointer: refused by look-up
+        eng.pdr_lpmd_accumulate(stale, metheor_amd.PdrLpmdParams())
+    with pytest.raises(metheor_amd.MthError):
+        stale.eng._check(stale.eng.L.mth_batch_release(stale.eng.h, metheor_amd.capi.C.byref(stale.c)))
+    # outstanding prepared batches at close: freed by the context
+    q1, q2 = eng.batch_prepare(bt), eng.batch_prepare(bt)
+    eng.mhl_accumulate(q1)
+    assert len(eng.mhl_fetch()["pos"]) > 0
+    eng.close()
+    q1.release(); q2.release()                             # after the close: nothing to do

@@ -3,7 +3,8 @@ thing the region shards share).  Every test here needs at least two visible GPUs
 tested on so far; on the first multi-GPU lease they are the first execution of RCCL between two devices WITH an assertion behind it:
 
 * `mth_allreduce_lpmd` over two contexts on two devices in one process (ncclCommInitAll) against the oracle's counters;
-* `mth_rccl_init_rank` + `mth_allreduce_lpmd_rank`, one process per GPU under `torch.distributed.run --nproc-per-node 2`;
+* `mth_rccl_init_rank` + `mth_allreduce_lpmd_rank`, one process per GPU under `torch.distributed.run --nproc-per-node 2` -- once,
+  and 13 times in a row (more reduces than the ring of slots holds: the reuse of a slot behind its done-event);
 * `metheor lpmd --gpus 2` and `metheor pdr --gpus 2` with the shards on distinct devices, against the oracle's text;
 * `bench.py --gpus 2`, weak and strong, `world_seen == 2` and no `"valid": false` in the line (that key marks the shared-device
   launcher test of tests/test_gpu_multirank.py).
@@ -95,6 +96,64 @@ print("RANK_RESULT " + json.dumps({"rank": rank, "device": local, **{k: int(g[k]
 e.close()
 dist.destroy_process_group()
 '''
+
+
+_RING_SCRIPT = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import metheor_amd
+from metheor_amd import PdrLpmdParams, synth
+from tests import util
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+local = int(os.environ.get("LOCAL_RANK", rank))
+torch.cuda.set_device(local)
+dist.init_process_group("gloo")
+rng = np.random.default_rng(5)
+cs = [synth.make_contig(0, 400_000, 60_000, 0.03, rng), synth.make_contig(1, 250_000, 35_000, 0.03, rng)]
+uid = [metheor_amd.Engine.rccl_unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid, src=0)
+e = metheor_amd.Engine(local)
+e.rccl_init_rank(uid[0], rank, world)
+bt = util.device_batch(cs[rank], device="cuda:%%d" %% local)
+e.reset()
+K = ("n_concordant", "n_discordant", "n_read", "n_valid_read")
+# (a) more reduces than the ring has slots (RED_RING = 4), back to back, nothing read in between: every slot is reused behind its
+#     done-event while the next batches' kernels are queued; the counters keep running (no reset), so the last reduce holds 7 x the totals
+for it in range(7):
+    e.pdr_lpmd_accumulate(bt, PdrLpmdParams())
+    e.allreduce_lpmd_rank()
+g = e.lpmd_global()
+print("RING_RESULT " + json.dumps({"rank": rank, "phase": "a", "mult": 7, **{k: int(g[k]) for k in K}}), flush=True)
+# (b) a read-back after every reduce (each drains the side stream): 8 x, 9 x, ... 13 x
+for it in range(6):
+    e.pdr_lpmd_accumulate(bt, PdrLpmdParams())
+    e.allreduce_lpmd_rank()
+    g = e.lpmd_global()
+    print("RING_RESULT " + json.dumps({"rank": rank, "phase": "b", "mult": 8 + it, **{k: int(g[k]) for k in K}}), flush=True)
+e.close()
+dist.destroy_process_group()
+'''
+
+
+@need2
+def test_allreduce_rank_form_ring_slot_reuse(tmp_path):
+    """VERDICT r05 item 7: mth_allreduce_lpmd_rank reduces out of place in a ring of RED_RING = 4 slots on a side stream (mth_rccl.hip: a slot is
+    reused behind its done-event) -- the one intricate part of the exchange step.  More reduces than slots, back to back and with a
+    read-back after each; the k-th reduce must hold k x the two ranks' totals (the counters are not reset in between)."""
+    from metheor_amd import synth
+    script = tmp_path / "ring.py"
+    script.write_text(_RING_SCRIPT % dict(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29633", str(script)], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    got = [json.loads(l.split(" ", 1)[1]) for l in r.stdout.splitlines() if l.startswith("RING_RESULT ")]
+    assert len(got) == 2 * 7
+    want = pyoracle.Reads.from_soa(*synth.concat_oracle_soa(_two_contigs())).lpmd()
+    for g in got:
+        for k in ("n_concordant", "n_discordant", "n_read", "n_valid_read"):
+            assert g[k] == g["mult"] * want[k], (g, k, want[k])
 
 
 @need2

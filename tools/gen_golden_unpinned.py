@@ -16,6 +16,22 @@ bam/ext.rs `BamRecordExtensions::reference_positions_full` = aligned_pairs_full(
 position, mapped to their reference position: one Option<i64> per QUERY base; M / = / X advance both and yield Some(ref); I and S
 yield None per base; D and N advance the reference only (nothing yielded: no query base); H yields nothing; P panics
 ("Padding (Cigar::Pad) is not supported.") -- that last one is recalled, not verifiable here, and is not part of the cases.
+
+CHECKLIST for a maintainer with `cargo` (rust-htslib 0.50.0, hts-sys 2.2.0): everything below is RECALLED, not read -- the crate is not
+under /root/reference.  Each line is one assumption the 52 record sets depend on; the Rust one-liner next to it checks it.
+  1. `Record::reference_positions_full()` yields exactly one item per query base (seq_len items; `H` and `P` add none).
+  2. For `M`, `=`, `X` the item is Some(reference position), 0-based, ascending by one per base.
+  3. For `I` and `S` the item is None (the base exists in the query, has no reference position).
+  4. `D` and `N` yield no item and advance the reference position by their length.
+  5. `Record::pos()` is the 0-based leftmost aligned position; the first non-None item equals it (readutil.rs:28-33 takes first / last
+     non-None as start_pos / end_pos -- so a read that begins with `S` or `I` starts at pos(), not before it).
+  6. `Record::flags()` is the raw u16 FLAG; the reference compares it with the literals 0, 99, 147 (readutil.rs:332-340), so 16, 83, 163
+     and every flag with a secondary / duplicate / QC bit take the `abspos - 1` arm -- nothing here depends on rust-htslib for that.
+  7. `Record::aux(b"XM")` returns the XM:Z string with one character per QUERY base (Bismark's convention), indexed by the same
+     query index as reference_positions_full (readutil.rs:326-330).
+  8. `Record::mapq()` is the raw u8; `Record::tid()` the i32 reference id, -1 for unmapped.
+  9. `HeaderView::tid2name` / `tid` map ids and names in @SQ order (bamutil.rs:17-25).
+     check: `for (i, p) in rec.reference_positions_full().enumerate() { println!("{i} {p:?}") }` on a record with CIGAR 3S5M2I4M3D6M2N5M.
 """
 import json
 import os
