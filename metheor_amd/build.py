@@ -22,7 +22,7 @@ HOST_LIB = os.path.join(HERE, "libmetheor_host.so")
 HOST_SOURCES = [os.path.join("host", "bam_reader.cpp"), os.path.join("host", "host_api.cpp"),
                 os.path.join("host", "parallel_decode.cpp"), os.path.join("host", "synth_bam.cpp"), os.path.join("host", "bai_index.cpp"), os.path.join("host", "sam_text.cpp")]
 HOST_HEADERS = [os.path.join("host", "bam_reader.h"), os.path.join("host", "parallel_decode.h"), os.path.join("host", "bai_internal.h"), os.path.join("host", "sam_text.h"), os.path.join("..", "..", "include", "metheor_host.h")]
-HEADERS = ["mth_common.h", "mth_ctx.h", "mth_scan.h", "mth_tile_dev.h", os.path.join("..", "..", "include", "metheor_hip.h")]
+HEADERS = ["mth_common.h", "mth_ctx.h", "mth_scan.h", "mth_tile_dev.h", "mth_wave_tile.h", os.path.join("..", "..", "include", "metheor_hip.h")]
 
 
 def _hipcc():

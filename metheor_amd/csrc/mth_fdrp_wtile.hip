@@ -36,6 +36,7 @@
 #include "mth_ctx.h"
 #include "mth_scan.h"
 #include "mth_tile_dev.h"
+#include "mth_wave_tile.h"
 
 namespace mth {
 
@@ -73,34 +74,6 @@ constexpr int FW_NZCAP = 1024;                           // non-zero qFDRP terms
 constexpr int FW_QC = 17 * 18 / 2;                      // codes ncpg (ncpg + 1) / 2 + ham, ham <= ncpg <= 16 (a reader's calls span <= 16 window sites)
 constexpr uint32_t FW_PASS = 1u, FW_BAD = 2u;           // per-read flags
 static_assert(FW_U == 2 && FW_WMAX + 2 * 200 + 1 <= 64 * 32 && FW_RCAP <= 256, "one bitmap word per lane; 8-bit read slots");
-
-__device__ __forceinline__ uint32_t fw_wave_max(uint32_t v) {   // wave-uniform result
-    v = max(v, MTH_DPP(v, 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x4e /*quad_perm [2,3,0,1]*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x141 /*row_half_mirror*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x140 /*row_mirror*/, 0xf, true));
-    // (readlane returns int: the maxima are taken as unsigned)
-    return max(max((uint32_t)__builtin_amdgcn_readlane(v, 0), (uint32_t)__builtin_amdgcn_readlane(v, 16)),
-               max((uint32_t)__builtin_amdgcn_readlane(v, 32), (uint32_t)__builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ uint32_t fw_wave_scan_max_incl(uint32_t v) {   // values >= 0; lanes outside a row read 0
-    v = max(v, MTH_DPP(v, 0x111 /*row_shr:1*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x112 /*row_shr:2*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x114 /*row_shr:4*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x118 /*row_shr:8*/, 0xf, true));
-    v = max(v, MTH_DPP(v, 0x142 /*row_bcast:15*/, 0xa, false));
-    v = max(v, MTH_DPP(v, 0x143 /*row_bcast:31*/, 0xc, false));
-    return v;
-}
-// lane `idx` of vec <- val (both wave-uniform, SALU-made: no VALU-written SGPR feeds the lane select)
-__device__ __forceinline__ uint32_t fw_writelane(uint32_t vec, const uint32_t val, const uint32_t idx) {
-    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(idx) : "m0");   // (one SGPR operand per VALU instruction on gfx9: the lane select goes through m0)
-    return vec;
-}
-// the lanes where p holds, as a mask (hip's __ballot goes through a select and a compare: two vector instructions more per call)
-__device__ __forceinline__ unsigned long long fw_ballot(const bool p) { return __builtin_amdgcn_ballot_w64(p); }
-// the wave's LDS writes are visible to its later reads (one wave per workgroup: no s_barrier)
-#define FW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 __global__ void k_fw_quot(float *q) {   // ham / ncpg by the same f32 division the reference does (qfdrp.rs:152); ncpg = 0 is never looked up
     const uint32_t t = threadIdx.x;

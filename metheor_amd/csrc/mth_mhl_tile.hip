@@ -624,7 +624,15 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     // and few enough candidate reads for the 16-bit bins.  A tile is a chain of ~6 dependent round trips and ~10 barriers whatever it
     // holds, so the widest tile that fits wins: config-3 density 0.319 / 0.220 / 0.144 ms at 4096 / 8192 / 16384 bp, config 2 0.209 /
     // 0.204 at 4096 / 8192 (16384 overflows the slots there: 1.27 ms)
-    int shift = 12;
+    // (round 6: the one-wave-per-tile form that pays for FDRP was built for MHL too -- parity-green and 30 % slower than this kernel, whose
+    // tile is eleven times larger: profiles/r06_mhl_wtile.md, tools/experiments/mth_mhl_wtile.hip)
+    const bool wt = false;
+    int shift = 12, W = 0;
+    int32_t idx_base = 0;
+    uint32_t ntiles = 0;
+    MhlTileArgs a;
+    a.trace = nullptr;
+    if (!wt) {
     {
         const double sites_per_bp = (double)d.n_cpgs / (double)d.n_reads / (double)std::max(d.max_span, 1);
         const double reads_per_bp = (double)d.n_reads / (double)region_len;
@@ -633,9 +641,7 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
             ++shift;
     }
     if (const char *e = getenv("MTH_MHL_TILE_SHIFT")) shift = std::min(16, std::max(12, atoi(e)));   // tests / tuning
-    const int W = 1 << shift;
-    int32_t idx_base = 0;
-    uint32_t ntiles = 0;
+    W = 1 << shift;
     int rc = build_read_index(ctx, d, W, idx_base, ntiles);
     if (rc) return rc;
     const uint32_t nbk = (ntiles + (1u << TILE_BUCKET_SHIFT) - 1) >> TILE_BUCKET_SHIFT;
@@ -643,7 +649,6 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     MTH_HIP(ctx, ctx->tile_bucket.reserve((size_t)nbk * 5 * sizeof(unsigned long long), s));
     MTH_HIP(ctx, hipMemsetAsync(ctx->tile_bucket.p, 0, (size_t)nbk * sizeof(unsigned long long), s));
     MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * W * sizeof(MhlRec), s));
-    MhlTileArgs a;
     a.read_start = d.read_start; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos; a.idx = idx_ptr(ctx);
     a.region_beg = d.region_beg; a.region_end = d.region_end; a.idx_base = idx_base; a.max_span = d.max_span;
     a.n_reads = d.n_reads; a.ntiles = ntiles; a.n_cpgs = (uint32_t)d.n_cpgs; a.min_depth = p.min_depth; a.min_cpgs = p.min_cpgs;
@@ -676,6 +681,7 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
                            ctx->tile_bucket.as<unsigned long long>(), ntiles, (uint32_t)W, ctx->d_state2, ctx->s_pos.as<int32_t>(),
                            ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->w_flags.as<uint32_t>(), ctx->w_aux.as<uint32_t>());
     }
+    }   // (!wt)
     if (!getenv("MTH_MHL_NO_WAVE_WALK")) {
         LaunchTimer lt(ctx, K_MHLWALK);
         MhlWaveArgs w;
@@ -687,7 +693,7 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
         hipLaunchKernelGGL(k_mhl_walk_wave, dim3(1024), dim3(256), 0, s, w);
     }
 #ifdef MTH_MT_TRACE
-    {
+    if (!wt) {
         std::vector<unsigned long long> hv((size_t)ntiles * 8);
         MTH_HIP(ctx, hipStreamSynchronize(s));
         MTH_HIP(ctx, hipMemcpy(hv.data(), a.trace, hv.size() * 8, hipMemcpyDeviceToHost));
