@@ -1342,6 +1342,8 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     // METHEOR_FDRP_WTILE=0 / 1 forces the choice (A/B, tests).
     const bool dense = d.n_reads && ((double)d.n_cpgs / (double)d.n_reads) > 6.0;
     const double cand = (double)d.n_reads * ((double)d.max_span + 2.0) / std::max<double>(1.0, (double)d.region_end - (double)d.region_beg);
+    // (round 6: a dense form of the tile pass -- 64-bit masks, sites up to 64 reads, term lists in HBM -- was built for the depths of config 4:
+    // parity-green, 4.2 ms against this file's k_fdrp_tile + k_fdrp_chain 3.4 ms: profiles/r06_fdrp_dense.md, tools/experiments/)
     bool wtile = !dense && d.max_span <= 200 && cand <= 16.0 && !getenv("METHEOR_FDRP_WALK4") && !getenv("METHEOR_FDRP_TILE");
     if (const char *e = getenv("METHEOR_FDRP_WTILE")) wtile = d.max_span <= 200 && atoi(e) != 0;
     if (wtile) {

@@ -20,7 +20,7 @@ TOL = 1e-6
 @pytest.fixture(autouse=True, params=["auto", "wtile", "wtile_sub", "wtile_heavy", "walk16", "walk32", "tile", "walk"])
 def walk_choice(request, monkeypatch):
     """every case eight times: with the host's own choice of kernel form; with the one-pass tile form forced (k_fdrp_wtile,
-    round 6: whatever it cannot hold is handed back to the general walk) -- as it is, starting from 256-position stretches, and
+    round 6: whatever it cannot hold is handed back to the general walk) -- as it is, starting from 192-position stretches, and
     with every stretch on its count-only path (every site handed back); with k_fdrp_walk4 forced (16 or 32 lanes per site, the
     rest handed back to the general walk -- on dense data mostly the hand-back path); with the read x read form forced
     (k_fdrp_tile + k_fdrp_chain, round 4); and with the wave-per-site walk alone"""

@@ -60,6 +60,10 @@ struct FwArgs {
     DevState *st;
     const uint16_t *pair_tab;     // (i | j << 8) of the k-th pair of n reads, reference loop order, at [n (n - 1) (n - 2) / 6 + k], n <= 64
     const float *quot;            // [ham * 9 + ncpg] = (float)ham / (float)ncpg, the division done once on the device (k_fw_quot)
+    // the dense form: the pairs' terms as byte codes in HBM, in the reference's (i, j) order; k_fdrp_chain adds them (mth_fdrp.hip)
+    uint8_t *terms;               // term lists (budget bytes), claimed per stretch through *cursor
+    unsigned long long *cursor;
+    unsigned long long budget;
     unsigned long long *trace;    // -DMTH_FW_TRACE builds: cycles per phase of each tile's first stretch (lane 0)
 };
 
@@ -73,12 +77,19 @@ constexpr int FW_LCAP = 64;                             // stored reads of a sit
 constexpr int FW_NZCAP = 1024;                           // non-zero qFDRP terms of a stretch's sites (more: the site is handed back)
 constexpr int FW_QC = 17 * 18 / 2;                      // codes ncpg (ncpg + 1) / 2 + ham, ham <= ncpg <= 16 (a reader's calls span <= 16 window sites)
 constexpr uint32_t FW_PASS = 1u, FW_BAD = 2u;           // per-read flags
+// the dense form (k_fdrp_wtile_dense: depth up to 64, a dozen calls a read -- BASELINE config 4): 64-bit masks (a reader spans <= 32 window
+// sites), ~1 200 calls a stretch taken 64 at a time, terms as codes ncpg (ncpg + 1) / 2 + ham with ncpg <= 21
+constexpr int FD_CCAP = 1536;                           // calls of a stretch's candidate reads
+constexpr int FD_LISTCAP = 2048;                        // >= C(64, 2) = 2016 codes of one site, staged in LDS
+constexpr uint32_t FD_NCPG_MAX = 21u;
+constexpr int FD_QC = (int)((FD_NCPG_MAX + 1u) * (FD_NCPG_MAX + 2u) / 2u);   // 253 codes: one byte
+static_assert(FW_U == 2 && FW_WMAX + 2 * 200 + 1 <= 64 * 32 && FW_RCAP <= 256, "one bitmap word per lane; 8-bit read slots");
 
 __global__ void k_fw_quot(float *q) {   // ham / ncpg by the same f32 division the reference does (qfdrp.rs:152); ncpg = 0 is never looked up
     const uint32_t t = threadIdx.x;
     uint32_t ncpg = 0;
     while ((ncpg + 1u) * (ncpg + 2u) / 2u <= t) ++ncpg;
-    if (t < (uint32_t)FW_QC) q[t] = ncpg ? (float)(t - ncpg * (ncpg + 1u) / 2u) / (float)ncpg : 0.0f;
+    if (t < (uint32_t)FD_QC) q[t] = ncpg ? (float)(t - ncpg * (ncpg + 1u) / 2u) / (float)ncpg : 0.0f;   // (the sparse form reads the first FW_QC entries)
 }
 
 // every pair of the n readers in s_list, lane = pair in the reference's loop order (fdrp.rs:128-141): the discordant pairs (returned) and,
@@ -106,6 +117,39 @@ __device__ __forceinline__ uint32_t fw_rounds(const uint16_t *s_list, const uint
         if (dsc && slot < (uint32_t)FW_NZCAP) s_nz[slot] = (uint8_t)(ncpg * (ncpg + 1u) / 2u + ham);
         const uint32_t c = (uint32_t)__popcll(nzb);
         disc += c; nzbase += c;
+    }
+    return disc;
+}
+
+// the same with 64-bit masks over rows of eight words {start | end << 16, first-call rank, mC (2), mM (2), mA (2)}; wide = some pair shares more
+// than FD_NCPG_MAX calls (its term has no code: the caller hands the site back)
+__device__ __forceinline__ uint32_t fw_rounds_dense(const uint16_t *s_list, const uint32_t *s_row, uint8_t *tp, const uint16_t *__restrict__ pair_tab,
+                                                    const int lane, const uint32_t n, uint32_t ent_next, const bool mo_any, const int32_t mo_m1, bool &wide) {
+    const uint32_t P = n * (n - 1u) / 2u;
+    const uint16_t *const tab = pair_tab + (n * (n - 1u) * (n - 2u)) / 6u;              // (n <= 1: no pair, the table is not read)
+    uint32_t disc = 0;
+    for (uint32_t k0p = 0; k0p < P; k0p += 64u) {
+        const uint32_t ent = ent_next;
+        if (k0p + 64u < P) ent_next = tab[min(k0p + 64u + (uint32_t)lane, P - 1u)];
+        const uint32_t li = s_list[ent & 0xffu], lj = s_list[ent >> 8];
+        const uint8_t *pi = reinterpret_cast<const uint8_t *>(s_row) + li, *pj = reinterpret_cast<const uint8_t *>(s_row) + lj;
+        const uint32_t sei = *reinterpret_cast<const uint32_t *>(pi), sej = *reinterpret_cast<const uint32_t *>(pj);
+        const uint2 ci = *reinterpret_cast<const uint2 *>(pi + 8), cj = *reinterpret_cast<const uint2 *>(pj + 8);     // mC
+        const uint4 mi = *reinterpret_cast<const uint4 *>(pi + 16), mj = *reinterpret_cast<const uint4 *>(pj + 16);   // mM, mA
+        // get_num_overlap_bases (fdrp.rs:97-107) = max(min(end) - max(start) + 1, 0) >= min_overlap (fdrp.rs:134)
+        const int32_t ovl = (int32_t)min(sei >> 16, sej >> 16) - (int32_t)max(sei & 0xffffu, sej & 0xffffu);
+        const bool pair_ok = (k0p + (uint32_t)lane < P) && (mo_any || ovl >= mo_m1);
+        const uint32_t hm0 = mi.z & mj.z & (mi.x ^ mj.x), hm1 = mi.w & mj.w & (mi.y ^ mj.y);   // both cover and call, states differ: fdrp.rs:114-115
+        const uint32_t ham = (uint32_t)__builtin_popcount(hm0) + (uint32_t)__builtin_popcount(hm1);
+        const uint32_t ncpg = (uint32_t)__builtin_popcount(ci.x & cj.x) + (uint32_t)__builtin_popcount(ci.y & cj.y);   // qfdrp.rs:109-119
+        const unsigned long long dm = fw_ballot(pair_ok && ham != 0u);               // fdrp.rs:138-140
+        disc += (uint32_t)__popcll(dm);
+        wide = wide || fw_ballot(pair_ok && ncpg > FD_NCPG_MAX) != 0ull;
+        // every pair's term goes to the site's list (staged in LDS: a global store per round made the next round's table load wait for it --
+        // loads and stores share one counter) at the pair's own index, as one byte: ncpg (ncpg + 1) / 2 + ham (the chain kernel's table gives
+        // ham / ncpg: +0.0 when ham is 0 -- x + 0.0 == x); a skipped pair, and the lanes past the last pair, are code 1 = 0 / 1
+        const uint32_t nc = min(ncpg, FD_NCPG_MAX);
+        tp[k0p + (uint32_t)lane] = (uint8_t)(pair_ok ? nc * (nc + 1u) / 2u + min(ham, nc) : 1u);
     }
     return disc;
 }
@@ -475,6 +519,339 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
     }
 }
 
+// The dense form of the kernel above: the same phases with 64-bit masks (bit = rank mod 64, a reader spans <= 32 window sites), rows of
+// eight words, ~1 200 calls a stretch taken 64 at a time and looked at twice (A2: bitmap; C1: ranks -- nothing of a call is kept in
+// registers), up to 4 096 non-zero terms a stretch.  For depths where a site holds tens of reads and a read a dozen calls (BASELINE config 4:
+// 50 x hotspots, -D 64): the pair rounds are the time, twenty of them per site.  A possible flush and more than 64 readers go to the walk.
+__global__ __launch_bounds__(64, 4) void k_fdrp_wtile_dense(const FwArgs a) {
+    constexpr int U = FW_U;
+    // ~6.5 KB of LDS per wave (the pair rounds dominate here: twenty per site at 50 reads)
+    __shared__ uint2 s_bp[64];                                // {site bits, sites in the words before}
+    __shared__ __attribute__((aligned(16))) uint32_t s_row[FW_RCAP * 8];   // {start | end << 16, first-call rank, mC (2 words), mM (2), mA (2)}
+    __shared__ uint16_t s_list[FW_LCAP];                      // D1: the readers of the site in hand (byte offsets of their rows, file order)
+    __shared__ __attribute__((aligned(16))) uint8_t s_codes[FD_LISTCAP];   // D1: the term codes of the site in hand (64 pairs a round), copied out in 16-byte pieces
+    uint8_t *const s_owner = s_codes;                         // A: call slot -> read slot + 1 where a read's calls begin, else 0
+    static_assert(FD_LISTCAP >= FD_CCAP, "the owner marks share the code staging");
+    __shared__ int32_t s_cpos[FW_SC];
+    __shared__ uint32_t s_sflag[FW_SC];                       // per core site: passing reads that call it | bit 31: one of them holds > 8 calls / spans > 16 window sites
+    const int lane = threadIdx.x;
+    // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
+    const uint32_t per_xcd = (a.ntiles + 7) / 8;
+    const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= a.ntiles) return;
+    const int32_t T0 = a.region_beg + (int32_t)(t * a.tile_w);
+    const int32_t T1 = (int32_t)min((int64_t)T0 + a.tile_w, (int64_t)a.region_end);
+    FdRec *__restrict__ out = a.scratch + (size_t)t * a.rows_per_tile;
+    const uint32_t cap = min(a.max_depth, (uint32_t)FW_LCAP);          // stored reads a site may hold here (fdrp.rs:81-85)
+    const uint32_t mind = max(a.min_depth, 1u);                         // fdrp.rs:239-243: an entry exists and holds >= min_depth reads
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t rows_out = 0, bad = 0;
+    uint32_t sub_w = a.force_sub ? 64u : a.tile_w;                     // stretch width (wave-uniform): halved when a stretch does not fit
+    bool heavy_redo = false;                                            // wave-uniform
+#ifdef MTH_FW_TRACE
+    unsigned long long tk[12];
+    for (int k = 0; k < 12; ++k) tk[k] = 0;
+    tk[11] = __builtin_readcyclecounter();
+#define FW_TK(k) do { tk[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FW_TK(k) do {} while (0)
+#endif
+    for (int64_t P0l = T0; P0l < T1;) {
+        const int32_t P0 = (int32_t)P0l;
+        const int32_t P1 = (int32_t)min(P0l + (int64_t)sub_w, (int64_t)T1);
+        const uint32_t Wp = (uint32_t)(P1 - P0);
+        // candidate reads: start in [P0 - max_span + 1, P1] (a reader of c calls c in [start - 1, end]; a flusher between two
+        // readers starts between them)
+        const uint32_t lo = __builtin_amdgcn_readfirstlane(min(a.idx[((uint32_t)P0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads));
+        const uint32_t hi = __builtin_amdgcn_readfirstlane(min(a.idx[(((uint32_t)P1 - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads));
+        const uint32_t R = hi - lo;
+        if (R > (uint32_t)FW_RCAP && sub_w > 64u) { sub_w = max((sub_w >> 1) & ~31u, 64u); continue; }
+        const bool heavy = R > (uint32_t)FW_RCAP || heavy_redo || a.force_heavy;
+        const uint32_t wbase = (uint32_t)P0 - (uint32_t)a.max_span - 1u;            // window offset 0
+        const uint32_t wbits = Wp + 2u * (uint32_t)a.max_span + 1u;
+        const uint32_t c_lo = (uint32_t)a.max_span + 1u, c_hi = c_lo + Wp;          // window offsets of the core [P0, P1)
+        FW_SYNC();                                                                  // the previous stretch's LDS is done with
+        s_bp[lane] = make_uint2(0u, 0u);
+        if (lane < FW_SC) s_sflag[lane] = 0u;
+        FW_SYNC();
+        FW_TK(0);
+        // ---- A1: the candidate reads, one per lane: fields, the pass test, the row's start | end, the owner mark of its first call ----
+        // (the calls themselves are taken one per LANE in A2 / C1: a read holds 1.4 calls at WGBS density, eight call slots per read
+        // -- the first form of this kernel -- spent most of their instructions on empty slots)
+        uint32_t fl[U], ncall[U];
+        uint32_t o0[U], o1[U], mq[U];
+        int32_t rs[U], re[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                                               // every chunk's fields are requested at once, with the call range's end
+            const uint32_t r = (uint32_t)(u * 64 + lane);
+            const uint32_t i = min(lo + r, hi ? hi - 1u : 0u);
+            o0[u] = a.cpg_off[i]; o1[u] = a.cpg_off[i + 1];
+            rs[u] = a.read_start[i]; re[u] = a.read_end[i]; mq[u] = a.read_mapq[i];
+        }
+        const uint32_t olast = __builtin_amdgcn_readfirstlane(a.cpg_off[hi]);
+        const uint32_t ofirst = R ? __builtin_amdgcn_readfirstlane(o0[0]) : olast;  // (lane 0 of chunk 0 is read lo)
+        const uint32_t C_n = heavy ? 0u : olast - ofirst;                            // calls of the stretch's candidate reads
+        if (C_n > (uint32_t)FD_CCAP) {
+            if (sub_w > 64u) { sub_w = max((sub_w >> 1) & ~31u, 64u); continue; }
+            heavy_redo = true; continue;
+        }
+        auto mark = [&](const uint32_t w, const uint32_t srel_m1) -> uint32_t {      // a passing read's call: the bitmap bit; window offset
+            const uint32_t rel = (w & 0x7fffffffu) - wbase;
+            bad |= (rel - srel_m1 > (uint32_t)a.max_span) ? 1u : 0u;                 // every call lies in [start - 1, start - 1 + max_span]
+            if (rel < wbits) atomicOr(&s_bp[rel >> 5].x, 1u << (rel & 31u));
+            return rel;
+        };
+        if (!heavy) {
+            for (int i = lane; i < FD_CCAP / 4; i += 64) reinterpret_cast<uint32_t *>(s_owner)[i] = 0u;
+            FW_SYNC();
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t r = (uint32_t)(u * 64 + lane);
+                fl[u] = 0u; ncall[u] = 0u;
+                if ((uint32_t)(u * 64) >= R) continue;                              // wave-uniform
+                const uint32_t n = r < R ? o1[u] - o0[u] : 0u;
+                const bool inr = r < R && (uint32_t)rs[u] - ((uint32_t)P0 - (uint32_t)a.max_span + 1u) <= Wp + (uint32_t)a.max_span - 1u;   // start in [P0 - max_span + 1, P1]
+                const bool pass = inr && mq[u] >= (uint32_t)a.min_qual && n > 0u;   // fdrp.rs:205, 208
+                if (pass) bad |= ((uint32_t)(re[u] - rs[u]) >= (uint32_t)a.max_span) ? 1u : 0u;   // max_span >= end - start + 1 (include/metheor_hip.h)
+                // start | end << 16 as window offsets (a passing read's start offset is >= 2: the word is non-zero exactly for them)
+                const uint32_t se = pass ? ((((uint32_t)rs[u] - wbase) & 0xffffu) | ((((uint32_t)re[u] - wbase) & 0xffffu) << 16)) : 0u;
+                *reinterpret_cast<uint4 *>(&s_row[r * 8]) = make_uint4(se, 0u, 0u, 0u);
+                *reinterpret_cast<uint4 *>(&s_row[r * 8 + 4]) = make_uint4(0u, 0u, 0u, 0u);
+                if (n) s_owner[o0[u] - ofirst] = (uint8_t)(r + 1u);                 // the read's first call (offsets < C_n <= FD_CCAP)
+                fl[u] = pass ? FW_PASS : 0u;
+                ncall[u] = n;
+            }
+        } else {
+            // count-only: more candidate reads / calls than the arrays hold -- the sites are found, every one of them is handed back
+            for (uint32_t r = (uint32_t)lane; r < R; r += 64) {
+                const uint32_t i = lo + r;
+                const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
+                const int32_t rs = a.read_start[i];
+                const bool pass = (int64_t)rs >= (int64_t)P0 - a.max_span + 1 && rs <= P1 && a.read_mapq[i] >= a.min_qual;
+                if (pass) for (uint32_t k = o0; k < o1; ++k) mark(a.cpg_pos[k], (uint32_t)rs - wbase - 1u);
+            }
+        }
+        FW_SYNC();
+        // ---- A2: the calls, one per lane (coalesced), 64 at a time: its read (the latest owner mark at or before it), the bitmap bit ----
+        // (a stretch holds ~1 200 calls here: nothing of a call is kept in registers -- C1 takes the same lanes again)
+        // the call of lane c: word, read slot + 1, "its read's first call", its read's start | end (0: the read does not pass)
+        auto call_of = [&](const uint32_t c, uint32_t &own_carry, uint32_t &w, uint32_t &r1, bool &head, uint32_t &se) {
+            const bool valid = c < C_n;
+            w = a.cpg_pos[ofirst + (valid ? c : 0u)];
+            const uint32_t own = valid ? (uint32_t)s_owner[c] : 0u;
+            r1 = max(fw_wave_scan_max_incl(own), own_carry);
+            own_carry = (uint32_t)__builtin_amdgcn_readlane(r1, 63);
+            head = own != 0u;
+            se = valid ? s_row[(r1 - 1u) * 8u] : 0u;                                 // (every call has an owner: r1 >= 1)
+        };
+        {
+            uint32_t own_carry = 0;
+            for (uint32_t c0 = 0; c0 < C_n; c0 += 64u) {
+                uint32_t w, r1, se; bool head;
+                call_of(c0 + (uint32_t)lane, own_carry, w, r1, head, se);
+                if (se) mark(w, (se & 0xffffu) - 1u);
+            }
+        }
+        FW_TK(1);
+        FW_SYNC();
+        // ---- B: ranks ----
+        const uint32_t wb = s_bp[lane].x;
+        const uint32_t wcnt = (uint32_t)__builtin_popcount(wb);
+        uint32_t pre = wave_scan_incl(wcnt) - wcnt;
+        s_bp[lane].y = pre;
+        FW_SYNC();
+        auto rank_of = [&](const uint32_t rel) {                                     // sites of the window below offset rel
+            const uint2 e = s_bp[rel >> 5];
+            return e.y + (uint32_t)__builtin_popcount(e.x & ((1u << (rel & 31u)) - 1u));
+        };
+        const uint32_t k0 = __builtin_amdgcn_readfirstlane(rank_of(c_lo)), k1 = __builtin_amdgcn_readfirstlane(rank_of(c_hi));
+        const uint32_t ncore = k1 - k0;
+        if (ncore > (uint32_t)FW_SC) { sub_w = max((min(sub_w, Wp) >> 1) & ~15u, 48u); continue; }   // (48 positions hold <= 24 sites)
+        // core site positions, rank order
+        {
+            uint32_t bits = wb;
+            while (bits) {
+                const uint32_t b = (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1u;
+                const uint32_t rel = (uint32_t)lane * 32u + b;
+                if (rel >= c_lo && rel < c_hi) s_cpos[pre - k0] = (int32_t)(wbase + rel);
+                ++pre;
+            }
+        }
+        FW_TK(2);
+        if (heavy) {
+            FW_SYNC();
+            if ((uint32_t)lane < ncore) {
+                FdRec rec; rec.pos = s_cpos[lane]; rec.f = 0.0f; rec.q = 0.0f; rec.nf = 4u << 24;
+                if (rows_out + lane < a.rows_per_tile) out[rows_out + lane] = rec;
+            }
+            rows_out += ncore;
+            heavy_redo = false;
+            P0l = P1;
+            continue;
+        }
+        // ---- C1: per call: its rank -> the read's masks (bit = rank mod 64), first-call rank ----
+        {
+            uint32_t own_carry = 0;
+            for (uint32_t c0 = 0; c0 < C_n; c0 += 64u) {
+                uint32_t w, r1, se; bool head;
+                call_of(c0 + (uint32_t)lane, own_carry, w, r1, head, se);
+                if (se) {
+                    const uint32_t r = r1 - 1u;
+                    const uint32_t rel = (w & 0x7fffffffu) - wbase;
+                    const uint32_t rk = rank_of(min(rel, wbits - 1u));
+                    const uint32_t bit = 1u << (rk & 31u), hw = (rk >> 5) & 1u;
+                    atomicOr(&s_row[r * 8 + 2 + hw], bit);
+                    if (rk - k0 < ncore) atomicAdd(&s_sflag[rk - k0], 1u);            // a core site's passing readers (fdrp.rs:226-231)
+                    if (w >> 31) atomicOr(&s_row[r * 8 + 4 + hw], bit);
+                    // the read's first call: its rank; the one call that can lie outside the covered bases, at start - 1 (readutil.rs:332-340)
+                    if (head) s_row[r * 8 + 1] = rk | ((rel < (se & 0xffffu)) ? 0x80000000u : 0u);
+                }
+            }
+        }
+        FW_SYNC();
+        // ---- C2: per read: the finished row, "its sites are handed back", the flush rule's prefix maximum ----
+        unsigned long long mCr[U];                                                   // kept for D1: call mask (0: not a reader of any list)
+        uint32_t r0r[U], pmr[U];                                                     // first-call rank; first-call rank + 1 of the passing reads before, maximum
+        uint32_t carry = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mCr[u] = 0ull; r0r[u] = 0u; pmr[u] = 0u;
+            if ((uint32_t)(u * 64) >= R) continue;                                  // wave-uniform
+            const uint32_t r = (uint32_t)(u * 64 + lane);
+            unsigned long long mC = 0;
+            uint32_t r0 = 0;
+            if (fl[u] & FW_PASS) {
+                const uint4 row = *reinterpret_cast<const uint4 *>(&s_row[r * 8]);
+                const uint2 rm = *reinterpret_cast<const uint2 *>(&s_row[r * 8 + 4]);
+                mC = ((unsigned long long)row.w << 32) | row.z; r0 = row.y & 0x7fffffffu;
+                // its highest rank from the mask (bit = rank mod 64): exact while its ranks span < 64 -- and if they do not, two of its
+                // calls may share a bit: fewer bits than calls
+                const uint32_t sh = r0 & 63u;
+                const unsigned long long rot = sh ? (mC >> sh) | (mC << (64u - sh)) : mC;
+                const uint32_t span = 63u - (uint32_t)__builtin_clzll(rot | 1ull);
+                if (span > 31u || (uint32_t)__builtin_popcountll(mC) != ncall[u]) fl[u] |= FW_BAD;
+                const unsigned long long mA = (row.y >> 31) ? mC & ~(1ull << sh) : mC;
+                const unsigned long long mM = (((unsigned long long)rm.y << 32) | rm.x) & mA;
+                if (fl[u] & FW_BAD) {
+                    // (> 32 window sites between its first and last call): every core site it calls is handed back
+                    const uint32_t q0 = a.cpg_off[lo + r];
+                    for (uint32_t k = q0; k < q0 + ncall[u]; ++k) {
+                        const uint32_t rel = (a.cpg_pos[k] & 0x7fffffffu) - wbase;
+                        if (rel < wbits) { const uint32_t q = rank_of(rel) - k0; if (q < ncore) atomicOr(&s_sflag[q], 0x80000000u); }
+                    }
+                    mC = 0ull;                                                       // not a reader of any list
+                }
+                *reinterpret_cast<uint2 *>(&s_row[r * 8 + 2]) = make_uint2((uint32_t)mC, (uint32_t)(mC >> 32));
+                *reinterpret_cast<uint4 *>(&s_row[r * 8 + 4]) = make_uint4((uint32_t)mM, (uint32_t)(mM >> 32), (uint32_t)mA, (uint32_t)(mA >> 32));
+            }
+            // first-call rank + 1 of the passing reads before this one, maximum (file order)
+            const uint32_t fc = (fl[u] & FW_PASS) ? r0 + 1u : 0u;
+            const uint32_t incl = fw_wave_scan_max_incl(fc);
+            pmr[u] = max(MTH_DPP(incl, 0x138 /*wave_shr:1*/, 0xf, true), carry);
+            carry = max(carry, (uint32_t)__builtin_amdgcn_readlane(incl, 63));
+            mCr[u] = mC; r0r[u] = r0;
+        }
+        FW_TK(3);
+        FW_SYNC();
+        // ---- D1: per site that can produce a row (wave-uniform loop): its readers in file order, then every pair of them, lane = pair
+        // in the reference's loop order ----
+        const uint32_t sf = s_sflag[lane & (FW_SC - 1)];
+        const uint32_t n_s = sf & 0x7fffffffu;                                       // lane = core site: reads that call it and pass (C1)
+        const bool in_core = (uint32_t)lane < ncore;
+        // handed back: a reader with > 8 calls / > 16 window sites; reservoir (fdrp.rs:87-94) / more reads than this kernel's list holds
+        bool redo = in_core && ((sf >> 31) || (n_s > cap && n_s >= mind));
+        const bool act = in_core && n_s >= mind && n_s <= cap && !redo;
+        uint32_t disc_vec = 0;
+        const bool mo_any = a.min_overlap <= 0;                                      // every pair overlaps enough
+        const int32_t mo_m1 = a.min_overlap - 1;
+        // list space: C(n, 2) bytes, rounded up to 64 (a round writes 64 codes; the chain kernel adds whole lines), per site that is
+        // evaluated here; one claim per stretch from a buffer whose size bounds them
+        const uint32_t lcap = act ? ((n_s * (n_s - 1u) / 2u + 63u) & ~63u) : 0u;
+        const uint32_t lincl = wave_scan_incl(lcap);
+        const uint32_t ltot = (uint32_t)__builtin_amdgcn_readlane(lincl, 63);
+        unsigned long long lbase = 0;
+        if (lane == 0 && ltot) lbase = atomicAdd(a.cursor, (unsigned long long)ltot);
+        lbase = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(lbase >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)lbase);
+        const bool lfits = lbase + ltot <= a.budget;                                 // (cannot fail: the budget bounds the sum over all sites)
+        const unsigned long long loff = lbase + lincl - lcap;                        // lane = site: first byte of its list (a multiple of 64)
+        if (!lfits && act) redo = true;
+        unsigned long long todo = fw_ballot(act && lfits);
+        // the k-th pair of n reads in the reference's loop order comes from a table (a.pair_tab; the closed form is a square root and two
+        // corrections per round); a site's first entries are requested while the site before it is in hand
+        auto first_ent = [&](const unsigned long long m) -> uint32_t {
+            if (!m) return 0u;
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane(n_s, (uint32_t)__builtin_ctzll(m));
+            const uint32_t P = n * (n - 1u) / 2u;
+            return P ? a.pair_tab[(n * (n - 1u) * (n - 2u)) / 6u + min((uint32_t)lane, P - 1u)] : 0u;
+        };
+        uint32_t ent_site = first_ent(todo);
+        while (todo) {
+            const uint32_t q = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t ent_first = ent_site;
+            ent_site = first_ent(todo);
+            const uint32_t rq = k0 + q;
+            FW_SYNC();                                                               // the site before this one is done with the list
+            // the site's readers in file order: slot = readers in the chunks before + in the lanes below
+            uint32_t n = 0;
+            bool flush = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if ((uint32_t)(u * 64) >= R) continue;                              // wave-uniform
+                const bool has = rq - r0r[u] < 32u && ((mCr[u] >> (rq & 63u)) & 1ull);
+                const unsigned long long b = fw_ballot(has);
+                // a passing read before one of them whose first call lies beyond the site (fdrp.rs:212): the readers may form two segments
+                flush = flush || fw_ballot(has && pmr[u] > rq + 1u) != 0ull;
+                if (has) s_list[min(__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, n)), (uint32_t)FW_LCAP - 1u)] = (uint16_t)((u * 64 + lane) * 32);
+                n += (uint32_t)__popcll(b);
+            }
+            if (flush) { if ((uint32_t)lane == q) redo = true; continue; }          // the walk decides (as the sparse form does)
+            FW_SYNC();
+            bool wide = false;                                                       // two readers share more than 21 calls: no code for the term
+            const unsigned long long off_q = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(loff >> 32), q) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)loff, q);
+            const uint32_t disc = fw_rounds_dense(s_list, s_row, s_codes, a.pair_tab, lane, n, ent_first, mo_any, mo_m1, wide);
+            FW_SYNC();
+            {   // the list to HBM: 16 bytes a lane (the list starts on a 64-byte boundary and owns a multiple of 64 bytes)
+                const uint32_t lbytes = (n * (n - 1u) / 2u + 63u) & ~63u;
+                uint8_t *const tp = a.terms + off_q;
+                for (uint32_t b = (uint32_t)lane * 16u; b < lbytes; b += 1024u) *reinterpret_cast<uint4 *>(tp + b) = *reinterpret_cast<const uint4 *>(s_codes + b);
+            }
+            if (wide) { if ((uint32_t)lane == q) redo = true; }
+            else if ((uint32_t)lane == q) disc_vec = disc;
+        }
+        FW_TK(4);
+        FW_SYNC();
+        // ---- rows: a site evaluated here leaves {discordant pairs, its list} for k_fdrp_chain (flag 8); the others are handed back (flag 4) ----
+        const bool emit = redo || act;
+        FdRec rec;
+        rec.pos = 0; rec.f = 0.0f; rec.q = 0.0f; rec.nf = 4u << 24;
+        if (emit) {
+            rec.pos = s_cpos[lane & (FW_SC - 1)];
+            if (!redo) { rec.f = __builtin_bit_cast(float, disc_vec); rec.q = __builtin_bit_cast(float, (uint32_t)(loff >> 6)); rec.nf = n_s | (8u << 24); }
+        }
+        const unsigned long long em = fw_ballot(emit);
+        if (emit && rows_out + (uint32_t)__popcll(em & lt_mask) < a.rows_per_tile) out[rows_out + (uint32_t)__popcll(em & lt_mask)] = rec;
+        rows_out += (uint32_t)__popcll(em);
+        FW_TK(5);
+#ifdef MTH_FW_TRACE
+        if (a.trace && P0 == T0) {   // why sites were handed back: a reader spanning > 16 window sites; more reads than the list holds; a possible flush; terms
+            const unsigned long long m1 = fw_ballot(in_core && (sf >> 31)), m2 = fw_ballot(in_core && !(sf >> 31) && n_s > cap && n_s >= mind), m3 = fw_ballot(redo) & ~m1 & ~m2;
+            unsigned long long nb = 0;
+            for (int u = 0; u < U; ++u) nb += (unsigned long long)__popcll(fw_ballot((fl[u] & FW_BAD) != 0u));
+            if (lane == 0) { a.trace[(size_t)t * 12 + 7] = (unsigned long long)__popcll(m1); a.trace[(size_t)t * 12 + 8] = (unsigned long long)__popcll(m2); a.trace[(size_t)t * 12 + 9] = (unsigned long long)__popcll(m3); a.trace[(size_t)t * 12 + 10] = nb; }
+        }
+        if (lane == 0 && a.trace && P0 == T0) { a.trace[(size_t)t * 12] = 1ull; a.trace[(size_t)t * 12 + 1] = tk[0] - tk[11]; for (int k = 1; k < 6; ++k) a.trace[(size_t)t * 12 + 1 + k] = tk[k] - tk[k - 1]; }
+#endif
+        P0l = P1;
+    }
+    if (bad & 1u) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
+    if (lane == 0) {
+        a.tile_cnt[t] = rows_out;
+        if (rows_out) atomicAdd(a.bucket + (t >> TILE_BUCKET_SHIFT), (unsigned long long)rows_out);
+    }
+}
+
 // exclusive scan of the buckets' row counts (one workgroup; a few thousand buckets)
 __global__ __launch_bounds__(1024) void k_fw_bucket_scan(const unsigned long long *__restrict__ bucket, unsigned long long *__restrict__ bucket_pre, const uint32_t nbk) {
     __shared__ unsigned long long part[1024];
@@ -498,7 +875,9 @@ __global__ __launch_bounds__(64 * FG_WAVES) void k_fdrp_wtile_gather(const FdRec
                                                                      const uint32_t rows_per_tile, DevState *__restrict__ sites_st,
                                                                      int32_t *__restrict__ site_pos, float *__restrict__ fdrp, float *__restrict__ qfdrp,
                                                                      uint32_t *__restrict__ nreads, uint32_t *__restrict__ flags,
-                                                                     uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_cnt) {
+                                                                     uint32_t *__restrict__ redo_list, uint32_t *__restrict__ redo_cnt,
+                                                                     unsigned long long *__restrict__ site_off, uint32_t *__restrict__ site_nz,
+                                                                     uint32_t *__restrict__ site_disc) {
     const int lane = threadIdx.x & 63, sub = lane >> 3, l8 = lane & 7;
     const uint32_t tw = (blockIdx.x * FG_WAVES + (threadIdx.x >> 6)) * 8u;          // the wave's first tile
     if (tw >= ntiles) return;
@@ -525,6 +904,12 @@ __global__ __launch_bounds__(64 * FG_WAVES) void k_fdrp_wtile_gather(const FdRec
         if (in) r = src[i];
         const uint32_t fg = r.nf >> 24;
         if (in) { site_pos[base + i] = r.pos; fdrp[base + i] = r.f; qfdrp[base + i] = r.q; nreads[base + i] = r.nf & 0xffffffu; flags[base + i] = fg; }
+        if (in && fg == 8u) {   // the dense form's rows: discordant pairs and the list's first byte / 64 ride in the value fields; k_fdrp_chain finishes them
+            const uint32_t n = r.nf & 0xffffffu;
+            site_off[base + i] = (unsigned long long)__builtin_bit_cast(uint32_t, r.q) << 6;
+            site_nz[base + i] = n * (n - 1u) / 2u;
+            site_disc[base + i] = __builtin_bit_cast(uint32_t, r.f);
+        }
         const unsigned long long hb = __ballot(in && fg == 4u);
         if (hb) {                                                                    // wave-uniform
             uint32_t at = 0;
@@ -539,7 +924,8 @@ __global__ __launch_bounds__(64 * FG_WAVES) void k_fdrp_wtile_gather(const FdRec
 // The tile pass of one batch: candidate-site arrays (ctx->s_pos, w_val = fdrp, w_aux = qfdrp, w_cov = stored reads, w_flags;
 // count in d_state2->n_sites) filled with the finished rows (flag 1) and the handed-back sites (flag 4, listed in redo_list /
 // *redo_cnt -- cleared by the caller); the fine read index is left for the walk.
-int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_t &p, const uint16_t *pair_tab, uint32_t *redo_list, uint32_t *redo_cnt) {
+int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_t &p, const int mode, const uint16_t *pair_tab, uint32_t *redo_list, uint32_t *redo_cnt,
+                      const FwTerms &tl) {
     hipStream_t s = ctx->stream;
     const int64_t region_len = (int64_t)d.region_end - d.region_beg;
     if (d.n_reads == 0 || region_len <= 0) return MTH_OK;
@@ -550,9 +936,9 @@ int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_
         const double rpb = (double)d.n_reads / (double)region_len;
         const double want = 128.0 - 2.0 * std::sqrt(128.0);                         // ~105 reads
         W = (int)(want / std::max(rpb, 1e-9)) - d.max_span;
-        W = std::max(256, std::min(FW_WMAX, W)) & ~63;
+        W = mode == 2 ? std::max(64, std::min(FW_WMAX, W)) & ~31 : std::max(256, std::min(FW_WMAX, W)) & ~63;
     }
-    if (const char *e = getenv("METHEOR_FDRP_WTILE_W")) W = std::min(FW_WMAX, std::max(64, atoi(e))) & ~63;   // tests / tuning
+    if (const char *e = getenv("METHEOR_FDRP_WTILE_W")) W = std::min(FW_WMAX, std::max(64, atoi(e))) & ~31;   // tests / tuning
     int32_t idx_base = 0;
     uint32_t ntiles = 0;
     int rc = build_read_index(ctx, d, W, idx_base, ntiles);
@@ -565,7 +951,7 @@ int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_
     MTH_HIP(ctx, ctx->scratch.reserve((size_t)ntiles * rows_per_tile * sizeof(FdRec), s));
     if (!ctx->f_quot.p) {
         MTH_HIP(ctx, ctx->f_quot.reserve(256 * sizeof(float), s));
-        hipLaunchKernelGGL(k_fw_quot, dim3(1), dim3(192), 0, s, ctx->f_quot.as<float>());
+        hipLaunchKernelGGL(k_fw_quot, dim3(1), dim3(256), 0, s, ctx->f_quot.as<float>());
     }
     FwArgs a;
     a.read_start = d.read_start; a.read_end = d.read_end; a.read_mapq = d.read_mapq; a.cpg_off = d.cpg_off; a.cpg_pos = d.cpg_pos;
@@ -577,6 +963,7 @@ int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_
     a.scratch = reinterpret_cast<FdRec *>(ctx->scratch.p); a.rows_per_tile = rows_per_tile;
     a.tile_cnt = ctx->tile_cnt.as<uint32_t>(); a.bucket = ctx->tile_bucket.as<unsigned long long>(); a.st = ctx->d_state; a.pair_tab = pair_tab;
     a.quot = ctx->f_quot.as<float>();
+    a.terms = tl.terms; a.cursor = tl.cursor; a.budget = tl.budget;
     const uint32_t grid = ((ntiles + 7) / 8) * 8;
     a.trace = nullptr;
 #ifdef MTH_FW_TRACE
@@ -588,7 +975,8 @@ int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_
 #endif
     {
         LaunchTimer lt(ctx, K_FDRPWTILE);
-        hipLaunchKernelGGL(k_fdrp_wtile, dim3(grid), dim3(64), 0, s, a);
+        if (mode == 2) hipLaunchKernelGGL(k_fdrp_wtile_dense, dim3(grid), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(k_fdrp_wtile, dim3(grid), dim3(64), 0, s, a);
     }
     {
         LaunchTimer lt(ctx, K_GATHER);
@@ -597,7 +985,8 @@ int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_
         hipLaunchKernelGGL(k_fdrp_wtile_gather, dim3((ntiles + FG_WAVES * 8 - 1) / (FG_WAVES * 8)), dim3(64 * FG_WAVES), 0, s,
                            reinterpret_cast<const FdRec *>(ctx->scratch.p), ctx->tile_cnt.as<uint32_t>(), bucket_pre,
                            ntiles, rows_per_tile, ctx->d_state2, ctx->s_pos.as<int32_t>(), ctx->w_val.as<float>(),
-                           reinterpret_cast<float *>(ctx->w_aux.p), ctx->w_cov.as<uint32_t>(), ctx->w_flags.as<uint32_t>(), redo_list, redo_cnt);
+                           reinterpret_cast<float *>(ctx->w_aux.p), ctx->w_cov.as<uint32_t>(), ctx->w_flags.as<uint32_t>(), redo_list, redo_cnt,
+                           tl.site_off, tl.site_nz, tl.site_disc);
     }
 #ifdef MTH_FW_TRACE
     {

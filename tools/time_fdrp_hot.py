@@ -19,3 +19,4 @@ n = r["n_reads"].astype(np.int64)
 print("ablate", os.environ.get("METHEOR_FDRP_ABLATE", "0"), {k: round(v[0], 4) for k, v in t.items() if v[1] > 0 and "fdrp" in k},
       "rows", len(n), "pairs %.3e" % float((n * (n - 1) // 2).sum()), "mean n %.1f" % float(n.mean()),
       "checksum %.6f %.6f" % (float(r["fdrp"].astype(np.float64).sum()), float(np.nansum(r["qfdrp"].astype(np.float64)))))
+print("all kernels", {k: round(v[0] / reps, 4) for k, v in t.items() if v[1] > 0})
