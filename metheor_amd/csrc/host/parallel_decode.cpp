@@ -205,6 +205,32 @@ struct Stopwatch {   // METHEOR_TIMING=1: decoder phase totals on stderr
 
 BgzfMap::~BgzfMap() { if (file && file_bytes) munmap(const_cast<uint8_t *>(file), file_bytes); }
 
+// The block-table walk below hops from one BGZF header to the next: the first touch of every page of the mapping, one page fault at
+// a time -- 0.7 s of a 17.8-GB file's 1.8-s run (bench.py e2e "large": startup_s 0.78 against 0.10 on the 1.8-GB file; VERDICT r05
+// item 6).  The mapping is populated first, in slices, by as many threads as the host has (page-cache hits: the faults are
+// independent): MADV_POPULATE_READ where the kernel has it (5.14), one read per page otherwise.
+static void prefault_parallel(const uint8_t *file, size_t fsz) {
+    if (fsz < ((size_t)64 << 20) || getenv("METHEOR_NO_PREFAULT")) return;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt ? nt : 4u, 32u));
+    const size_t page = 4096, slice = (((fsz + nt - 1) / nt) + page - 1) / page * page;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t b = (size_t)t * slice, e = std::min(fsz, b + slice);
+        if (b >= e) break;
+        th.emplace_back([file, b, e, page]() {
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+            if (madvise(const_cast<uint8_t *>(file) + b, e - b, MADV_POPULATE_READ) == 0) return;
+            volatile uint8_t sink = 0;
+            for (size_t o = b; o < e; o += page) sink = sink + file[o];
+            (void)sink;
+        });
+    }
+    for (auto &x : th) x.join();
+}
+
 bool bgzf_map(const std::string &path, BgzfMap &out, std::string &err) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) { err = "cannot open " + path; return false; }
@@ -216,6 +242,7 @@ bool bgzf_map(const std::string &path, BgzfMap &out, std::string &err) {
     if (fsz && file == MAP_FAILED) { err = "cannot mmap " + path; return false; }
     out.file = file; out.file_bytes = fsz;
     out.coff.clear(); out.csize.clear(); out.isize.clear();
+    prefault_parallel(file, fsz);
     size_t o = 0;
     while (o < fsz) {
         if (o + 18 > fsz || file[o] != 31 || file[o + 1] != 139 || file[o + 2] != 8 || !(file[o + 3] & 4)) { err = "not a BGZF file (bad block header)"; return false; }

@@ -1668,12 +1668,28 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     }
     if (const char *e = getenv("MTH_PDR_WIDE")) { const int k = atoi(e); wide_shift = k >= 14 && k <= 16 ? k : 0; }
     const int tile_w = wide_shift ? 1 << wide_shift : 4096;
-    const uint32_t ntiles = (uint32_t)((region_len + tile_w - 1) / tile_w);
+    // Wide form: the tile need not be as wide as its slice.  A chr1-sized contig is 2.12 rounds of 65536-position tiles over the chip's
+    // 1 792 resident workgroups (7 on each of 256 CUs) and ends on a nearly empty third round; tiles of region / (3 x 1 792) positions
+    // make three full rounds of smaller tiles.  Only where the last round would be less than half full, and never below
+    // half the slice (the chain of round trips per tile is what the wide form exists to pay less often).  MTH_PDR_WIDE_W forces a width.
+    uint32_t tile_w_rt = 0;
+    if (wide_shift) {
+        const double slots = 7.0 * 256.0, rounds = (double)region_len / (double)tile_w / slots;
+        const double frac = rounds - std::floor(rounds);
+        if (rounds > 1.0 && rounds < 8.0 && frac > 0.02 && frac < 0.5) {
+            const uint64_t w = (uint64_t)std::ceil((double)region_len / (std::ceil(rounds) * slots));
+            const uint32_t wr = (uint32_t)((w + 63) & ~63ull);
+            if (wr >= (uint32_t)tile_w / 2 && wr < (uint32_t)tile_w) tile_w_rt = wr;
+        }
+        if (const char *e = getenv("MTH_PDR_WIDE_W")) { const int k = atoi(e); tile_w_rt = (k >= 1024 && k < tile_w) ? (uint32_t)k & ~63u : 0u; }
+    }
+    const uint32_t tile_step = tile_w_rt ? tile_w_rt : (uint32_t)tile_w;
+    const uint32_t ntiles = (uint32_t)((region_len + tile_step - 1) / tile_step);
     if (ntiles == 0) return MTH_OK;
     // index origin: a whole number of quanta below the region so that halo reads are indexed
     const int32_t ext = ((b.max_span + 2 + IDX_Q - 1) / IDX_Q) * IDX_Q;
     const int32_t idx_base = b.region_beg - ext;
-    const uint32_t nq = (uint32_t)(((int64_t)ntiles * tile_w + ext) >> IDX_QSHIFT) + 2;
+    const uint32_t nq = (uint32_t)(((int64_t)ntiles * tile_step + ext) >> IDX_QSHIFT) + 2;
 
     // The dense tile kernel's own index: one entry per tile in each of two families (k_build_index<2>).  Site discovery for the walk
     // measures (sink) leaves the fine index behind for them; the wide form looks up arbitrary stretch bounds.  MTH_COARSE_INDEX=0: A/B.
@@ -1730,6 +1746,7 @@ int launch_pdr_lpmd(mth_ctx *ctx, const mth_batch_t &b, const mth_pdr_lpmd_param
     a.min_dist = p.lpmd_min_distance; a.max_dist = p.lpmd_max_distance;
     a.pdr_min_qual = p.pdr_min_qual; a.lpmd_min_qual = p.lpmd_min_qual;
     a.want_pdr = p.want_pdr; a.want_lpmd = p.want_lpmd;
+    a.tile_w_rt = tile_w_rt;
     RunArgs ra;
     ra.run_tile0 = reinterpret_cast<uint32_t *>(b_bucket.as<unsigned long long>() + n_bucket_words);
     ra.run_rows = ra.run_tile0 + (((size_t)G + 2u) / 2u) * 2u;

@@ -57,8 +57,10 @@ __global__ __launch_bounds__(PW_B, MTH_PW_OCC) void k_pdr_lpmd_wide(const TileAr
     const uint32_t per_xcd = (ntiles + 7) / 8;
     const uint32_t t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= ntiles) return;
-    const int32_t T0 = a.region_beg + (int32_t)(t * W);
-    const int32_t T1 = (int32_t)min((int64_t)T0 + W, (int64_t)a.region_end);
+    // (a tile may be narrower than its scratch slice: the host picks the width that fills whole rounds of resident workgroups)
+    const uint32_t Wt = a.tile_w_rt ? a.tile_w_rt : (uint32_t)W;
+    const int32_t T0 = a.region_beg + (int32_t)(t * Wt);
+    const int32_t T1 = (int32_t)min((int64_t)T0 + Wt, (int64_t)a.region_end);
     const RelT *__restrict__ rel = reinterpret_cast<const RelT *>(a.cpg_rel);
     SiteRec *__restrict__ out = a.scratch + (size_t)t * W;
     slot_tabs_init(tabs, tid);

@@ -47,6 +47,7 @@ struct TileArgs {
     uint32_t min_cpgs;
     int32_t  min_dist, max_dist;
     uint8_t  pdr_min_qual, lpmd_min_qual, want_pdr, want_lpmd;
+    uint32_t tile_w_rt;    // wide form only: positions per tile when it is not the slice width 1 << SHIFT (0: it is) -- see launch_pdr_lpmd
 #ifdef MTH_TILE_TRACE
     unsigned long long *trace;     // experiment build: 8 ticks per tile (tools/tile_trace.py)
 #endif
