@@ -63,10 +63,14 @@ struct FwArgs {
     unsigned long long *trace;    // -DMTH_FW_TRACE builds: cycles per phase of each tile's first stretch (lane 0)
 };
 
-constexpr int FW_WMAX = 1600;                           // the tile + 200 on either side fit a 64-word bitmap, one word per lane
-constexpr int FW_U = 2;                                 // 64-read chunks of a stretch
+#ifndef MTH_FW_U
+#define MTH_FW_U 2
+#endif
+constexpr int FW_U = MTH_FW_U;                          // 64-read chunks of a stretch
+constexpr int FW_WPT = FW_U > 2 ? 2 : 1;                // bitmap words per lane
+constexpr int FW_WMAX = FW_WPT * 2048 - 448;            // the tile + 200 on either side fit the bitmap (1600 / 3648 positions)
 constexpr int FW_RCAP = 64 * FW_U;                      // candidate reads of a stretch (more: the stretch is halved)
-constexpr int FW_V = 4;                                 // 64-call chunks of a stretch
+constexpr int FW_V = FW_U > 2 ? 6 : 4;                  // 64-call chunks of a stretch
 constexpr int FW_CCAP = 64 * FW_V;                      // calls of a stretch's candidate reads (more: the stretch is halved)
 constexpr int FW_SC = 32;                               // core sites of a stretch (one per lane; a denser stretch is halved)
 constexpr int FW_LCAP = 64;                             // stored reads of a site here (more: handed back)
@@ -120,7 +124,7 @@ __device__ __forceinline__ uint32_t fw_rounds(const uint16_t *s_list, const uint
 __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
     constexpr int U = FW_U;
     // 5 KB of LDS per wave: 32 waves per CU (the kernel is bound by each wave's own chain of round trips: what counts is waves in flight)
-    __shared__ uint2 s_bp[64];                                // {site bits, sites in the words before}
+    __shared__ uint2 s_bp[64 * FW_WPT];                       // {site bits, sites in the words before}; lane l owns words FW_WPT l ..
     __shared__ __attribute__((aligned(16))) uint32_t s_row[FW_RCAP * 4];   // {start | end << 16, mC, first-call rank -> mA, mM}
     __shared__ uint16_t s_list[FW_LCAP];                      // D1: the readers of the site in hand (byte offsets of their rows, file order)
     __shared__ float s_quot[FW_QC];                           // [ncpg (ncpg + 1) / 2 + ham] = ham / ncpg (a division is ten vector instructions)
@@ -167,7 +171,8 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         const uint32_t wbits = Wp + 2u * (uint32_t)a.max_span + 1u;
         const uint32_t c_lo = (uint32_t)a.max_span + 1u, c_hi = c_lo + Wp;          // window offsets of the core [P0, P1)
         FW_SYNC();                                                                  // the previous stretch's LDS is done with
-        s_bp[lane] = make_uint2(0u, 0u);
+#pragma unroll
+        for (int q = 0; q < FW_WPT; ++q) s_bp[lane * FW_WPT + q] = make_uint2(0u, 0u);
         if (lane < FW_SC) s_sflag[lane] = 0u;
         FW_SYNC();
         FW_TK(0);
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
             return rel;
         };
         if (!heavy) {
-            reinterpret_cast<uint32_t *>(s_owner)[lane] = 0u;
+            for (int i = lane; i < FW_CCAP / 4; i += 64) reinterpret_cast<uint32_t *>(s_owner)[i] = 0u;
             FW_SYNC();
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -250,10 +255,14 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         FW_TK(1);
         FW_SYNC();
         // ---- B: ranks ----
-        const uint32_t wb = s_bp[lane].x;
-        const uint32_t wcnt = (uint32_t)__builtin_popcount(wb);
+        uint32_t wb[FW_WPT], wcnt = 0;
+#pragma unroll
+        for (int q = 0; q < FW_WPT; ++q) { wb[q] = s_bp[lane * FW_WPT + q].x; wcnt += (uint32_t)__builtin_popcount(wb[q]); }
         uint32_t pre = wave_scan_incl(wcnt) - wcnt;
-        s_bp[lane].y = pre;
+        const uint32_t pre0 = pre;
+#pragma unroll
+        for (int q = 0; q < FW_WPT; ++q) { s_bp[lane * FW_WPT + q].y = pre; pre += (uint32_t)__builtin_popcount(wb[q]); }
+        pre = pre0;
         FW_SYNC();
         auto rank_of = [&](const uint32_t rel) {                                     // sites of the window below offset rel
             const uint2 e = s_bp[rel >> 5];
@@ -263,12 +272,13 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         const uint32_t ncore = k1 - k0;
         if (ncore > (uint32_t)FW_SC) { sub_w = max((min(sub_w, Wp) >> 1) & ~15u, 48u); continue; }   // (48 positions hold <= 24 sites)
         // core site positions, rank order
-        {
-            uint32_t bits = wb;
+#pragma unroll
+        for (int q = 0; q < FW_WPT; ++q) {
+            uint32_t bits = wb[q];
             while (bits) {
                 const uint32_t b = (uint32_t)__builtin_ctz(bits);
                 bits &= bits - 1u;
-                const uint32_t rel = (uint32_t)lane * 32u + b;
+                const uint32_t rel = (uint32_t)(lane * FW_WPT + q) * 32u + b;
                 if (rel >= c_lo && rel < c_hi) s_cpos[pre - k0] = (int32_t)(wbase + rel);
                 ++pre;
             }
@@ -388,6 +398,7 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
             // the branch's code sits here, in a loop of its own behind this one, or out of line (15 %); a site per thousand is not worth it)
             if (flush) { if ((uint32_t)lane == q) redo = true; continue; }
 #else
+            static_assert(FW_U == 2, "the exact flush branch is written for two chunks of reads");
             if (flush) {
                 // (rare: a few sites per thousand)  The flush rule, exactly (fdrp.rs:212-223): a passing read whose first call lies beyond the
                 // site closes the open segment; two readers share a segment iff no such read lies between them.  F = flushers before a
@@ -548,7 +559,7 @@ int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_
     int W;
     {
         const double rpb = (double)d.n_reads / (double)region_len;
-        const double want = 128.0 - 2.0 * std::sqrt(128.0);                         // ~105 reads
+        const double want = (double)FW_RCAP - 2.0 * std::sqrt((double)FW_RCAP);     // ~105 of 128 reads
         W = (int)(want / std::max(rpb, 1e-9)) - d.max_span;
         W = std::max(256, std::min(FW_WMAX, W)) & ~63;
     }
