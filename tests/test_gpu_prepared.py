@@ -225,7 +225,7 @@ def test_handle_validation_by_registry_and_free_on_close():
     import copy
     import metheor_amd
     from metheor_amd import synth
-    c = synth.make_contig(0, 200_000, 8_000, 0.02, np.random.default_rng(5))
+    c = synth.make_contig(0, 500_000, 60_000, 0.02, np.random.default_rng(5))
     eng = metheor_amd.Engine(0)
     bt = util.device_batch(c, device="cuda:0")
     p = eng.batch_prepare(bt)
