@@ -94,3 +94,25 @@ def test_plan_genome_covers_every_read_once():
         assert seen == contigs
         sizes = [sum(b - a for _, a, b in r) for r in plan]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_order_line_puts_scalars_first_and_a_summary_last():
+    """the bench line carries every secondary figure as a top-level scalar right behind the contract's keys and once
+    more in a `summary` object at the END of the line (a driver log keeps the line's tail)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 0.1, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": "w"},
+           "roofline": {"frac": 0.43, "frac_l3_resident": 0.48}, "timed_region_s": 1.0,
+           "all7": {"seven_measures_ms": 9.7, "per_pass_ms_one_sync_each": {"fdrp+qfdrp": 4.8, "mhl": 2.5}, "prepared_batches": {"seven_measures_ms": 8.8}},
+           "fdrp_pairs": {"pass_ms": 3.6}, "e2e": {"M_reads_per_s_median": 40.0, "large": {"M_reads_per_s_median": 60.0}}, "cpu_baseline": {"value": 16.0}}
+    line = bench.order_line(out)
+    keys = list(line.keys())
+    assert keys[:13] == ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
+    assert keys[-1] == "summary"
+    first_nested = min(i for i, k in enumerate(keys) if isinstance(line[k], dict) and k != "config")
+    for k in ("e2e_10M_median", "e2e_100M_median", "all7_ms", "all7_prepared_ms", "all7_fdrp_pass_ms", "fdrp_pairs_ms", "roofline_frac_two_batches"):
+        assert k in line and keys.index(k) < first_nested and line["summary"][k] == line[k]
+    assert line["all7_ms"] == 9.7 and line["e2e_100M_median"] == 60.0 and set(out) <= set(line)
