@@ -1344,7 +1344,11 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     const double cand = (double)d.n_reads * ((double)d.max_span + 2.0) / std::max<double>(1.0, (double)d.region_end - (double)d.region_beg);
     // (round 6: a dense form of the tile pass -- 64-bit masks, sites up to 64 reads, term lists in HBM -- was built for the depths of config 4:
     // parity-green, 4.2 ms against this file's k_fdrp_tile + k_fdrp_chain 3.4 ms: profiles/r06_fdrp_dense.md, tools/experiments/)
-    bool wtile = !dense && d.max_span <= 200 && cand <= 16.0 && !getenv("METHEOR_FDRP_WALK4") && !getenv("METHEOR_FDRP_TILE");
+    // (sparse calls -- <= 2 a read -- up to ~40 candidate reads a site: a site holds up to 64 readers there; measured on a chr1-sized contig
+    // at density 0.0091: 24 M reads (15 x) 1.48 -> 0.85 ms a pass, 32 M reads (20 x: the read x read form until round 6) 2.92 -> 1.39 ms.
+    // Config 2 -- 25.6 x, 3 calls a read -- keeps the read x read form: 1.35 ms against 2.1)
+    const bool sparse_calls = d.n_reads && (double)d.n_cpgs / (double)d.n_reads <= 2.0;
+    bool wtile = sparse_calls && d.max_span <= 200 && cand <= 40.0 && !getenv("METHEOR_FDRP_WALK4") && !getenv("METHEOR_FDRP_TILE");
     if (const char *e = getenv("METHEOR_FDRP_WTILE")) wtile = d.max_span <= 200 && atoi(e) != 0;
     if (wtile) {
         // the candidate-site arrays the tile pass fills itself (no discovery pass)
