@@ -28,6 +28,7 @@
 //
 // Reservoir branch (depth > max_depth): the reference draws from an OS-seeded RNG (fdrp.rs:90), so
 // there is nothing to be bit-equal to; device and oracle share the counter-based sample_j below.
+#include <cmath>
 #include <type_traits>
 
 #include "mth_ctx.h"
@@ -1344,11 +1345,14 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     const double cand = (double)d.n_reads * ((double)d.max_span + 2.0) / std::max<double>(1.0, (double)d.region_end - (double)d.region_beg);
     // (round 6: a dense form of the tile pass -- 64-bit masks, sites up to 64 reads, term lists in HBM -- was built for the depths of config 4:
     // parity-green, 4.2 ms against this file's k_fdrp_tile + k_fdrp_chain 3.4 ms: profiles/r06_fdrp_dense.md, tools/experiments/)
-    // (sparse calls -- <= 2 a read -- up to ~40 candidate reads a site: a site holds up to 64 readers there; measured on a chr1-sized contig
-    // at density 0.0091: 24 M reads (15 x) 1.48 -> 0.85 ms a pass, 32 M reads (20 x: the read x read form until round 6) 2.92 -> 1.39 ms.
-    // Config 2 -- 25.6 x, 3 calls a read -- keeps the read x read form: 1.35 ms against 2.1)
+    // How deep: a site holds up to 64 readers there, but readers beyond max_depth are the reservoir's (handed back), so the depth must
+    // stay 4 sigma below max_depth (CLI default 40: ~22 candidate reads a site).  Measured on a chr1-sized contig at density 0.0091,
+    // pass ms, this form against rounds 2-5's choice: 16 M reads (10 x) 0.45 / 0.615, 24 M 0.85 / 1.48, 32 M (20 x) 1.26 / 2.91 (the
+    // read x read form), 48 M (29 x) 3.06 / 3.45 (hand-backs 0.7), 64 M (39 x) 10.5 / 4.8.  Sparse calls only (<= 2 a read):
+    // config 2 -- 25.6 x, 3 calls a read -- 2.1 / 1.35.
     const bool sparse_calls = d.n_reads && (double)d.n_cpgs / (double)d.n_reads <= 2.0;
-    bool wtile = sparse_calls && d.max_span <= 200 && cand <= 40.0 && !getenv("METHEOR_FDRP_WALK4") && !getenv("METHEOR_FDRP_TILE");
+    bool wtile = sparse_calls && d.max_span <= 200 && cand <= 24.0 && cand + 4.0 * std::sqrt(cand) <= (double)params->max_depth &&
+                 !getenv("METHEOR_FDRP_WALK4") && !getenv("METHEOR_FDRP_TILE");
     if (const char *e = getenv("METHEOR_FDRP_WTILE")) wtile = d.max_span <= 200 && atoi(e) != 0;
     if (wtile) {
         // the candidate-site arrays the tile pass fills itself (no discovery pass)

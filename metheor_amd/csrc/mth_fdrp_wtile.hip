@@ -121,10 +121,6 @@ __device__ __forceinline__ uint32_t fw_rounds(const uint16_t *s_list, const uint
 // (slot = readers so far + ballot prefix), and the non-zero terms of a site's pairs are packed in the reference's loop order
 // as they are made -- D2 adds ~20 terms a site, not ~66 codes.  The kernel is bound by vector-instruction issue (a wave64
 // instruction occupies its SIMD for four cycles): what counts is instructions per read and per pair round.
-// DEEP (more than ~16 candidate reads a site: 15-40 x WGBS, config 2): the sites of a stretch are taken in groups whose pairs fit the term
-// array, the ordered sums after each group; stretches are halved further.  An instance of its own: the WGBS instance's registers are
-// at the 64 of eight waves per SIMD, and the group logic inside the same loop cost every site 13 %.
-template <bool DEEP>
 __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
     constexpr int U = FW_U;
     // 5 KB of LDS per wave: 32 waves per CU (the kernel is bound by each wave's own chain of round trips: what counts is waves in flight)
@@ -169,8 +165,7 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         const uint32_t lo = __builtin_amdgcn_readfirstlane(min(a.idx[((uint32_t)P0 - (uint32_t)a.max_span + 1u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads));
         const uint32_t hi = __builtin_amdgcn_readfirstlane(min(a.idx[(((uint32_t)P1 - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads));
         const uint32_t R = hi - lo;
-        const uint32_t sub_min = DEEP ? 64u : 192u;                                 // stretches are not halved below this for reads / calls (then: count-only)
-        if (R > (uint32_t)FW_RCAP && sub_w > sub_min) { sub_w = max((sub_w >> 1) & ~31u, sub_min); continue; }
+        if (R > (uint32_t)FW_RCAP && sub_w > 192u) { sub_w = max((sub_w >> 1) & ~31u, 192u); continue; }
         const bool heavy = R > (uint32_t)FW_RCAP || heavy_redo || a.force_heavy;
         const uint32_t wbase = (uint32_t)P0 - (uint32_t)a.max_span - 1u;            // window offset 0
         const uint32_t wbits = Wp + 2u * (uint32_t)a.max_span + 1u;
@@ -198,7 +193,7 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         const uint32_t ofirst = R ? __builtin_amdgcn_readfirstlane(o0[0]) : olast;  // (lane 0 of chunk 0 is read lo)
         const uint32_t C_n = heavy ? 0u : olast - ofirst;                            // calls of the stretch's candidate reads
         if (C_n > (uint32_t)FW_CCAP) {
-            if (sub_w > sub_min) { sub_w = max((sub_w >> 1) & ~31u, sub_min); continue; }
+            if (sub_w > 192u) { sub_w = max((sub_w >> 1) & ~31u, 192u); continue; }
             heavy_redo = true; continue;
         }
         auto mark = [&](const uint32_t w, const uint32_t srel_m1) -> uint32_t {      // a passing read's call: the bitmap bit; window offset
@@ -361,30 +356,9 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         const uint32_t n_s = sf & 0x7fffffffu;                                       // lane = core site: reads that call it and pass (C1)
         const bool in_core = (uint32_t)lane < ncore;
         // handed back: a reader with > 8 calls / > 16 window sites; reservoir (fdrp.rs:87-94) / more reads than this kernel's list holds
-        const uint32_t Pq = n_s * (n_s - 1u) / 2u;                                   // lane = core site: its pairs = its terms at most
-        bool redo = in_core && ((sf >> 31) || ((n_s > cap || (DEEP && Pq > (uint32_t)FW_NZCAP)) && n_s >= mind));
+        bool redo = in_core && ((sf >> 31) || (n_s > cap && n_s >= mind));
         const bool act = in_core && n_s >= mind && n_s <= cap && !redo;
         uint32_t disc_vec = 0, nzoff_vec = 0, nzcnt_vec = 0, n_seg = 0;              // n_seg: stored reads when the readers form several segments
-        float q_sum = 0.0f;                                                          // lane = site: its ordered sum of terms (qfdrp.rs:152)
-        bool pend = false;                                                           // lane = site: its terms sit in the term array, not yet summed
-// one lane per pending site: the ordered f32 sum over its terms -- the reference's order (x + 0.0 == x: the zero terms are not kept); four
-// codes, then their four quotients, per trip; then the term array starts over
-#define FW_D2_SUMS() do {                                                                                                           \
-            FW_SYNC();                                                                                                               \
-            if (pend) {                                                                                                              \
-                float q_ = 0.0f;                                                                                                     \
-                uint32_t i_ = 0;                                                                                                     \
-                for (; i_ + 4u <= nzcnt_vec; i_ += 4u) {                                                                             \
-                    const uint32_t c0 = s_nz[nzoff_vec + i_], c1 = s_nz[nzoff_vec + i_ + 1u], c2 = s_nz[nzoff_vec + i_ + 2u], c3 = s_nz[nzoff_vec + i_ + 3u]; \
-                    const float t0 = s_quot[c0], t1 = s_quot[c1], t2 = s_quot[c2], t3 = s_quot[c3];                                  \
-                    q_ += t0; q_ += t1; q_ += t2; q_ += t3;                                                                          \
-                }                                                                                                                    \
-                for (; i_ < nzcnt_vec; ++i_) q_ += s_quot[s_nz[nzoff_vec + i_]];                                                     \
-                q_sum = q_; pend = false;                                                                                            \
-            }                                                                                                                        \
-            FW_SYNC();                                                                                                               \
-            nzbase = 0;                                                                                                              \
-        } while (0)
         bool no_row = false;
         const bool mo_any = a.min_overlap <= 0;                                      // every pair overlaps enough
         const int32_t mo_m1 = a.min_overlap - 1;
@@ -398,24 +372,9 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
             const uint32_t P = n * (n - 1u) / 2u;
             return P ? a.pair_tab[(n * (n - 1u) * (n - 2u)) / 6u + min((uint32_t)lane, P - 1u)] : 0u;
         };
-        // The term array holds the non-zero terms of the sites evaluated since the last sums (D2).  Sites are taken in groups whose pairs
-        // fit it even if every term were non-zero: one group at WGBS depth, a group every few sites at 25 x (gstart: the sites that open one)
-        unsigned long long gstart = 0;
-        if (DEEP && wave_sum(act ? Pq : 0u) > (uint32_t)FW_NZCAP) {
-            uint32_t acc = 0;
-            for (unsigned long long m = todo; m; m &= m - 1ull) {
-                const uint32_t qq = (uint32_t)__builtin_ctzll(m), pp = (uint32_t)__builtin_amdgcn_readlane(Pq, qq);
-                if (acc + pp > (uint32_t)FW_NZCAP) { gstart |= 1ull << qq; acc = 0; }
-                acc += pp;
-            }
-        }
         uint32_t ent_site = first_ent(todo);
-        do {
-        bool started = false;
         while (todo) {
             const uint32_t q = (uint32_t)__builtin_ctzll(todo);
-            if (DEEP && started && ((gstart >> q) & 1ull)) break;                    // the next group: after this one's sums
-            started = true;
             todo &= todo - 1ull;
             const uint32_t ent_first = ent_site;
             ent_site = first_ent(todo);
@@ -470,18 +429,16 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
             }
 #endif
             FW_SYNC();
+            const uint32_t nz0 = nzbase;
             // (the table entries were requested for n_s readers: another n after a flush)
             const uint32_t Pn = n * (n - 1u) / 2u;
-            const uint32_t nz0 = nzbase;
             const uint32_t ent0 = !flush ? ent_first : (Pn ? (uint32_t)a.pair_tab[(n * (n - 1u) * (n - 2u)) / 6u + min((uint32_t)lane, Pn - 1u)] : 0u);
             const uint32_t disc = fw_rounds(s_list, s_row, s_nz, a.pair_tab, lane, n, ent0, nzbase, mo_any, mo_m1);
-            if (nzbase > (uint32_t)FW_NZCAP) {                                       // more non-zero terms than the array holds at all (> 45 readers): the walk
+            if (nzbase > (uint32_t)FW_NZCAP) {                                       // the term array is full: this site goes to the walk
                 nzbase = nz0;
                 if ((uint32_t)lane == q) redo = true;
-            } else if ((uint32_t)lane == q) { disc_vec = disc; nzoff_vec = nz0; nzcnt_vec = nzbase - nz0; pend = true; }
+            } else if ((uint32_t)lane == q) { disc_vec = disc; nzoff_vec = nz0; nzcnt_vec = nzbase - nz0; }
         }
-        if (DEEP) { FW_D2_SUMS(); }
-        } while (DEEP && todo);
         FW_TK(4);
         FW_SYNC();
         // ---- D2: one lane per site ----
@@ -491,18 +448,15 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         if (emit) {
             rec.pos = s_cpos[lane & (FW_SC - 1)];
             if (!redo) {
-                float q = q_sum;
-                if (!DEEP) {
-                    // qfdrp.rs:152, the reference's order (x + 0.0 == x: the zero terms are not kept); four codes, then their four quotients, per trip
-                    q = 0.0f;
-                    uint32_t i = 0;
-                    for (; i + 4u <= nzcnt_vec; i += 4u) {
-                        const uint32_t c0 = s_nz[nzoff_vec + i], c1 = s_nz[nzoff_vec + i + 1u], c2 = s_nz[nzoff_vec + i + 2u], c3 = s_nz[nzoff_vec + i + 3u];
-                        const float t0 = s_quot[c0], t1 = s_quot[c1], t2 = s_quot[c2], t3 = s_quot[c3];
-                        q += t0; q += t1; q += t2; q += t3;
-                    }
-                    for (; i < nzcnt_vec; ++i) q += s_quot[s_nz[nzoff_vec + i]];
+                float q = 0.0f;
+                // qfdrp.rs:152, the reference's order (x + 0.0 == x: the zero terms are not kept); four codes, then their four quotients, per trip
+                uint32_t i = 0;
+                for (; i + 4u <= nzcnt_vec; i += 4u) {
+                    const uint32_t c0 = s_nz[nzoff_vec + i], c1 = s_nz[nzoff_vec + i + 1u], c2 = s_nz[nzoff_vec + i + 2u], c3 = s_nz[nzoff_vec + i + 3u];
+                    const float t0 = s_quot[c0], t1 = s_quot[c1], t2 = s_quot[c2], t3 = s_quot[c3];
+                    q += t0; q += t1; q += t2; q += t3;
                 }
+                for (; i < nzcnt_vec; ++i) q += s_quot[s_nz[nzoff_vec + i]];
                 // (num_reads * (num_reads - 1)) as f32 / 2.0 in usize arithmetic (fdrp.rs:143)
                 const uint32_t nr = n_seg ? n_seg : n_s;
                 const unsigned long long prod = (unsigned long long)nr * (unsigned long long)(nr - 1u);
@@ -648,12 +602,7 @@ int launch_fdrp_wtile(mth_ctx *ctx, const mth_batch_t &d, const mth_fdrp_params_
 #endif
     {
         LaunchTimer lt(ctx, K_FDRPWTILE);
-        // (the deep instance from ~16 candidate reads a site, or where the calls are dense enough that a site's pairs crowd the term array)
-        const double cand = (double)d.n_reads * ((double)d.max_span + 2.0) / (double)region_len;
-        bool deep = cand > 16.0 || (double)d.n_cpgs / (double)d.n_reads > 2.0;      // (denser calls only when the form is forced: tests)
-        if (const char *e = getenv("METHEOR_FDRP_WTILE_DEEP")) deep = atoi(e) != 0;
-        if (deep) hipLaunchKernelGGL(k_fdrp_wtile<true>, dim3(grid), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL(k_fdrp_wtile<false>, dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_fdrp_wtile, dim3(grid), dim3(64), 0, s, a);
     }
     {
         LaunchTimer lt(ctx, K_GATHER);

@@ -17,14 +17,14 @@ f32 = np.float32
 TOL = 1e-6
 
 
-@pytest.fixture(autouse=True, params=["auto", "wtile", "wtile_sub", "wtile_heavy", "wtile_shallow", "walk16", "walk32", "tile", "walk"])
+@pytest.fixture(autouse=True, params=["auto", "wtile", "wtile_sub", "wtile_heavy", "walk16", "walk32", "tile", "walk"])
 def walk_choice(request, monkeypatch):
     """every case eight times: with the host's own choice of kernel form; with the one-pass tile form forced (k_fdrp_wtile,
     round 6: whatever it cannot hold is handed back to the general walk) -- as it is, starting from 192-position stretches, and
     with every stretch on its count-only path (every site handed back); with k_fdrp_walk4 forced (16 or 32 lanes per site, the
     rest handed back to the general walk -- on dense data mostly the hand-back path); with the read x read form forced
     (k_fdrp_tile + k_fdrp_chain, round 4); and with the wave-per-site walk alone"""
-    for k in ("METHEOR_FDRP_WALK4", "METHEOR_FDRP_TILE", "METHEOR_FDRP_WTILE", "METHEOR_FDRP_WTILE_SUB", "METHEOR_FDRP_WTILE_HEAVY", "METHEOR_FDRP_WTILE_DEEP"):
+    for k in ("METHEOR_FDRP_WALK4", "METHEOR_FDRP_TILE", "METHEOR_FDRP_WTILE", "METHEOR_FDRP_WTILE_SUB", "METHEOR_FDRP_WTILE_HEAVY"):
         monkeypatch.delenv(k, raising=False)
     if request.param.startswith("wtile"):
         monkeypatch.setenv("METHEOR_FDRP_WTILE", "1")
@@ -32,8 +32,6 @@ def walk_choice(request, monkeypatch):
             monkeypatch.setenv("METHEOR_FDRP_WTILE_SUB", "1")
         if request.param == "wtile_heavy":
             monkeypatch.setenv("METHEOR_FDRP_WTILE_HEAVY", "1")
-        if request.param == "wtile_shallow":                      # the WGBS-depth instance of the kernel whatever the batch's depth (the other
-            monkeypatch.setenv("METHEOR_FDRP_WTILE_DEEP", "0")    # forms pick the instance from the batch: the deep one on most test data)
     elif request.param.startswith("walk") and len(request.param) > 4:
         monkeypatch.setenv("METHEOR_FDRP_WALK4", request.param[4:])
         monkeypatch.setenv("METHEOR_FDRP_TILE", "0")
@@ -267,7 +265,7 @@ def test_max_depth_above_64(eng, walk_choice):
     sites beyond 256 stored reads by a third pass with rows in HBM scratch (round 2: the reference has no such limit;
     output_validation.rs runs --max-depth 100); only max_depth > 16384 is refused"""
     from metheor_amd import MthError, synth
-    if walk_choice in ("walk16", "walk32", "wtile_sub", "wtile_heavy", "wtile_shallow"):
+    if walk_choice in ("walk16", "walk32", "wtile_sub", "wtile_heavy"):
         pytest.skip("40 s a form: the deep passes sit behind the first pass whatever its form -- host's choice, tile and walk cover them")
     c = synth.make_contig(0, 300_000, 50_000, 0.03, np.random.default_rng(91))           # ~25x: every site below 64 reads
     reads = pyoracle.Reads.from_soa(*synth.to_oracle_soa(c))
