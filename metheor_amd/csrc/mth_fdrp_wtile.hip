@@ -2,31 +2,36 @@
 //
 // Rounds 2-5 ran this depth class (about a dozen candidate reads per site) as four launches: a full PDR-style site discovery
 // (k_pdr_lpmd_tile into a sink + its gather), k_fdrp_walk4 (four sites per wave, every site re-loading its candidate reads from
-// HBM and re-deriving their call masks), k_fdrp_walk for what that handed back, and the emit.  Here one workgroup owns a tile of
-// 4096 reference positions and keeps everything the tile's sites need in LDS:
-//   A  every candidate read once (one per thread): fields, <= 8 calls; the calls of the reads that pass (mapq, >= 1 CpG:
-//      fdrp.rs:205-210) set bits in a position bitmap of the tile + max_span on either side -- the tile's SITES -- and are kept
-//      as 16-bit window offsets.
-//   B  prefix popcount over the bitmap: a position's RANK among the window's sites.
-//   C  per read: its calls as ranks -> three 32-bit masks (calls, covered calls, methylated covered calls) with bit = rank mod 32
-//      (a stored read spans <= 16 ranks here -- else its sites are handed back -- so two reads that share a site never alias);
-//      per site: its readers IN FILE ORDER as a list of read slots (ballots per 64-read chunk: count, prefix over chunks, place);
-//      the flush rule (fdrp.rs:212-223) as an exclusive prefix maximum of the passing reads' first-call ranks: a reader that
-//      has a passing read with a first call beyond the site before it may sit behind a flush -> the site is handed back.
-//   D1 every pair of every site's readers, flat over the workgroup's threads (lane = pair, all lanes busy whatever the sites'
-//      depths): overlap bases, shared calls, Hamming count from the two reads' rows -> one byte (ham * 9 + ncpg, 0 = skipped
-//      pair) at the pair's LEXICOGRAPHIC index in the site's code list (fdrp.rs:128-141 loop order).
-//   D2 one thread per site: the ordered f32 sum over the list (qfdrp.rs:152; quotients from a table filled by the same
+// HBM and re-deriving their call masks), k_fdrp_walk for what that handed back, and the emit.  Here ONE WAVE owns a tile of
+// ~1 500 reference positions (the width follows the batch's read and call density: launch_fdrp_wtile) and keeps everything the
+// tile's sites need in 5 KB of LDS -- no workgroup barrier anywhere, 32 waves per CU:
+//   A1 every candidate read once (one per lane, two 64-read chunks): fields, the pass test (mapq, >= 1 CpG: fdrp.rs:205-210),
+//      its row's start | end, an owner mark at its first call's slot.
+//   A2 every call once (one per lane, coalesced): its read = the latest owner mark at or before it (a wave max-scan); the calls
+//      of the passing reads set bits in a position bitmap of the tile + max_span on either side -- the tile's SITES.
+//   B  prefix popcount over the bitmap: a position's RANK among the window's sites; the core sites' positions.
+//   C1 per call: its rank -> the read's three 32-bit masks (calls, covered calls, methylated covered calls; bit = rank mod 32: a
+//      stored read spans <= 16 ranks here -- else its sites are handed back -- so two reads that share a site never alias) and
+//      the site's reader count, all by LDS atomics.
+//   C2 per read: the finished row; the flush rule (fdrp.rs:212-223) as an exclusive prefix maximum of the passing reads'
+//      first-call ranks: a reader that has a passing read with a first call beyond the site before it may sit behind a flush
+//      -> the site is handed back.
+//   D1 per site that can produce a row (>= min_depth readers): its readers IN FILE ORDER as a list of row offsets (ballots per
+//      chunk), then every pair of them, lane = pair in the reference's loop order (fdrp.rs:128-141; index -> (i, j) from a
+//      table, the next site's entries requested ahead): overlap bases, shared calls, Hamming count from the two rows; the
+//      non-zero terms as one byte each (ncpg (ncpg + 1) / 2 + ham), packed in that order.
+//   D2 one lane per site: the ordered f32 sum over its terms (qfdrp.rs:152; quotients from a table filled by the same
 //      division), the discordant count, fdrp.rs:143 / qfdrp.rs:155.
 // Rows go to the tile's scratch slice, sorted by position (ranks ascend); k_fdrp_wtile_gather packs the slices into the
 // candidate-site arrays the rest of the FDRP pipeline works on (k_fdrp_walk for the handed-back sites -- flag 4 -- and the
 // emit).  No discovery launch, no per-site global loads, no hand-back of merely deep sites (a site holds up to 64 reads here).
 //
 // Only the common shape is computed here; everything else is handed back and stays bit-identical (k_fdrp_walk, call-by-call path):
-// a reader with > 8 calls or spanning > 16 window sites, more readers than min(max_depth, 64) (reservoir: fdrp.rs:87-94), a
-// possible flush between two readers.  Spans > 200 bp never come here (host side; add_read's window test, fdrp.rs:58-63).
-// A stretch with more candidate reads / sites / readers / pairs than the LDS arrays hold is redone in halves (down to 256
-// positions; beyond that every site of the stretch is handed back).
+// a reader with > 16 calls or spanning > 16 window sites, more readers than min(max_depth, 64) (reservoir: fdrp.rs:87-94), a
+// possible flush between two readers, a site whose terms do not fit the term array.  Spans > 200 bp never come here (host side;
+// add_read's window test, fdrp.rs:58-63).  A stretch with more candidate reads / calls / sites than the LDS arrays hold is redone
+// in halves (down to 192 positions; beyond that every site of the stretch is handed back).
+// How it got here, step by step with counters: profiles/r06_wtile_pmc.md.
 #include <algorithm>
 #include <cstdio>
 #include <cmath>
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
     __shared__ __attribute__((aligned(4))) uint8_t s_nz[FW_NZCAP];   // D: the sites' non-zero terms as codes, each site's in the reference's loop order
     uint8_t *const s_owner = s_nz;                            // A: call slot -> read slot + 1 where a read's calls begin, else 0
     __shared__ int32_t s_cpos[FW_SC];
-    __shared__ uint32_t s_sflag[FW_SC];                       // per core site: passing reads that call it | bit 31: one of them holds > 8 calls / spans > 16 window sites
+    __shared__ uint32_t s_sflag[FW_SC];                       // per core site: passing reads that call it | bit 31: one of them spans > 16 window sites
     static_assert(FW_NZCAP >= FW_CCAP, "the owner marks share the term array");
     const int lane = threadIdx.x;
     // block b runs on XCD b % 8 (observed; speed only): give each XCD a contiguous run of tiles
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(64, 8) void k_fdrp_wtile(const FwArgs a) {
         const uint32_t sf = s_sflag[lane & (FW_SC - 1)];
         const uint32_t n_s = sf & 0x7fffffffu;                                       // lane = core site: reads that call it and pass (C1)
         const bool in_core = (uint32_t)lane < ncore;
-        // handed back: a reader with > 8 calls / > 16 window sites; reservoir (fdrp.rs:87-94) / more reads than this kernel's list holds
+        // handed back: a reader spanning > 16 window sites; reservoir (fdrp.rs:87-94) / more reads than this kernel's list holds
         bool redo = in_core && ((sf >> 31) || (n_s > cap && n_s >= mind));
         const bool act = in_core && n_s >= mind && n_s <= cap && !redo;
         uint32_t disc_vec = 0, nzoff_vec = 0, nzcnt_vec = 0, n_seg = 0;              // n_seg: stored reads when the readers form several segments

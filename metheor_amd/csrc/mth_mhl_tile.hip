@@ -159,8 +159,12 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                 for (int u = 0; u < MT_U; ++u) {
                     const uint32_t i = b0 + (uint32_t)u * MT_B + tid, ii = min(i, hi - 1);
                     const bool has = i < hi && o1s[u] != o0s[u];                 // a read without a CpG neither flushes nor contributes (mhl.rs:162)
+#ifdef MTH_MT_NOFLUSH1
+                    fw[u] = 0u; st[u] = 0; (void)has; mq[u] = a.read_mapq[ii];
+#else
                     fw[u] = has ? a.cpg_pos[o0s[u]] : 0u;
                     st[u] = a.read_start[ii]; mq[u] = a.read_mapq[ii];
+#endif
                     const uint32_t in = min(i + (uint32_t)MT_U * MT_B, hi - 1);
                     o0n[u] = a.cpg_off[in]; o1n[u] = a.cpg_off[in + 1];
                 }
@@ -168,6 +172,7 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                 for (int u = 0; u < MT_U; ++u) {
                     const uint32_t i = b0 + (uint32_t)u * MT_B + tid;
                     const uint32_t n = i < hi ? o1s[u] - o0s[u] : 0u;
+#ifndef MTH_MT_NOFLUSH1
                     if (n && !(a.dbg & 1)) {
                         // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (rule of the PDR tile kernel):
                         // the first call here, a contributor's other calls in phase 2
@@ -185,6 +190,7 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                             }
                         }
                     }
+#endif
                     const bool contrib = n != 0 && mq[u] >= a.min_qual && n >= a.min_cpgs && !(a.dbg & 2);      // mhl.rs:176, 181
                     if (heavy) {                                                   // (rare: slots made and counted straight from memory)
                         if (contrib && mhl_count_only(a.cpg_pos, o0s[u], o1s[u], (uint32_t)st[u] - 1u, (uint32_t)a.max_span, (uint32_t)P0, Wp, tkey, thist, bad))
