@@ -13,7 +13,7 @@ static const char *kKernelNames[K_NUM] = {"k_build_index", "k_pdr_lpmd_tile", "k
                                           "k_quartet_bound", "k_quartet_tile", "k_quartet_insert", "k_quartet_emit",
                                           "k_mhl_walk", "k_mhl_walk_big", "k_mhl_emit", "k_pdr_walk",
                                           "k_fdrp_walk", "k_fdrp_emit", "k_pairs", "k_pairs_tile", "k_decode", "k_inflate", "k_crc32", "k_mhl_tile", "k_pdr_lpmd_wide",
-                                          "k_fdrp_tile", "k_fdrp_chain", "k_fdrp_walk4", "k_fdrp_wtile"};
+                                          "k_fdrp_tile", "k_fdrp_chain", "k_fdrp_walk4", "k_fdrp_wtile", "k_mhl_rowcheck"};
 
 __global__ void k_lpmd_add2(DevState *st, long long n_read, long long n_valid) { st->lpmd[2] += n_read; st->lpmd[3] += n_valid; }
 

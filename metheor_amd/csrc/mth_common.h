@@ -50,6 +50,6 @@ struct SiteRec {  // per-tile scratch row
     uint32_t n_conc, n_disc, pad;
 };
 
-enum KernelId { K_INDEX = 0, K_TILE, K_GATHER, K_QBOUND, K_QTILE, K_QINSERT, K_QEMIT, K_MHLWALK, K_MHLWALKBIG, K_MHLEMIT, K_PDRWALK, K_FDRPWALK, K_FDRPEMIT, K_PAIRS, K_PAIRSTILE, K_DECODE, K_INFLATE, K_CRC, K_MHLTILE, K_WIDE, K_FDRPTILE, K_FDRPCHAIN, K_FDRPWALK4, K_FDRPWTILE, K_NUM };
+enum KernelId { K_INDEX = 0, K_TILE, K_GATHER, K_QBOUND, K_QTILE, K_QINSERT, K_QEMIT, K_MHLWALK, K_MHLWALKBIG, K_MHLEMIT, K_PDRWALK, K_FDRPWALK, K_FDRPEMIT, K_PAIRS, K_PAIRSTILE, K_DECODE, K_INFLATE, K_CRC, K_MHLTILE, K_WIDE, K_FDRPTILE, K_FDRPCHAIN, K_FDRPWALK4, K_FDRPWTILE, K_MHLROWCHK, K_NUM };
 
 }  // namespace mth

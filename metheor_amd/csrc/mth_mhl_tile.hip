@@ -25,6 +25,7 @@
 // Output: per tile, rows sorted by position in a scratch slice (site, mhl, coverage, flag); k_mhl_tile_gather packs the slices
 // into the candidate-site arrays the rest of the MHL pipeline (k_mhl_walk_big / _huge, k_mhl_emit) already works on.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <vector>
 
@@ -85,7 +86,7 @@ __device__ __noinline__ bool mhl_count_only(const uint32_t *__restrict__ cpg_pos
     return over;
 }
 
-template <int MT_SHIFT>
+template <int MT_SHIFT, bool ROWCHK>
 #ifndef MTH_MT_OCC
 #define MTH_MT_OCC 6
 #endif
@@ -93,7 +94,11 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
     constexpr int W = 1 << MT_SHIFT;
     __shared__ uint32_t tkey[MT_S], taux[MT_S];
     __shared__ uint32_t thist[MT_S * MT_HW];
+#ifdef MTH_MT_KEEPF
     __shared__ uint32_t F[W / 32];
+#else
+    __shared__ uint32_t F[ROWCHK ? 1 : W / 32];
+#endif
     // the contributor queue (phases 1 and 2) and the sort arrays of the row phase share their LDS
     __shared__ uint32_t q_or_sort[MT_Q > 2 * MT_B ? MT_Q : 2 * MT_B];
     __shared__ uint32_t bcnt[MT_B];
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
         static_assert(MT_S == MT_B, "one slot per thread");
         tkey[tid] = MT_EMPTY; taux[tid] = 0u;
         for (int i = tid; i < MT_S * MT_HW; i += MT_B) thist[i] = 0u;
-        for (int i = tid; i < W / 32; i += MT_B) F[i] = 0u;
+        if constexpr (!ROWCHK) for (int i = tid; i < W / 32; i += MT_B) F[i] = 0u;
         bcnt[tid] = 0u;
         if (tid == 0) { s_over = 0u; s_qn = 0u; }
         __syncthreads();
@@ -159,12 +164,10 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                 for (int u = 0; u < MT_U; ++u) {
                     const uint32_t i = b0 + (uint32_t)u * MT_B + tid, ii = min(i, hi - 1);
                     const bool has = i < hi && o1s[u] != o0s[u];                 // a read without a CpG neither flushes nor contributes (mhl.rs:162)
-#ifdef MTH_MT_NOFLUSH1
-                    fw[u] = 0u; st[u] = 0; (void)has; mq[u] = a.read_mapq[ii];
-#else
-                    fw[u] = has ? a.cpg_pos[o0s[u]] : 0u;
-                    st[u] = a.read_start[ii]; mq[u] = a.read_mapq[ii];
-#endif
+                    // (ROWCHK: no flusher marks here -- neither the start nor the dependent first-call load is needed per read)
+                    if constexpr (ROWCHK) { fw[u] = 0u; st[u] = 0; (void)has; }
+                    else { fw[u] = has ? a.cpg_pos[o0s[u]] : 0u; st[u] = a.read_start[ii]; }
+                    mq[u] = a.read_mapq[ii];
                     const uint32_t in = min(i + (uint32_t)MT_U * MT_B, hi - 1);
                     o0n[u] = a.cpg_off[in]; o1n[u] = a.cpg_off[in + 1];
                 }
@@ -172,8 +175,7 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                 for (int u = 0; u < MT_U; ++u) {
                     const uint32_t i = b0 + (uint32_t)u * MT_B + tid;
                     const uint32_t n = i < hi ? o1s[u] - o0s[u] : 0u;
-#ifndef MTH_MT_NOFLUSH1
-                    if (n && !(a.dbg & 1)) {
+                    if (!ROWCHK && n && !(a.dbg & 1)) {
                         // candidate ranges rely on every call lying in [start - 1, start - 1 + max_span] (rule of the PDR tile kernel):
                         // the first call here, a contributor's other calls in phase 2
                         const uint32_t first = fw[u] & 0x7fffffffu;
@@ -190,10 +192,10 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                             }
                         }
                     }
-#endif
                     const bool contrib = n != 0 && mq[u] >= a.min_qual && n >= a.min_cpgs && !(a.dbg & 2);      // mhl.rs:176, 181
                     if (heavy) {                                                   // (rare: slots made and counted straight from memory)
-                        if (contrib && mhl_count_only(a.cpg_pos, o0s[u], o1s[u], (uint32_t)st[u] - 1u, (uint32_t)a.max_span, (uint32_t)P0, Wp, tkey, thist, bad))
+                        const uint32_t sm1h = ROWCHK ? (uint32_t)a.read_start[min(i, hi - 1)] - 1u : (uint32_t)st[u] - 1u;
+                        if (contrib && mhl_count_only(a.cpg_pos, o0s[u], o1s[u], sm1h, (uint32_t)a.max_span, (uint32_t)P0, Wp, tkey, thist, bad))
                             s_over = 1u;
                         continue;
                     }
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
             const int32_t c = (int32_t)key;
             // handed on: under a flusher's mark, or a reverse read with start == c + 1 calls c after a read of that start whose
             // first CpG lies beyond c
-            if (!hand_on) hand_on = (F[(key - (uint32_t)P0) >> 5] >> ((key - (uint32_t)P0) & 31u)) & 1u;
+            if (!ROWCHK && !hand_on) hand_on = (F[(key - (uint32_t)P0) >> 5] >> ((key - (uint32_t)P0) & 31u)) & 1u;
             const uint32_t self = aux & 0x7fffffffu;
             if (!hand_on && self && !(a.dbg & 8)) {
                 const uint32_t K = lo + self - 1u;          // the last contributor that calls its own start - 1 here
@@ -470,6 +472,59 @@ __global__ __launch_bounds__(64 * MG_WAVES) void k_mhl_tile_gather(const MhlRec 
         if (r.flags == 4u) hand_list[atomicAdd(reinterpret_cast<unsigned long long *>(&sites_st->lpmd[0]), 1ull)] = (uint32_t)(base + i);
     }
     if (t == ntiles - 1 && lane == 0) sites_st->n_sites = base + n;
+}
+
+
+// ---- the flush rule for the ROWS only (k_mhl_tile<.., ROWCHK = true>) ------------------------------------------------------
+// With sparse calls (WGBS: 1.35 CpGs a read, one read in twenty contributes, ~3 rows per 16 384-bp tile) the tile kernel's
+// per-read flusher marks -- the read's start, a DEPENDENT load of its first call, the bitmap atomics -- were 29 % of the kernel for
+// a test that only the rows need.  Here 16 lanes take one finished row c and look at the reads that can be its flushers: >= 1
+// CpG, start <= c < first CpG (mhl.rs:162-173), so start in [c - max_span + 2, c].  The same criterion as the bitmap's, read by
+// read; a row that has one is handed on (flag 4, listed for k_mhl_walk_wave) exactly as before.
+struct MhlRowChkArgs {
+    const int32_t  *read_start;
+    const uint32_t *cpg_off, *cpg_pos, *idx;
+    DevState *sites_st;               // n_sites; lpmd[0] = entries of hand_list
+    const int32_t *site_pos;
+    uint32_t *flags, *hand_list;
+    DevState *st;
+    int32_t idx_base, max_span;
+    uint32_t n_reads;
+};
+
+__global__ __launch_bounds__(256) void k_mhl_rowcheck(const MhlRowChkArgs a) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const uint32_t wv = (blockIdx.x * 256u + threadIdx.x) >> 6, nwv = (gridDim.x * 256u) >> 6;
+    const uint32_t n_sites = (uint32_t)a.sites_st->n_sites;
+    uint32_t bad = 0;
+    for (uint32_t j0 = wv * 4u; j0 < n_sites; j0 += nwv * 4u) {               // wave-uniform
+        const uint32_t j = j0 + ((uint32_t)lane >> 4);
+        const bool live = j < n_sites && a.flags[j] == 1u;
+        const int32_t c = live ? a.site_pos[j] : 0;
+        uint32_t rlo = 0, rhi = 0;
+        if (live) {
+            rlo = min(a.idx[((uint32_t)c - (uint32_t)a.max_span + 2u - (uint32_t)a.idx_base) >> IDX_QSHIFT], a.n_reads);
+            rhi = min(a.idx[(((uint32_t)c - (uint32_t)a.idx_base) >> IDX_QSHIFT) + 1], a.n_reads);
+        }
+        bool fl = false;
+        for (uint32_t i = rlo + (uint32_t)sub; __any(i < rhi); i += 16u) {
+            if (i < rhi) {
+                const int32_t s = a.read_start[i];
+                const uint32_t q0 = a.cpg_off[i], q1 = a.cpg_off[i + 1];
+                if (q1 != q0 && s <= c) {
+                    const uint32_t first = a.cpg_pos[q0] & 0x7fffffffu;
+                    bad |= (first - ((uint32_t)s - 1u) > (uint32_t)a.max_span) ? 1u : 0u;
+                    fl = fl || (int32_t)first > c;
+                }
+            }
+        }
+        const unsigned long long b = __ballot(fl);
+        if (live && sub == 0 && ((b >> (lane & 48)) & 0xffffull)) {
+            a.flags[j] = 4u;
+            a.hand_list[atomicAdd(reinterpret_cast<unsigned long long *>(&a.sites_st->lpmd[0]), 1ull)] = j;
+        }
+    }
+    if (bad) atomicOr(&a.st->err, (uint32_t)ERRB_SPAN);
 }
 
 
@@ -638,13 +693,35 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     uint32_t ntiles = 0;
     MhlTileArgs a;
     a.trace = nullptr;
+    // the flush rule per read (position bitmap in the tile kernel) or per finished row (k_mhl_rowcheck): rows are few where calls are
+    // sparse -- at <= 2 CpGs a read one read in twenty reaches min_cpgs = 4 -- and there the per-read marks (start, a dependent first-call
+    // load, bitmap atomics) were 29 % of the tile kernel for a test only the rows need (chr1-sized contig at config-3 density: 0.170 ->
+    // 0.130 ms + 0.009 for the row kernel); config 2 (2.94 CpGs a read, 100 rows a tile) keeps the marks
+    bool rowchk = (double)d.n_cpgs <= 2.0 * (double)d.n_reads;
+    if (const char *e = getenv("MTH_MHL_ROWCHK")) rowchk = atoi(e) != 0;                               // tests / tuning
     if (!wt) {
     {
-        const double sites_per_bp = (double)d.n_cpgs / (double)d.n_reads / (double)std::max(d.max_span, 1);
+        const double cpr = (double)d.n_cpgs / (double)d.n_reads;
+        const double sites_per_bp = cpr / (double)std::max(d.max_span, 1);
         const double reads_per_bp = (double)d.n_reads / (double)region_len;
         while (shift < 14 && sites_per_bp * (double)(2 << shift) <= 0.65 * MT_S &&
                reads_per_bp * (double)((2 << shift) + d.max_span + 2 * IDX_Q) <= 0.75 * MT_HEAVY)
             ++shift;
+        // Without the marks a tile's cost is its contributors', and a slot is taken only by a site that a CONTRIBUTOR calls: 32 768-position
+        // tiles where those sites fit (config 3: MHL pass 2.21 -> 1.56 ms; 65 536 overflows the slots on a chr1-sized contig: 0.092 ->
+        // 0.227 ms) and the region still gives three rounds of tiles.  The share of such sites: a covering read has min_cpgs - 1 other
+        // CpGs with probability pc (Poisson at the batch's calls per read); overlapping readers are far from independent -- sqrt(depth)
+        // of them counted (measured at 10 x: 0.35 of the sites).  An underestimate costs time only (the stretch is redone in halves).
+        if (rowchk && shift == 14) {
+            double pc = 1.0, term = std::exp(-cpr);
+            for (uint32_t k = 0; k + 1 < p.min_cpgs && k < 64; ++k) { pc -= term; term *= cpr / (double)(k + 1); }
+            pc = std::min(1.0, std::max(pc, 0.0));
+            const double depth = reads_per_bp * (double)std::max(d.max_span, 1);
+            const double share = 1.0 - std::pow(1.0 - pc, std::max(1.0, std::sqrt(depth)));
+            if (sites_per_bp * share * 32768.0 <= 0.5 * MT_S && reads_per_bp * (double)(32768 + d.max_span + 2 * IDX_Q) <= 0.75 * MT_HEAVY &&
+                region_len >= 3ll * 1536 * 32768)
+                shift = 15;
+        }
     }
     if (const char *e = getenv("MTH_MHL_TILE_SHIFT")) shift = std::min(16, std::max(12, atoi(e)));   // tests / tuning
     W = 1 << shift;
@@ -674,11 +751,14 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     const uint32_t grid = ((ntiles + 7) / 8) * 8;
     {
         LaunchTimer lt(ctx, K_MHLTILE);
-        if (shift == 12) hipLaunchKernelGGL((k_mhl_tile<12>), dim3(grid), dim3(MT_B), 0, s, a);
-        else if (shift == 13) hipLaunchKernelGGL((k_mhl_tile<13>), dim3(grid), dim3(MT_B), 0, s, a);
-        else if (shift == 14) hipLaunchKernelGGL((k_mhl_tile<14>), dim3(grid), dim3(MT_B), 0, s, a);
-        else if (shift == 15) hipLaunchKernelGGL((k_mhl_tile<15>), dim3(grid), dim3(MT_B), 0, s, a);
-        else hipLaunchKernelGGL((k_mhl_tile<16>), dim3(grid), dim3(MT_B), 0, s, a);
+#define MTH_MT_LAUNCH(SH) do { if (rowchk) hipLaunchKernelGGL((k_mhl_tile<SH, true>), dim3(grid), dim3(MT_B), 0, s, a); \
+                                else hipLaunchKernelGGL((k_mhl_tile<SH, false>), dim3(grid), dim3(MT_B), 0, s, a); } while (0)
+        if (shift == 12) MTH_MT_LAUNCH(12);
+        else if (shift == 13) MTH_MT_LAUNCH(13);
+        else if (shift == 14) MTH_MT_LAUNCH(14);
+        else if (shift == 15) MTH_MT_LAUNCH(15);
+        else MTH_MT_LAUNCH(16);
+#undef MTH_MT_LAUNCH
     }
     {
         LaunchTimer lt(ctx, K_GATHER);
@@ -686,6 +766,14 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
                            reinterpret_cast<const MhlRec *>(ctx->scratch.p), ctx->tile_cnt.as<uint32_t>(),
                            ctx->tile_bucket.as<unsigned long long>(), ntiles, (uint32_t)W, ctx->d_state2, ctx->s_pos.as<int32_t>(),
                            ctx->w_val.as<float>(), ctx->w_cov.as<uint32_t>(), ctx->w_flags.as<uint32_t>(), ctx->w_aux.as<uint32_t>());
+    }
+    if (rowchk) {
+        LaunchTimer lt(ctx, K_MHLROWCHK);
+        MhlRowChkArgs rc;
+        rc.read_start = d.read_start; rc.cpg_off = d.cpg_off; rc.cpg_pos = d.cpg_pos; rc.idx = idx_ptr(ctx);
+        rc.sites_st = ctx->d_state2; rc.site_pos = ctx->s_pos.as<int32_t>(); rc.flags = ctx->w_flags.as<uint32_t>();
+        rc.hand_list = ctx->w_aux.as<uint32_t>(); rc.st = ctx->d_state; rc.idx_base = idx_base; rc.max_span = d.max_span; rc.n_reads = d.n_reads;
+        hipLaunchKernelGGL(k_mhl_rowcheck, dim3(2048), dim3(256), 0, s, rc);
     }
     }   // (!wt)
     if (!getenv("MTH_MHL_NO_WAVE_WALK")) {

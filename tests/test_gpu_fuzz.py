@@ -134,7 +134,20 @@ def test_random_scenario_all_measures(eng, seed):
 
     # MHL
     mk = dict(min_depth=int(rng.choice([0, 1, 5, 10])), min_cpgs=int(rng.choice([1, 2, 4])), min_qual=mq)
-    T_mhl.check(T_mhl.run_device(eng, cs, mk, regions=regions), reads, mk)
+    m0 = T_mhl.run_device(eng, cs, mk, regions=regions)
+    T_mhl.check(m0, reads, mk)
+    # ... with the flush rule looked at per finished row (k_mhl_rowcheck: the host's choice for sparse calls) and per read (position
+    # bitmap in the tile kernel), whatever the batch's density: the same rows bit for bit
+    for envs in ({"MTH_MHL_ROWCHK": "1"}, {"MTH_MHL_ROWCHK": "0"}, {"MTH_MHL_ROWCHK": "1", "MTH_MHL_FORCE_SUB": "1"},
+                 {"MTH_MHL_ROWCHK": "1", "MTH_MHL_TILE_SHIFT": "15"}):
+        os.environ.update(envs)
+        try:
+            m1 = T_mhl.run_device(eng, cs, mk, regions=regions)
+        finally:
+            for k_ in envs:
+                del os.environ[k_]
+        assert len(m0["pos"]) == len(m1["pos"]), envs
+        assert all((m0[k] == m1[k]).all() for k in ("tid", "pos", "cov")) and (m0["mhl"].view(np.uint32) == m1["mhl"].view(np.uint32)).all(), envs
 
     # FDRP / qFDRP (a reverse read spanning >= 202 bp can index -1 in the reference and panics there: forward only then)
     fcs, freads = cs, reads

@@ -16,13 +16,15 @@ f32 = np.float32
 TOL = 1e-6
 
 
-@pytest.fixture(autouse=True, params=["tile", "walk", "tile-sub", "tile-hand-on", "tile-hand-on-big"])
+@pytest.fixture(autouse=True, params=["tile", "walk", "tile-sub", "tile-hand-on", "tile-hand-on-big", "tile-rowchk", "tile-rowchk-sub", "tile-rowchk-32k", "tile-marks"])
 def mhl_form(request, monkeypatch):
     """every case runs through the one-pass tile form (mth_mhl_tile.hip, the default), through round 2's discovery + per-site walk
     (MTH_MHL_WALK=1), through the tile form started with 256-position sub-ranges (the path a tile with more sites than slots
     takes) and through the tile form with every site handed on to the exact walks (the path of sites with several segments): the
-    wave-per-site walk (k_mhl_walk_wave), or -- "big" -- the lane-per-site walk that takes what the wave walk leaves"""
-    for k in ("MTH_MHL_WALK", "MTH_MHL_FORCE_SUB", "MTH_MHL_FORCE_HAND_ON", "MTH_MHL_NO_WAVE_WALK"):
+    wave-per-site walk (k_mhl_walk_wave), or -- "big" -- the lane-per-site walk that takes what the wave walk leaves; and with the
+    flush rule looked at per finished row (k_mhl_rowcheck, round 6: the host's choice for batches of <= 2 CpGs a read) or per read
+    (the tile kernel's position bitmap) whatever the batch's density"""
+    for k in ("MTH_MHL_WALK", "MTH_MHL_FORCE_SUB", "MTH_MHL_FORCE_HAND_ON", "MTH_MHL_NO_WAVE_WALK", "MTH_MHL_ROWCHK", "MTH_MHL_TILE_SHIFT"):
         monkeypatch.delenv(k, raising=False)
     if request.param == "walk":
         monkeypatch.setenv("MTH_MHL_WALK", "1")
@@ -30,6 +32,16 @@ def mhl_form(request, monkeypatch):
         monkeypatch.setenv("MTH_MHL_FORCE_SUB", "1")
     elif request.param == "tile-hand-on":
         monkeypatch.setenv("MTH_MHL_FORCE_HAND_ON", "1")
+    elif request.param == "tile-rowchk":
+        monkeypatch.setenv("MTH_MHL_ROWCHK", "1")
+    elif request.param == "tile-rowchk-sub":
+        monkeypatch.setenv("MTH_MHL_ROWCHK", "1")
+        monkeypatch.setenv("MTH_MHL_FORCE_SUB", "1")
+    elif request.param == "tile-rowchk-32k":        # the 32 768-position tiles the host takes on large sparse-call regions
+        monkeypatch.setenv("MTH_MHL_ROWCHK", "1")
+        monkeypatch.setenv("MTH_MHL_TILE_SHIFT", "15")
+    elif request.param == "tile-marks":
+        monkeypatch.setenv("MTH_MHL_ROWCHK", "0")
     elif request.param == "tile-hand-on-big":
         monkeypatch.setenv("MTH_MHL_FORCE_HAND_ON", "1")
         monkeypatch.setenv("MTH_MHL_NO_WAVE_WALK", "1")
