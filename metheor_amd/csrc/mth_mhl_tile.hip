@@ -697,7 +697,7 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     // sparse -- at <= 2 CpGs a read one read in twenty reaches min_cpgs = 4 -- and there the per-read marks (start, a dependent first-call
     // load, bitmap atomics) were 29 % of the tile kernel for a test only the rows need (chr1-sized contig at config-3 density: 0.170 ->
     // 0.130 ms + 0.009 for the row kernel); config 2 (2.94 CpGs a read, 100 rows a tile) keeps the marks
-    bool rowchk = (double)d.n_cpgs <= 2.0 * (double)d.n_reads;
+    bool rowchk = (double)d.n_cpgs <= 1.8 * (double)d.n_reads;       // (density sweep, profiles/r06_mhl_rowcheck.md: even at 2.0)
     if (const char *e = getenv("MTH_MHL_ROWCHK")) rowchk = atoi(e) != 0;                               // tests / tuning
     if (!wt) {
     {
