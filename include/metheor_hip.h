@@ -252,7 +252,9 @@ int  mth_quartet_fetch(mth_ctx_t *ctx, uint32_t min_depth, uint64_t *n_rows, int
  * Exact stream semantics of the reference, including its flush / re-open of sites:
  * flush on strict '<' by any read with >= 1 CpG, before the mapq / min_cpgs filters.  Reads with
  * more than 16384 CpGs covering a site are refused (MTH_ERR_CAPACITY); reads with 513..16384 take a walk whose
- * histograms live in 256 MB of HBM scratch. */
+ * histograms live in 256 MB of HBM scratch.  MTH_ERR_SPAN (a call outside [start - 1, start - 1 + max_span]) is
+ * raised for the reads the pass evaluates: every contributing read, and -- on batches of <= 1.8 calls a read, where
+ * the flush rule is looked at per finished row -- the reads around a row; otherwise every read's first call. */
 typedef struct {
     uint32_t min_depth;  /* -d 10 */
     uint32_t min_cpgs;   /* -p 4  */
