@@ -55,7 +55,10 @@ struct MhlTileArgs {
     unsigned long long *trace;    // -DMTH_MT_TRACE builds: cycles per phase, summed over the sub-ranges (thread 0 of each workgroup)
 };
 
-constexpr int MT_S = 256, MT_B = 256, MT_U = 2, MT_NC = 8, MT_LCAP = 16;
+#ifndef MTH_MT_U
+#define MTH_MT_U 2
+#endif
+constexpr int MT_S = 256, MT_B = 256, MT_U = MTH_MT_U, MT_NC = 8, MT_LCAP = 16;
 // slot h: tkey[h] = position; taux[h] bit 31 = "a read with > 16 CpGs calls it", low bits = largest (index - lo + 1) of a contributor
 // calling its own start - 1; thist[17 h ..]: words 0..7 hn, 8..15 hm (bin b in half (b - 1) & 1 of word (b - 1) >> 1); the 17th word
 // is padding: with 16 the slots' words fall on 4 of the 64 LDS banks (measured: contributions 0.17 -> 0.22 ms)
@@ -303,6 +306,9 @@ __global__ __launch_bounds__(MT_B, MTH_MT_OCC) void k_mhl_tile(const MhlTileArgs
                 for (int o = 32; o > 0; o >>= 1) max_runs = max(max_runs, (uint32_t)__shfl_xor((int)max_runs, o, 64));
                 max_runs = __builtin_amdgcn_readfirstlane(max_runs);
                 const uint32_t rel_idx = i - lo + 1u;
+                // (NEGATIVE, round 6, rows-checked form, same box twice: the first probes of all eight calls issued together before the
+                // increments -- one LDS round trip instead of eight -- 0.093 / 0.093 ms against 0.093 / 0.094; three or four reads per
+                // thread and trip in phase 1 (-DMTH_MT_U): 0.090-0.096.  profiles/r06_mhl_rowcheck.md)
 #pragma unroll
                 for (int k = 0; k < MT_NC; ++k) {
                     if (!__any((uint32_t)k < nl)) break;                            // wave-uniform
