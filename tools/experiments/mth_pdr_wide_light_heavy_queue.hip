@@ -150,53 +150,13 @@ __global__ __launch_bounds__(PW_B, MTH_PW_OCC) void k_pdr_lpmd_wide(const TileAr
             __syncthreads();
             // ---- phase 2: first the reads of <= 4 calls (front of the queue) with four call slots -- one 16-byte load of calls, half the
             // slot arithmetic, three pair diagonals --, then the others with eight
-            auto phase2 = [&](auto nbc, const uint32_t qn, const bool back) {
-            constexpr int NB = decltype(nbc)::value;
-            for (uint32_t j0 = 0; j0 < qn; j0 += PW_B) {
-                const uint32_t j = j0 + tid;
-                const bool act = j < qn;
-                const uint32_t i = c0 + (act ? (uint32_t)rq[back ? (uint32_t)PW_QCAP - 1u - j : j] : 0u);
-                const uint32_t o0 = a.cpg_off[i], o1 = a.cpg_off[i + 1];
-                const uint32_t n = act ? o1 - o0 : 0u;
-                uint32_t v[NB];
-                int32_t r[NB];
-#pragma unroll
-                for (int k = 0; k < NB; ++k) { v[k] = 0u; r[k] = 0; }
-                uint32_t rraw0 = 0, rraw1 = 0;
-                static_assert(PW_NB == 8 && (NB == 4 || NB == 8), "one or two 16-byte loads per read");
-                if (__all(!act || (unsigned long long)o0 + NB <= (unsigned long long)a.n_cpgs)) {
-                    if (act) {
-                        const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0);
-                        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-                        if constexpr (NB == 8) {
-                            const u32x4_a4 y = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0 + 4);
-                            v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-                            if constexpr (PACKED) { const u32x2_a1 z = *reinterpret_cast<const u32x2_a1 *>(rel + o0); rraw0 = z.x; rraw1 = z.y; }
-                            else {
-                                const u32x4_a2 z = *reinterpret_cast<const u32x4_a2 *>(rel + o0);
-                                r[0] = (int32_t)(z.x & 0xffffu); r[1] = (int32_t)(z.x >> 16); r[2] = (int32_t)(z.y & 0xffffu); r[3] = (int32_t)(z.y >> 16);
-                                r[4] = (int32_t)(z.z & 0xffffu); r[5] = (int32_t)(z.z >> 16); r[6] = (int32_t)(z.w & 0xffffu); r[7] = (int32_t)(z.w >> 16);
-                            }
-                        } else {
-                            if constexpr (PACKED) rraw0 = *reinterpret_cast<const u32_a1 *>(rel + o0);
-                            else {
-                                const u32x2_a2 z = *reinterpret_cast<const u32x2_a2 *>(rel + o0);
-                                r[0] = (int32_t)(z.x & 0xffffu); r[1] = (int32_t)(z.x >> 16); r[2] = (int32_t)(z.y & 0xffffu); r[3] = (int32_t)(z.y >> 16);
-                            }
-                        }
-                    }
-                } else if (act) {                               // the batch's last reads: a window of 8 would leave the arrays
-#pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        const uint32_t kk = o0 + min((uint32_t)k, n - 1);
-                        v[k] = a.cpg_pos[kk];
-                        const uint32_t rv = (uint32_t)rel[kk];
-                        if constexpr (PACKED) { if (k < 4) rraw0 |= rv << (8 * k); else rraw1 |= rv << (8 * (k - 4)); }
-                        else r[k] = (int32_t)rv;
-                    }
-                }
-                const int32_t s = a.read_start[i];
-                const uint32_t mq = a.read_mapq[i];
+            auto phase2 = [&](auto nbc, auto ec, const uint32_t qn, const bool back) {
+            constexpr int NB = decltype(nbc)::value, E = decltype(ec)::value;          // call slots; queue entries per thread and trip
+            static_assert(PW_NB == 8 && (NB == 4 || NB == 8), "one or two 16-byte loads per read");
+            // everything of a queued read after its loads
+            auto compute = [&](const bool act, const uint32_t i, const uint32_t o0, const uint32_t n, uint32_t (&v)[NB], int32_t (&r)[NB],
+                               const uint32_t rraw0, const uint32_t rraw1, const int32_t s, const uint32_t mq) {
+                (void)i; (void)rraw1;
                 const bool owned = act && s >= P0 && s < P1;
                 const bool lp_ok = lp_possible && owned && mq >= a.lpmd_min_qual && n > 1;
                 const bool pdr_ok = act && a.want_pdr && n >= a.min_cpgs && mq >= a.pdr_min_qual;
@@ -333,10 +293,85 @@ __global__ __launch_bounds__(PW_B, MTH_PW_OCC) void k_pdr_lpmd_wide(const TileAr
                     if (any_long && go && n > (uint32_t)PW_NB)
                         for (uint32_t k = PW_NB; k < n; ++k) insert(a.cpg_pos[o0 + k]);
                 }
+            };
+            // E entries per thread: their offsets, then ALL their loads, then the work -- twice the bytes in flight per lane at the register
+            // cost of one 8-slot entry when the entries hold four slots
+            for (uint32_t j0 = 0; j0 < qn; j0 += PW_B * E) {
+                bool act[E];
+                uint32_t ii[E], o0[E], n[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t j = j0 + (uint32_t)e * PW_B + tid;
+                    act[e] = j < qn;
+                    ii[e] = c0 + (act[e] ? (uint32_t)rq[back ? (uint32_t)PW_QCAP - 1u - j : j] : 0u);
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    o0[e] = a.cpg_off[ii[e]];
+                    const uint32_t o1 = a.cpg_off[ii[e] + 1];
+                    n[e] = act[e] ? o1 - o0[e] : 0u;
+                }
+                uint32_t v[E][NB];
+                int32_t r[E][NB];
+                uint32_t rraw0[E], rraw1[E];
+                int32_t s[E];
+                uint32_t mq[E];
+                bool inb = true;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) { v[e][k] = 0u; r[e][k] = 0; }
+                    rraw0[e] = 0; rraw1[e] = 0;
+                    inb = inb && (!act[e] || (unsigned long long)o0[e] + NB <= (unsigned long long)a.n_cpgs);
+                }
+                if (__all(inb)) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (act[e]) {
+                            const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0[e]);
+                            v[e][0] = x.x; v[e][1] = x.y; v[e][2] = x.z; v[e][3] = x.w;
+                            if constexpr (NB == 8) {
+                                const u32x4_a4 y = *reinterpret_cast<const u32x4_a4 *>(a.cpg_pos + o0[e] + 4);
+                                v[e][4] = y.x; v[e][5] = y.y; v[e][6] = y.z; v[e][7] = y.w;
+                                if constexpr (PACKED) { const u32x2_a1 z = *reinterpret_cast<const u32x2_a1 *>(rel + o0[e]); rraw0[e] = z.x; rraw1[e] = z.y; }
+                                else {
+                                    const u32x4_a2 z = *reinterpret_cast<const u32x4_a2 *>(rel + o0[e]);
+                                    r[e][0] = (int32_t)(z.x & 0xffffu); r[e][1] = (int32_t)(z.x >> 16); r[e][2] = (int32_t)(z.y & 0xffffu); r[e][3] = (int32_t)(z.y >> 16);
+                                    r[e][4] = (int32_t)(z.z & 0xffffu); r[e][5] = (int32_t)(z.z >> 16); r[e][6] = (int32_t)(z.w & 0xffffu); r[e][7] = (int32_t)(z.w >> 16);
+                                }
+                            } else {
+                                if constexpr (PACKED) rraw0[e] = *reinterpret_cast<const u32_a1 *>(rel + o0[e]);
+                                else {
+                                    const u32x2_a2 z = *reinterpret_cast<const u32x2_a2 *>(rel + o0[e]);
+                                    r[e][0] = (int32_t)(z.x & 0xffffu); r[e][1] = (int32_t)(z.x >> 16); r[e][2] = (int32_t)(z.y & 0xffffu); r[e][3] = (int32_t)(z.y >> 16);
+                                }
+                            }
+                        }
+                } else {                                        // the batch's last reads: a window of NB calls would leave the arrays
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (act[e]) {
+#pragma unroll
+                            for (int k = 0; k < NB; ++k) {
+                                const uint32_t kk = o0[e] + min((uint32_t)k, n[e] - 1);
+                                v[e][k] = a.cpg_pos[kk];
+                                const uint32_t rv = (uint32_t)rel[kk];
+                                if constexpr (PACKED) { if (k < 4) rraw0[e] |= rv << (8 * k); else rraw1[e] |= rv << (8 * (k - 4)); }
+                                else r[e][k] = (int32_t)rv;
+                            }
+                        }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) { s[e] = a.read_start[ii[e]]; mq[e] = a.read_mapq[ii[e]]; }
+#pragma unroll
+                for (int e = 0; e < E; ++e) compute(act[e], ii[e], o0[e], n[e], v[e], r[e], rraw0[e], rraw1[e], s[e], mq[e]);
             }
             };
-            phase2(std::integral_constant<int, 4>{}, s_qn, false);
-            phase2(std::integral_constant<int, 8>{}, s_qh, true);
+#ifndef MTH_PW_E4
+#define MTH_PW_E4 2
+#endif
+            phase2(std::integral_constant<int, 4>{}, std::integral_constant<int, MTH_PW_E4>{}, s_qn, false);
+            phase2(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{}, s_qh, true);
         }
         __syncthreads();
         const uint32_t over = s_over;
