@@ -1131,6 +1131,7 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            bool wide_row = false;                                                              // a stored read with more than 21 calls on window sites
             if (!redo && (uint32_t)lane < nS) {
                 uint32_t src = (uint32_t)lane;
                 for (uint32_t t = nS; t < n_sel; ++t) src = draw[t] == (uint8_t)(lane + 1) ? t : src;
@@ -1138,6 +1139,7 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                 const uint32_t pk = s_pack[r];
                 const int32_t rs = s_start[r];
                 const unsigned long long mc = s_mC[r], mm = s_mM[r];
+                wide_row = (uint32_t)__popcll(mc) > FT_NCPG_MAX;
                 const uint32_t ab = pk >> 16;
                 const unsigned long long ma = ab == 0xffu ? mc : mc & ~(1ull << ab);
                 uint32_t *rw = rows + (uint32_t)lane * 8u;
@@ -1151,6 +1153,7 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
             uint32_t disc = 0;
             bool wide = false;
             float q_wide = 0.0f;
+            const bool maybe_wide = __any(wide_row);                                            // else no pair shares more than 21 calls
             const unsigned long long off_v = s_off[k];
             const unsigned long long off = ((unsigned long long)sgpr((uint32_t)(off_v >> 32)) << 32) | sgpr((uint32_t)off_v);
             if (!redo) {
@@ -1158,34 +1161,44 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                 const uint16_t *const tab = a.pair_tab + (nS * (nS - 1u) * (nS - 2u)) / 6u;
                 uint8_t *const tp = a.terms + off;
                 uint32_t ent_next = tab[P ? min(lane, P - 1) : 0];
-                uint32_t over = 0;
-                for (int k0 = 0; k0 < P; k0 += 64) {
+                // (round 6: the kernel runs at 0.94 of the vector unit, so the round was counted instruction by instruction -- hipcc -S:
+                // 48 -> 40.  max(ov, 0) >= min_overlap is ov - 1 >= min_overlap - 1 when min_overlap >= 1 and true otherwise; the
+                // discordant pairs are counted on the scalar unit from a ballot; "more than 21 shared calls" can only happen when a
+                // stored read holds more than 21 calls -- known before the rounds, and such a site (CpG every 7 bp) takes the chained rounds
+                // below straight away; ncpg (ncpg + 1) as one multiply-add; 32-bit pair indices.)
+                const bool mo_any = a.min_overlap <= 0;
+                const int32_t mo_m1 = a.min_overlap - 1;
+                const uint32_t Pu = maybe_wide ? 0u : (uint32_t)P;                              // (a wide site: no listed terms, the chained rounds below)
+                uint32_t disc_s = 0;                                                            // wave-uniform
+                for (uint32_t k0 = 0; k0 < Pu; k0 += 64u) {
                     const uint32_t ent = ent_next;
-                    if (k0 + 64 < P) ent_next = tab[min(k0 + 64 + lane, P - 1)];
-                    const int pi = (int)(ent & 0xffu), pj = (int)(ent >> 8);
-                    const uint32_t *ri = rows + pi * 8, *rj = rows + pj * 8;
+                    if (k0 + 64u < Pu) ent_next = tab[min(k0 + 64u + (uint32_t)lane, Pu - 1u)];
+                    const uint32_t pi = ent & 0xffu, pj = ent >> 8;
+                    const uint32_t *ri = rows + pi * 8u, *rj = rows + pj * 8u;
                     const int32_t si = (int32_t)ri[0], ei = (int32_t)ri[1], sj = (int32_t)rj[0], ej = (int32_t)rj[1];
-                    const int32_t ov = min(ei, ej) - max(si, sj) + 1;                           // get_num_overlap_bases, fdrp.rs:97-107
-                    const bool pair_ok = (k0 + lane < P) & (max(ov, 0) >= a.min_overlap);        // fdrp.rs:134
+                    const int32_t ov_m1 = min(ei, ej) - max(si, sj);                            // get_num_overlap_bases - 1, fdrp.rs:97-107
+                    const bool pair_ok = (k0 + (uint32_t)lane < Pu) && (mo_any || ov_m1 >= mo_m1);   // fdrp.rs:134
                     const uint32_t ncpg = __builtin_popcount(ri[2] & rj[2]) + __builtin_popcount(ri[3] & rj[3]);   // qfdrp.rs:109-119
                     const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) +
                                          __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));                      // fdrp.rs:114-115
-                    disc += (pair_ok && ham != 0u) ? 1u : 0u;                                   // fdrp.rs:138-140
-                    over = max(over, pair_ok ? ncpg : 0u);                                                // (more than 21 shared calls: looked at once, after the rounds)
+                    disc_s += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pair_ok && ham != 0u));   // fdrp.rs:138-140
                     // Every pair's term goes to the site's list at the pair's own index, as one byte: ncpg (ncpg + 1) / 2 + ham (the
                     // chain kernel's table gives ham / ncpg: +0.0 when ham is 0 -- x + 0.0 == x -- and NaN for 0 / 0); a skipped
                     // pair is code 1 = 0 / 1.  Four codes per dword (two DPP ORs inside each quad of lanes), 16 lanes store 64 bytes.
-                    const uint32_t code = pair_ok ? __umul24(ncpg, ncpg + 1u) / 2u + ham : 1u;
+                    uint32_t tri2;                                                               // ncpg (ncpg + 1) in one instruction
+                    asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(tri2) : "v"(ncpg));
+                    const uint32_t code = pair_ok ? (tri2 >> 1) + ham : 1u;
                     uint32_t pk = code << (8 * (lane & 3));
                     pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, true);
                     pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x4e /*quad_perm [2,3,0,1]*/, 0xf, 0xf, true);
-                    if ((lane & 3) == 0) *reinterpret_cast<uint32_t *>(tp + k0 + lane) = pk;
+                    if ((lane & 3) == 0) *reinterpret_cast<uint32_t *>(tp + (k0 + (uint32_t)lane)) = pk;
                 }
+                disc = lane == 0 ? disc_s : 0u;                                                  // (summed over the wave below)
                 // A pair that shares more than 21 calls: its code did not fit a byte and the list is void.  The site is CpG-dense -- handed to
                 // the wave-per-site walk it takes the call-by-call path with calls beyond the registers, up to a millisecond for ONE site --
                 // so its rounds are run again HERE with the ordered sum chained in the wave (one DPP add per pair, as the walk's compact
                 // finalize does it): a few thousand such sites per batch, and the chain kernel sees none of them.
-                wide = __any(over > FT_NCPG_MAX);
+                wide = maybe_wide;
                 if (wide) {
                     disc = 0;
                     ent_next = tab[P ? min(lane, P - 1) : 0];
