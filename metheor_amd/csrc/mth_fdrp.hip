@@ -78,6 +78,7 @@ struct FdrpArgs {
     unsigned long long *site_off;     // per site: first byte of its list
     uint32_t *site_nz, *site_disc;    // per site: listed terms, discordant pairs
     uint32_t *redo_list, *redo_cnt;   // the sites k_fdrp_tile / k_fdrp_wtile handed back, one after the other (k_fdrp_walk takes them wave by wave)
+    uint32_t wide_rows;               // tests: k_fdrp_tile keeps every site's rows in the eight-word form (METHEOR_FDRP_TILE_WIDE_ROWS=1)
     uint32_t no_compact;              // the site list holds only the sites that can produce a row (k_fdrp_wtile): no window of ALL sites around c
 };
 
@@ -1132,6 +1133,14 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             bool wide_row = false;                                                              // a stored read with more than 21 calls on window sites
+            // The stored reads' rows in one of two forms (round 6).  NARROW, when every stored read's calls lie within 16 consecutive
+            // window sites (any two readers of the site then lie within 31 of them: bit = window site mod 32 is unambiguous): four words
+            // -- start | end << 16 relative to c - 4096, and the three masks folded to 32 bits -- one 16-byte LDS read per operand and
+            // round instead of two, half the mask arithmetic.  The round's four 16-byte reads were this kernel's other limit beside the
+            // vector unit (0.94 busy; LDS 51 % with 41 % bank conflicts).  WIDE (64-bit masks, eight words) otherwise.
+            bool span_wide = false;
+            int32_t row_s = 0, row_e = 0;
+            unsigned long long row_c = 0, row_a = 0, row_m = 0;
             if (!redo && (uint32_t)lane < nS) {
                 uint32_t src = (uint32_t)lane;
                 for (uint32_t t = nS; t < n_sel; ++t) src = draw[t] == (uint8_t)(lane + 1) ? t : src;
@@ -1142,10 +1151,22 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                 wide_row = (uint32_t)__popcll(mc) > FT_NCPG_MAX;
                 const uint32_t ab = pk >> 16;
                 const unsigned long long ma = ab == 0xffu ? mc : mc & ~(1ull << ab);
-                uint32_t *rw = rows + (uint32_t)lane * 8u;
-                rw[0] = (uint32_t)rs; rw[1] = (uint32_t)(rs + (int32_t)(pk & 0xffu));
-                rw[2] = (uint32_t)mc; rw[3] = (uint32_t)(mc >> 32); rw[4] = (uint32_t)ma; rw[5] = (uint32_t)(ma >> 32);
-                rw[6] = (uint32_t)mm; rw[7] = (uint32_t)(mm >> 32);
+                span_wide = mc == 0ull || 63u - (uint32_t)__builtin_clzll(mc) - (uint32_t)__builtin_ctzll(mc) > 15u;
+                row_s = rs; row_e = rs + (int32_t)(pk & 0xffu); row_c = mc; row_a = ma; row_m = mm;
+            }
+            const bool narrow = !a.wide_rows && !__any(span_wide);                              // wave-uniform
+            if (!redo && (uint32_t)lane < nS) {
+                if (narrow) {
+                    const uint32_t base = (uint32_t)c - 4096u;                                  // (spans <= 200 bp here: both offsets fit 16 bits)
+                    *reinterpret_cast<uint4 *>(rows + (uint32_t)lane * 4u) =
+                        make_uint4((((uint32_t)row_s - base) & 0xffffu) | (((uint32_t)row_e - base) << 16), (uint32_t)row_c | (uint32_t)(row_c >> 32),
+                                   (uint32_t)row_a | (uint32_t)(row_a >> 32), (uint32_t)row_m | (uint32_t)(row_m >> 32));
+                } else {
+                    uint32_t *rw = rows + (uint32_t)lane * 8u;
+                    rw[0] = (uint32_t)row_s; rw[1] = (uint32_t)row_e;
+                    rw[2] = (uint32_t)row_c; rw[3] = (uint32_t)(row_c >> 32); rw[4] = (uint32_t)row_a; rw[5] = (uint32_t)(row_a >> 32);
+                    rw[6] = (uint32_t)row_m; rw[7] = (uint32_t)(row_m >> 32);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1168,8 +1189,31 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                 // below straight away; ncpg (ncpg + 1) as one multiply-add; 32-bit pair indices.)
                 const bool mo_any = a.min_overlap <= 0;
                 const int32_t mo_m1 = a.min_overlap - 1;
-                const uint32_t Pu = maybe_wide ? 0u : (uint32_t)P;                              // (a wide site: no listed terms, the chained rounds below)
                 uint32_t disc_s = 0;                                                            // wave-uniform
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                for (uint32_t k0 = 0; narrow && k0 < (uint32_t)P; k0 += 64u) {                  // (narrow rows: never a pair with > 21 shared calls)
+                    const uint32_t ent = ent_next;
+                    if (k0 + 64u < (uint32_t)P) ent_next = tab[min(k0 + 64u + (uint32_t)lane, (uint32_t)P - 1u)];
+                    typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+                    const u32x4_a16 *const rows4 = reinterpret_cast<const u32x4_a16 *>(rows);
+                    const u32x4_a16 ri = rows4[ent & 0xffu], rj = rows4[ent >> 8];
+                    // both halves at once: the larger start in the low half of one, the smaller end in the high half of the other
+                    const u16x2 lo2 = __builtin_elementwise_max(__builtin_bit_cast(u16x2, ri.x), __builtin_bit_cast(u16x2, rj.x));
+                    const u16x2 hi2 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, ri.x), __builtin_bit_cast(u16x2, rj.x));
+                    const int32_t ov_m1 = (int32_t)hi2.y - (int32_t)lo2.x;                      // get_num_overlap_bases - 1, fdrp.rs:97-107
+                    const bool pair_ok = (k0 + (uint32_t)lane < (uint32_t)P) & (mo_any | (ov_m1 >= mo_m1));   // fdrp.rs:134 (no short circuit: one 16-byte read per row)
+                    const uint32_t ncpg = (uint32_t)__builtin_popcount(ri.y & rj.y);            // qfdrp.rs:109-119
+                    const uint32_t ham = (uint32_t)__builtin_popcount(ri.z & rj.z & (ri.w ^ rj.w));   // fdrp.rs:114-115
+                    disc_s += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pair_ok && ham != 0u));  // fdrp.rs:138-140
+                    uint32_t tri2;
+                    asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(tri2) : "v"(ncpg));
+                    const uint32_t code = pair_ok ? (tri2 >> 1) + ham : 1u;
+                    uint32_t pk = code << (8 * (lane & 3));
+                    pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, true);
+                    pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x4e /*quad_perm [2,3,0,1]*/, 0xf, 0xf, true);
+                    if ((lane & 3) == 0) *reinterpret_cast<uint32_t *>(tp + (k0 + (uint32_t)lane)) = pk;
+                }
+                const uint32_t Pu = (maybe_wide || narrow) ? 0u : (uint32_t)P;                  // (a wide site: no listed terms, the chained rounds below)
                 for (uint32_t k0 = 0; k0 < Pu; k0 += 64u) {
                     const uint32_t ent = ent_next;
                     if (k0 + 64u < Pu) ent_next = tab[min(k0 + 64u + (uint32_t)lane, Pu - 1u)];
@@ -1417,6 +1461,7 @@ int mth_fdrp_accumulate(mth_ctx_t *ctx, const mth_batch_t *batch, const mth_fdrp
     a.min_qual = params->min_qual;
     a.rows_scratch = nullptr; a.slots_cap = 0;
     a.redo_list = nullptr; a.redo_cnt = nullptr; a.no_compact = 0u;
+    a.wide_rows = getenv("METHEOR_FDRP_TILE_WIDE_ROWS") ? 1u : 0u;
     a.terms = nullptr; a.cursor = nullptr; a.budget = 0; a.site_off = nullptr; a.site_nz = nullptr; a.site_disc = nullptr;
     if (!ctx->f_pairtab.p) {
         // the pairs of n stored reads in the reference's (i, j) loop order (fdrp.rs:129-141), n = 2..64, one after the other

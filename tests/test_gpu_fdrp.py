@@ -17,14 +17,15 @@ f32 = np.float32
 TOL = 1e-6
 
 
-@pytest.fixture(autouse=True, params=["auto", "wtile", "wtile_sub", "wtile_heavy", "walk16", "walk32", "tile", "walk"])
+@pytest.fixture(autouse=True, params=["auto", "wtile", "wtile_sub", "wtile_heavy", "walk16", "walk32", "tile", "tile_wide_rows", "walk"])
 def walk_choice(request, monkeypatch):
     """every case eight times: with the host's own choice of kernel form; with the one-pass tile form forced (k_fdrp_wtile,
     round 6: whatever it cannot hold is handed back to the general walk) -- as it is, starting from 192-position stretches, and
     with every stretch on its count-only path (every site handed back); with k_fdrp_walk4 forced (16 or 32 lanes per site, the
     rest handed back to the general walk -- on dense data mostly the hand-back path); with the read x read form forced
-    (k_fdrp_tile + k_fdrp_chain, round 4); and with the wave-per-site walk alone"""
-    for k in ("METHEOR_FDRP_WALK4", "METHEOR_FDRP_TILE", "METHEOR_FDRP_WTILE", "METHEOR_FDRP_WTILE_SUB", "METHEOR_FDRP_WTILE_HEAVY"):
+    (k_fdrp_tile + k_fdrp_chain, round 4: its stored reads' rows in the four-word form where every reader spans <= 16 window sites
+    -- round 6 -- and in the eight-word form forced); and with the wave-per-site walk alone"""
+    for k in ("METHEOR_FDRP_WALK4", "METHEOR_FDRP_TILE", "METHEOR_FDRP_WTILE", "METHEOR_FDRP_WTILE_SUB", "METHEOR_FDRP_WTILE_HEAVY", "METHEOR_FDRP_TILE_WIDE_ROWS"):
         monkeypatch.delenv(k, raising=False)
     if request.param.startswith("wtile"):
         monkeypatch.setenv("METHEOR_FDRP_WTILE", "1")
@@ -35,8 +36,10 @@ def walk_choice(request, monkeypatch):
     elif request.param.startswith("walk") and len(request.param) > 4:
         monkeypatch.setenv("METHEOR_FDRP_WALK4", request.param[4:])
         monkeypatch.setenv("METHEOR_FDRP_TILE", "0")
-    elif request.param == "tile":
+    elif request.param.startswith("tile"):
         monkeypatch.setenv("METHEOR_FDRP_TILE", "1")
+        if request.param == "tile_wide_rows":
+            monkeypatch.setenv("METHEOR_FDRP_TILE_WIDE_ROWS", "1")
     elif request.param == "walk":
         monkeypatch.setenv("METHEOR_FDRP_TILE", "0")
         monkeypatch.setenv("METHEOR_FDRP_WALK4", "0")

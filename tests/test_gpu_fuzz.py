@@ -83,7 +83,7 @@ def fdrp_checked(eng, cs, fk, regions, reads):
     d0 = T_fdrp.run_device(eng, cs, fk, regions=regions)
     T_fdrp.check(d0, reads, fk)
     for env in (dict(METHEOR_FDRP_WTILE="1"), dict(METHEOR_FDRP_WTILE="1", METHEOR_FDRP_WTILE_SUB="1"), dict(METHEOR_FDRP_WTILE="0"),
-                dict(METHEOR_FDRP_WALK4="16", METHEOR_FDRP_TILE="0"), dict(METHEOR_FDRP_TILE="1"), dict(METHEOR_FDRP_WALK4="0", METHEOR_FDRP_TILE="0")):
+                dict(METHEOR_FDRP_WALK4="16", METHEOR_FDRP_TILE="0"), dict(METHEOR_FDRP_TILE="1"), dict(METHEOR_FDRP_TILE="1", METHEOR_FDRP_TILE_WIDE_ROWS="1"), dict(METHEOR_FDRP_WALK4="0", METHEOR_FDRP_TILE="0")):
         os.environ.update(env)
         try:
             d1 = T_fdrp.run_device(eng, cs, fk, regions=regions)
