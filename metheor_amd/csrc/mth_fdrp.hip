@@ -1204,14 +1204,14 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                     const bool pair_ok = (k0 + (uint32_t)lane < (uint32_t)P) & (mo_any | (ov_m1 >= mo_m1));   // fdrp.rs:134 (no short circuit: one 16-byte read per row)
                     const uint32_t ncpg = (uint32_t)__builtin_popcount(ri.y & rj.y);            // qfdrp.rs:109-119
                     const uint32_t ham = (uint32_t)__builtin_popcount(ri.z & rj.z & (ri.w ^ rj.w));   // fdrp.rs:114-115
-                    disc_s += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pair_ok && ham != 0u));  // fdrp.rs:138-140
+                    // fdrp.rs:138-140: the discordant pairs are exactly the pairs with a non-zero term; only those are listed (x + 0.0 == x),
+                    // packed in the pairs' own order
+                    const bool dsc = pair_ok && ham != 0u;
+                    const unsigned long long nzm = __builtin_amdgcn_ballot_w64(dsc);
                     uint32_t tri2;
                     asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(tri2) : "v"(ncpg));
-                    const uint32_t code = pair_ok ? (tri2 >> 1) + ham : 1u;
-                    uint32_t pk = code << (8 * (lane & 3));
-                    pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, true);
-                    pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x4e /*quad_perm [2,3,0,1]*/, 0xf, 0xf, true);
-                    if ((lane & 3) == 0) *reinterpret_cast<uint32_t *>(tp + (k0 + (uint32_t)lane)) = pk;
+                    if (dsc) tp[disc_s + __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u))] = (uint8_t)((tri2 >> 1) + ham);
+                    disc_s += (uint32_t)__popcll(nzm);
                 }
                 const uint32_t Pu = (maybe_wide || narrow) ? 0u : (uint32_t)P;                  // (a wide site: no listed terms, the chained rounds below)
                 for (uint32_t k0 = 0; k0 < Pu; k0 += 64u) {
@@ -1225,18 +1225,15 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                     const uint32_t ncpg = __builtin_popcount(ri[2] & rj[2]) + __builtin_popcount(ri[3] & rj[3]);   // qfdrp.rs:109-119
                     const uint32_t ham = __builtin_popcount(ri[4] & rj[4] & (ri[6] ^ rj[6])) +
                                          __builtin_popcount(ri[5] & rj[5] & (ri[7] ^ rj[7]));                      // fdrp.rs:114-115
-                    disc_s += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pair_ok && ham != 0u));   // fdrp.rs:138-140
-                    // Every pair's term goes to the site's list at the pair's own index, as one byte: ncpg (ncpg + 1) / 2 + ham (the
-                    // chain kernel's table gives ham / ncpg: +0.0 when ham is 0 -- x + 0.0 == x -- and NaN for 0 / 0); a skipped
-                    // pair is code 1 = 0 / 1.  Four codes per dword (two DPP ORs inside each quad of lanes), 16 lanes store 64 bytes.
+                    const bool dsc = pair_ok && ham != 0u;                                       // fdrp.rs:138-140
+                    const unsigned long long nzm = __builtin_amdgcn_ballot_w64(dsc);
                     uint32_t tri2;                                                               // ncpg (ncpg + 1) in one instruction
                     asm("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(tri2) : "v"(ncpg));
-                    const uint32_t code = pair_ok ? (tri2 >> 1) + ham : 1u;
-                    uint32_t pk = code << (8 * (lane & 3));
-                    pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, true);
-                    pk |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pk, 0x4e /*quad_perm [2,3,0,1]*/, 0xf, 0xf, true);
-                    if ((lane & 3) == 0) *reinterpret_cast<uint32_t *>(tp + (k0 + (uint32_t)lane)) = pk;
+                    if (dsc) tp[disc_s + __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u))] = (uint8_t)((tri2 >> 1) + ham);
+                    disc_s += (uint32_t)__popcll(nzm);
                 }
+                // the list's last 64-byte line is filled up with code 1 = 0 / 1 = +0.0: k_fdrp_chain adds whole lines
+                if (!maybe_wide && (uint32_t)lane < ((64u - (disc_s & 63u)) & 63u)) tp[disc_s + (uint32_t)lane] = (uint8_t)1;
                 disc = lane == 0 ? disc_s : 0u;                                                  // (summed over the wave below)
                 // A pair that shares more than 21 calls: its code did not fit a byte and the list is void.  The site is CpG-dense -- handed to
                 // the wave-per-site walk it takes the call-by-call path with calls beyond the registers, up to a millisecond for ONE site --
@@ -1277,7 +1274,7 @@ __global__ __launch_bounds__(256, 7) void k_fdrp_tile(const FdrpArgs a) {
                         const unsigned long long prod = (unsigned long long)(long long)nS * (unsigned long long)((long long)nS - 1);
                         const float den = (float)prod / 2.0f;                                   // fdrp.rs:143
                         a.fdrp[j] = (float)disc / den; a.qfdrp[j] = q_wide / den; a.flags[j] = 1u;
-                    } else { a.site_off[j] = off; a.site_nz[j] = (nS * (nS - 1u)) >> 1; a.site_disc[j] = disc; a.flags[j] = FD_CHAIN; }
+                    } else { a.site_off[j] = off; a.site_nz[j] = disc; a.site_disc[j] = disc; a.flags[j] = FD_CHAIN; }
                 }
             }
         }
