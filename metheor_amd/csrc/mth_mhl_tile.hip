@@ -693,7 +693,6 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     // 0.204 at 4096 / 8192 (16384 overflows the slots there: 1.27 ms)
     // (round 6: the one-wave-per-tile form that pays for FDRP was built for MHL too -- parity-green and 30 % slower than this kernel, whose
     // tile is eleven times larger: profiles/r06_mhl_wtile.md, tools/experiments/mth_mhl_wtile.hip)
-    const bool wt = false;
     int shift = 12, W = 0;
     int32_t idx_base = 0;
     uint32_t ntiles = 0;
@@ -705,7 +704,6 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
     // 0.130 ms + 0.009 for the row kernel); config 2 (2.94 CpGs a read, 100 rows a tile) keeps the marks
     bool rowchk = (double)d.n_cpgs <= 1.8 * (double)d.n_reads;       // (density sweep, profiles/r06_mhl_rowcheck.md: even at 2.0)
     if (const char *e = getenv("MTH_MHL_ROWCHK")) rowchk = atoi(e) != 0;                               // tests / tuning
-    if (!wt) {
     {
         const double cpr = (double)d.n_cpgs / (double)d.n_reads;
         const double sites_per_bp = cpr / (double)std::max(d.max_span, 1);
@@ -781,7 +779,6 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
         rc.hand_list = ctx->w_aux.as<uint32_t>(); rc.st = ctx->d_state; rc.idx_base = idx_base; rc.max_span = d.max_span; rc.n_reads = d.n_reads;
         hipLaunchKernelGGL(k_mhl_rowcheck, dim3(2048), dim3(256), 0, s, rc);
     }
-    }   // (!wt)
     if (!getenv("MTH_MHL_NO_WAVE_WALK")) {
         LaunchTimer lt(ctx, K_MHLWALK);
         MhlWaveArgs w;
@@ -793,7 +790,7 @@ int launch_mhl_tile(mth_ctx *ctx, const mth_batch_t &d, const mth_mhl_params_t &
         hipLaunchKernelGGL(k_mhl_walk_wave, dim3(1024), dim3(256), 0, s, w);
     }
 #ifdef MTH_MT_TRACE
-    if (!wt) {
+    {
         std::vector<unsigned long long> hv((size_t)ntiles * 8);
         MTH_HIP(ctx, hipStreamSynchronize(s));
         MTH_HIP(ctx, hipMemcpy(hv.data(), a.trace, hv.size() * 8, hipMemcpyDeviceToHost));
